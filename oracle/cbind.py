@@ -1,0 +1,152 @@
+"""ctypes binding of oracle/libnltgv2_oracle.so (TEST INFRASTRUCTURE, see oracle/__init__.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def oracle_lib_path():
+    return os.path.join(_HERE, "libnltgv2_oracle.so")
+
+
+def build_oracle(force=False):
+    """Compile the C restatement with the committed Makefile (gcc only, seconds)."""
+    if force or not os.path.exists(oracle_lib_path()):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return oracle_lib_path()
+
+
+class OracleParams(C.Structure):
+    _fields_ = [("data_factor", C.c_float), ("step_x", C.c_float), ("step_q", C.c_float),
+                ("theta", C.c_float), ("x_min", C.c_float), ("x_max", C.c_float)]
+
+
+class _Graph(C.Structure):
+    _fields_ = [("V", C.c_int32), ("E", C.c_int32),
+                ("pos", C.c_void_p), ("edges", C.c_void_p), ("alpha", C.c_void_p),
+                ("beta", C.c_void_p), ("z", C.c_void_p), ("wgt", C.c_void_p),
+                ("x", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("xb", C.c_void_p), ("w1b", C.c_void_p), ("w2b", C.c_void_p),
+                ("q", C.c_void_p)]
+
+
+class TriParams(C.Structure):
+    _fields_ = [("do_oblique_triangle_filter", C.c_int32), ("oblique_normal_thresh", C.c_float),
+                ("oblique_idepth_diff_factor", C.c_float), ("oblique_idepth_diff_abs", C.c_float),
+                ("do_edge_length_filter", C.c_int32), ("edge_length_thresh", C.c_float),
+                ("do_idepth_triangle_filter", C.c_int32), ("min_triangle_idepth", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_oracle())
+        _lib.nltgv2_solve.restype = C.c_int
+    return _lib
+
+
+def default_params(data_factor=0.15, step_x=1e-3, step_q=125.0, theta=0.25, x_min=0.0, x_max=10.0):
+    """Defaults: reference cfg/flame_offline_tum.yaml:93-96; clamp 0..10 is upstream recall."""
+    return OracleParams(data_factor, step_x, step_q, theta, x_min, x_max)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class COracle:
+    """Holds one graph + solver state in NumPy arrays and steps it with the C restatement."""
+
+    def __init__(self, pos, edges, alpha, beta, z, wgt, x0=None):
+        self.pos = _f32(pos).reshape(-1, 2)
+        self.edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        self.V, self.E = self.pos.shape[0], self.edges.shape[0]
+        self.alpha, self.beta, self.z, self.wgt = _f32(alpha), _f32(beta), _f32(z), _f32(wgt)
+        assert self.alpha.shape == (self.E,) and self.beta.shape == (self.E,)
+        assert self.z.shape == (self.V,) and self.wgt.shape == (self.V,)
+        self.x = _f32(self.z if x0 is None else x0).copy()
+        self.w1 = np.zeros(self.V, np.float32)
+        self.w2 = np.zeros(self.V, np.float32)
+        self.xb, self.w1b, self.w2b = self.x.copy(), self.w1.copy(), self.w2.copy()
+        self.q = np.zeros((self.E, 3), np.float32)
+
+    def set_state(self, x=None, w1=None, w2=None, xb=None, w1b=None, w2b=None, q=None):
+        for name, val in dict(x=x, w1=w1, w2=w2, xb=xb, w1b=w1b, w2b=w2b).items():
+            if val is not None:
+                getattr(self, name)[:] = _f32(val)
+        if q is not None:
+            self.q[:] = _f32(q).reshape(self.E, 3)
+
+    def _g(self):
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        return _Graph(self.V, self.E, p(self.pos), p(self.edges), p(self.alpha), p(self.beta),
+                      p(self.z), p(self.wgt), p(self.x), p(self.w1), p(self.w2), p(self.xb),
+                      p(self.w1b), p(self.w2b), p(self.q))
+
+    def solve(self, params, num_iters):
+        g = self._g()
+        rc = _load().nltgv2_solve(C.byref(params), C.byref(g), int(num_iters))
+        if rc != 0:
+            raise MemoryError("nltgv2_solve")
+        return self.x
+
+    def dual_step(self, params):
+        g = self._g()
+        _load().nltgv2_dual_step(C.byref(params), C.byref(g))
+
+    def primal_step(self, params):
+        g = self._g()
+        xp, w1p, w2p = (np.empty(self.V, np.float32) for _ in range(3))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _load().nltgv2_primal_step(C.byref(params), C.byref(g), vp(xp), vp(w1p), vp(w2p))
+        return xp, w1p, w2p
+
+    def extragradient_step(self, params, xp, w1p, w2p):
+        g = self._g()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _load().nltgv2_extragradient_step(C.byref(params), C.byref(g), vp(xp), vp(w1p), vp(w2p))
+
+    def costs(self, params):
+        g = self._g()
+        s, d = C.c_double(), C.c_double()
+        _load().nltgv2_costs(C.byref(params), C.byref(g), C.byref(s), C.byref(d))
+        return s.value, d.value
+
+    def apply_K(self, x, w1, w2):
+        g = self._g()
+        Ku = np.empty((self.E, 3), np.float32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        x, w1, w2 = _f32(x), _f32(w1), _f32(w2)
+        _load().nltgv2_apply_K(C.byref(g), vp(x), vp(w1), vp(w2), vp(Ku))
+        return Ku
+
+    def apply_KT(self, q):
+        g = self._g()
+        q = _f32(q).reshape(self.E, 3)
+        out = [np.empty(self.V, np.float32) for _ in range(3)]
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        _load().nltgv2_apply_KT(C.byref(g), vp(q), vp(out[0]), vp(out[1]), vp(out[2]))
+        return out
+
+
+def triangles(tri_params, Kinv, pos, x, tris):
+    """Per-triangle stage (row a8).  Returns (tri_normals[T,3], tri_valid[T], vtx_normals[V,3])."""
+    pos = _f32(pos).reshape(-1, 2)
+    x = _f32(x)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    V, T = pos.shape[0], tris.shape[0]
+    Kinv = _f32(Kinv).reshape(9)
+    tn = np.empty((T, 3), np.float32)
+    tv = np.empty(T, np.uint8)
+    vn = np.empty((V, 3), np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    _load().nltgv2_triangles(C.byref(tri_params), vp(Kinv), C.c_int32(V), C.c_int32(T), vp(pos),
+                             vp(x), vp(tris), vp(tn), vp(tv), vp(vn))
+    return tn, tv, vn

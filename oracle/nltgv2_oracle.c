@@ -1,0 +1,260 @@
+/*
+ * oracle/nltgv2_oracle.c -- see nltgv2_oracle.h.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED
+ * (the solver source, robustrobotics/flame, is absent from /root/reference and un-pinned:
+ * reference README.md:73, CMakeLists.txt:57).  Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off.
+ *
+ * Every function cites the SURVEY.md section-8a row it restates and the reference lines that
+ * show the quantity crossing the flame::Flame boundary.
+ */
+#include "nltgv2_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* projection of one dual component onto [-1,1]: v / max(1,|v|)   */
+static inline float proj_unit(float v) { return v / fmaxf(1.0f, fabsf(v)); }
+
+/* Row a2: internal::dualStep.  step_q crosses the boundary at reference
+ * src/flame_offline_tum.cc:244 (cfg/flame_offline_tum.yaml:95). */
+void nltgv2_dual_step(const nltgv2_params* p, nltgv2_graph* g) {
+  const float sigma = p->step_q;
+  for (int32_t e = 0; e < g->E; ++e) {
+    const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+    const float dx = g->pos[2 * i] - g->pos[2 * j];
+    const float dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+    float t = g->xb[i] - g->xb[j];
+    t = fmaf(-g->w1b[i], dx, t);
+    t = fmaf(-g->w2b[i], dy, t);
+    const float K1 = g->alpha[e] * t;
+    const float K2 = g->beta[e] * (g->w1b[i] - g->w1b[j]);
+    const float K3 = g->beta[e] * (g->w2b[i] - g->w2b[j]);
+    float* q = g->q + 3 * e;
+    q[0] = proj_unit(fmaf(sigma, K1, q[0]));
+    q[1] = proj_unit(fmaf(sigma, K2, q[1]));
+    q[2] = proj_unit(fmaf(sigma, K3, q[2]));
+  }
+}
+
+/* Row a3: internal::primalStep incl. proxL1.  step_x and data_factor cross the boundary at
+ * reference src/flame_offline_tum.cc:242-243 (yaml :93-94). */
+void nltgv2_primal_step(const nltgv2_params* p, nltgv2_graph* g, float* xp, float* w1p,
+                        float* w2p) {
+  const float tau = p->step_x;
+  memcpy(xp, g->x, sizeof(float) * g->V);
+  memcpy(w1p, g->w1, sizeof(float) * g->V);
+  memcpy(w2p, g->w2, sizeof(float) * g->V);
+  /* u <- u - tau K^T q, scattered in ascending edge order */
+  for (int32_t e = 0; e < g->E; ++e) {
+    const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+    const float dx = g->pos[2 * i] - g->pos[2 * j];
+    const float dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+    const float* q = g->q + 3 * e;
+    const float aq = g->alpha[e] * q[0];
+    const float b2 = g->beta[e] * q[1];
+    const float b3 = g->beta[e] * q[2];
+    const float s1 = fmaf(-dx, aq, b2); /* -alpha dx q1 + beta q2 */
+    const float s2 = fmaf(-dy, aq, b3);
+    g->x[i] = fmaf(-tau, aq, g->x[i]);
+    g->w1[i] = fmaf(-tau, s1, g->w1[i]);
+    g->w2[i] = fmaf(-tau, s2, g->w2[i]);
+    g->x[j] = fmaf(-tau, -aq, g->x[j]);
+    g->w1[j] = fmaf(-tau, -b2, g->w1[j]);
+    g->w2[j] = fmaf(-tau, -b3, g->w2[j]);
+  }
+  /* L1 prox toward the data term, then idepth clamp */
+  const float tl = tau * p->data_factor;
+  for (int32_t v = 0; v < g->V; ++v) {
+    const float t = tl * g->wgt[v];
+    const float x = g->x[v], z = g->z[v];
+    const float r = x - z;
+    float xn = (r > t) ? (x - t) : ((r < -t) ? (x + t) : z);
+    xn = fminf(fmaxf(xn, p->x_min), p->x_max);
+    g->x[v] = xn;
+  }
+}
+
+/* Row a4: internal::extraGradientStep.  theta crosses at src/flame_offline_tum.cc:245. */
+void nltgv2_extragradient_step(const nltgv2_params* p, nltgv2_graph* g, const float* xp,
+                               const float* w1p, const float* w2p) {
+  const float th = p->theta;
+  for (int32_t v = 0; v < g->V; ++v) {
+    g->xb[v] = fmaf(th, g->x[v] - xp[v], g->x[v]);
+    g->w1b[v] = fmaf(th, g->w1[v] - w1p[v], g->w1[v]);
+    g->w2b[v] = fmaf(th, g->w2[v] - w2p[v], g->w2[v]);
+  }
+}
+
+/* Row a5: step() = dual; primal; extra-gradient (gated by do_nltgv2, reference
+ * src/flame_offline_tum.cc:234, and driven from Flame::update, :578). */
+void nltgv2_step(const nltgv2_params* p, nltgv2_graph* g, float* scratch) {
+  float* xp = scratch;
+  float* w1p = scratch + g->V;
+  float* w2p = scratch + 2 * (size_t)g->V;
+  nltgv2_dual_step(p, g);
+  nltgv2_primal_step(p, g, xp, w1p, w2p);
+  nltgv2_extragradient_step(p, g, xp, w1p, w2p);
+}
+
+int nltgv2_solve(const nltgv2_params* p, nltgv2_graph* g, int num_iters) {
+  float* scratch = (float*)malloc(sizeof(float) * 3 * (size_t)(g->V > 0 ? g->V : 1));
+  if (!scratch) return -1;
+  for (int it = 0; it < num_iters; ++it) nltgv2_step(p, g, scratch);
+  free(scratch);
+  return 0;
+}
+
+/* Row a6: smoothnessCost / dataCost behind the stat keys nltgv2_total_smoothness_cost and
+ * nltgv2_total_data_cost (reference src/utils.cc:131-136, msg/FlameStats.msg:22-25). */
+void nltgv2_costs(const nltgv2_params* p, const nltgv2_graph* g, double* smooth, double* data) {
+  double s = 0.0, d = 0.0;
+  for (int32_t e = 0; e < g->E; ++e) {
+    const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+    const float dx = g->pos[2 * i] - g->pos[2 * j];
+    const float dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+    float t = g->x[i] - g->x[j];
+    t = fmaf(-g->w1[i], dx, t);
+    t = fmaf(-g->w2[i], dy, t);
+    const float c1 = g->alpha[e] * fabsf(t);
+    const float c2 = g->beta[e] * fabsf(g->w1[i] - g->w1[j]);
+    const float c3 = g->beta[e] * fabsf(g->w2[i] - g->w2[j]);
+    s += (double)c1 + (double)c2 + (double)c3;
+  }
+  for (int32_t v = 0; v < g->V; ++v) {
+    const float c = (p->data_factor * g->wgt[v]) * fabsf(g->x[v] - g->z[v]);
+    d += (double)c;
+  }
+  *smooth = s;
+  *data = d;
+}
+
+void nltgv2_apply_K(const nltgv2_graph* g, const float* x, const float* w1, const float* w2,
+                    float* Ku) {
+  for (int32_t e = 0; e < g->E; ++e) {
+    const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+    const float dx = g->pos[2 * i] - g->pos[2 * j];
+    const float dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+    float t = x[i] - x[j];
+    t = fmaf(-w1[i], dx, t);
+    t = fmaf(-w2[i], dy, t);
+    Ku[3 * e] = g->alpha[e] * t;
+    Ku[3 * e + 1] = g->beta[e] * (w1[i] - w1[j]);
+    Ku[3 * e + 2] = g->beta[e] * (w2[i] - w2[j]);
+  }
+}
+
+void nltgv2_apply_KT(const nltgv2_graph* g, const float* q, float* kx, float* kw1, float* kw2) {
+  memset(kx, 0, sizeof(float) * g->V);
+  memset(kw1, 0, sizeof(float) * g->V);
+  memset(kw2, 0, sizeof(float) * g->V);
+  for (int32_t e = 0; e < g->E; ++e) {
+    const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+    const float dx = g->pos[2 * i] - g->pos[2 * j];
+    const float dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+    const float aq = g->alpha[e] * q[3 * e];
+    const float b2 = g->beta[e] * q[3 * e + 1];
+    const float b3 = g->beta[e] * q[3 * e + 2];
+    kx[i] += aq;
+    kw1[i] += fmaf(-dx, aq, b2);
+    kw2[i] += fmaf(-dy, aq, b3);
+    kx[j] -= aq;
+    kw1[j] -= b2;
+    kw2[j] -= b3;
+  }
+}
+
+/* ---- Row a8: per-triangle stage.  Outputs feed getInverseDepthMesh(&vtx,&idepths,&normals,
+ * &triangles,&tri_validity,&edges) (reference src/flame_offline_tum.cc:628-635); filter
+ * parameters are loaded at :168-192 (yaml :38-53).  The upstream arithmetic is not in the
+ * reference tree, so this is the build's own precise statement of those filters. ---- */
+static inline void backproject(const float K[9], float u, float v, float x, float P[3]) {
+  const float depth = 1.0f / x;
+  const float r0 = fmaf(K[0], u, fmaf(K[1], v, K[2]));
+  const float r1 = fmaf(K[3], u, fmaf(K[4], v, K[5]));
+  const float r2 = fmaf(K[6], u, fmaf(K[7], v, K[8]));
+  P[0] = r0 * depth;
+  P[1] = r1 * depth;
+  P[2] = r2 * depth;
+}
+
+static inline float dot3(const float a[3], const float b[3]) {
+  return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
+}
+
+void nltgv2_triangles(const nltgv2_tri_params* tp, const float Kinv[9], int32_t V, int32_t T,
+                      const float* pos, const float* x, const int32_t* tris, float* tri_normals,
+                      uint8_t* tri_valid, float* vtx_normals) {
+  const float cos_thresh = (float)cos((double)tp->oblique_normal_thresh);
+  const float max_len = tp->edge_length_thresh * (float)tp->width;
+  const float max_len2 = max_len * max_len;
+  memset(vtx_normals, 0, sizeof(float) * 3 * (size_t)V);
+  for (int32_t t = 0; t < T; ++t) {
+    const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+    const float xa = x[a], xb = x[b], xc = x[c];
+    float* n = tri_normals + 3 * (size_t)t;
+    const int ok = isfinite(xa) && isfinite(xb) && isfinite(xc) && xa > 0.0f && xb > 0.0f &&
+                   xc > 0.0f;
+    if (!ok) {
+      n[0] = n[1] = n[2] = 0.0f;
+      tri_valid[t] = 0;
+      continue;
+    }
+    float Pa[3], Pb[3], Pc[3];
+    backproject(Kinv, pos[2 * a], pos[2 * a + 1], xa, Pa);
+    backproject(Kinv, pos[2 * b], pos[2 * b + 1], xb, Pb);
+    backproject(Kinv, pos[2 * c], pos[2 * c + 1], xc, Pc);
+    const float e1[3] = {Pb[0] - Pa[0], Pb[1] - Pa[1], Pb[2] - Pa[2]};
+    const float e2[3] = {Pc[0] - Pa[0], Pc[1] - Pa[1], Pc[2] - Pa[2]};
+    float nn[3] = {fmaf(e1[1], e2[2], -(e1[2] * e2[1])), fmaf(e1[2], e2[0], -(e1[0] * e2[2])),
+                   fmaf(e1[0], e2[1], -(e1[1] * e2[0]))};
+    const float len = sqrtf(dot3(nn, nn));
+    if (len > 0.0f) {
+      nn[0] /= len; nn[1] /= len; nn[2] /= len;
+    } else {
+      nn[0] = 0.0f; nn[1] = 0.0f; nn[2] = -1.0f;
+    }
+    /* orient toward the camera (origin): n . P_a <= 0 */
+    if (dot3(nn, Pa) > 0.0f) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; }
+    n[0] = nn[0]; n[1] = nn[1]; n[2] = nn[2];
+
+    uint8_t valid = 1;
+    const float xmin = fminf(xa, fminf(xb, xc)), xmax = fmaxf(xa, fmaxf(xb, xc));
+    if (tp->do_idepth_triangle_filter && xmin < tp->min_triangle_idepth) valid = 0;
+    if (tp->do_edge_length_filter) {
+      const float ux[3] = {pos[2 * a] - pos[2 * b], pos[2 * b] - pos[2 * c], pos[2 * c] - pos[2 * a]};
+      const float uy[3] = {pos[2 * a + 1] - pos[2 * b + 1], pos[2 * b + 1] - pos[2 * c + 1],
+                           pos[2 * c + 1] - pos[2 * a + 1]};
+      for (int k = 0; k < 3; ++k)
+        if (fmaf(ux[k], ux[k], uy[k] * uy[k]) > max_len2) valid = 0;
+    }
+    if (tp->do_oblique_triangle_filter) {
+      /* viewing ray through the centroid */
+      float ray[3] = {(Pa[0] + Pb[0]) + Pc[0], (Pa[1] + Pb[1]) + Pc[1], (Pa[2] + Pb[2]) + Pc[2]};
+      const float rl = sqrtf(dot3(ray, ray));
+      if (rl > 0.0f) {
+        ray[0] /= rl; ray[1] /= rl; ray[2] /= rl;
+        const float cosang = -dot3(nn, ray); /* angle between normal and the ray back to camera */
+        if (cosang < cos_thresh) valid = 0;
+      }
+      const float diff = xmax - xmin;
+      if (diff > tp->oblique_idepth_diff_abs && diff > tp->oblique_idepth_diff_factor * xmax)
+        valid = 0;
+    }
+    tri_valid[t] = valid;
+    /* vertex normals: sum of incident triangle normals in ascending triangle order */
+    const int32_t vs[3] = {a, b, c};
+    for (int k = 0; k < 3; ++k) {
+      float* vn = vtx_normals + 3 * (size_t)vs[k];
+      vn[0] += nn[0]; vn[1] += nn[1]; vn[2] += nn[2];
+    }
+  }
+  for (int32_t v = 0; v < V; ++v) {
+    float* vn = vtx_normals + 3 * (size_t)v;
+    const float len = sqrtf(dot3(vn, vn));
+    if (len > 0.0f) {
+      vn[0] /= len; vn[1] /= len; vn[2] /= len;
+    } else {
+      vn[0] = 0.0f; vn[1] = 0.0f; vn[2] = -1.0f;
+    }
+  }
+}

@@ -1,0 +1,92 @@
+/*
+ * oracle/nltgv2_oracle.h -- CPU restatement of FLaME's NLTGV2-L1 graph regulariser.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under flame_ros_amd/ or include/ may include, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY UNPINNED.  The algorithm lives in the un-vendored, un-pinned dependency
+ * robustrobotics/flame (reference: CMakeLists.txt:57 find_package(flame), README.md:12-13,73
+ * clones master HEAD).  Its source is not under /root/reference, the reference holds no tests or
+ * golden vectors (CMakeLists.txt:271-281 is a commented template), so this file restates the
+ * published algorithm (Greene & Roy, ICCV'17, cited at reference README.md:21-23; SURVEY.md
+ * section 8a rows a2-a6) and is pinned only by analytic known-answer tests and an independent
+ * float64 NumPy restatement (oracle/nltgv2_np.py).  What the reference DOES pin is the parameter
+ * set that crosses the boundary: rparams.{data_factor,step_x,step_q,theta}
+ * (reference src/flame_offline_tum.cc:242-245, defaults cfg/flame_offline_tum.yaml:93-96) and the
+ * cost stat keys nltgv2_{total,avg}_{smoothness,data}_cost (reference src/utils.cc:131-136,
+ * msg/FlameStats.msg:22-25).
+ *
+ * Arithmetic contract (what "bit-exact vs the oracle" means for the HIP path): float32, every
+ * fused multiply-add is an explicit fmaf(), nothing else may be contracted (build with
+ * -ffp-contract=off), and the primal scatter visits edges in ascending edge index.
+ */
+#ifndef NLTGV2_ORACLE_H_
+#define NLTGV2_ORACLE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirrors flame::Params::rparams (reference src/flame_offline_tum.cc:242-245) + idepth clamp */
+typedef struct {
+  float data_factor; /* lambda, cfg/flame_offline_tum.yaml:93 */
+  float step_x;      /* tau,    :94 */
+  float step_q;      /* sigma,  :95 */
+  float theta;       /* :96 */
+  float x_min, x_max; /* idepth clamp after the prox (upstream default recalled 0..10) */
+} nltgv2_params;
+
+/* Graph in plain arrays.  Edge e is oriented edges[2e] -> edges[2e+1] (source i, target j). */
+typedef struct {
+  int32_t V, E;
+  const float* pos;     /* 2V pixel coords (u,v) */
+  const int32_t* edges; /* 2E */
+  const float* alpha;   /* E */
+  const float* beta;    /* E */
+  const float* z;       /* V data term (measured idepth) */
+  const float* wgt;     /* V data weight */
+  float* x;  float* w1;  float* w2;    /* V primal */
+  float* xb; float* w1b; float* w2b;   /* V extrapolated primal */
+  float* q;                            /* 3E dual, interleaved q1,q2,q3 per edge */
+} nltgv2_graph;
+
+void nltgv2_dual_step(const nltgv2_params* p, nltgv2_graph* g);
+/* primal step; xp/w1p/w2p (each V floats) receive the pre-step values */
+void nltgv2_primal_step(const nltgv2_params* p, nltgv2_graph* g, float* xp, float* w1p, float* w2p);
+void nltgv2_extragradient_step(const nltgv2_params* p, nltgv2_graph* g, const float* xp,
+                               const float* w1p, const float* w2p);
+/* one PD iteration = dual; primal; extra-gradient.  scratch = 3V floats */
+void nltgv2_step(const nltgv2_params* p, nltgv2_graph* g, float* scratch);
+/* num_iters iterations; returns 0, or -1 on allocation failure */
+int nltgv2_solve(const nltgv2_params* p, nltgv2_graph* g, int num_iters);
+/* smoothness and data cost (float32 terms, float64 accumulation) */
+void nltgv2_costs(const nltgv2_params* p, const nltgv2_graph* g, double* smooth, double* data);
+
+/* K u and K^T q, exposed for the adjointness known-answer test.  u=(x,w1,w2) 3 arrays of V,
+ * Ku = 3E interleaved; KTq = 3 arrays of V. */
+void nltgv2_apply_K(const nltgv2_graph* g, const float* x, const float* w1, const float* w2,
+                    float* Ku);
+void nltgv2_apply_KT(const nltgv2_graph* g, const float* q, float* kx, float* kw1, float* kw2);
+
+/* ---- per-triangle stage ---- */
+typedef struct {
+  int32_t do_oblique_triangle_filter; /* cfg/flame_offline_tum.yaml:40 */
+  float oblique_normal_thresh;        /* :41 rad */
+  float oblique_idepth_diff_factor;   /* :42 */
+  float oblique_idepth_diff_abs;      /* :43 */
+  int32_t do_edge_length_filter;      /* :47 */
+  float edge_length_thresh;           /* :48 fraction of image width */
+  int32_t do_idepth_triangle_filter;  /* :52 */
+  float min_triangle_idepth;          /* :53 */
+  int32_t width, height;
+} nltgv2_tri_params;
+
+/* tris = 3T vertex ids.  Outputs: tri_normals 3T, tri_valid T, vtx_normals 3V. */
+void nltgv2_triangles(const nltgv2_tri_params* tp, const float Kinv[9], int32_t V, int32_t T,
+                      const float* pos, const float* x, const int32_t* tris, float* tri_normals,
+                      uint8_t* tri_valid, float* vtx_normals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
