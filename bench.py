@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""bench.py -- primal-dual iterations/s of the NLTGV2-L1 graph regulariser on MI355X.
+
+One "step" = one pass of the hot path over one frame: `iters` PD iterations on a resident
+synthetic Delaunay graph (BASELINE.json config: 50k vertices / 150k edges / 500 iterations; the
+cost of an iteration is data independent, so successive steps simply keep iterating the resident
+state).  N>1 GPUs: one process per GPU, every rank regularises its own frame (replicas, weak
+scaling, no data-path collective).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(g, iters, budget_s=12.0):
+    """The oracle (our restatement of upstream's sequential step(); kind = "port") timed on the
+    host, one thread, on a bounded sample of the same workload."""
+    from oracle import COracle
+    from oracle.cbind import default_params as oparams
+    o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    p = oparams()
+    o.solve(p, 5)  # warm-up
+    chunk = max(10, iters // 10)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        o.solve(p, chunk)
+        done += chunk
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or done >= 20 * iters:
+            break
+    return {"value": done / dt, "unit": "PD iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d PD iterations of the same %d-vertex/%d-edge graph, 1 thread, gcc -O3 "
+                      "x86-64-v3 (oracle/nltgv2_oracle.c)" % (done, g.V, g.E)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="50k", choices=["5k", "50k", "200k"])
+    ap.add_argument("--iters", type=int, default=0, help="PD iterations per step (0 = config)")
+    ap.add_argument("--path", type=int, default=0)
+    ap.add_argument("--tile-own", type=int, default=0)
+    ap.add_argument("--tile-depth", type=int, default=0)
+    ap.add_argument("--tile-threads", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from flame_ros_amd import graphgen
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+
+    g, cfg_iters = graphgen.named(args.workload, seed=rank)
+    iters = args.iters or cfg_iters
+    opts = {}
+    if args.path: opts["path"] = args.path
+    if args.tile_own: opts["tile_own"] = args.tile_own
+    if args.tile_depth: opts["tile_depth"] = args.tile_depth
+    if args.tile_threads: opts["tile_threads"] = args.tile_threads
+    if args.no_graph: opts["use_graph"] = 0
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris,
+                         device=local_rank, **opts)
+    p = default_params()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        r.sync()
+
+    for _ in range(args.warmup):
+        r.step(p, iters, sync=False)
+    barrier()
+    dev_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.step(p, iters, sync=False)
+    r.sync()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch device time with HIP events on the solve stream (outside the timed region so the
+    # event pairs do not perturb it): same launches, one solve at a time
+    ev_ms = []
+    for _ in range(min(args.steps, 10)):
+        r.step(p, iters, sync=True)
+        ms, launches = r.last_solve_ms()
+        ev_ms.append(ms)
+    ev_ms.sort()
+    solve_ms = ev_ms[len(ev_ms) // 2]
+
+    if rank == 0:
+        total_iters = world * args.steps * iters
+        alg_bytes_iter = 84 * g.E + 60 * g.V
+        path = r.info("path")
+        iters_per_launch = iters / max(launches, 1)
+        launch_us = solve_ms * 1e3 / max(launches, 1)
+        achieved = alg_bytes_iter * iters_per_launch / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "primal-dual iterations/sec on a %d-vertex / %d-edge Delaunay graph" % (g.V, g.E),
+            "value": total_iters / elapsed, "unit": "PD iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic %s-vertex Delaunay graph, %d PD iterations per frame, "
+                                   "one frame per GPU" % (args.workload, iters),
+                       "V": g.V, "E": g.E, "iters_per_step": iters, "parallelism": "replicas%d" % world,
+                       "path": {1: "global", 2: "tile"}[path], "num_tiles": r.info("num_tiles"),
+                       "tile_depth": r.info("tile_depth"), "tile_threads": r.info("tile_threads"),
+                       "hipgraph": not args.no_graph},
+            "frames_per_s": world * args.steps / elapsed,
+            "us_per_iteration": elapsed / (args.steps * iters) * 1e6,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_tile" if path == 2 else "k_dual+k_primal",
+                         "launch_us": launch_us, "iters_per_launch": iters_per_launch,
+                         "alg_bytes_per_iter": alg_bytes_iter,
+                         "note": "achieved = (84E+60V) x iterations per launch / mean launch "
+                                 "duration (HIP events on the solve stream, incl. launch gaps). The "
+                                 "tile path keeps state in LDS across iterations, so its real HBM "
+                                 "traffic is below the per-iteration algorithmic bytes."},
+        }
+        if not args.no_cpu:
+            cb = cpu_baseline(g, iters, args.cpu_budget)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_1thread"] = out["value"] / world / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+// flame_ros_amd/csrc/common.h -- structures shared by the host plan builder and the HIP kernels.
+//
+// Device data layout (all "internal" order = tile-major: the own vertices / own edges of tile t
+// are contiguous, tiles follow a recursive-coordinate-bisection order so neighbours in the image
+// are neighbours in memory):
+//   vtxA[V] float4 {x, w1, w2, z}        primal state + data term      (ping-pong x2)
+//   vtxB[V] float4 {xb, w1b, w2b, wgt}   extrapolated state + weight   (ping-pong x2)
+//   q[E]    float4 {q1, q2, q3, 0}       dual state                    (ping-pong x2)
+//   eij[E]  int2   {i, j}                internal endpoints, i = source (global path)
+//   ew[E]   float4 {alpha, beta, dx, dy} d = pos_i - pos_j
+//   grow[V+1], ginc[2E]                  vertex -> incident edges, ascending ORIGINAL edge id,
+//                                        bit 31 set when the vertex is the edge's target
+// Tile plan (tile path): per tile a TileDesc + slices of the flat arrays t_vmap / t_eij /
+// t_ew / t_emap / t_srow (see TileDesc).
+#pragma once
+#include <stdint.h>
+
+namespace flamehip {
+
+constexpr int kMaxDepth = 16;  // max halo depth (iterations per tile launch)
+
+struct SolveParams {
+  float lambda, tau, sigma, theta, x_min, x_max;
+  float tl;  // tau * lambda, rounded once on the host exactly like the oracle does
+};
+
+// One LDS-resident subdomain.  Local vertices are ordered by ring (graph distance from the own
+// set): ring 0 = own = internal ids [vstart, vstart+n_own); ring r>0 listed in t_vmap.  Local
+// edges are ordered by level = max(ring_i, ring_j); the first e_own of them are owned
+// (source vertex is own) = internal edge ids [estart, estart+e_own); the rest listed in t_emap.
+struct TileDesc {
+  int32_t vstart, n_own, n_ext;
+  int32_t estart, e_own, e_loc;
+  int32_t n_upd;      // local vertices that are ever updated (ring <= depth-1, or all if depth 0)
+  int32_t depth;      // halo depth D (0: isolated tile, any number of iterations per launch)
+  int32_t vmap_off;   // into t_vmap: n_ext - n_own internal vertex ids
+  int32_t emap_off;   // into t_emap: e_loc - e_own internal edge ids
+  int32_t erec_off;   // into t_eij / t_ew: e_loc records
+  int32_t srow_off;   // into t_srow: n_upd packed {slot_begin | degree << 16}
+  int32_t nslots;     // 2 * e_loc incidence slots
+  int32_t ring_end[kMaxDepth + 1];   // ring_end[r] = #local vertices with ring <= r
+  int32_t level_end[kMaxDepth + 1];  // level_end[l] = #local edges with level <= l
+};
+
+// Local edge record halves.
+//   t_eij[e] = {li | lj << 16, slot_src | slot_dst << 16}   (local vertex ids / incidence slots)
+//   t_ew[e]  = {alpha, beta, dx, dy}
+
+}  // namespace flamehip

@@ -1,0 +1,592 @@
+// flame_ros_amd/csrc/flame_hip.cpp -- C ABI of libflame_hip.so (include/flame_hip.h): handle
+// management, upload (plan build + H2D), the PD-iteration driver (global path / tile path,
+// optional hipGraph replay), costs, triangle stage, download.
+//
+// Boundary: replaces the regulariser loop and per-triangle stage inside flame::Flame::update()
+// (reference call sites src/flame_offline_tum.cc:578-579, results out :628-635, stats
+// src/utils.cc:131-136).  No CPU fallback exists here: without a device every compute entry
+// point returns FLAME_HIP_ERR_NODEVICE.
+#include "../../include/flame_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+
+using namespace flamehip;
+
+#define HIPCHK(expr)                                             \
+  do {                                                           \
+    hipError_t e__ = (expr);                                     \
+    if (e__ != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e__;  \
+  } while (0)
+
+namespace {
+
+struct GraphExecEntry {
+  int32_t iters;
+  int cur;
+  SolveParams p;
+  hipGraphExec_t exec;
+  int launches;
+};
+
+template <class T>
+int dev_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+  if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
+  if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
+  return 0;
+}
+
+template <class T>
+int h2d(T* dst, const std::vector<T>& src) {
+  if (src.empty()) return 0;
+  HIPCHK(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+bool all_finite(const float* p, size_t n) {
+  for (size_t k = 0; k < n; ++k)
+    if (!std::isfinite(p[k])) return false;
+  return true;
+}
+
+}  // namespace
+
+struct flame_hip_graph {
+  int device = -1;
+  int32_t V = 0, E = 0, T = 0;
+  bool uploaded = false;
+  PlanOptions opt;
+  int use_graph = 1;
+  Plan plan;
+  int path = 0;  // resolved path after upload
+
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int last_launches = 0;
+
+  float4* A[2] = {nullptr, nullptr};
+  float4* B[2] = {nullptr, nullptr};
+  float4* q[2] = {nullptr, nullptr};
+  int cur = 0;
+  int2* eij = nullptr;
+  float4* ew = nullptr;
+  int32_t* grow = nullptr;
+  int32_t* ginc = nullptr;
+  float2* pos = nullptr;
+  // tiles
+  TileDesc* tiles = nullptr;
+  int32_t* t_vmap = nullptr;
+  int32_t* t_emap = nullptr;
+  uint2* t_eij = nullptr;
+  float4* t_ew = nullptr;
+  uint32_t* t_srow = nullptr;
+  // triangles
+  int32_t* tris = nullptr;
+  int32_t* trow = nullptr;
+  int32_t* tinc = nullptr;
+  float4* tri_normals = nullptr;
+  float4* vtx_normals = nullptr;
+  uint8_t* tri_valid = nullptr;
+  // costs
+  double* partials = nullptr;
+
+  std::vector<GraphExecEntry> execs;
+
+  void free_device() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    for (auto& e : execs) (void)hipGraphExecDestroy(e.exec);
+    execs.clear();
+    void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
+                    t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
+                    tri_valid, partials};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
+    eij = nullptr; ew = nullptr; grow = ginc = nullptr; pos = nullptr; tiles = nullptr;
+    t_vmap = t_emap = nullptr; t_eij = nullptr; t_ew = nullptr; t_srow = nullptr;
+    tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
+    partials = nullptr;
+  }
+};
+
+extern "C" {
+
+int flame_hip_version(void) { return 100; }
+
+const char* flame_hip_strerror(int code) {
+  switch (code) {
+    case FLAME_HIP_OK: return "ok";
+    case FLAME_HIP_ERR_ARG: return "invalid argument";
+    case FLAME_HIP_ERR_STATE: return "invalid call order (graph not uploaded?)";
+    case FLAME_HIP_ERR_NAN: return "non-finite input";
+    case FLAME_HIP_ERR_ALLOC: return "allocation failed";
+    case FLAME_HIP_ERR_NODEVICE: return "no HIP device (plan-only handle or no GPU present)";
+    default: break;
+  }
+  if (code <= FLAME_HIP_ERR_HIP) return hipGetErrorString((hipError_t)(FLAME_HIP_ERR_HIP - code));
+  return "unknown error";
+}
+
+int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t E, int32_t T) {
+  if (!out) return FLAME_HIP_ERR_ARG;
+  *out = nullptr;
+  if (V < 0 || E < 0 || T < 0) return FLAME_HIP_ERR_ARG;
+  flame_hip_graph* g = new (std::nothrow) flame_hip_graph();
+  if (!g) return FLAME_HIP_ERR_ALLOC;
+  g->V = V; g->E = E; g->T = T;
+  g->device = device;
+  if (device >= 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device >= n) { delete g; return FLAME_HIP_ERR_NODEVICE; }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+      delete g;
+      return FLAME_HIP_ERR_NODEVICE;
+    }
+    g->opt.lds_bytes = (int64_t)prop.sharedMemPerBlock > 0 ? (int64_t)prop.sharedMemPerBlock : 64 * 1024;
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) {
+      delete g;
+      return FLAME_HIP_ERR_NODEVICE;
+    }
+  }
+  *out = g;
+  return 0;
+}
+
+void flame_hip_graph_destroy(flame_hip_graph* g) {
+  if (!g) return;
+  if (g->device >= 0) {
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    g->free_device();
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+  }
+  delete g;
+}
+
+int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
+  if (!g || !key) return FLAME_HIP_ERR_ARG;
+  const std::string k(key);
+  if (k == "path") {
+    if (value < 0 || value > 2) return FLAME_HIP_ERR_ARG;
+    g->opt.path = value;
+  } else if (k == "tile_own") {
+    if (value < 0) return FLAME_HIP_ERR_ARG;
+    g->opt.tile_own = value;
+  } else if (k == "tile_depth") {
+    if (value < 0 || value > kMaxDepth) return FLAME_HIP_ERR_ARG;
+    g->opt.tile_depth = value;
+  } else if (k == "tile_threads") {
+    if (value != 0 && value != 256 && value != 512 && value != 1024) return FLAME_HIP_ERR_ARG;
+    g->opt.tile_threads = value;
+  } else if (k == "use_graph") {
+    g->use_graph = value != 0;
+  } else if (k == "lds_bytes") {
+    if (value < 1024) return FLAME_HIP_ERR_ARG;
+    g->opt.lds_bytes = value;
+  } else {
+    return FLAME_HIP_ERR_ARG;
+  }
+  return 0;
+}
+
+int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value) {
+  if (!g || !key || !value) return FLAME_HIP_ERR_ARG;
+  const std::string k(key);
+  const Plan& P = g->plan;
+  if (k == "V") *value = g->V;
+  else if (k == "E") *value = g->E;
+  else if (k == "T") *value = g->T;
+  else if (k == "path") *value = g->path;
+  else if (k == "num_tiles") *value = (int64_t)P.tiles.size();
+  else if (k == "tile_threads") *value = P.tile_threads;
+  else if (k == "tile_ept") *value = P.tile_ept;
+  else if (k == "tile_vpt") *value = P.tile_vpt;
+  else if (k == "tile_depth") *value = P.tile_depth;
+  else if (k == "tile_lds_bytes") *value = P.tile_lds_bytes;
+  else if (k == "tile_ext_vertices") { int64_t s = 0; for (auto& t : P.tiles) s += t.n_ext; *value = s; }
+  else if (k == "tile_loc_edges") { int64_t s = 0; for (auto& t : P.tiles) s += t.e_loc; *value = s; }
+  else if (k == "device") *value = g->device;
+  else if (k == "lds_bytes") *value = g->opt.lds_bytes;
+  else return FLAME_HIP_ERR_ARG;
+  return 0;
+}
+
+int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* edges,
+                           const float* alpha, const float* beta, const float* z,
+                           const float* wgt, const float* x0, const int32_t* tris) {
+  if (!g) return FLAME_HIP_ERR_ARG;
+  const int32_t V = g->V, E = g->E;
+  if ((V > 0 && (!pos || !z || !wgt)) || (E > 0 && (!edges || !alpha || !beta)))
+    return FLAME_HIP_ERR_ARG;
+  if (!all_finite(pos, 2 * (size_t)V) || !all_finite(z, V) || !all_finite(wgt, V) ||
+      !all_finite(alpha, E) || !all_finite(beta, E) || (x0 && !all_finite(x0, V)))
+    return FLAME_HIP_ERR_NAN;
+  g->uploaded = false;
+  int rc = build_plan(g->opt, V, E, g->T, pos, edges, alpha, beta, tris, &g->plan);
+  if (rc != 0) return rc;
+  const Plan& P = g->plan;
+  g->path = (P.has_tiles && g->opt.path != FLAME_HIP_PATH_GLOBAL) ? FLAME_HIP_PATH_TILE
+                                                                   : FLAME_HIP_PATH_GLOBAL;
+  if (g->opt.path == FLAME_HIP_PATH_TILE && !P.has_tiles) return FLAME_HIP_ERR_ARG;
+  if (g->device < 0) {  // plan-only handle (host-logic tests): no device work
+    g->uploaded = true;
+    return 0;
+  }
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  g->free_device();
+  if (P.has_tiles) {
+    if (!tile_config_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return FLAME_HIP_ERR_STATE;
+    HIPCHK(prepare_tile(P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes));
+  }
+
+  // initial state in internal order
+  std::vector<float4> hA(V), hB(V);
+  std::vector<float2> hpos(V);
+  for (int32_t k = 0; k < V; ++k) {
+    const int32_t o = P.v_i2o[k];
+    const float xi = x0 ? x0[o] : z[o];
+    hA[k] = make_float4(xi, 0.f, 0.f, z[o]);
+    hB[k] = make_float4(xi, 0.f, 0.f, wgt[o]);
+    hpos[k] = make_float2(pos[2 * o], pos[2 * o + 1]);
+  }
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dev_alloc(&g->A[b], V))) return rc;
+    if ((rc = dev_alloc(&g->B[b], V))) return rc;
+    if ((rc = dev_alloc(&g->q[b], E))) return rc;
+    HIPCHK(hipMemset(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1)));
+  }
+  g->cur = 0;
+  if ((rc = h2d(g->A[0], hA)) || (rc = h2d(g->B[0], hB))) return rc;
+  if ((rc = dev_alloc(&g->pos, V)) || (rc = h2d(g->pos, hpos))) return rc;
+  if ((rc = dev_alloc(&g->eij, E)) || (rc = dev_alloc(&g->ew, E)) ||
+      (rc = dev_alloc(&g->grow, (size_t)V + 1)) || (rc = dev_alloc(&g->ginc, 2 * (size_t)E)))
+    return rc;
+  static_assert(sizeof(Int2) == sizeof(int2) && sizeof(Float4) == sizeof(float4) &&
+                    sizeof(UInt2) == sizeof(uint2), "layout");
+  if (E > 0) {
+    HIPCHK(hipMemcpy(g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpy(g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
+  if (P.has_tiles) {
+    if ((rc = dev_alloc(&g->tiles, P.tiles.size())) || (rc = h2d(g->tiles, P.tiles)) ||
+        (rc = dev_alloc(&g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->t_vmap, P.t_vmap)) ||
+        (rc = dev_alloc(&g->t_emap, P.t_emap.size())) || (rc = h2d(g->t_emap, P.t_emap)) ||
+        (rc = dev_alloc(&g->t_srow, P.t_srow.size())) || (rc = h2d(g->t_srow, P.t_srow)) ||
+        (rc = dev_alloc(&g->t_eij, P.t_eij.size())) || (rc = dev_alloc(&g->t_ew, P.t_ew.size())))
+      return rc;
+    if (!P.t_eij.empty()) {
+      HIPCHK(hipMemcpy(g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
+    }
+  }
+  if (P.T > 0) {
+    if ((rc = dev_alloc(&g->tris, P.tris.size())) || (rc = h2d(g->tris, P.tris)) ||
+        (rc = dev_alloc(&g->trow, P.trow.size())) || (rc = h2d(g->trow, P.trow)) ||
+        (rc = dev_alloc(&g->tinc, P.tinc.size())) || (rc = h2d(g->tinc, P.tinc)) ||
+        (rc = dev_alloc(&g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(&g->tri_valid, (size_t)P.T)))
+      return rc;
+  }
+  if ((rc = dev_alloc(&g->vtx_normals, (size_t)V))) return rc;
+  if ((rc = dev_alloc(&g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
+  g->uploaded = true;
+  g->timed = false;
+  return 0;
+}
+
+static int require_device(const flame_hip_graph* g) {
+  if (!g) return FLAME_HIP_ERR_ARG;
+  if (!g->uploaded) return FLAME_HIP_ERR_STATE;
+  if (g->device < 0) return FLAME_HIP_ERR_NODEVICE;
+  return 0;
+}
+
+int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, const float* w2,
+                        const float* xb, const float* w1b, const float* w2b, const float* q) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  const int32_t V = g->V, E = g->E;
+  const Plan& P = g->plan;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  if (x || w1 || w2 || xb || w1b || w2b) {
+    std::vector<float4> hA(V), hB(V);
+    if (V > 0) {
+      HIPCHK(hipMemcpy(hA.data(), g->A[g->cur], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hB.data(), g->B[g->cur], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
+    }
+    for (int32_t k = 0; k < V; ++k) {
+      const int32_t o = P.v_i2o[k];
+      if (x) hA[k].x = x[o];
+      if (w1) hA[k].y = w1[o];
+      if (w2) hA[k].z = w2[o];
+      if (xb) hB[k].x = xb[o];
+      if (w1b) hB[k].y = w1b[o];
+      if (w2b) hB[k].z = w2b[o];
+    }
+    if ((rc = h2d(g->A[g->cur], hA)) || (rc = h2d(g->B[g->cur], hB))) return rc;
+  }
+  if (q && E > 0) {
+    std::vector<float4> hq(E);
+    for (int32_t k = 0; k < E; ++k) {
+      const int32_t o = P.e_i2o[k];
+      hq[k] = make_float4(q[3 * o], q[3 * o + 1], q[3 * o + 2], 0.f);
+    }
+    if ((rc = h2d(g->q[g->cur], hq))) return rc;
+  }
+  return 0;
+}
+
+// Enqueue the launches of `num_iters` PD iterations on stream s, starting from buffer `cur`.
+// Returns the buffer index holding the result through *cur_out.
+static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t num_iters,
+                              hipStream_t s, int cur, int* cur_out, int* launches) {
+  const Plan& P = g->plan;
+  *launches = 0;
+  if (g->path == FLAME_HIP_PATH_TILE) {
+    TileArgs a;
+    a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
+    a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
+    const int per = P.tile_depth > 0 ? P.tile_depth : num_iters;
+    for (int32_t done = 0; done < num_iters;) {
+      const int32_t n = std::min<int32_t>(per, num_iters - done);
+      a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];
+      a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
+      a.iters = n;
+      HIPCHK(launch_tile(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a));
+      cur ^= 1;
+      done += n;
+      ++*launches;
+    }
+  } else {
+    for (int32_t it = 0; it < num_iters; ++it) {
+      HIPCHK(launch_dual(s, g->E, g->eij, g->ew, g->B[cur], g->q[cur], sp.sigma));
+      HIPCHK(launch_primal(s, g->V, g->grow, g->ginc, g->ew, g->q[cur], g->A[cur], g->B[cur], sp));
+      *launches += 2;
+    }
+  }
+  *cur_out = cur;
+  return 0;
+}
+
+int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_iters,
+                    void* stream) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!p || num_iters < 0) return FLAME_HIP_ERR_ARG;
+  if (!std::isfinite(p->data_factor) || !std::isfinite(p->step_x) || !std::isfinite(p->step_q) ||
+      !std::isfinite(p->theta) || std::isnan(p->x_min) || std::isnan(p->x_max))
+    return FLAME_HIP_ERR_NAN;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  SolveParams sp;
+  sp.lambda = p->data_factor; sp.tau = p->step_x; sp.sigma = p->step_q; sp.theta = p->theta;
+  sp.x_min = p->x_min; sp.x_max = p->x_max;
+  sp.tl = p->step_x * p->data_factor;
+  HIPCHK(hipEventRecord(g->ev0, s));
+  int launches = 0, cur_out = g->cur;
+  if (num_iters > 0 && g->V > 0) {
+    if (g->use_graph && s == g->stream) {
+      GraphExecEntry* hit = nullptr;
+      for (auto& e : g->execs)
+        if (e.iters == num_iters && e.cur == g->cur && std::memcmp(&e.p, &sp, sizeof(sp)) == 0) hit = &e;
+      if (!hit) {
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_iterations(g, sp, num_iters, s, g->cur, &cur_out, &launches);
+        hipError_t ee = hipStreamEndCapture(s, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIPCHK(ee);
+        hipGraphExec_t exec = nullptr;
+        ee = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIPCHK(ee);
+        if (g->execs.size() >= 8) {
+          (void)hipGraphExecDestroy(g->execs.front().exec);
+          g->execs.erase(g->execs.begin());
+        }
+        g->execs.push_back({num_iters, g->cur, sp, exec, launches});
+        hit = &g->execs.back();
+      }
+      HIPCHK(hipGraphLaunch(hit->exec, s));
+      launches = hit->launches;
+      // parity of the result buffer: tile path flips once per launch, global path never
+      cur_out = (g->path == FLAME_HIP_PATH_TILE) ? (g->cur ^ (launches & 1)) : g->cur;
+    } else {
+      rc = enqueue_iterations(g, sp, num_iters, s, g->cur, &cur_out, &launches);
+      if (rc) return rc;
+    }
+  }
+  g->cur = cur_out;
+  g->last_launches = launches;
+  HIPCHK(hipEventRecord(g->ev1, s));
+  g->timed = true;
+  return 0;
+}
+
+int flame_hip_sync(flame_hip_graph* g) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(g->device));
+  if (g->timed) HIPCHK(hipEventSynchronize(g->ev1));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  return 0;
+}
+
+int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!g->timed) return FLAME_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipEventSynchronize(g->ev1));
+  float t = 0.f;
+  HIPCHK(hipEventElapsedTime(&t, g->ev0, g->ev1));
+  if (ms) *ms = t;
+  if (launches) *launches = g->last_launches;
+  return 0;
+}
+
+int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smooth, double* data) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!p) return FLAME_HIP_ERR_ARG;
+  if ((rc = flame_hip_sync(g))) return rc;
+  const int nb = costs_num_blocks(g->V, g->E);
+  HIPCHK(launch_costs(g->stream, g->V, g->E, g->eij, g->ew, g->A[g->cur], g->B[g->cur],
+                      p->data_factor, g->partials));
+  std::vector<double> h(2 * (size_t)nb);
+  HIPCHK(hipMemcpyAsync(h.data(), g->partials, sizeof(double) * h.size(), hipMemcpyDeviceToHost, g->stream));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  double s = 0.0, d = 0.0;
+  for (int b = 0; b < nb; ++b) { s += h[2 * b]; d += h[2 * b + 1]; }
+  if (smooth) *smooth = s;
+  if (data) *data = d;
+  return 0;
+}
+
+int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
+                        float* vtx_normals, uint8_t* tri_valid, float* tri_normals) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!Kinv || !tp) return FLAME_HIP_ERR_ARG;
+  if (g->plan.T <= 0 && g->T > 0) return FLAME_HIP_ERR_STATE;  // created with T but uploaded without tris
+  if ((rc = flame_hip_sync(g))) return rc;
+  const int32_t V = g->V, T = g->plan.T;
+  TriParamsDev d;
+  d.do_oblique = tp->do_oblique_triangle_filter;
+  d.do_edge = tp->do_edge_length_filter;
+  d.do_idepth = tp->do_idepth_triangle_filter;
+  d.cos_thresh = (float)std::cos((double)tp->oblique_normal_thresh);
+  d.diff_factor = tp->oblique_idepth_diff_factor;
+  d.diff_abs = tp->oblique_idepth_diff_abs;
+  const float max_len = tp->edge_length_thresh * (float)tp->width;
+  d.max_len2 = max_len * max_len;
+  d.min_idepth = tp->min_triangle_idepth;
+  for (int k = 0; k < 9; ++k) d.Kinv[k] = Kinv[k];
+  HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
+                          g->tri_normals, g->tri_valid, g->vtx_normals));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  const Plan& P = g->plan;
+  if (vtx_normals && V > 0) {
+    std::vector<float4> h(V);
+    HIPCHK(hipMemcpy(h.data(), g->vtx_normals, sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
+    for (int32_t k = 0; k < V; ++k) {
+      const int32_t o = P.v_i2o[k];
+      vtx_normals[3 * o] = h[k].x; vtx_normals[3 * o + 1] = h[k].y; vtx_normals[3 * o + 2] = h[k].z;
+    }
+  }
+  if (tri_valid && T > 0)
+    HIPCHK(hipMemcpy(tri_valid, g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
+  if (tri_normals && T > 0) {
+    std::vector<float4> h(T);
+    HIPCHK(hipMemcpy(h.data(), g->tri_normals, sizeof(float4) * (size_t)T, hipMemcpyDeviceToHost));
+    for (int32_t t = 0; t < T; ++t) {
+      tri_normals[3 * t] = h[t].x; tri_normals[3 * t + 1] = h[t].y; tri_normals[3 * t + 2] = h[t].z;
+    }
+  }
+  return 0;
+}
+
+static int download_impl(flame_hip_graph* g, bool bar, float* a0, float* a1, float* a2, float* q) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if ((rc = flame_hip_sync(g))) return rc;
+  const int32_t V = g->V, E = g->E;
+  const Plan& P = g->plan;
+  if ((a0 || a1 || a2) && V > 0) {
+    std::vector<float4> h(V);
+    HIPCHK(hipMemcpy(h.data(), bar ? g->B[g->cur] : g->A[g->cur], sizeof(float4) * (size_t)V,
+                     hipMemcpyDeviceToHost));
+    for (int32_t k = 0; k < V; ++k) {
+      const int32_t o = P.v_i2o[k];
+      if (a0) a0[o] = h[k].x;
+      if (a1) a1[o] = h[k].y;
+      if (a2) a2[o] = h[k].z;
+    }
+  }
+  if (q && E > 0) {
+    std::vector<float4> h(E);
+    HIPCHK(hipMemcpy(h.data(), g->q[g->cur], sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost));
+    for (int32_t k = 0; k < E; ++k) {
+      const int32_t o = P.e_i2o[k];
+      q[3 * o] = h[k].x; q[3 * o + 1] = h[k].y; q[3 * o + 2] = h[k].z;
+    }
+  }
+  return 0;
+}
+
+int flame_hip_download(flame_hip_graph* g, float* x, float* w1, float* w2, float* q) {
+  return download_impl(g, false, x, w1, w2, q);
+}
+
+int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b) {
+  return download_impl(g, true, xb, w1b, w2b, nullptr);
+}
+
+// Debug/test hook: copy a named plan array to the caller (host logic tests, no device needed).
+// Returns the element count (>= 0) or a negative error; copies min(count, cap) elements.
+int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, void* buf,
+                                   int64_t cap_bytes) {
+  if (!g || !name || !g->uploaded) return FLAME_HIP_ERR_ARG;
+  const Plan& P = g->plan;
+  const std::string k(name);
+  const void* src = nullptr;
+  int64_t n = 0, esz = 4;
+  if (k == "v_o2i") { src = P.v_o2i.data(); n = (int64_t)P.v_o2i.size(); }
+  else if (k == "v_i2o") { src = P.v_i2o.data(); n = (int64_t)P.v_i2o.size(); }
+  else if (k == "e_o2i") { src = P.e_o2i.data(); n = (int64_t)P.e_o2i.size(); }
+  else if (k == "e_i2o") { src = P.e_i2o.data(); n = (int64_t)P.e_i2o.size(); }
+  else if (k == "grow") { src = P.grow.data(); n = (int64_t)P.grow.size(); }
+  else if (k == "ginc") { src = P.ginc.data(); n = (int64_t)P.ginc.size(); }
+  else if (k == "eij") { src = P.eij.data(); n = (int64_t)P.eij.size(); esz = 8; }
+  else if (k == "tiles") { src = P.tiles.data(); n = (int64_t)P.tiles.size(); esz = sizeof(TileDesc); }
+  else if (k == "t_vmap") { src = P.t_vmap.data(); n = (int64_t)P.t_vmap.size(); }
+  else if (k == "t_emap") { src = P.t_emap.data(); n = (int64_t)P.t_emap.size(); }
+  else if (k == "t_eij") { src = P.t_eij.data(); n = (int64_t)P.t_eij.size(); esz = 8; }
+  else if (k == "t_srow") { src = P.t_srow.data(); n = (int64_t)P.t_srow.size(); }
+  else return FLAME_HIP_ERR_ARG;
+  if (buf && cap_bytes > 0 && n > 0) std::memcpy(buf, src, (size_t)std::min<int64_t>(cap_bytes, n * esz));
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// flame_ros_amd/csrc/kernels.h -- launch wrappers of the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace flamehip {
+
+struct TileArgs {
+  const TileDesc* tiles;
+  const int32_t* t_vmap;
+  const int32_t* t_emap;
+  const uint2* t_eij;
+  const float4* t_ew;
+  const uint32_t* t_srow;
+  const float4* A_src;
+  const float4* B_src;
+  const float4* q_src;
+  float4* A_dst;
+  float4* B_dst;
+  float4* q_dst;
+  SolveParams p;
+  int32_t iters;   // iterations in this launch (<= tile depth unless depth == 0)
+  int32_t ntiles;
+};
+
+// ---- global path: one dual + one primal kernel per PD iteration ----
+hipError_t launch_dual(hipStream_t s, int32_t E, const int2* eij, const float4* ew,
+                       const float4* B, float4* q, float sigma);
+hipError_t launch_primal(hipStream_t s, int32_t V, const int32_t* grow, const int32_t* ginc,
+                         const float4* ew, const float4* q, float4* A, float4* B, SolveParams p);
+
+// ---- tile path: `iters` PD iterations per launch on LDS-resident subdomains ----
+hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes,
+                       const TileArgs& a);
+bool tile_config_exists(int nt, int ept, int vpt);
+// one-time per configuration: opt in to > 48 KiB of dynamic LDS (not capturable in a hipGraph)
+hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes);
+
+// ---- costs: per-block float64 partial sums (partials[2*b] smooth, [2*b+1] data) ----
+int costs_num_blocks(int32_t V, int32_t E);
+hipError_t launch_costs(hipStream_t s, int32_t V, int32_t E, const int2* eij, const float4* ew,
+                        const float4* A, const float4* B, float lambda, double* partials);
+
+// ---- per-triangle stage ----
+struct TriParamsDev {
+  int32_t do_oblique, do_edge, do_idepth;
+  float cos_thresh, diff_factor, diff_abs, max_len2, min_idepth;
+  float Kinv[9];
+};
+hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* pos,
+                            const float4* A, const int32_t* tris, const int32_t* trow,
+                            const int32_t* tinc, TriParamsDev tp, float4* tri_normals,
+                            uint8_t* tri_valid, float4* vtx_normals);
+
+}  // namespace flamehip

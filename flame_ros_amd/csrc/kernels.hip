@@ -1,0 +1,448 @@
+// flame_ros_amd/csrc/kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4).
+//
+// The hot path is FLaME's NLTGV2-L1 primal-dual iteration on the Delaunay vertex graph (upstream
+// optimizers::nltgv2_l1_graph_regularizer::step(), driven from flame::Flame::update(), called at
+// reference src/flame_offline_tum.cc:578).  It is a sparse-graph
+// stencil at ~0.4 flop/byte: no MFMA, the levers are coalescing, LDS residency and launch count.
+//
+// Arithmetic contract (bit-exact against oracle/nltgv2_oracle.c): float32, explicit fmaf only
+// (this file is compiled with -ffp-contract=off), per-vertex accumulation of -tau K^T q in
+// ascending ORIGINAL edge id.  The projection v / max(1,|v|) equals clamp(v,-1,1) bit-for-bit
+// for every non-NaN v (v/1 = v; v/|v| = +-1), so it is one v_med3_f32.
+#include "kernels.h"
+
+namespace flamehip {
+namespace {
+
+__device__ __forceinline__ float proj_unit(float v) {
+  return __builtin_amdgcn_fmed3f(v, -1.0f, 1.0f);
+}
+
+// dual ascent of one edge (row a2).  bi/bj = {xb, w1b, w2b, *} of source/target, w = {alpha,
+// beta, dx, dy}.  Updates q in place.
+__device__ __forceinline__ void dual_edge(const float4& bi, const float4& bj, const float4& w,
+                                          float sigma, float& q1, float& q2, float& q3) {
+  float t = bi.x - bj.x;
+  t = fmaf(-bi.y, w.z, t);
+  t = fmaf(-bi.z, w.w, t);
+  const float K1 = w.x * t;
+  const float K2 = w.y * (bi.y - bj.y);
+  const float K3 = w.y * (bi.z - bj.z);
+  q1 = proj_unit(fmaf(sigma, K1, q1));
+  q2 = proj_unit(fmaf(sigma, K2, q2));
+  q3 = proj_unit(fmaf(sigma, K3, q3));
+}
+
+// L1 prox toward the data term + idepth clamp (row a3, proxL1)
+__device__ __forceinline__ float prox_l1(float x, float z, float t, float x_min, float x_max) {
+  const float r = x - z;
+  float xn = (r > t) ? (x - t) : ((r < -t) ? (x + t) : z);
+  return fminf(fmaxf(xn, x_min), x_max);
+}
+
+// ------------------------------------------------------------------------------------------
+// Global path.  Edge-parallel dual, vertex-parallel CSR primal (+prox +extra-gradient fused).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dual(int32_t E, const int2* __restrict__ eij,
+                                              const float4* __restrict__ ew,
+                                              const float4* __restrict__ B,
+                                              float4* __restrict__ q, float sigma) {
+  const int32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int2 ij = eij[e];
+  const float4 w = ew[e];
+  const float4 bi = B[ij.x], bj = B[ij.y];
+  float4 qq = q[e];
+  dual_edge(bi, bj, w, sigma, qq.x, qq.y, qq.z);
+  q[e] = qq;
+}
+
+__global__ __launch_bounds__(256) void k_primal(int32_t V, const int32_t* __restrict__ grow,
+                                                const int32_t* __restrict__ ginc,
+                                                const float4* __restrict__ ew,
+                                                const float4* __restrict__ q,
+                                                float4* __restrict__ A, float4* __restrict__ B,
+                                                SolveParams p) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const float4 a = A[v];
+  const float wgt = B[v].w;
+  float x = a.x, w1 = a.y, w2 = a.z;
+  const int32_t s0 = grow[v], s1 = grow[v + 1];
+  const float ntau = -p.tau;
+  for (int32_t s = s0; s < s1; ++s) {
+    const int32_t ent = ginc[s];
+    const int32_t k = ent & 0x7fffffff;
+    const float4 qq = q[k];
+    const float4 w = ew[k];
+    const float aq = w.x * qq.x, b2 = w.y * qq.y, b3 = w.y * qq.z;
+    float cx, c1, c2;
+    if (ent >= 0) {  // v is the source
+      cx = aq; c1 = fmaf(-w.z, aq, b2); c2 = fmaf(-w.w, aq, b3);
+    } else {
+      cx = -aq; c1 = -b2; c2 = -b3;
+    }
+    x = fmaf(ntau, cx, x);
+    w1 = fmaf(ntau, c1, w1);
+    w2 = fmaf(ntau, c2, w2);
+  }
+  x = prox_l1(x, a.w, p.tl * wgt, p.x_min, p.x_max);
+  const float xb = fmaf(p.theta, x - a.x, x);
+  const float w1b = fmaf(p.theta, w1 - a.y, w1);
+  const float w2b = fmaf(p.theta, w2 - a.z, w2);
+  A[v] = make_float4(x, w1, w2, a.w);
+  B[v] = make_float4(xb, w1b, w2b, wgt);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile path.  One workgroup = one subdomain (own vertices + depth-D halo) resident in LDS and
+// registers for `iters` PD iterations; see common.h TileDesc and DESIGN.md.
+//   registers : per-thread EPT edges {ids, slots, alpha, beta, dx, dy, q1..3}, VPT vertices
+//   LDS       : bar[n_ext] float4 {xb,w1b,w2b,-}; c0/c1/c2[nslots] per-incidence -K^T q terms
+// Phase D (edge threads) gathers bar[] of both endpoints, ascends q, scatters the two endpoint
+// contributions into the endpoints' incidence slots; phase P (vertex threads) sums its slots in
+// slot order (= ascending original edge id => deterministic and oracle-exact), prox,
+// extra-gradient, publishes the new bar[].  Two workgroup barriers per iteration, no atomics.
+// ------------------------------------------------------------------------------------------
+template <int NT, int EPT, int VPT>
+__global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileDesc& D = a.tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int n_own = D.n_own, n_ext = D.n_ext, n_upd = D.n_upd;
+  const int e_own = D.e_own, e_loc = D.e_loc, depth = D.depth;
+  float4* bar = reinterpret_cast<float4*>(smem);
+  float* c0 = reinterpret_cast<float*>(smem + (size_t)n_ext * 16);
+  float* c1 = c0 + D.nslots;
+  float* c2 = c1 + D.nslots;
+
+  // active-set cutoffs live in lanes: lane l < 32 holds ring_end[l], lane 32+l holds level_end[l]
+  const int lane = tid & 63;
+  int cut = 0;
+  if ((lane & 31) <= kMaxDepth) cut = (lane < 32) ? D.ring_end[lane & 31] : D.level_end[lane & 31];
+
+  // ---- load vertices ----
+  float vx[VPT], vw1[VPT], vw2[VPT], vz[VPT], vwgt[VPT], vxb[VPT], vw1b[VPT], vw2b[VPT];
+  uint32_t vs[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int lv = k * NT + tid;
+    vx[k] = vw1[k] = vw2[k] = vz[k] = vwgt[k] = vxb[k] = vw1b[k] = vw2b[k] = 0.0f;
+    vs[k] = 0;
+    if (lv < n_upd) {
+      const int gi = (lv < n_own) ? (D.vstart + lv) : a.t_vmap[D.vmap_off + lv - n_own];
+      const float4 A = a.A_src[gi];
+      const float4 B = a.B_src[gi];
+      vx[k] = A.x; vw1[k] = A.y; vw2[k] = A.z; vz[k] = A.w;
+      vxb[k] = B.x; vw1b[k] = B.y; vw2b[k] = B.z; vwgt[k] = B.w;
+      vs[k] = a.t_srow[D.srow_off + lv];
+      bar[lv] = B;
+    }
+  }
+  for (int lv = n_upd + tid; lv < n_ext; lv += NT)  // outermost ring: read-only
+    bar[lv] = a.B_src[a.t_vmap[D.vmap_off + lv - n_own]];
+
+  // ---- load edges ----
+  uint32_t eij[EPT], esl[EPT];
+  float4 ew[EPT];
+  float q1[EPT], q2[EPT], q3[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int le = k * NT + tid;
+    eij[k] = 0; esl[k] = 0xffffffffu;
+    ew[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    q1[k] = q2[k] = q3[k] = 0.0f;
+    if (le < e_loc) {
+      const uint2 r = a.t_eij[D.erec_off + le];
+      eij[k] = r.x; esl[k] = r.y;
+      ew[k] = a.t_ew[D.erec_off + le];
+      const int gq = (le < e_own) ? (D.estart + le) : a.t_emap[D.emap_off + le - e_own];
+      const float4 qq = a.q_src[gq];
+      q1[k] = qq.x; q2[k] = qq.y; q3[k] = qq.z;
+    }
+  }
+  __syncthreads();
+
+  const float sigma = a.p.sigma, ntau = -a.p.tau, theta = a.p.theta, tl = a.p.tl;
+  const float x_min = a.p.x_min, x_max = a.p.x_max;
+  const int iters = a.iters;
+  for (int it = 1; it <= iters; ++it) {
+    const int rem = iters - it;
+    const int v_act = __builtin_amdgcn_readlane(cut, min(rem, depth));
+    const int e_act = __builtin_amdgcn_readlane(cut, 32 + min(rem + 1, depth));
+    // ---- phase D: dual ascent + scatter of -K^T q terms into incidence slots ----
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int le = k * NT + tid;
+      if (le < e_act) {
+        const float4 bi = bar[eij[k] & 0xffffu];
+        const float4 bj = bar[eij[k] >> 16];
+        dual_edge(bi, bj, ew[k], sigma, q1[k], q2[k], q3[k]);
+        const float aq = ew[k].x * q1[k], b2 = ew[k].y * q2[k], b3 = ew[k].y * q3[k];
+        const uint32_t ss = esl[k] & 0xffffu, sd = esl[k] >> 16;
+        if (ss != 0xffffu) {
+          c0[ss] = aq;
+          c1[ss] = fmaf(-ew[k].z, aq, b2);
+          c2[ss] = fmaf(-ew[k].w, aq, b3);
+        }
+        if (sd != 0xffffu) {
+          c0[sd] = -aq;
+          c1[sd] = -b2;
+          c2[sd] = -b3;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase P: primal descent, prox, extra-gradient ----
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int lv = k * NT + tid;
+      if (lv < v_act) {
+        const int sb = vs[k] & 0xffffu, se = sb + (vs[k] >> 16);
+        const float xp = vx[k], w1p = vw1[k], w2p = vw2[k];
+        float x = xp, w1 = w1p, w2 = w2p;
+        for (int s = sb; s < se; ++s) {
+          x = fmaf(ntau, c0[s], x);
+          w1 = fmaf(ntau, c1[s], w1);
+          w2 = fmaf(ntau, c2[s], w2);
+        }
+        x = prox_l1(x, vz[k], tl * vwgt[k], x_min, x_max);
+        vxb[k] = fmaf(theta, x - xp, x);
+        vw1b[k] = fmaf(theta, w1 - w1p, w1);
+        vw2b[k] = fmaf(theta, w2 - w2p, w2);
+        vx[k] = x; vw1[k] = w1; vw2[k] = w2;
+        bar[lv] = make_float4(vxb[k], vw1b[k], vw2b[k], 0.0f);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write back what this tile owns ----
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int lv = k * NT + tid;
+    if (lv < n_own) {
+      a.A_dst[D.vstart + lv] = make_float4(vx[k], vw1[k], vw2[k], vz[k]);
+      a.B_dst[D.vstart + lv] = make_float4(vxb[k], vw1b[k], vw2b[k], vwgt[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int le = k * NT + tid;
+    if (le < e_own) a.q_dst[D.estart + le] = make_float4(q1[k], q2[k], q3[k], 0.0f);
+  }
+}
+
+template <int NT, int EPT, int VPT>
+hipError_t launch_tile_t(hipStream_t s, size_t lds, const TileArgs& a) {
+  hipLaunchKernelGGL((k_tile<NT, EPT, VPT>), dim3(a.ntiles), dim3(NT), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int NT, int EPT, int VPT>
+hipError_t prepare_tile_t(size_t lds) {
+  if (lds <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<NT, EPT, VPT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+// ------------------------------------------------------------------------------------------
+// Costs (row a6): float32 terms, float64 block partials, summed on the host in block order.
+// ------------------------------------------------------------------------------------------
+constexpr int kCostBlocks = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2* __restrict__ eij,
+                                               const float4* __restrict__ ew,
+                                               const float4* __restrict__ A,
+                                               const float4* __restrict__ B, float lambda,
+                                               double* __restrict__ partials) {
+  __shared__ double red[2][4];
+  double s = 0.0, d = 0.0;
+  for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
+    const int2 ij = eij[e];
+    const float4 w = ew[e];
+    const float4 ai = A[ij.x], aj = A[ij.y];
+    float t = ai.x - aj.x;
+    t = fmaf(-ai.y, w.z, t);
+    t = fmaf(-ai.z, w.w, t);
+    const float t1 = w.x * fabsf(t);
+    const float t2 = w.y * fabsf(ai.y - aj.y);
+    const float t3 = w.y * fabsf(ai.z - aj.z);
+    s += (double)t1 + (double)t2 + (double)t3;
+  }
+  for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+    const float4 a = A[v];
+    const float c = (lambda * B[v].w) * fabsf(a.x - a.w);
+    d += (double)c;
+  }
+  s = wave_sum(s);
+  d = wave_sum(d);
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wid] = s; red[1][wid] = d; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-triangle stage (row a8): plane normal via Kinv back-projection, validity filters, vertex
+// normals as the normalised sum of incident triangle normals in ascending triangle id.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return fmaf(az, bz, fmaf(ay, by, ax * bx));
+}
+
+__device__ __forceinline__ void backproject(const float* K, float2 uv, float x, float& X,
+                                            float& Y, float& Z) {
+  const float depth = 1.0f / x;
+  X = fmaf(K[0], uv.x, fmaf(K[1], uv.y, K[2])) * depth;
+  Y = fmaf(K[3], uv.x, fmaf(K[4], uv.y, K[5])) * depth;
+  Z = fmaf(K[6], uv.x, fmaf(K[7], uv.y, K[8])) * depth;
+}
+
+__global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict__ pos,
+                                             const float4* __restrict__ A,
+                                             const int32_t* __restrict__ tris, TriParamsDev tp,
+                                             float4* __restrict__ tri_normals,
+                                             uint8_t* __restrict__ tri_valid) {
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+  const float xa = A[a].x, xb = A[b].x, xc = A[c].x;
+  const bool ok = isfinite(xa) && isfinite(xb) && isfinite(xc) && xa > 0.0f && xb > 0.0f && xc > 0.0f;
+  if (!ok) {
+    tri_normals[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    tri_valid[t] = 0;
+    return;
+  }
+  const float2 pa = pos[a], pb = pos[b], pc = pos[c];
+  float Pax, Pay, Paz, Pbx, Pby, Pbz, Pcx, Pcy, Pcz;
+  backproject(tp.Kinv, pa, xa, Pax, Pay, Paz);
+  backproject(tp.Kinv, pb, xb, Pbx, Pby, Pbz);
+  backproject(tp.Kinv, pc, xc, Pcx, Pcy, Pcz);
+  const float e1x = Pbx - Pax, e1y = Pby - Pay, e1z = Pbz - Paz;
+  const float e2x = Pcx - Pax, e2y = Pcy - Pay, e2z = Pcz - Paz;
+  float nx = fmaf(e1y, e2z, -(e1z * e2y));
+  float ny = fmaf(e1z, e2x, -(e1x * e2z));
+  float nz = fmaf(e1x, e2y, -(e1y * e2x));
+  const float len = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+  if (len > 0.0f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = -1.f; }
+  if (dot3(nx, ny, nz, Pax, Pay, Paz) > 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+  uint8_t valid = 1;
+  const float xmin = fminf(xa, fminf(xb, xc)), xmax = fmaxf(xa, fmaxf(xb, xc));
+  if (tp.do_idepth && xmin < tp.min_idepth) valid = 0;
+  if (tp.do_edge) {
+    const float ux0 = pa.x - pb.x, ux1 = pb.x - pc.x, ux2 = pc.x - pa.x;
+    const float uy0 = pa.y - pb.y, uy1 = pb.y - pc.y, uy2 = pc.y - pa.y;
+    if (fmaf(ux0, ux0, uy0 * uy0) > tp.max_len2) valid = 0;
+    if (fmaf(ux1, ux1, uy1 * uy1) > tp.max_len2) valid = 0;
+    if (fmaf(ux2, ux2, uy2 * uy2) > tp.max_len2) valid = 0;
+  }
+  if (tp.do_oblique) {
+    float rx = (Pax + Pbx) + Pcx, ry = (Pay + Pby) + Pcy, rz = (Paz + Pbz) + Pcz;
+    const float rl = sqrtf(dot3(rx, ry, rz, rx, ry, rz));
+    if (rl > 0.0f) {
+      rx /= rl; ry /= rl; rz /= rl;
+      const float cosang = -dot3(nx, ny, nz, rx, ry, rz);
+      if (cosang < tp.cos_thresh) valid = 0;
+    }
+    const float diff = xmax - xmin;
+    if (diff > tp.diff_abs && diff > tp.diff_factor * xmax) valid = 0;
+  }
+  tri_normals[t] = make_float4(nx, ny, nz, 0.f);
+  tri_valid[t] = valid;
+}
+
+__global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* __restrict__ trow,
+                                                     const int32_t* __restrict__ tinc,
+                                                     const float4* __restrict__ tri_normals,
+                                                     float4* __restrict__ vtx_normals) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  for (int32_t s = trow[v]; s < trow[v + 1]; ++s) {
+    const float4 n = tri_normals[tinc[s]];
+    nx += n.x; ny += n.y; nz += n.z;
+  }
+  const float len = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+  if (len > 0.0f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = -1.f; }
+  vtx_normals[v] = make_float4(nx, ny, nz, 0.f);
+}
+
+}  // namespace
+
+hipError_t launch_dual(hipStream_t s, int32_t E, const int2* eij, const float4* ew,
+                       const float4* B, float4* q, float sigma) {
+  if (E <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_dual, dim3((E + 255) / 256), dim3(256), 0, s, E, eij, ew, B, q, sigma);
+  return hipGetLastError();
+}
+
+hipError_t launch_primal(hipStream_t s, int32_t V, const int32_t* grow, const int32_t* ginc,
+                         const float4* ew, const float4* q, float4* A, float4* B, SolveParams p) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_primal, dim3((V + 255) / 256), dim3(256), 0, s, V, grow, ginc, ew, q, A, B, p);
+  return hipGetLastError();
+}
+
+#define FLAME_TILE_CFGS(X)                                                             \
+  X(256, 2, 1) X(256, 3, 1) X(256, 4, 1) X(256, 6, 1) X(256, 4, 2) X(256, 6, 2)         \
+  X(512, 2, 1) X(512, 3, 1) X(512, 4, 1) X(512, 6, 1) X(512, 4, 2) X(512, 6, 2)         \
+  X(1024, 2, 1) X(1024, 3, 1) X(1024, 4, 1) X(1024, 6, 1) X(1024, 4, 2) X(1024, 6, 2)
+
+bool tile_config_exists(int nt, int ept, int vpt) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return true;
+  FLAME_TILE_CFGS(X)
+#undef X
+  return false;
+}
+
+hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes,
+                       const TileArgs& a) {
+  if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_t<N, Ep, Vp>(s, lds_bytes, a);
+  FLAME_TILE_CFGS(X)
+#undef X
+  return hipErrorInvalidConfiguration;
+}
+
+hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return prepare_tile_t<N, Ep, Vp>(lds_bytes);
+  FLAME_TILE_CFGS(X)
+#undef X
+  return hipErrorInvalidConfiguration;
+}
+
+int costs_num_blocks(int32_t, int32_t) { return kCostBlocks; }
+
+hipError_t launch_costs(hipStream_t s, int32_t V, int32_t E, const int2* eij, const float4* ew,
+                        const float4* A, const float4* B, float lambda, double* partials) {
+  hipLaunchKernelGGL(k_costs, dim3(kCostBlocks), dim3(256), 0, s, V, E, eij, ew, A, B, lambda, partials);
+  return hipGetLastError();
+}
+
+hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* pos,
+                            const float4* A, const int32_t* tris, const int32_t* trow,
+                            const int32_t* tinc, TriParamsDev tp, float4* tri_normals,
+                            uint8_t* tri_valid, float4* vtx_normals) {
+  if (T > 0) {
+    hipLaunchKernelGGL(k_tri, dim3((T + 255) / 256), dim3(256), 0, s, T, pos, A, tris, tp, tri_normals, tri_valid);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (V > 0) {
+    hipLaunchKernelGGL(k_vtx_normals, dim3((V + 255) / 256), dim3(256), 0, s, V, trow, tinc, tri_normals, vtx_normals);
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+
+}  // namespace flamehip

@@ -1,0 +1,56 @@
+// flame_ros_amd/csrc/plan.h -- host-side graph plan: locality reordering, CSR incidence lists and
+// the partition of the Delaunay vertex graph into LDS-resident tiles with depth-D halos.
+//
+// Upstream builds a Boost adjacency_list per frame inside Flame::update (SURVEY.md 8a rows a1,
+// a7; results visible at reference src/flame_offline_tum.cc:628-635).  Here the same graph is
+// flattened into the arrays of common.h.  Pure C++ (no HIP) so it is testable without a GPU.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace flamehip {
+
+struct PlanOptions {
+  int path = 0;          // FLAME_HIP_PATH_*
+  int tile_own = 0;      // target own vertices per tile (0 = auto)
+  int tile_depth = 0;    // halo depth (0 = auto)
+  int tile_threads = 0;  // workgroup size (0 = auto)
+  int64_t lds_bytes = 160 * 1024;
+};
+
+struct Float4 { float x, y, z, w; };
+struct Int2 { int32_t x, y; };
+struct UInt2 { uint32_t x, y; };
+
+struct Plan {
+  int32_t V = 0, E = 0, T = 0;
+  // permutations
+  std::vector<int32_t> v_o2i, v_i2o, e_o2i, e_i2o;
+  // global-path arrays (internal order)
+  std::vector<Int2> eij;
+  std::vector<Float4> ew;
+  std::vector<int32_t> grow, ginc;
+  // triangle stage: internal vertex ids per triangle (original triangle order) + vertex->tri CSR
+  std::vector<int32_t> tris;
+  std::vector<int32_t> trow, tinc;
+  // tile plan
+  bool has_tiles = false;
+  int tile_threads = 0, tile_ept = 0, tile_vpt = 0, tile_depth = 0;
+  int64_t tile_lds_bytes = 0;
+  std::vector<TileDesc> tiles;
+  std::vector<int32_t> t_vmap, t_emap;
+  std::vector<UInt2> t_eij;
+  std::vector<Float4> t_ew;
+  std::vector<uint32_t> t_srow;
+  std::string note;  // why the tile path was not built, if so
+};
+
+// Builds the plan.  Returns 0 or a FLAME_HIP_ERR_* code (bad indices).
+int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const float* pos,
+               const int32_t* edges, const float* alpha, const float* beta, const int32_t* tris,
+               Plan* out);
+
+}  // namespace flamehip

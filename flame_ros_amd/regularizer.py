@@ -1,0 +1,152 @@
+"""Host-side mirror of upstream's regulariser interface over the C ABI.
+
+Names follow upstream `flame::optimizers::nltgv2_l1_graph_regularizer` ([UPSTREAM-RECALL], the
+parameters are pinned by reference src/flame_offline_tum.cc:242-245): `Params(data_factor, step_x,
+step_q, theta)`, `step()`, `smoothnessCost()`, `dataCost()`.  Everything computes on the GPU
+through libflame_hip.so; there is no CPU path in this module.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+from .lib import Params, TriParams, FlameHipError  # noqa: F401
+
+
+def default_params(data_factor=0.15, step_x=1e-3, step_q=125.0, theta=0.25, x_min=0.0, x_max=10.0):
+    """Defaults of cfg/flame_offline_tum.yaml:93-96 (reference)."""
+    return Params(data_factor, step_x, step_q, theta, x_min, x_max)
+
+
+def default_tri_params(width=640, height=480):
+    """Defaults of cfg/flame_offline_tum.yaml:38-53 (reference)."""
+    return TriParams(1, 1.57, 0.35, 0.1, 1, 0.333, 1, 0.01, width, height)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class GraphRegularizer:
+    """One Delaunay vertex graph resident on one GPU (a `flame_hip_graph` handle)."""
+
+    def __init__(self, pos, edges, alpha, beta, z, wgt, x0=None, tris=None, device=0, **options):
+        self._lib = _l.load()
+        self._h = C.c_void_p()
+        pos = _f32(pos).reshape(-1, 2)
+        edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        alpha, beta, z, wgt = _f32(alpha), _f32(beta), _f32(z), _f32(wgt)
+        self.V, self.E = pos.shape[0], edges.shape[0]
+        if alpha.shape != (self.E,) or beta.shape != (self.E,) or z.shape != (self.V,) or \
+                wgt.shape != (self.V,):
+            raise ValueError("array shapes do not match V/E")
+        x0 = None if x0 is None else _f32(x0)
+        if tris is not None:
+            tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        self.T = 0 if tris is None else tris.shape[0]
+        _l.check(self._lib.flame_hip_graph_create(C.byref(self._h), device, self.V, self.E, self.T),
+                 "flame_hip_graph_create")
+        try:
+            for k, v in options.items():
+                _l.check(self._lib.flame_hip_set_option(self._h, k.encode(), int(v)),
+                         "flame_hip_set_option(%s)" % k)
+            _l.check(self._lib.flame_hip_graph_upload(self._h, _ptr(pos), _ptr(edges), _ptr(alpha),
+                                                      _ptr(beta), _ptr(z), _ptr(wgt), _ptr(x0),
+                                                      _ptr(tris)), "flame_hip_graph_upload")
+        except Exception:
+            self.close()
+            raise
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.flame_hip_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- info --
+    def info(self, key):
+        v = C.c_int64()
+        _l.check(self._lib.flame_hip_get_info(self._h, key.encode(), C.byref(v)), "flame_hip_get_info")
+        return v.value
+
+    def plan_array(self, name, dtype):
+        n = self._lib.flame_hip_debug_plan_array(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise FlameHipError(int(n), "flame_hip_debug_plan_array")
+        out = np.zeros(int(n), dtype=dtype)
+        if n:
+            self._lib.flame_hip_debug_plan_array(self._h, name.encode(), _ptr(out), out.nbytes)
+        return out
+
+    # -- the path --
+    def set_state(self, x=None, w1=None, w2=None, xb=None, w1b=None, w2b=None, q=None):
+        arrs = [None if a is None else _f32(a) for a in (x, w1, w2, xb, w1b, w2b, q)]
+        _l.check(self._lib.flame_hip_set_state(self._h, *[_ptr(a) for a in arrs]), "flame_hip_set_state")
+
+    def step(self, params, num_iters=1, stream=None, sync=True):
+        """num_iters x (dualStep; primalStep; extraGradientStep)."""
+        _l.check(self._lib.flame_hip_solve(self._h, C.byref(params), int(num_iters), stream),
+                 "flame_hip_solve")
+        if sync:
+            self.sync()
+
+    solve = step
+
+    def sync(self):
+        _l.check(self._lib.flame_hip_sync(self._h), "flame_hip_sync")
+
+    def last_solve_ms(self):
+        ms, n = C.c_float(), C.c_int32()
+        _l.check(self._lib.flame_hip_last_solve_ms(self._h, C.byref(ms), C.byref(n)),
+                 "flame_hip_last_solve_ms")
+        return ms.value, n.value
+
+    def costs(self, params):
+        s, d = C.c_double(), C.c_double()
+        _l.check(self._lib.flame_hip_costs(self._h, C.byref(params), C.byref(s), C.byref(d)),
+                 "flame_hip_costs")
+        return s.value, d.value
+
+    def smoothnessCost(self, params):
+        return self.costs(params)[0]
+
+    def dataCost(self, params):
+        return self.costs(params)[1]
+
+    def download(self, with_q=True):
+        x, w1, w2 = (np.empty(self.V, np.float32) for _ in range(3))
+        q = np.empty((self.E, 3), np.float32) if with_q else None
+        _l.check(self._lib.flame_hip_download(self._h, _ptr(x), _ptr(w1), _ptr(w2), _ptr(q)),
+                 "flame_hip_download")
+        return x, w1, w2, q
+
+    def download_bar(self):
+        xb, w1b, w2b = (np.empty(self.V, np.float32) for _ in range(3))
+        _l.check(self._lib.flame_hip_download_bar(self._h, _ptr(xb), _ptr(w1b), _ptr(w2b)),
+                 "flame_hip_download_bar")
+        return xb, w1b, w2b
+
+    def triangles(self, Kinv, tri_params):
+        Kinv = _f32(Kinv).reshape(9)
+        vn = np.empty((self.V, 3), np.float32)
+        tv = np.empty(self.T, np.uint8)
+        tn = np.empty((self.T, 3), np.float32)
+        _l.check(self._lib.flame_hip_triangles(self._h, _ptr(Kinv), C.byref(tri_params), _ptr(vn),
+                                               _ptr(tv), _ptr(tn)), "flame_hip_triangles")
+        return tn, tv, vn

@@ -1,0 +1,126 @@
+/*
+ * include/flame_hip.h -- C ABI of libflame_hip.so: FLaME's NLTGV2-L1 graph regulariser and
+ * per-triangle stage as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Upstream, flame::Flame::update() (called at reference
+ * src/flame_offline_tum.cc:578-579,593-594, src/flame_offline_asl.cc:520,535,
+ * src/flame_nodelet.cc:634-635) runs N x optimizers::nltgv2_l1_graph_regularizer::step() on the
+ * Delaunay vertex graph and then the per-triangle stage whose results leave through
+ * getInverseDepthMesh() (src/flame_offline_tum.cc:628-635).  A maintainer replaces that inner
+ * loop by the calls below (INTEGRATION.md shows the binding); the C++ facade in include/flame/
+ * does exactly that.
+ *
+ * Conventions: return 0 = ok, negative = error (flame_hip_strerror()); no exceptions, no global
+ * state.  All pointers are HOST pointers owned by the caller for the duration of the call unless
+ * the name says _dev.  One handle is not thread-safe; distinct handles are.  Edge e is oriented
+ * edges[2e] -> edges[2e+1]; the orientation matters (the source vertex's plane slopes enter K1).
+ * All arithmetic is float32 and bit-reproducible: identical inputs give identical bits on every
+ * solver path and partitioning (see DESIGN.md "Arithmetic contract").
+ */
+#ifndef FLAME_HIP_H_
+#define FLAME_HIP_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* flame::Params::rparams as loaded at reference src/flame_offline_tum.cc:242-245
+ * (defaults cfg/flame_offline_tum.yaml:93-96) + the idepth clamp applied after the prox. */
+typedef struct {
+  float data_factor; /* lambda  (regularization/nltgv2/data_factor) */
+  float step_x;      /* tau     (.../step_x) */
+  float step_q;      /* sigma   (.../step_q) */
+  float theta;       /* extra-gradient weight (.../theta) */
+  float x_min, x_max;
+} flame_hip_params;
+
+/* Triangle filter parameters as loaded at reference src/flame_offline_tum.cc:168-192
+ * (cfg/flame_offline_tum.yaml:38-53). */
+typedef struct {
+  int32_t do_oblique_triangle_filter;
+  float oblique_normal_thresh;      /* rad */
+  float oblique_idepth_diff_factor; /* relative max/min idepth difference */
+  float oblique_idepth_diff_abs;    /* absolute max/min idepth difference */
+  int32_t do_edge_length_filter;
+  float edge_length_thresh; /* fraction of image width */
+  int32_t do_idepth_triangle_filter;
+  float min_triangle_idepth;
+  int32_t width, height;
+} flame_hip_tri_params;
+
+typedef struct flame_hip_graph flame_hip_graph; /* opaque; owns device buffers */
+
+enum {
+  FLAME_HIP_OK = 0,
+  FLAME_HIP_ERR_ARG = -1,     /* bad argument (NULL, negative size, index out of range) */
+  FLAME_HIP_ERR_STATE = -2,   /* call order (e.g. solve before upload) */
+  FLAME_HIP_ERR_NAN = -3,     /* non-finite input */
+  FLAME_HIP_ERR_ALLOC = -4,   /* host or device allocation failed */
+  FLAME_HIP_ERR_NODEVICE = -5,
+  FLAME_HIP_ERR_HIP = -1000   /* -(1000 + hipError_t) */
+};
+
+/* Solver paths (flame_hip_set_option key "path"). */
+enum {
+  FLAME_HIP_PATH_AUTO = 0,
+  FLAME_HIP_PATH_GLOBAL = 1, /* two kernels per iteration over global arrays */
+  FLAME_HIP_PATH_TILE = 2    /* LDS-resident tiles, several iterations per launch */
+};
+
+/* Replaces: construction of the regulariser graph inside Flame::update. */
+int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t E, int32_t T);
+void flame_hip_graph_destroy(flame_hip_graph* g);
+
+/* Options are set BEFORE upload.  Keys: "path" (enum above), "tile_own" (target own vertices
+ * per tile), "tile_depth" (halo depth = iterations per launch), "tile_threads", "use_graph"
+ * (replay launches from a hipGraph).  Unknown key -> FLAME_HIP_ERR_ARG. */
+int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value);
+int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value);
+
+/* Replaces: graph sync inside Flame::update (row a7): vertex positions, oriented edge list,
+ * edge weights, data terms.  pos 2V, edges 2E, alpha/beta E, z/wgt V, x0 V or NULL (= z),
+ * tris 3T or NULL.  State is reset to x = x0, w = 0, x_bar = x, w_bar = 0, q = 0. */
+int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* edges,
+                           const float* alpha, const float* beta, const float* z,
+                           const float* wgt, const float* x0, const int32_t* tris);
+
+/* Overwrite solver state (any pointer may be NULL = keep).  q is 3E interleaved. */
+int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, const float* w2,
+                        const float* xb, const float* w1b, const float* w2b, const float* q);
+
+/* Replaces: the loop of nltgv2_l1_graph_regularizer::step() calls (rows a2-a5).  Asynchronous on
+ * the handle's stream unless stream != NULL (a hipStream_t), in which case it runs there. */
+int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_iters,
+                    void* stream);
+int flame_hip_sync(flame_hip_graph* g);
+/* Device time of the last flame_hip_solve in ms (HIP events on the solve's stream) and the
+ * number of kernel launches it made.  Synchronises. */
+int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches);
+
+/* Replaces: smoothnessCost()/dataCost() behind the stat keys nltgv2_total_smoothness_cost and
+ * nltgv2_total_data_cost (reference src/utils.cc:131-136).  Synchronises. */
+int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smooth, double* data);
+
+/* Replaces: the per-triangle stage feeding getInverseDepthMesh (row a8).  Kinv row-major 3x3.
+ * Outputs (any may be NULL): vtx_normals 3V, tri_valid T, tri_normals 3T.  Synchronises. */
+int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
+                        float* vtx_normals, uint8_t* tri_valid, float* tri_normals);
+
+/* Results out (any pointer may be NULL).  Caller's vertex/edge order.  Synchronises. */
+int flame_hip_download(flame_hip_graph* g, float* x, float* w1, float* w2, float* q);
+int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b);
+
+/* Debug/test hook (no device needed; works on a handle created with device = -1): copies the
+ * named host-side plan array ("v_o2i", "e_o2i", "grow", "ginc", "eij", "tiles", "t_vmap",
+ * "t_emap", "t_eij", "t_srow", ...) and returns its element count, or a negative error. */
+int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, void* buf,
+                                   int64_t cap_bytes);
+
+const char* flame_hip_strerror(int code);
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int flame_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+The oracle restates upstream's sequential step() (parity vs upstream itself is
+UNPINNED, see oracle/nltgv2_oracle.h); the arithmetic contract makes every solver path and every
+partitioning produce the oracle's exact float32 bits, so the tolerance here is zero.  The
+north_star tolerance (1e-4 RMS idepth) is asserted as well, trivially.
+"""
+import numpy as np
+import pytest
+
+from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_tri_params
+from oracle.cbind import triangles as oracle_triangles, TriParams as OTri
+from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params, random_state
+
+pytestmark = pytest.mark.gpu
+
+PATHS = {
+    "global": dict(path=1),
+    "tile_auto": dict(path=2),
+    "tile_small": dict(path=2, tile_own=64, tile_depth=2),
+    "tile_deep": dict(path=2, tile_own=256, tile_depth=6),
+    "tile_nograph": dict(path=2, use_graph=0),
+}
+
+
+def run_both(g, opts, iters, state_seed=None, chunks=None):
+    o = make_oracle(g)
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, **opts)
+    if state_seed is not None:
+        st = random_state(g, state_seed)
+        o.set_state(**st)
+        r.set_state(**st)
+    po, pg = oracle_params(), default_params()
+    for n in (chunks or [iters]):
+        o.solve(po, n)
+        r.step(pg, n)
+    return o, r
+
+
+def compare_state(o, r, what):
+    x, w1, w2, q = r.download()
+    xb, w1b, w2b = r.download_bar()
+    assert_bit_equal(x, o.x, what + " x")
+    assert_bit_equal(w1, o.w1, what + " w1")
+    assert_bit_equal(w2, o.w2, what + " w2")
+    assert_bit_equal(q, o.q, what + " q")
+    assert_bit_equal(xb, o.xb, what + " xb")
+    assert_bit_equal(w1b, o.w1b, what + " w1b")
+    assert_bit_equal(w2b, o.w2b, what + " w2b")
+    rms = float(np.sqrt(np.mean((x.astype(np.float64) - o.x) ** 2)))
+    assert rms <= 1e-4  # north_star tolerance
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+@pytest.mark.parametrize("V,iters", [(1200, 50), (5000, 200)])
+def test_solve_matches_oracle(gpu, path, V, iters):
+    g = graphgen.synthetic(V, seed=1)
+    o, r = run_both(g, PATHS[path], iters)
+    compare_state(o, r, "%s V=%d" % (path, V))
+    if path.startswith("tile"):
+        assert r.info("path") == 2
+
+
+@pytest.mark.parametrize("path", ["global", "tile_auto", "tile_small"])
+def test_random_state_and_ragged_iteration_counts(gpu, path):
+    """Non-trivial initial state; iteration counts that are not multiples of the tile depth."""
+    g = graphgen.synthetic(3000, seed=2)
+    o, r = run_both(g, PATHS[path], None, state_seed=3, chunks=[1, 2, 3, 5, 7, 0, 13])
+    compare_state(o, r, path)
+
+
+def test_dataset_shaped_graphs(gpu):
+    """Config 1 / 3 stand-ins: TUM 640x480 @ win 16 (one LDS tile), EuRoC 752x480 @ win 8."""
+    for (w, h, win, iters) in ((640, 480, 16, 200), (752, 480, 8, 200)):
+        g = graphgen.dataset_shaped(w, h, win)
+        o, r = run_both(g, {}, iters)
+        compare_state(o, r, "win%d" % win)
+
+
+def test_costs_match_oracle(gpu):
+    g = graphgen.synthetic(5000, seed=4)
+    o, r = run_both(g, {}, 100)
+    so, do = o.costs(oracle_params())
+    sg, dg = r.costs(default_params())
+    assert abs(sg - so) <= 1e-9 * abs(so) and abs(dg - do) <= 1e-9 * abs(do)
+    assert r.smoothnessCost(default_params()) == sg and r.dataCost(default_params()) == dg
+
+
+def test_triangle_stage_matches_oracle(gpu):
+    g = graphgen.synthetic(5000, seed=5)
+    o, r = run_both(g, {}, 50)
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    tp = default_tri_params(640, 480)
+    otp = OTri(*[getattr(tp, f[0]) for f in tp._fields_])
+    tn_o, tv_o, vn_o = oracle_triangles(otp, Kinv, g.pos, o.x, g.tris)
+    tn, tv, vn = r.triangles(Kinv, tp)
+    assert_bit_equal(tn, tn_o, "tri normals")
+    assert np.array_equal(tv, tv_o)
+    assert_bit_equal(vn, vn_o, "vertex normals")
+    assert 0 < tv.sum() < len(tv)  # the filters reject some but not all triangles
+
+
+def test_full_size_50k_properties(gpu):
+    """BASELINE config 4 size: oracle comparison on the full 500 iterations + size-independent
+    properties (determinism across paths, dual feasibility, energy decrease)."""
+    g, iters = graphgen.named("50k")
+    o, r = run_both(g, {}, iters)
+    compare_state(o, r, "50k")
+    _, r2 = run_both(g, PATHS["global"], 0)
+    r2.step(default_params(), iters)
+    assert_bit_equal(r2.download()[0], r.download()[0], "tile vs global path")
+    q = r.download()[3]
+    assert np.all(np.abs(q) <= 1.0)
+    s1, d1 = r.costs(default_params())
+    r0 = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    s0, d0 = r0.costs(default_params())
+    assert s1 + d1 < s0 + d0
+
+
+def test_edge_cases(gpu):
+    p = default_params()
+    # empty graph, single vertex, single edge, two components
+    r = GraphRegularizer(np.zeros((0, 2)), np.zeros((0, 2), np.int32), [], [], [], [])
+    r.step(p, 5)
+    assert r.download()[0].shape == (0,)
+    r = GraphRegularizer([[1.0, 2.0]], np.zeros((0, 2), np.int32), [], [], [0.5], [1.0])
+    r.step(p, 5)
+    assert r.download()[0][0] == np.float32(0.5)
+    g = graphgen.synthetic(40, seed=7)
+    for opts in (dict(path=1), dict(path=2), dict(path=2, tile_own=8, tile_depth=3)):
+        o, r = run_both(g, opts, 33, state_seed=8)
+        compare_state(o, r, "tiny %s" % opts)
