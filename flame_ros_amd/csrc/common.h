@@ -17,7 +17,9 @@
 
 namespace flamehip {
 
-constexpr int kMaxDepth = 16;  // max halo depth (iterations per tile launch)
+constexpr int kMaxDepth = 16;    // max halo depth (iterations per tile launch)
+constexpr int kProfWords = 2 * kMaxDepth + 4;  // debug timeline words per tile
+constexpr int kDummySlots = 64;  // per-lane trash slots behind the incidence slots (inert writes)
 
 struct SolveParams {
   float lambda, tau, sigma, theta, x_min, x_max;
@@ -25,19 +27,19 @@ struct SolveParams {
 };
 
 // One LDS-resident subdomain.  Local vertices are ordered by ring (graph distance from the own
-// set): ring 0 = own = internal ids [vstart, vstart+n_own); ring r>0 listed in t_vmap.  Local
+// set): ring 0 = own = internal ids [vstart, vstart+n_own); t_vmap lists all n_ext ids.  Local
 // edges are ordered by level = max(ring_i, ring_j); the first e_own of them are owned
-// (source vertex is own) = internal edge ids [estart, estart+e_own); the rest listed in t_emap.
+// (source vertex is own) = internal edge ids [estart, estart+e_own); t_emap lists all e_loc ids.
 struct TileDesc {
   int32_t vstart, n_own, n_ext;
   int32_t estart, e_own, e_loc;
   int32_t n_upd;      // local vertices that are ever updated (ring <= depth-1, or all if depth 0)
   int32_t depth;      // halo depth D (0: isolated tile, any number of iterations per launch)
-  int32_t vmap_off;   // into t_vmap: n_ext - n_own internal vertex ids
-  int32_t emap_off;   // into t_emap: e_loc - e_own internal edge ids
+  int32_t vmap_off;   // into t_vmap: n_ext internal vertex ids (gather list, own first)
+  int32_t emap_off;   // into t_emap: e_loc internal edge ids (gather list of q, owned first)
   int32_t erec_off;   // into t_eij / t_ew: e_loc records
-  int32_t srow_off;   // into t_srow: n_upd packed {slot_begin | degree << 16}
-  int32_t nslots;     // 2 * e_loc incidence slots
+  int32_t srow_off;   // into t_srow: n_upd packed {slot of incidence 0 | degree << 16}
+  int32_t nslots;     // incidence slots (transposed per 64-vertex group: slot(j) = slot0 + 64 j)
   int32_t ring_end[kMaxDepth + 1];   // ring_end[r] = #local vertices with ring <= r
   int32_t level_end[kMaxDepth + 1];  // level_end[l] = #local edges with level <= l
 };

@@ -40,7 +40,7 @@ struct GraphExecEntry {
 template <class T>
 int dev_alloc(T** p, size_t n) {
   *p = nullptr;
-  if (n == 0) n = 1;
+  n += 1;  // one pad element: kernels clamp indices of empty lists to element 0
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
   if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
   if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
@@ -101,6 +101,9 @@ struct flame_hip_graph {
   uint8_t* tri_valid = nullptr;
   // costs
   double* partials = nullptr;
+  // debug timeline of the tile kernel
+  int profile = 0;
+  unsigned long long* prof = nullptr;
 
   std::vector<GraphExecEntry> execs;
 
@@ -111,7 +114,7 @@ struct flame_hip_graph {
     execs.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
                     t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
-                    tri_valid, partials};
+                    tri_valid, partials, prof};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
@@ -119,6 +122,7 @@ struct flame_hip_graph {
     t_vmap = t_emap = nullptr; t_eij = nullptr; t_ew = nullptr; t_srow = nullptr;
     tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
     partials = nullptr;
+    prof = nullptr;
   }
 };
 
@@ -198,6 +202,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->opt.tile_threads = value;
   } else if (k == "use_graph") {
     g->use_graph = value != 0;
+  } else if (k == "profile") {
+    g->profile = value != 0;
   } else if (k == "lds_bytes") {
     if (value < 1024) return FLAME_HIP_ERR_ARG;
     g->opt.lds_bytes = value;
@@ -309,6 +315,10 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   }
   if ((rc = dev_alloc(&g->vtx_normals, (size_t)V))) return rc;
   if ((rc = dev_alloc(&g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
+  if (g->profile && P.has_tiles) {
+    if ((rc = dev_alloc(&g->prof, P.tiles.size() * kProfWords))) return rc;
+    HIPCHK(hipMemset(g->prof, 0, sizeof(unsigned long long) * P.tiles.size() * kProfWords));
+  }
   g->uploaded = true;
   g->timed = false;
   return 0;
@@ -367,6 +377,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     TileArgs a;
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
+    a.prof = g->prof;
     const int per = P.tile_depth > 0 ? P.tile_depth : num_iters;
     for (int32_t done = 0; done < num_iters;) {
       const int32_t n = std::min<int32_t>(per, num_iters - done);
@@ -584,6 +595,16 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
   else if (k == "t_emap") { src = P.t_emap.data(); n = (int64_t)P.t_emap.size(); }
   else if (k == "t_eij") { src = P.t_eij.data(); n = (int64_t)P.t_eij.size(); esz = 8; }
   else if (k == "t_srow") { src = P.t_srow.data(); n = (int64_t)P.t_srow.size(); }
+  else if (k == "profile") {  // device timeline of the LAST tile launch (set_option profile=1)
+    if (!g->prof) return FLAME_HIP_ERR_STATE;
+    n = (int64_t)P.tiles.size() * kProfWords; esz = 8;
+    if (buf && cap_bytes > 0) {
+      if (hipDeviceSynchronize() != hipSuccess) return FLAME_HIP_ERR_HIP;
+      if (hipMemcpy(buf, g->prof, (size_t)std::min<int64_t>(cap_bytes, n * esz), hipMemcpyDeviceToHost) != hipSuccess)
+        return FLAME_HIP_ERR_HIP;
+    }
+    return n;
+  }
   else return FLAME_HIP_ERR_ARG;
   if (buf && cap_bytes > 0 && n > 0) std::memcpy(buf, src, (size_t)std::min<int64_t>(cap_bytes, n * esz));
   return n;

@@ -22,6 +22,7 @@ struct TileArgs {
   SolveParams p;
   int32_t iters;   // iterations in this launch (<= tile depth unless depth == 0)
   int32_t ntiles;
+  unsigned long long* prof;  // debug timeline, kProfWords words per tile, or nullptr
 };
 
 // ---- global path: one dual + one primal kernel per PD iteration ----

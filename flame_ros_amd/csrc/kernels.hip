@@ -104,117 +104,196 @@ __global__ __launch_bounds__(256) void k_primal(int32_t V, const int32_t* __rest
 // slot order (= ascending original edge id => deterministic and oracle-exact), prox,
 // extra-gradient, publishes the new bar[].  Two workgroup barriers per iteration, no atomics.
 // ------------------------------------------------------------------------------------------
+// LDS float4 read that keeps all four lanes live, so the compiler emits ds_read_b128 (4 LDS cycles
+// per wave) instead of ds_read_b96 (8 cycles) when only x,y,z are consumed.
+__device__ __forceinline__ float4 lds_read4(const float4* p) {
+  float4 v = *p;
+  asm volatile("" ::"v"(v.w));
+  return v;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Phase D on the first K of this thread's edges: every gather is issued before the first use.
+template <int K, int EPT>
+__device__ __forceinline__ void tile_phase_d(const float4* bar, float* c0, float* c1, float* c2,
+                                             const uint32_t (&eij)[EPT], const uint32_t (&ess)[EPT],
+                                             const uint32_t (&esd)[EPT], const float4 (&ew)[EPT],
+                                             float (&q1)[EPT], float (&q2)[EPT], float (&q3)[EPT],
+                                             float sigma) {
+  float4 bi[K], bj[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    bi[k] = lds_read4(bar + (eij[k] & 0xffffu));
+    bj[k] = lds_read4(bar + (eij[k] >> 16));
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    dual_edge(bi[k], bj[k], ew[k], sigma, q1[k], q2[k], q3[k]);
+    const float aq = ew[k].x * q1[k], b2 = ew[k].y * q2[k], b3 = ew[k].y * q3[k];
+    c0[ess[k]] = aq;
+    c1[ess[k]] = fmaf(-ew[k].z, aq, b2);
+    c2[ess[k]] = fmaf(-ew[k].w, aq, b3);
+    c0[esd[k]] = -aq;
+    c1[esd[k]] = -b2;
+    c2[esd[k]] = -b3;
+  }
+}
+
+// nk (number of active edge blocks) is wave-uniform: dispatch to the matching unrolled body
+template <int K, int EPT>
+struct PhaseD {
+  static __device__ __forceinline__ void run(int nk, const float4* bar, float* c0, float* c1,
+                                             float* c2, const uint32_t (&eij)[EPT],
+                                             const uint32_t (&ess)[EPT], const uint32_t (&esd)[EPT],
+                                             const float4 (&ew)[EPT], float (&q1)[EPT],
+                                             float (&q2)[EPT], float (&q3)[EPT], float sigma) {
+    if (nk == K) tile_phase_d<K, EPT>(bar, c0, c1, c2, eij, ess, esd, ew, q1, q2, q3, sigma);
+    else PhaseD<K - 1, EPT>::run(nk, bar, c0, c1, c2, eij, ess, esd, ew, q1, q2, q3, sigma);
+  }
+};
+template <int EPT>
+struct PhaseD<0, EPT> {
+  static __device__ __forceinline__ void run(int, const float4*, float*, float*, float*,
+                                             const uint32_t (&)[EPT], const uint32_t (&)[EPT],
+                                             const uint32_t (&)[EPT], const float4 (&)[EPT],
+                                             float (&)[EPT], float (&)[EPT], float (&)[EPT], float) {}
+};
+
 template <int NT, int EPT, int VPT>
 __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TileDesc& D = a.tiles[blockIdx.x];
   const int tid = threadIdx.x;
+  const unsigned long long t_start = __builtin_readcyclecounter();
   const int n_own = D.n_own, n_ext = D.n_ext, n_upd = D.n_upd;
   const int e_own = D.e_own, e_loc = D.e_loc, depth = D.depth;
+  if (n_ext == 0) return;  // empty tile (more tiles than vertices)
+  const int cstride = D.nslots + kDummySlots;
   float4* bar = reinterpret_cast<float4*>(smem);
   float* c0 = reinterpret_cast<float*>(smem + (size_t)n_ext * 16);
-  float* c1 = c0 + D.nslots;
-  float* c2 = c1 + D.nslots;
+  float* c1 = c0 + cstride;
+  float* c2 = c1 + cstride;
+  const int lane = tid & 63;
+  const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
+  const uint32_t dummy = (uint32_t)(D.nslots + lane);  // per-lane trash slot: inert writes/reads
 
   // active-set cutoffs live in lanes: lane l < 32 holds ring_end[l], lane 32+l holds level_end[l]
-  const int lane = tid & 63;
   int cut = 0;
   if ((lane & 31) <= kMaxDepth) cut = (lane < 32) ? D.ring_end[lane & 31] : D.level_end[lane & 31];
 
-  // ---- load vertices ----
-  float vx[VPT], vw1[VPT], vw2[VPT], vz[VPT], vwgt[VPT], vxb[VPT], vw1b[VPT], vw2b[VPT];
+  // ---- global loads: index lists first, then every dependent gather, nothing waited between ----
+  int gi[VPT];
   uint32_t vs[VPT];
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
-    vx[k] = vw1[k] = vw2[k] = vz[k] = vwgt[k] = vxb[k] = vw1b[k] = vw2b[k] = 0.0f;
-    vs[k] = 0;
-    if (lv < n_upd) {
-      const int gi = (lv < n_own) ? (D.vstart + lv) : a.t_vmap[D.vmap_off + lv - n_own];
-      const float4 A = a.A_src[gi];
-      const float4 B = a.B_src[gi];
-      vx[k] = A.x; vw1[k] = A.y; vw2[k] = A.z; vz[k] = A.w;
-      vxb[k] = B.x; vw1b[k] = B.y; vw2b[k] = B.z; vwgt[k] = B.w;
-      vs[k] = a.t_srow[D.srow_off + lv];
-      bar[lv] = B;
-    }
+    gi[k] = a.t_vmap[D.vmap_off + min(lv, n_ext - 1)];
+    vs[k] = a.t_srow[D.srow_off + min(lv, n_upd - 1)];
   }
-  for (int lv = n_upd + tid; lv < n_ext; lv += NT)  // outermost ring: read-only
-    bar[lv] = a.B_src[a.t_vmap[D.vmap_off + lv - n_own]];
-
-  // ---- load edges ----
-  uint32_t eij[EPT], esl[EPT];
+  uint2 er[EPT];
   float4 ew[EPT];
+  int qi[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int lec = min(k * NT + tid, max(e_loc - 1, 0));  // arrays carry one pad element
+    er[k] = a.t_eij[D.erec_off + lec];
+    ew[k] = a.t_ew[D.erec_off + lec];
+    qi[k] = a.t_emap[D.emap_off + lec];
+  }
+  float4 vA[VPT], vB[VPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) { vA[k] = a.A_src[gi[k]]; vB[k] = a.B_src[gi[k]]; }
   float q1[EPT], q2[EPT], q3[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
-    const int le = k * NT + tid;
-    eij[k] = 0; esl[k] = 0xffffffffu;
-    ew[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    q1[k] = q2[k] = q3[k] = 0.0f;
-    if (le < e_loc) {
-      const uint2 r = a.t_eij[D.erec_off + le];
-      eij[k] = r.x; esl[k] = r.y;
-      ew[k] = a.t_ew[D.erec_off + le];
-      const int gq = (le < e_own) ? (D.estart + le) : a.t_emap[D.emap_off + le - e_own];
-      const float4 qq = a.q_src[gq];
-      q1[k] = qq.x; q2[k] = qq.y; q3[k] = qq.z;
-    }
+    const float4 qq = a.q_src[e_loc > 0 ? qi[k] : 0];
+    q1[k] = qq.x; q2[k] = qq.y; q3[k] = qq.z;
+  }
+
+  float vx[VPT], vw1[VPT], vw2[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT], vw1b[VPT], vw2b[VPT];
+  int wdeg[VPT];
+  const float tl = a.p.tl;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int lv = k * NT + tid;
+    vx[k] = vA[k].x; vw1[k] = vA[k].y; vw2[k] = vA[k].z; vz[k] = vA[k].w;
+    vxb[k] = vB[k].x; vw1b[k] = vB[k].y; vw2b[k] = vB[k].z; vwgt[k] = vB[k].w;
+    vt[k] = tl * vwgt[k];
+    if (lv >= n_upd) vs[k] = 0;  // outermost ring / padding lanes: no incidence slots
+    if (lv < n_ext) bar[lv] = vB[k];
+    wdeg[k] = wave_max((int)(vs[k] >> 16));
+  }
+  uint32_t eij[EPT], ess[EPT], esd[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const bool real = (k * NT + tid) < e_loc;
+    eij[k] = real ? er[k].x : 0u;  // padding edges gather local vertex 0 and write trash slots
+    const uint32_t ss = er[k].y & 0xffffu, sd = er[k].y >> 16;
+    ess[k] = (real && ss != 0xffffu) ? ss : dummy;
+    esd[k] = (real && sd != 0xffffu) ? sd : dummy;
   }
   __syncthreads();
+  // optional in-kernel timeline (debug): [tile][0]=start, [1]=loaded, [2it]=after phase D of
+  // iteration it, [2it+1]=after phase P, [kProfWords-1]=end
+  unsigned long long* prof = a.prof ? a.prof + (size_t)blockIdx.x * kProfWords : nullptr;
+  if (prof && tid == 0) { prof[0] = t_start; prof[1] = __builtin_readcyclecounter(); }
 
-  const float sigma = a.p.sigma, ntau = -a.p.tau, theta = a.p.theta, tl = a.p.tl;
+  const float sigma = a.p.sigma, ntau = -a.p.tau, theta = a.p.theta;
   const float x_min = a.p.x_min, x_max = a.p.x_max;
   const int iters = a.iters;
   for (int it = 1; it <= iters; ++it) {
     const int rem = iters - it;
+    // Active sets are prefixes (vertices by ring, edges by level).  Lanes past the cutoff inside
+    // an active block keep computing on stale data: by construction that garbage only reaches
+    // vertices/edges that are themselves past the cutoff, and nothing past it is written back.
     const int v_act = __builtin_amdgcn_readlane(cut, min(rem, depth));
     const int e_act = __builtin_amdgcn_readlane(cut, 32 + min(rem + 1, depth));
-    // ---- phase D: dual ascent + scatter of -K^T q terms into incidence slots ----
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int le = k * NT + tid;
-      if (le < e_act) {
-        const float4 bi = bar[eij[k] & 0xffffu];
-        const float4 bj = bar[eij[k] >> 16];
-        dual_edge(bi, bj, ew[k], sigma, q1[k], q2[k], q3[k]);
-        const float aq = ew[k].x * q1[k], b2 = ew[k].y * q2[k], b3 = ew[k].y * q3[k];
-        const uint32_t ss = esl[k] & 0xffffu, sd = esl[k] >> 16;
-        if (ss != 0xffffu) {
-          c0[ss] = aq;
-          c1[ss] = fmaf(-ew[k].z, aq, b2);
-          c2[ss] = fmaf(-ew[k].w, aq, b3);
-        }
-        if (sd != 0xffffu) {
-          c0[sd] = -aq;
-          c1[sd] = -b2;
-          c2[sd] = -b3;
-        }
-      }
-    }
+    // wave-uniform: this wave's k-th edge block covers local edges [k NT + wbase, +64)
+    const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
+    // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
+    PhaseD<EPT, EPT>::run(nk, bar, c0, c1, c2, eij, ess, esd, ew, q1, q2, q3, sigma);
     __syncthreads();
-    // ---- phase P: primal descent, prox, extra-gradient ----
+    if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it] = __builtin_readcyclecounter();
+    // ---- phase P: primal descent (slot order = ascending original edge id), prox, extra-grad ----
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      const int lv = k * NT + tid;
-      if (lv < v_act) {
-        const int sb = vs[k] & 0xffffu, se = sb + (vs[k] >> 16);
+      if (k * NT + wbase < v_act) {  // wave-uniform
+        const int lv = k * NT + tid;
+        const int sb = (int)(vs[k] & 0xffffu), deg = (int)(vs[k] >> 16);
         const float xp = vx[k], w1p = vw1[k], w2p = vw2[k];
         float x = xp, w1 = w1p, w2 = w2p;
-        for (int s = sb; s < se; ++s) {
-          x = fmaf(ntau, c0[s], x);
-          w1 = fmaf(ntau, c1[s], w1);
-          w2 = fmaf(ntau, c2[s], w2);
+        // transposed slots: incidence j of this lane is at sb + 64 j (conflict-free across lanes);
+        // the group is padded to the wave's max degree, so reads past deg stay in bounds
+        for (int j = 0; j < wdeg[k]; j += 4) {  // wave-uniform trip count
+          float t0[4], t1[4], t2[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int s = sb + 64 * min(j + u, wdeg[k] - 1);
+            t0[u] = c0[s]; t1[u] = c1[s]; t2[u] = c2[s];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool on = (j + u) < deg;
+            x = on ? fmaf(ntau, t0[u], x) : x;
+            w1 = on ? fmaf(ntau, t1[u], w1) : w1;
+            w2 = on ? fmaf(ntau, t2[u], w2) : w2;
+          }
         }
-        x = prox_l1(x, vz[k], tl * vwgt[k], x_min, x_max);
+        x = prox_l1(x, vz[k], vt[k], x_min, x_max);
         vxb[k] = fmaf(theta, x - xp, x);
         vw1b[k] = fmaf(theta, w1 - w1p, w1);
         vw2b[k] = fmaf(theta, w2 - w2p, w2);
         vx[k] = x; vw1[k] = w1; vw2[k] = w2;
-        bar[lv] = make_float4(vxb[k], vw1b[k], vw2b[k], 0.0f);
+        if (lv < n_upd) bar[lv] = make_float4(vxb[k], vw1b[k], vw2b[k], 0.0f);
       }
     }
     __syncthreads();
+    if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it + 1] = __builtin_readcyclecounter();
   }
 
   // ---- write back what this tile owns ----
@@ -231,6 +310,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     const int le = k * NT + tid;
     if (le < e_own) a.q_dst[D.estart + le] = make_float4(q1[k], q2[k], q3[k], 0.0f);
   }
+  if (prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
 
 template <int NT, int EPT, int VPT>

@@ -47,13 +47,17 @@ const TileCfg kCfgs[] = {
 };
 
 bool pick_cfg(int want_nt, int e_max, int upd_max, TileCfg* out) {
-  for (const TileCfg& c : kCfgs) {
-    if (want_nt && c.nt != want_nt) continue;
-    if ((int64_t)c.nt * c.ept >= e_max && (int64_t)c.nt * c.vpt >= upd_max) {
-      *out = c;
-      return true;
+  // first pass: the smallest workgroup that keeps <= 4 edges per thread (no spills, short serial
+  // chains); second pass: anything that fits
+  for (int pass = 0; pass < 2; ++pass)
+    for (const TileCfg& c : kCfgs) {
+      if (want_nt && c.nt != want_nt) continue;
+      if (pass == 0 && c.ept > 4) continue;
+      if ((int64_t)c.nt * c.ept >= e_max && (int64_t)c.nt * c.vpt >= upd_max) {
+        *out = c;
+        return true;
+      }
     }
-  }
   return false;
 }
 
@@ -82,6 +86,9 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   bool single = (opt.tile_own <= 0 || opt.tile_own >= V) && single_fits;
   if (single) { tile_own = std::max(V, 1); depth = 0; }
 
+  std::vector<int32_t> deg_o(V, 0);
+  for (int32_t e = 0; e < E; ++e) { deg_o[edges[2 * e]]++; deg_o[edges[2 * e + 1]]++; }
+
   for (int attempt = 0; attempt < 6; ++attempt) {
     const int ntiles = V == 0 ? 0 : (V + tile_own - 1) / tile_own;
     // ---- vertex order: RCB leaves = tiles ----
@@ -90,7 +97,11 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     std::vector<int32_t> leaf_start;
     if (V > 0) rcb(pos, idx, 0, V, ntiles, &leaf_start);
     leaf_start.push_back(V);
-    for (int t = 0; t < ntiles; ++t) std::sort(idx.begin() + leaf_start[t], idx.begin() + leaf_start[t + 1]);
+    // inside a tile the order is free (everything lives in LDS): sort by degree so the lanes of a
+    // wave walk incidence lists of similar length
+    for (int t = 0; t < ntiles; ++t)
+      std::sort(idx.begin() + leaf_start[t], idx.begin() + leaf_start[t + 1],
+                [&](int32_t a, int32_t b) { return deg_o[a] != deg_o[b] ? deg_o[a] > deg_o[b] : a < b; });
     P.v_i2o = idx;
     P.v_o2i.assign(V, 0);
     for (int32_t k = 0; k < V; ++k) P.v_o2i[idx[k]] = k;
@@ -187,7 +198,10 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
               const int32_t u = (P.ginc[s] < 0) ? P.eij[k].x : P.eij[k].y;
               if (stamp[u] != t) { stamp[u] = t; ring[u] = r; next.push_back(u); }
             }
-          std::sort(next.begin(), next.end());
+          std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) {
+            const int32_t da = P.grow[a + 1] - P.grow[a], db = P.grow[b + 1] - P.grow[b];
+            return da != db ? da > db : a < b;
+          });
           for (int32_t u : next) { lidx[u] = (int32_t)ext.size(); ext.push_back(u); }
           frontier.swap(next);
         }
@@ -198,7 +212,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       D.n_upd = depth == 0 ? D.n_ext : D.ring_end[depth - 1];
       if (D.n_ext > 65535) { ok = false; break; }
       D.vmap_off = (int32_t)P.t_vmap.size();
-      for (int32_t k = D.n_own; k < D.n_ext; ++k) P.t_vmap.push_back(ext[k]);
+      for (int32_t k = 0; k < D.n_ext; ++k) P.t_vmap.push_back(ext[k]);
       // local edges: visit each ext vertex's outgoing (source-role) incidences
       les.clear();
       for (int32_t lv = 0; lv < D.n_ext; ++lv) {
@@ -233,10 +247,9 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         }
       }
       D.emap_off = (int32_t)P.t_emap.size();
-      for (int32_t le = D.e_own; le < D.e_loc; ++le) P.t_emap.push_back(les[le].k);
+      for (int32_t le = 0; le < D.e_loc; ++le) P.t_emap.push_back(les[le].k);
       // incidence slots of updated vertices, ascending original edge id
       D.srow_off = (int32_t)P.t_srow.size();
-      std::vector<int32_t> local_of_edge;  // internal edge id -> local (via sorted lookup)
       // slot assignment: walk updated vertices, their ginc lists are already in original order
       std::vector<uint16_t> slot_src(D.e_loc, 0xffff), slot_dst(D.e_loc, 0xffff);
       {
@@ -244,22 +257,32 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         std::vector<std::pair<int32_t, int32_t>> tab(D.e_loc);
         for (int32_t le = 0; le < D.e_loc; ++le) tab[le] = {les[le].k, le};
         std::sort(tab.begin(), tab.end());
-        int32_t slot = 0;
-        for (int32_t lv = 0; lv < D.n_upd; ++lv) {
-          const int32_t v = ext[lv];
-          const int32_t deg = P.grow[v + 1] - P.grow[v];
-          if (slot + deg > 65535 || deg > 65535) { ok = false; break; }
-          P.t_srow.push_back((uint32_t)slot | ((uint32_t)deg << 16));
-          for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s) {
-            const int32_t k = P.ginc[s] & 0x7fffffff;
-            auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(k, (int32_t)-1));
-            if (it == tab.end() || it->first != k) { ok = false; P.note = "halo closure invariant"; break; }
-            if (P.ginc[s] < 0) slot_dst[it->second] = (uint16_t)slot; else slot_src[it->second] = (uint16_t)slot;
-            ++slot;
+        // Transposed incidence slots: the 64 vertices a wave updates together form a group; the
+        // j-th incidence of lane l lives at base + 64 j + l, so phase P reads are conflict-free.
+        int32_t base = 0;
+        for (int32_t g0 = 0; g0 < D.n_upd && ok; g0 += 64) {
+          const int32_t g1 = std::min(g0 + 64, D.n_upd);
+          int32_t width = 0;
+          for (int32_t lv = g0; lv < g1; ++lv) width = std::max(width, P.grow[ext[lv] + 1] - P.grow[ext[lv]]);
+          if (base + 64 * width + kDummySlots > 65535) { ok = false; break; }
+          for (int32_t lv = g0; lv < g1; ++lv) {
+            const int32_t v = ext[lv];
+            const int32_t deg = P.grow[v + 1] - P.grow[v];
+            const int32_t s0 = base + (lv - g0);
+            P.t_srow.push_back((uint32_t)s0 | ((uint32_t)deg << 16));
+            int32_t j = 0;
+            for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s, ++j) {
+              const int32_t k = P.ginc[s] & 0x7fffffff;
+              auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(k, (int32_t)-1));
+              if (it == tab.end() || it->first != k) { ok = false; P.note = "halo closure invariant"; break; }
+              const uint16_t slot = (uint16_t)(s0 + 64 * j);
+              if (P.ginc[s] < 0) slot_dst[it->second] = slot; else slot_src[it->second] = slot;
+            }
+            if (!ok) break;
           }
-          if (!ok) break;
+          base += 64 * width;
         }
-        D.nslots = slot;
+        D.nslots = base;
       }
       if (!ok) break;
       D.erec_off = (int32_t)P.t_eij.size();
@@ -270,8 +293,8 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         P.t_ew.push_back(P.ew[k]);
       }
       e_max = std::max(e_max, D.e_loc);
-      upd_max = std::max(upd_max, D.n_upd);
-      lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)D.nslots * 12);
+      upd_max = std::max(upd_max, D.n_ext);  // every local vertex gets a register slot
+      lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots) * 12);
     }
     TileCfg cfg{};
     if (ok && lds_max > lds_cap) ok = false;

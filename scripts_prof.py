@@ -1,0 +1,31 @@
+"""dev helper: in-kernel timeline of the tile kernel (cycles) per tile."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from flame_ros_amd import graphgen
+from flame_ros_amd.regularizer import GraphRegularizer, default_params
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument('--workload', default='50k'); ap.add_argument('--own', type=int, default=0); ap.add_argument('--depth', type=int, default=0); ap.add_argument('--nt', type=int, default=0)
+a = ap.parse_args()
+g, iters = graphgen.named(a.workload)
+opts = dict(profile=1, use_graph=0)
+if a.own: opts['tile_own'] = a.own
+if a.depth: opts['tile_depth'] = a.depth
+if a.nt: opts['tile_threads'] = a.nt
+r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, **opts)
+p = default_params()
+r.step(p, iters); r.step(p, iters)
+d = r.info('tile_depth')
+r.step(p, d)
+t = r.plan_array('profile', np.uint64).reshape(-1, 36).astype(np.int64)
+ms, n = r.last_solve_ms()
+print('tiles', len(t), 'depth', d, 'nt', r.info('tile_threads'), 'ept', r.info('tile_ept'), 'vpt', r.info('tile_vpt'), 'launch ms', ms)
+t0 = t[:, 0].min()
+load = t[:, 1] - t[:, 0]
+store = t[:, 35] - t[:, 2 * d + 1]
+print('start skew (cycles) p50 %d max %d' % (np.median(t[:, 0] - t0), (t[:, 0] - t0).max()))
+print('load   p50 %d  max %d' % (np.median(load), load.max()))
+for k in range(1, d + 1):
+    pd = t[:, 2 * k] - t[:, 2 * k - 1]; pp = t[:, 2 * k + 1] - t[:, 2 * k]
+    print('iter%d  D p50 %d max %d | P p50 %d max %d' % (k, np.median(pd), pd.max(), np.median(pp), pp.max()))
+print('store  p50 %d  max %d' % (np.median(store), store.max()))
+print('total  p50 %d  max %d ; span %d' % (np.median(t[:, 35] - t[:, 0]), (t[:, 35] - t[:, 0]).max(), t[:, 35].max() - t0))
