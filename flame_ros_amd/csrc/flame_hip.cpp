@@ -101,6 +101,12 @@ struct flame_hip_graph {
   uint8_t* tri_valid = nullptr;
   // costs
   double* partials = nullptr;
+  // halo exchange lists (internal ids), see flame_hip_halo_register
+  int32_t n_send_v = 0, n_send_e = 0, n_recv_v = 0, n_recv_e = 0;
+  int32_t* halo_send_v = nullptr;
+  int32_t* halo_send_e = nullptr;
+  int32_t* halo_recv_v = nullptr;
+  int32_t* halo_recv_e = nullptr;
   // debug timeline of the tile kernel
   int profile = 0;
   unsigned long long* prof = nullptr;
@@ -114,7 +120,7 @@ struct flame_hip_graph {
     execs.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
                     t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
-                    tri_valid, partials, prof};
+                    tri_valid, partials, prof, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
@@ -123,6 +129,8 @@ struct flame_hip_graph {
     tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
     partials = nullptr;
     prof = nullptr;
+    halo_send_v = halo_send_e = halo_recv_v = halo_recv_e = nullptr;
+    n_send_v = n_send_e = n_recv_v = n_recv_e = 0;
   }
 };
 
@@ -572,6 +580,68 @@ int flame_hip_download(flame_hip_graph* g, float* x, float* w1, float* w2, float
 
 int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b) {
   return download_impl(g, true, xb, w1b, w2b, nullptr);
+}
+
+static int upload_index_list(const std::vector<int32_t>& map, int32_t limit, int32_t n,
+                             const int32_t* ids, int32_t** dev) {
+  std::vector<int32_t> h((size_t)(n > 0 ? n : 0));
+  for (int32_t k = 0; k < n; ++k) {
+    if (ids[k] < 0 || ids[k] >= limit) return FLAME_HIP_ERR_ARG;
+    h[k] = map[ids[k]];
+  }
+  if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
+  int rc = dev_alloc(dev, h.size());
+  if (rc) return rc;
+  return h2d(*dev, h);
+}
+
+int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t* send_v,
+                            int32_t n_send_e, const int32_t* send_e, int32_t n_recv_v,
+                            const int32_t* recv_v, int32_t n_recv_e, const int32_t* recv_e) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (n_send_v < 0 || n_send_e < 0 || n_recv_v < 0 || n_recv_e < 0) return FLAME_HIP_ERR_ARG;
+  if ((n_send_v && !send_v) || (n_send_e && !send_e) || (n_recv_v && !recv_v) || (n_recv_e && !recv_e))
+    return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  const Plan& P = g->plan;
+  if ((rc = upload_index_list(P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
+      (rc = upload_index_list(P.e_o2i, g->E, n_send_e, send_e, &g->halo_send_e)) ||
+      (rc = upload_index_list(P.v_o2i, g->V, n_recv_v, recv_v, &g->halo_recv_v)) ||
+      (rc = upload_index_list(P.e_o2i, g->E, n_recv_e, recv_e, &g->halo_recv_e)))
+    return rc;
+  g->n_send_v = n_send_v; g->n_send_e = n_send_e; g->n_recv_v = n_recv_v; g->n_recv_e = n_recv_e;
+  return 0;
+}
+
+int flame_hip_halo_bytes(const flame_hip_graph* g, int64_t* send_bytes, int64_t* recv_bytes) {
+  if (!g) return FLAME_HIP_ERR_ARG;
+  if (send_bytes) *send_bytes = 16 * (2 * (int64_t)g->n_send_v + g->n_send_e);
+  if (recv_bytes) *recv_bytes = 16 * (2 * (int64_t)g->n_recv_v + g->n_recv_e);
+  return 0;
+}
+
+int flame_hip_halo_pack(flame_hip_graph* g, void* send_buf_dev, void* stream) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!send_buf_dev && (g->n_send_v + g->n_send_e) > 0) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  HIPCHK(launch_halo_pack(s, g->n_send_v, g->n_send_e, g->halo_send_v, g->halo_send_e,
+                          g->A[g->cur], g->B[g->cur], g->q[g->cur], (float4*)send_buf_dev));
+  return 0;
+}
+
+int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* stream) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!recv_buf_dev && (g->n_recv_v + g->n_recv_e) > 0) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  HIPCHK(launch_halo_unpack(s, g->n_recv_v, g->n_recv_e, g->halo_recv_v, g->halo_recv_e,
+                            (const float4*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
+  return 0;
 }
 
 // Debug/test hook: copy a named plan array to the caller (host logic tests, no device needed).

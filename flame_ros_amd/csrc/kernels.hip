@@ -457,7 +457,60 @@ __global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* _
   vtx_normals[v] = make_float4(nx, ny, nz, 0.f);
 }
 
+// ------------------------------------------------------------------------------------------
+// Halo exchange (multi-GPU subdomains): gather the full state of listed own
+// vertices / edges into a contiguous send buffer, scatter a received buffer into halo entries.
+// Layout: nv x {A, B} float4 pairs, then ne x q float4.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_pack(int32_t nv, int32_t ne,
+                                                   const int32_t* __restrict__ vidx,
+                                                   const int32_t* __restrict__ eidx,
+                                                   const float4* __restrict__ A,
+                                                   const float4* __restrict__ B,
+                                                   const float4* __restrict__ q,
+                                                   float4* __restrict__ out) {
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nv) {
+    const int32_t v = vidx[t];
+    out[2 * t] = A[v];
+    out[2 * t + 1] = B[v];
+  } else if (t < nv + ne) {
+    out[2 * nv + (t - nv)] = q[eidx[t - nv]];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_halo_unpack(int32_t nv, int32_t ne,
+                                                     const int32_t* __restrict__ vidx,
+                                                     const int32_t* __restrict__ eidx,
+                                                     const float4* __restrict__ in,
+                                                     float4* __restrict__ A, float4* __restrict__ B,
+                                                     float4* __restrict__ q) {
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < nv) {
+    const int32_t v = vidx[t];
+    A[v] = in[2 * t];
+    B[v] = in[2 * t + 1];
+  } else if (t < nv + ne) {
+    q[eidx[t - nv]] = in[2 * nv + (t - nv)];
+  }
+}
+
 }  // namespace
+
+hipError_t launch_halo_pack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
+                            const int32_t* eidx, const float4* A, const float4* B, const float4* q,
+                            float4* out) {
+  if (nv + ne <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_pack, dim3((nv + ne + 255) / 256), dim3(256), 0, s, nv, ne, vidx, eidx, A, B, q, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_halo_unpack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
+                              const int32_t* eidx, const float4* in, float4* A, float4* B, float4* q) {
+  if (nv + ne <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_unpack, dim3((nv + ne + 255) / 256), dim3(256), 0, s, nv, ne, vidx, eidx, in, A, B, q);
+  return hipGetLastError();
+}
 
 hipError_t launch_dual(hipStream_t s, int32_t E, const int2* eij, const float4* ew,
                        const float4* B, float4* q, float sigma) {

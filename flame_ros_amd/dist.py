@@ -1,0 +1,254 @@
+"""Multi-GPU modes of the regulariser (one process per GPU, torch.distributed; "nccl" = RCCL).
+
+SURVEY.md 8(e).  The reference is a single CPU process (no NCCL/MPI anywhere), so there is no
+call pattern to mirror; two modes exist because the path shards in two ways:
+
+* replicas  -- independent frames (graphs) per rank, no data-path collective: the natural
+               data-parallel axis of FLaME (one depth-graph per camera frame).  Weak scaling.
+* partition -- ONE graph cut into `world` subdomains by recursive coordinate bisection; each rank
+               holds its own vertices plus D halo rings and iterates D times between neighbour
+               exchanges of the full solver state (exact: each iteration invalidates one ring).
+               The exchange is `batch_isend_irecv` (ncclSend/ncclRecv over xGMI) on device buffers
+               filled by the halo pack/unpack kernels of libflame_hip.so.  METIS is not available in
+               this image, RCB is used instead (planar graph: cut ~ sqrt(V)).
+
+Because every vertex sums its incident edges in ascending ORIGINAL edge id on every path, the
+partitioned result is bit-identical to the single-GPU (and oracle) result.
+
+The local solver is pluggable (`SubdomainSolver` protocol) so the world_size-2 gloo tests can run
+the exchange logic on CPU with the oracle as the local solver; the product class is
+`HipSubdomainSolver` (GPU only, no fallback).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+
+# ---------------------------------------------------------------- replicas mode
+def shard_frames(num_frames, rank, world):
+    """Frames (independent graphs) handled by `rank`: round-robin, no communication."""
+    return list(range(rank, num_frames, world))
+
+
+# ---------------------------------------------------------------- partition mode
+def rcb_parts(pos, nparts):
+    """Recursive coordinate bisection into `nparts` near-equal parts; returns part id per vertex."""
+    part = np.zeros(len(pos), np.int32)
+
+    def rec(idx, lo, n):
+        if n == 1 or len(idx) <= 1:
+            part[idx] = lo
+            return
+        ext = pos[idx].max(0) - pos[idx].min(0)
+        axis = int(ext[1] > ext[0])
+        n1 = n // 2
+        k = (len(idx) * n1) // n
+        order = idx[np.lexsort((idx, pos[idx, axis]))]
+        rec(order[:k], lo, n1)
+        rec(order[k:], lo + n1, n - n1)
+
+    rec(np.arange(len(pos)), 0, nparts)
+    return part
+
+
+@dataclass
+class Subdomain:
+    rank: int
+    depth: int
+    vid: np.ndarray        # [n_ext] global vertex ids, own first (ascending), then halo (ascending)
+    n_own: int
+    ring: np.ndarray       # [n_ext] graph distance from the own set
+    eid: np.ndarray        # [e_loc] global edge ids, ascending (keeps every vertex's sum order)
+    edges: np.ndarray      # [e_loc,2] local vertex ids, orientation preserved
+    e_owned: np.ndarray    # [e_loc] bool: this rank owns the edge (= owns its source vertex)
+    recv_v: dict           # owner rank -> local halo vertex ids whose state that rank sends
+    recv_e: dict           # owner rank -> local edge ids whose q that rank sends
+
+
+def build_subdomain(pos, edges, part, rank, depth):
+    """Own vertices of `rank` + `depth` halo rings, the local edge set, and what to receive."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import dijkstra
+    V, E = len(pos), len(edges)
+    own = np.flatnonzero(part == rank)
+    A = sp.coo_matrix((np.ones(E), (edges[:, 0], edges[:, 1])), shape=(V, V))
+    A = (A + A.T).tocsr()
+    if len(own):
+        dist = dijkstra(A, unweighted=True, indices=own, min_only=True, limit=depth)
+    else:
+        dist = np.full(V, np.inf)
+    halo = np.flatnonzero((dist > 0) & (dist <= depth))
+    vid = np.concatenate([own, halo]).astype(np.int64)
+    ring_g = np.full(V, depth + 1, np.int64)
+    ring_g[vid] = dist[vid].astype(np.int64)
+    lid = -np.ones(V, np.int64)
+    lid[vid] = np.arange(len(vid))
+    ri, rj = ring_g[edges[:, 0]], ring_g[edges[:, 1]]
+    keep = (ri <= depth) & (rj <= depth) & (np.minimum(ri, rj) < max(depth, 1))
+    eid = np.flatnonzero(keep)
+    loc = lid[edges[eid]].astype(np.int32)
+    e_owner = part[edges[eid, 0]]
+    recv_v, recv_e = {}, {}
+    for r in np.unique(part[halo]) if len(halo) else []:
+        recv_v[int(r)] = (len(own) + np.flatnonzero(part[halo] == r)).astype(np.int32)
+    for r in np.unique(e_owner):
+        if r != rank:
+            recv_e[int(r)] = np.flatnonzero(e_owner == r).astype(np.int32)
+    return Subdomain(rank, depth, vid, len(own), ring_g[vid], eid, loc, e_owner == rank, recv_v, recv_e)
+
+
+class PartitionedSolver:
+    """Drives `num_iters` PD iterations of ONE graph over all ranks of the default process group.
+
+    make_solver(sub, pos, edges, alpha, beta, z, wgt, x0) must return an object with
+      halo_register(send_v, send_e, recv_v, recv_e); halo_pack() -> tensor; halo_unpack(tensor);
+      step(params, n); download() -> (x, w1, w2, q)
+    operating on the subdomain's LOCAL numbering.
+    """
+
+    def __init__(self, pos, edges, alpha, beta, z, wgt, make_solver, depth=8, x0=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
+        self.V, self.E, self.depth = len(pos), len(edges), depth
+        self.part = rcb_parts(pos, self.world)
+        sub = self.sub = build_subdomain(pos, edges, self.part, self.rank, depth)
+        f = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+        self.solver = make_solver(sub, pos[sub.vid], sub.edges, f(alpha)[sub.eid], f(beta)[sub.eid],
+                                  f(z)[sub.vid], f(wgt)[sub.vid],
+                                  None if x0 is None else f(x0)[sub.vid])
+        # tell every owner which of its vertices / edges (global ids) this rank needs
+        want = {r: (sub.vid[v].tolist(), sub.eid[sub.recv_e.get(r, np.zeros(0, np.int32))].tolist())
+                for r, v in sub.recv_v.items()}
+        for r, e in sub.recv_e.items():
+            want.setdefault(r, ([], sub.eid[e].tolist()))
+        allwant = [None] * self.world
+        dist.all_gather_object(allwant, want)
+        g2l_v = {int(g): i for i, g in enumerate(sub.vid[:sub.n_own])}
+        g2l_e = {int(g): i for i, g in enumerate(sub.eid)}
+        self.peers = sorted(set(want) | {r for r in range(self.world) if self.rank in allwant[r]})
+        send_v, send_e, recv_v, recv_e = [], [], [], []
+        self.send_cnt, self.recv_cnt = {}, {}
+        for r in self.peers:
+            wv, we = allwant[r].get(self.rank, ([], []))
+            sv = [g2l_v[g] for g in wv]
+            se = [g2l_e[g] for g in we]
+            rv = sub.recv_v.get(r, np.zeros(0, np.int32)).tolist()
+            re_ = sub.recv_e.get(r, np.zeros(0, np.int32)).tolist()
+            self.send_cnt[r] = (len(sv), len(se))
+            self.recv_cnt[r] = (len(rv), len(re_))
+            send_v += sv; send_e += se; recv_v += rv; recv_e += re_
+        self.n_send = (len(send_v), len(send_e))
+        self.n_recv = (len(recv_v), len(recv_e))
+        i32 = lambda a: np.asarray(a, np.int32)  # noqa: E731
+        self.solver.halo_register(i32(send_v), i32(send_e), i32(recv_v), i32(recv_e))
+
+    # packed buffer layout: all vertex records (8 floats each, peers in order) then all edge
+    # records (4 floats each, peers in order) -> per-peer messages are two slices each
+    def _slices(self, cnt, n):
+        out, ov, oe = {}, 0, 8 * n[0]
+        for r in self.peers:
+            nv, ne = cnt[r]
+            out[r] = ((ov, ov + 8 * nv), (oe, oe + 4 * ne))
+            ov += 8 * nv
+            oe += 4 * ne
+        return out
+
+    def exchange(self):
+        if self.world == 1 or not self.peers:
+            return
+        dist = self.dist
+        sbuf = self.solver.halo_pack()
+        rbuf = sbuf.new_empty(8 * self.n_recv[0] + 4 * self.n_recv[1])
+        ops, ssl, rsl = [], self._slices(self.send_cnt, self.n_send), self._slices(self.recv_cnt, self.n_recv)
+        for r in self.peers:
+            for a, b in ssl[r]:
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, sbuf[a:b], r))
+            for a, b in rsl[r]:
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, rbuf[a:b], r))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.solver.halo_unpack(rbuf)
+
+    def step(self, params, num_iters):
+        done = 0
+        while done < num_iters:
+            n = min(self.depth, num_iters - done)
+            self.solver.step(params, n)
+            done += n
+            if done < num_iters:
+                self.exchange()
+        self._stale = True
+
+    def gather_solution(self):
+        """x, w1, w2 (V) and q (E,3) of the whole graph on every rank (verification helper)."""
+        x, w1, w2, q = self.solver.download()
+        s = self.sub
+        own_e = np.flatnonzero(s.e_owned)
+        mine = (s.vid[:s.n_own], x[:s.n_own], w1[:s.n_own], w2[:s.n_own], s.eid[own_e], q[own_e])
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, mine)
+        X, W1, W2 = (np.zeros(self.V, np.float32) for _ in range(3))
+        Q = np.zeros((self.E, 3), np.float32)
+        for vid, px, p1, p2, eid, pq in parts:
+            X[vid], W1[vid], W2[vid] = px, p1, p2
+            Q[eid] = pq
+        return X, W1, W2, Q
+
+
+class HipSubdomainSolver:
+    """The product local solver: one subdomain on one MI355X through libflame_hip.so.  Halo
+    buffers are torch CUDA tensors; kernels and RCCL ops are ordered on torch's current stream."""
+
+    def __init__(self, sub, pos, edges, alpha, beta, z, wgt, x0, device=0, **options):
+        import ctypes as C
+
+        import torch
+
+        from . import lib as _l
+        from .regularizer import GraphRegularizer
+        self._C, self._l, self.torch = C, _l, torch
+        self.device = torch.device("cuda", device)
+        options.setdefault("use_graph", 0)  # solves run on torch's stream, not the handle's
+        self.reg = GraphRegularizer(pos, edges, alpha, beta, z, wgt, x0=x0, device=device, **options)
+        self.n_send = self.n_recv = (0, 0)
+
+    def _stream(self):
+        return self._C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def halo_register(self, send_v, send_e, recv_v, recv_e):
+        p = lambda a: a.ctypes.data_as(self._C.c_void_p)  # noqa: E731
+        self._l.check(self.reg._lib.flame_hip_halo_register(
+            self.reg._h, len(send_v), p(send_v), len(send_e), p(send_e), len(recv_v), p(recv_v),
+            len(recv_e), p(recv_e)), "flame_hip_halo_register")
+        self.n_send, self.n_recv = (len(send_v), len(send_e)), (len(recv_v), len(recv_e))
+
+    def halo_pack(self):
+        buf = self.torch.empty(8 * self.n_send[0] + 4 * self.n_send[1], dtype=self.torch.float32,
+                               device=self.device)
+        self._l.check(self.reg._lib.flame_hip_halo_pack(self.reg._h, self._C.c_void_p(buf.data_ptr()),
+                                                        self._stream()), "flame_hip_halo_pack")
+        return buf
+
+    def halo_unpack(self, buf):
+        assert buf.is_cuda and buf.dtype == self.torch.float32 and buf.is_contiguous()
+        self._l.check(self.reg._lib.flame_hip_halo_unpack(self.reg._h, self._C.c_void_p(buf.data_ptr()),
+                                                          self._stream()), "flame_hip_halo_unpack")
+
+    def step(self, params, n):
+        self.reg.step(params, n, stream=self._stream(), sync=False)
+
+    def download(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return self.reg.download()
+
+
+def make_hip_solver(device=0, **options):
+    def f(sub, pos, edges, alpha, beta, z, wgt, x0):
+        return HipSubdomainSolver(sub, pos, edges, alpha, beta, z, wgt, x0, device=device, **options)
+    return f

@@ -52,6 +52,10 @@ SYMBOLS = {
     "flame_hip_triangles": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _VP, _VP, _VP]),
     "flame_hip_download": (C.c_int, [_VP] + [_VP] * 4),
     "flame_hip_download_bar": (C.c_int, [_VP] + [_VP] * 3),
+    "flame_hip_halo_register": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _I32, _VP]),
+    "flame_hip_halo_bytes": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
+    "flame_hip_halo_pack": (C.c_int, [_VP, _VP, _VP]),
+    "flame_hip_halo_unpack": (C.c_int, [_VP, _VP, _VP]),
     "flame_hip_debug_plan_array": (_I64, [_VP, C.c_char_p, _VP, _I64]),
     "flame_hip_strerror": (C.c_char_p, [C.c_int]),
     "flame_hip_version": (C.c_int, []),

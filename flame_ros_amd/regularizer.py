@@ -85,11 +85,15 @@ class GraphRegularizer:
         _l.check(self._lib.flame_hip_get_info(self._h, key.encode(), C.byref(v)), "flame_hip_get_info")
         return v.value
 
+    _PLAN_ELEM_BYTES = {"eij": 8, "t_eij": 8, "profile": 8, "tiles": C.sizeof(_l.TileDesc)}
+
     def plan_array(self, name, dtype):
+        """Debug hook: copy of a host-side plan array (works on plan-only handles, device=-1)."""
         n = self._lib.flame_hip_debug_plan_array(self._h, name.encode(), None, 0)
         if n < 0:
             raise FlameHipError(int(n), "flame_hip_debug_plan_array")
-        out = np.zeros(int(n), dtype=dtype)
+        nbytes = int(n) * self._PLAN_ELEM_BYTES.get(name, 4)
+        out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
         if n:
             self._lib.flame_hip_debug_plan_array(self._h, name.encode(), _ptr(out), out.nbytes)
         return out

@@ -1,0 +1,111 @@
+"""CPU, world_size 2 and 3 over gloo: the N>1 paths of flame_ros_amd/dist.py.
+
+The exchange logic (RCB partition, halo rings, request lists, packed P2P messages, D iterations
+between exchanges) is the product code; the LOCAL solver is injected: here the CPU oracle (test
+infrastructure), on the GPU box `HipSubdomainSolver`.  The partitioned result must be bit-identical
+to the serial oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from flame_ros_amd import dist as fdist
+from oracle import COracle
+from oracle.cbind import default_params
+from tests.util import graphgen
+
+
+class OracleSubdomainSolver:
+    def __init__(self, sub, pos, edges, alpha, beta, z, wgt, x0):
+        self.o = COracle(pos, edges, alpha, beta, z, wgt, x0=x0)
+
+    def halo_register(self, send_v, send_e, recv_v, recv_e):
+        self.sv, self.se, self.rv, self.re = send_v, send_e, recv_v, recv_e
+
+    def halo_pack(self):
+        o = self.o
+        v = np.stack([o.x, o.w1, o.w2, o.z, o.xb, o.w1b, o.w2b, o.wgt], 1)[self.sv]
+        q = np.concatenate([o.q[self.se], np.zeros((len(self.se), 1), np.float32)], 1)
+        return torch.from_numpy(np.concatenate([v.ravel(), q.ravel()]).astype(np.float32))
+
+    def halo_unpack(self, buf):
+        o, b = self.o, buf.numpy()
+        nv = len(self.rv)
+        v = b[:8 * nv].reshape(nv, 8)
+        for k, a in enumerate((o.x, o.w1, o.w2, None, o.xb, o.w1b, o.w2b, None)):
+            if a is not None:
+                a[self.rv] = v[:, k]
+        o.q[self.re] = b[8 * nv:].reshape(-1, 4)[:, :3]
+
+    def step(self, params, n):
+        self.o.solve(params, n)
+
+    def download(self):
+        return self.o.x, self.o.w1, self.o.w2, self.o.q
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, V, depth, iters, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = graphgen.synthetic(V, seed=11)
+        p = default_params()
+        ps = fdist.PartitionedSolver(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt,
+                                     lambda *a: OracleSubdomainSolver(*a), depth=depth)
+        assert ps.sub.n_own > 0 and len(ps.peers) >= 1
+        ps.step(p, iters)
+        x, w1, w2, q = ps.gather_solution()
+        # replicas mode: frames are sharded round-robin, aggregate = max time over ranks
+        frames = fdist.shard_frames(7, rank, world)
+        t = torch.tensor([float(len(frames))])
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        assert int(t.item()) == 7
+        if rank == 0:
+            np.savez(out, x=x, w1=w1, w2=w2, q=q, halo=len(ps.sub.vid) - ps.sub.n_own)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,depth,iters", [(2, 4, 19), (3, 2, 9), (2, 1, 5)])
+def test_partitioned_solve_matches_serial_oracle(tmp_path, world, depth, iters):
+    V = 1500
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), V, depth, iters, out), nprocs=world, join=True)
+    g = graphgen.synthetic(V, seed=11)
+    o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    o.solve(default_params(), iters)
+    r = np.load(out)
+    assert int(r["halo"]) > 0
+    for k, want in (("x", o.x), ("w1", o.w1), ("w2", o.w2), ("q", o.q)):
+        assert np.array_equal(r[k].view(np.uint32), want.view(np.uint32)), k
+
+
+def test_rcb_and_subdomain_structure():
+    g = graphgen.synthetic(2000, seed=3)
+    part = fdist.rcb_parts(g.pos, 8)
+    counts = np.bincount(part, minlength=8)
+    assert counts.min() >= 249 and counts.max() <= 251
+    cut = int((part[g.edges[:, 0]] != part[g.edges[:, 1]]).sum())
+    assert cut < 0.15 * g.E  # planar RCB cut ~ sqrt(V) per boundary
+    sub = fdist.build_subdomain(g.pos, g.edges, part, 3, 3)
+    assert np.all(part[sub.vid[:sub.n_own]] == 3) and np.all(sub.ring[:sub.n_own] == 0)
+    assert sub.ring.max() == 3 and np.all(np.diff(sub.eid) > 0)
+    assert np.array_equal(sub.vid[sub.edges], g.edges[sub.eid])  # orientation preserved
+    owned = part[g.edges[sub.eid, 0]] == 3
+    assert np.array_equal(owned, sub.e_owned)
+    # every edge incident to an own vertex is local (so own vertices see all their neighbours)
+    inc = np.isin(g.edges, sub.vid[:sub.n_own]).any(1)
+    assert np.all(np.isin(np.flatnonzero(inc), sub.eid))
+    assert fdist.shard_frames(10, 1, 4) == [1, 5, 9]
