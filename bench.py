@@ -40,6 +40,24 @@ def cpu_baseline(g, iters, budget_s=12.0):
                       "x86-64-v3 (oracle/nltgv2_oracle.c)" % (done, g.V, g.E)}
 
 
+def profiled_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
+    collect.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH x2 gfx950 correction).  PMC counters
+    cannot be read inside an un-profiled run, so this is the figure of the last committed profile
+    of the same workload, or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % workload))):
+        try:
+            d = json.load(open(f))
+            for k, v in d.get("traffic_bytes_per_launch", {}).items():
+                if kernel in k:
+                    best = {"bytes_per_launch": v, "source": os.path.relpath(f, ROOT)}
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +188,10 @@ def main():
                                  "tile path keeps state in LDS across iterations, so its real HBM "
                                  "traffic is below the per-iteration algorithmic bytes."},
         }
+        tr = profiled_traffic(args.workload, "k_tile" if path == 2 else "k_primal")
+        if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
+            out["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
         if not args.no_cpu:
             cb = cpu_baseline(g, iters, args.cpu_budget)
             out["cpu_baseline"] = cb

@@ -81,8 +81,13 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   const int64_t lds_cap = opt.lds_bytes;
   // an isolated single tile holds the whole graph when it fits the largest kernel config
   const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 24) <= lds_cap;
-  int tile_own = opt.tile_own > 0 ? opt.tile_own : 192;
-  int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : 4;
+  // Auto sizing (measured on MI355X, DESIGN.md "Tile sizing"): one tile per CU when the graph
+  // allows it (256 CUs), never below 32 own vertices (halo overhead) or above 196 (LDS / threads);
+  // when there are more tiles than CUs prefer the shallower halo whose tiles co-reside on a CU.
+  const int auto_own = std::max(32, std::min(196, (V + 255) / 256));
+  const int auto_depth = (V + auto_own - 1) / auto_own > 256 ? 3 : 4;
+  int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
+  int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
   bool single = (opt.tile_own <= 0 || opt.tile_own >= V) && single_fits;
   if (single) { tile_own = std::max(V, 1); depth = 0; }
 
@@ -308,7 +313,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     }
     // did not fit: shrink the tiles (a single tile becomes a halo'd partition) and retry
     P.tiles.clear();
-    if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : 192; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : 4; }
+    if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }
     else tile_own = std::max(16, tile_own / 2);
   }
   P.has_tiles = false;
