@@ -1,0 +1,90 @@
+// tests/cpp/facade_conformance.cc -- exercises include/flame/flame.h the way flame_ros does
+// (reference src/flame_offline_tum.cc:404-412 construct, :578 update, :628-635 mesh out,
+// :706-707 stats, src/utils.cc:117-136 stat keys).  Reads a graph (pos, mu, tris) from a binary
+// file written by the Python test, runs one update, writes idepths / validity / normals / costs
+// back.  Exit code 0 = update ok, 3 = update returned false (no device), other = harness error.
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "flame/flame.h"
+
+static bool read_all(const char* path, std::vector<char>* buf) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return false;
+  std::fseek(f, 0, SEEK_END);
+  long n = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  buf->resize(n);
+  bool ok = std::fread(buf->data(), 1, n, f) == static_cast<size_t>(n);
+  std::fclose(f);
+  return ok;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 10;
+  std::vector<char> buf;
+  if (!read_all(argv[1], &buf)) return 11;
+  const int32_t* hdr = reinterpret_cast<const int32_t*>(buf.data());
+  const int32_t V = hdr[0], T = hdr[1], iters = hdr[2], device = hdr[3];
+  const float* pos = reinterpret_cast<const float*>(hdr + 4);
+  const float* mu = pos + 2 * V;
+  const int32_t* tri = reinterpret_cast<const int32_t*>(mu + V);
+
+  flame::Params params;  // defaults = cfg/flame_offline_tum.yaml
+  params.nltgv2_iterations = iters;
+  params.hip_device = device;
+  params.rparams.data_factor = 0.15f;
+  params.rparams.step_x = 0.001f;
+  params.rparams.step_q = 125.0f;
+  params.rparams.theta = 0.25f;
+  flame::Matrix3f K, Kinv;  // cfg/kinect.yaml: 525/525/319.5/239.5
+  K(0, 0) = 525.f; K(0, 1) = 0.f; K(0, 2) = 319.5f; K(1, 0) = 0.f; K(1, 1) = 525.f; K(1, 2) = 239.5f;
+  K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
+  Kinv(0, 0) = 1.f / 525.f; Kinv(0, 1) = 0.f; Kinv(0, 2) = -319.5f / 525.f;
+  Kinv(1, 0) = 0.f; Kinv(1, 1) = 1.f / 525.f; Kinv(1, 2) = -239.5f / 525.f;
+  Kinv(2, 0) = 0.f; Kinv(2, 1) = 0.f; Kinv(2, 2) = 1.f;
+  std::shared_ptr<flame::Flame> sensor = std::make_shared<flame::Flame>(640, 480, K, Kinv, params);
+
+  std::vector<flame::Point2f> vtx(V);
+  std::vector<float> idepth(V), var(V, 1e-4f);
+  std::vector<flame::Triangle> tris(T);
+  for (int v = 0; v < V; ++v) { vtx[v] = flame::Point2f(pos[2 * v], pos[2 * v + 1]); idepth[v] = mu[v]; }
+  for (int t = 0; t < T; ++t) tris[t] = flame::Triangle(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]);
+
+  const bool first = sensor->stats().stats("fps_max") <= 0.0f;  // missing key reads as <= 0
+  if (!first) return 12;
+  bool ok = sensor->updateGraph(0.0, 0, vtx, idepth, var, tris);
+  std::printf("update=%d hip_error=%d\n", ok ? 1 : 0, static_cast<int>(sensor->stats().stats("hip_error")));
+  if (!ok) return 3;
+
+  std::vector<flame::Point2f> ovtx;
+  std::vector<float> oid;
+  std::vector<flame::Vector3f> normals;
+  std::vector<flame::Triangle> otris;
+  std::vector<bool> validity;
+  std::vector<flame::Edge> edges;
+  sensor->getInverseDepthMesh(&ovtx, &oid, &normals, &otris, &validity, &edges);
+  std::vector<float> rmu, rvar;
+  sensor->getRawIDepths(&ovtx, &rmu, &rvar);
+  if (static_cast<int>(oid.size()) != V || static_cast<int>(validity.size()) != T) return 13;
+  const auto& st = sensor->stats().stats();
+  if (st.find("nltgv2_total_smoothness_cost") == st.end() || st.find("num_edges") == st.end()) return 14;
+
+  FILE* f = std::fopen(argv[2], "wb");
+  if (!f) return 15;
+  std::fwrite(oid.data(), 4, V, f);
+  for (int v = 0; v < V; ++v) { float n[3] = {normals[v](0), normals[v](1), normals[v](2)}; std::fwrite(n, 4, 3, f); }
+  for (int t = 0; t < T; ++t) { unsigned char b = validity[t] ? 1 : 0; std::fwrite(&b, 1, 1, f); }
+  std::fclose(f);
+  f = std::fopen(argv[3], "w");
+  if (!f) return 16;
+  std::fprintf(f, "%d %.17g %.17g %.17g %.17g\n", static_cast<int>(edges.size()),
+               sensor->stats().stats("nltgv2_total_smoothness_cost"),
+               sensor->stats().stats("nltgv2_total_data_cost"),
+               sensor->stats().stats("nltgv2_avg_smoothness_cost"),
+               sensor->stats().timings("update"));
+  std::fclose(f);
+  return 0;
+}
