@@ -159,6 +159,13 @@ class PartitionedSolver:
     def exchange(self):
         if self.world == 1 or not self.peers:
             return
+        ctx = getattr(self.solver, "stream_context", None)
+        if ctx is None:
+            return self._exchange()
+        with ctx():  # pack, P2P and unpack are all ordered on the solver's stream
+            return self._exchange()
+
+    def _exchange(self):
         dist = self.dist
         sbuf = self.solver.halo_pack()
         rbuf = sbuf.new_empty(8 * self.n_recv[0] + 4 * self.n_recv[1])
@@ -205,7 +212,7 @@ class HipSubdomainSolver:
     """The product local solver: one subdomain on one MI355X through libflame_hip.so.  Halo
     buffers are torch CUDA tensors; kernels and RCCL ops are ordered on torch's current stream."""
 
-    def __init__(self, sub, pos, edges, alpha, beta, z, wgt, x0, device=0, **options):
+    def __init__(self, sub, pos, edges, alpha, beta, z, wgt, x0, device=0, stream=None, **options):
         import ctypes as C
 
         import torch
@@ -214,12 +221,19 @@ class HipSubdomainSolver:
         from .regularizer import GraphRegularizer
         self._C, self._l, self.torch = C, _l, torch
         self.device = torch.device("cuda", device)
-        options.setdefault("use_graph", 0)  # solves run on torch's stream, not the handle's
+        # One explicit (non-default) torch stream orders everything: solver kernels, halo
+        # pack/unpack, torch copies and the RCCL P2P ops issued under stream_context().  (A NULL
+        # stream would mean "the handle's own stream" to the C ABI, unordered with torch.)
+        self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
+        options.setdefault("use_graph", 0)  # solves run on the torch stream, not the handle's
         self.reg = GraphRegularizer(pos, edges, alpha, beta, z, wgt, x0=x0, device=device, **options)
         self.n_send = self.n_recv = (0, 0)
 
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
     def _stream(self):
-        return self._C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return self._C.c_void_p(self.stream.cuda_stream)
 
     def halo_register(self, send_v, send_e, recv_v, recv_e):
         p = lambda a: a.ctypes.data_as(self._C.c_void_p)  # noqa: E731
@@ -229,8 +243,9 @@ class HipSubdomainSolver:
         self.n_send, self.n_recv = (len(send_v), len(send_e)), (len(recv_v), len(recv_e))
 
     def halo_pack(self):
-        buf = self.torch.empty(8 * self.n_send[0] + 4 * self.n_send[1], dtype=self.torch.float32,
-                               device=self.device)
+        with self.stream_context():
+            buf = self.torch.empty(8 * self.n_send[0] + 4 * self.n_send[1],
+                                   dtype=self.torch.float32, device=self.device)
         self._l.check(self.reg._lib.flame_hip_halo_pack(self.reg._h, self._C.c_void_p(buf.data_ptr()),
                                                         self._stream()), "flame_hip_halo_pack")
         return buf
@@ -244,7 +259,7 @@ class HipSubdomainSolver:
         self.reg.step(params, n, stream=self._stream(), sync=False)
 
     def download(self):
-        self.torch.cuda.current_stream(self.device).synchronize()
+        self.stream.synchronize()
         return self.reg.download()
 
 

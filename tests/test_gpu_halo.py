@@ -19,8 +19,10 @@ def test_subdomains_on_one_gpu(gpu, world, depth, iters):
     g = graphgen.synthetic(6000, seed=21)
     part = fdist.rcb_parts(g.pos, world)
     subs = [fdist.build_subdomain(g.pos, g.edges, part, r, depth) for r in range(world)]
+    shared = torch.cuda.Stream("cuda:0")  # one stream orders all subdomains and the copies below
     solvers = [fdist.HipSubdomainSolver(s, g.pos[s.vid], s.edges, g.alpha[s.eid], g.beta[s.eid],
-                                        g.z[s.vid], g.wgt[s.vid], None, device=0) for s in subs]
+                                        g.z[s.vid], g.wgt[s.vid], None, device=0, stream=shared)
+               for s in subs]
     # request lists, as PartitionedSolver builds them through all_gather_object
     send = {(o, r): ([], []) for o in range(world) for r in range(world)}
     for r, s in enumerate(subs):
@@ -66,16 +68,17 @@ def test_subdomains_on_one_gpu(gpu, world, depth, iters):
             break
         packed = [sv.halo_pack() for sv in solvers]
         for r in range(world):
-            peers = [o for o in range(world) if o != r]
-            recv_cnt = {o: offs[o][r] for o in peers}          # what o sends to r
-            rbuf = torch.empty(8 * sum(c[0] for c in recv_cnt.values()) + 4 * sum(c[1] for c in recv_cnt.values()),
-                               dtype=torch.float32, device="cuda:0")
-            rs = slices(recv_cnt, peers)
-            for o in peers:
-                ss = slices(offs[o], [q for q in range(world) if q != o])[r]
-                for (a, b), (c, d) in zip(ss, rs[o]):
-                    rbuf[c:d] = packed[o][a:b]
-            solvers[r].halo_unpack(rbuf)
+          with torch.cuda.stream(shared):
+              peers = [o for o in range(world) if o != r]
+              recv_cnt = {o: offs[o][r] for o in peers}          # what o sends to r
+              rbuf = torch.empty(8 * sum(c[0] for c in recv_cnt.values()) + 4 * sum(c[1] for c in recv_cnt.values()),
+                                 dtype=torch.float32, device="cuda:0")
+              rs = slices(recv_cnt, peers)
+              for o in peers:
+                  ss = slices(offs[o], [q for q in range(world) if q != o])[r]
+                  for (a, b), (c, d) in zip(ss, rs[o]):
+                      rbuf[c:d] = packed[o][a:b]
+              solvers[r].halo_unpack(rbuf)
     o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
     o.solve(oracle_params(), iters)
     for r, s in enumerate(subs):
