@@ -162,13 +162,20 @@ def main():
     frame_ms = None
     if not partition:
         ts = []
-        for _ in range(3):
+        import ctypes as C
+        rf = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris,
+                              device=local_rank, **opts)
+        pp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        for _ in range(4):  # one persistent handle, re-uploaded per frame (streaming use)
             t0f = time.perf_counter()
-            with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris,
-                                  device=local_rank, **opts) as rf:
-                rf.step(p, iters, sync=False)
-                rf.download(with_q=False)
+            rc = rf._lib.flame_hip_graph_upload(rf._h, pp(g.pos), pp(g.edges), pp(g.alpha), pp(g.beta),
+                                                pp(g.z), pp(g.wgt), None, pp(g.tris))
+            assert rc == 0, rc
+            rf.step(p, iters, sync=False)
+            rf.download(with_q=False)
             ts.append((time.perf_counter() - t0f) * 1e3)
+        rf.close()
+        ts = ts[1:]
         frame_ms = sorted(ts)[1]
 
     if rank == 0:
@@ -206,7 +213,7 @@ def main():
             out["host_inclusive"] = {"ms_per_frame": frame_ms, "frames_per_s": 1e3 / frame_ms,
                                      "iterations_per_s": iters * 1e3 / frame_ms,
                                      "note": "host arrays in -> plan build (CPU) + H2D + solve + D2H, "
-                                             "new handle per frame; informational, never `value`"}
+                                             "one handle re-uploaded per frame; informational, never `value`"}
         tr = profiled_traffic(args.workload, "k_tile" if path == 2 else "k_primal")
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
             out["roofline"]["traffic"] = tr["bytes_per_launch"]

@@ -4,6 +4,10 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../../include/flame_hip.h"
 
@@ -38,6 +42,36 @@ void rcb(const float* pos, std::vector<int32_t>& idx, int lo, int hi, int leaves
   rcb(pos, idx, mid, hi, l2, leaf_start);
 }
 
+// Same bisection, but the two halves of the top `par_levels` levels run on separate threads; each
+// half appends its leaves to its own list, concatenated in order (identical result).
+void rcb_par(const float* pos, std::vector<int32_t>& idx, int lo, int hi, int leaves,
+             std::vector<int32_t>* leaf_start, int par_levels) {
+  if (par_levels <= 0 || leaves <= 1 || hi - lo <= 4096) {
+    rcb(pos, idx, lo, hi, leaves, leaf_start);
+    return;
+  }
+  float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
+  for (int k = lo; k < hi; ++k)
+    for (int a = 0; a < 2; ++a) {
+      const float p = pos[2 * idx[k] + a];
+      mn[a] = std::min(mn[a], p);
+      mx[a] = std::max(mx[a], p);
+    }
+  const int axis = (mx[1] - mn[1] > mx[0] - mn[0]) ? 1 : 0;
+  const int l1 = leaves / 2, l2 = leaves - l1;
+  const int mid = lo + (int)(((int64_t)(hi - lo) * l1) / leaves);
+  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                   [&](int32_t a, int32_t b) {
+                     const float pa = pos[2 * a + axis], pb = pos[2 * b + axis];
+                     return pa < pb || (pa == pb && a < b);
+                   });
+  std::vector<int32_t> right;
+  std::thread th([&] { rcb_par(pos, idx, mid, hi, l2, &right, par_levels - 1); });
+  rcb_par(pos, idx, lo, mid, l1, leaf_start, par_levels - 1);
+  th.join();
+  leaf_start->insert(leaf_start->end(), right.begin(), right.end());
+}
+
 struct TileCfg { int nt, ept, vpt; };
 // instantiated kernel configurations (must match kernels.hip)
 const TileCfg kCfgs[] = {
@@ -67,7 +101,20 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
                const int32_t* edges, const float* alpha, const float* beta, const int32_t* tris,
                Plan* out) {
   Plan& P = *out;
-  P = Plan();
+  P.has_tiles = false;
+  P.tile_threads = P.tile_ept = P.tile_vpt = P.tile_depth = 0;
+  P.tile_lds_bytes = 0;
+  P.note.clear();
+  P.tiles.clear();
+  P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
+  const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[plan] %-14s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
   P.V = V; P.E = E; P.T = tris ? T : 0;
   for (int32_t e = 0; e < E; ++e) {
     const int32_t i = edges[2 * e], j = edges[2 * e + 1];
@@ -100,13 +147,14 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     std::vector<int32_t> idx(V);
     std::iota(idx.begin(), idx.end(), 0);
     std::vector<int32_t> leaf_start;
-    if (V > 0) rcb(pos, idx, 0, V, ntiles, &leaf_start);
+    if (V > 0) rcb_par(pos, idx, 0, V, ntiles, &leaf_start, opt.host_threads == 1 ? 0 : 3);
     leaf_start.push_back(V);
     // inside a tile the order is free (everything lives in LDS): sort by degree so the lanes of a
     // wave walk incidence lists of similar length
     for (int t = 0; t < ntiles; ++t)
       std::sort(idx.begin() + leaf_start[t], idx.begin() + leaf_start[t + 1],
                 [&](int32_t a, int32_t b) { return deg_o[a] != deg_o[b] ? deg_o[a] > deg_o[b] : a < b; });
+    lap("rcb+degsort");
     P.v_i2o = idx;
     P.v_o2i.assign(V, 0);
     for (int32_t k = 0; k < V; ++k) P.v_o2i[idx[k]] = k;
@@ -115,19 +163,19 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       for (int k = leaf_start[t]; k < leaf_start[t + 1]; ++k) tile_of[k] = t;
 
     // ---- edge order: (owner tile of the source, level 0 before level 1, original id) ----
+    // counting sort over the 2 * ntiles buckets; visiting e in ascending original id keeps each
+    // bucket in original order
     std::vector<int32_t> eorder(E);
-    std::iota(eorder.begin(), eorder.end(), 0);
-    auto ekey = [&](int32_t e) {
-      const int32_t i = P.v_o2i[edges[2 * e]], j = P.v_o2i[edges[2 * e + 1]];
-      const int64_t own = tile_of[i];
-      const int64_t lvl = (tile_of[j] == tile_of[i]) ? 0 : 1;
-      return (own << 33) | (lvl << 32) | (int64_t)e;
-    };
     {
-      std::vector<int64_t> keys(E);
-      for (int32_t e = 0; e < E; ++e) keys[e] = ekey(e);
-      std::sort(keys.begin(), keys.end());
-      for (int32_t k = 0; k < E; ++k) eorder[k] = (int32_t)(keys[k] & 0xffffffffll);
+      std::vector<int32_t>& cnt = P.b_fill;
+      cnt.assign(2 * (size_t)ntiles + 1, 0);
+      auto bucket = [&](int32_t e) {
+        const int32_t ti = tile_of[P.v_o2i[edges[2 * e]]], tj = tile_of[P.v_o2i[edges[2 * e + 1]]];
+        return 2 * ti + (ti == tj ? 0 : 1);
+      };
+      for (int32_t e = 0; e < E; ++e) cnt[bucket(e) + 1]++;
+      for (size_t b = 0; b + 1 < cnt.size(); ++b) cnt[b + 1] += cnt[b];
+      for (int32_t e = 0; e < E; ++e) eorder[cnt[bucket(e)]++] = e;
     }
     P.e_i2o = eorder;
     P.e_o2i.assign(E, 0);
@@ -140,6 +188,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       P.eij[k] = {P.v_o2i[io], P.v_o2i[jo]};
       P.ew[k] = {alpha[e], beta[e], pos[2 * io] - pos[2 * jo], pos[2 * io + 1] - pos[2 * jo + 1]};
     }
+    lap("edge order");
     // ---- incidence CSR, ascending ORIGINAL edge id per vertex ----
     P.grow.assign(V + 1, 0);
     for (int32_t e = 0; e < E; ++e) { P.grow[P.eij[e].x + 1]++; P.grow[P.eij[e].y + 1]++; }
@@ -153,6 +202,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         P.ginc[fill[P.eij[k].y]++] = k | (int32_t)0x80000000;
       }
     }
+    lap("csr");
     // ---- triangles ----
     P.tris.clear(); P.trow.clear(); P.tinc.clear();
     if (P.T > 0) {
@@ -168,10 +218,10 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     }
     if (opt.path == FLAME_HIP_PATH_GLOBAL) { P.note = "global path requested"; return 0; }
 
+    lap("triangles");
     // ---- tiles ----
     P.tiles.assign(ntiles, TileDesc());
     P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
-    std::vector<int32_t> stamp(V, -1), ring(V, 0), lidx(V, 0);
     int e_max = 0, upd_max = 0;
     int64_t lds_max = 0;
     bool ok = true;
@@ -180,127 +230,172 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     for (int32_t k = 0; k < E; ++k) estart[tile_of[P.eij[k].x] + 1]++;
     for (int t = 0; t < ntiles; ++t) estart[t + 1] += estart[t];
 
-    std::vector<int32_t> ext, frontier, next;
-    struct LE { int32_t level, notown, orig, k; };
-    std::vector<LE> les;
-    for (int t = 0; t < ntiles && ok; ++t) {
-      TileDesc& D = P.tiles[t];
-      D.vstart = leaf_start[t];
-      D.n_own = leaf_start[t + 1] - leaf_start[t];
-      D.depth = depth;
-      ext.clear();
-      frontier.clear();
-      for (int32_t v = D.vstart; v < D.vstart + D.n_own; ++v) {
-        stamp[v] = t; ring[v] = 0; lidx[v] = (int32_t)ext.size(); ext.push_back(v); frontier.push_back(v);
-      }
-      D.ring_end[0] = (int32_t)ext.size();
-      for (int r = 1; r <= kMaxDepth; ++r) {
-        if (r <= depth) {
-          next.clear();
-          for (int32_t v : frontier)
-            for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s) {
-              const int32_t k = P.ginc[s] & 0x7fffffff;
-              const int32_t u = (P.ginc[s] < 0) ? P.eij[k].x : P.eij[k].y;
-              if (stamp[u] != t) { stamp[u] = t; ring[u] = r; next.push_back(u); }
-            }
-          std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) {
-            const int32_t da = P.grow[a + 1] - P.grow[a], db = P.grow[b + 1] - P.grow[b];
-            return da != db ? da > db : a < b;
-          });
-          for (int32_t u : next) { lidx[u] = (int32_t)ext.size(); ext.push_back(u); }
-          frontier.swap(next);
+    // Tiles are independent: build them on a few host threads, each with its own scratch, then
+    // concatenate in tile order (so the result does not depend on the thread count).
+    typedef TileBuild TileOut;
+    std::vector<TileOut>& outs = P.tile_build;
+    if ((int)outs.size() < ntiles) outs.resize(ntiles);
+    for (int t = 0; t < ntiles; ++t) { outs[t].ok = true; outs[t].note = nullptr; }
+    const int nthreads = (int)std::min<int64_t>(opt.host_threads > 0 ? opt.host_threads : 8,
+                                                std::max(1, ntiles / 8));
+    if ((int)P.scratch.size() < nthreads) P.scratch.resize(nthreads);
+    auto build_range = [&](int tid_, int t0, int t1) {
+      ThreadScratch& S = P.scratch[tid_];
+      S.stamp.assign(V, -1); S.ring.resize(V); S.lidx.resize(V); S.estamp.assign(E, -1); S.eloc.resize(E);
+      std::vector<int32_t>&stamp = S.stamp, &ring = S.ring, &lidx = S.lidx, &estamp = S.estamp, &eloc = S.eloc;
+      std::vector<int32_t>&ext = S.ext, &frontier = S.frontier, &next = S.next, &lk = S.lk;
+      std::vector<uint64_t>& keys = S.keys;
+      std::vector<uint16_t>&slot_src = S.slot_src, &slot_dst = S.slot_dst;
+      for (int t = t0; t < t1; ++t) {
+        TileDesc& D = P.tiles[t];
+        TileOut& O = outs[t];
+        D.vstart = leaf_start[t];
+        D.n_own = leaf_start[t + 1] - leaf_start[t];
+        D.depth = depth;
+        ext.clear();
+        frontier.clear();
+        for (int32_t v = D.vstart; v < D.vstart + D.n_own; ++v) {
+          stamp[v] = t; ring[v] = 0; lidx[v] = (int32_t)ext.size(); ext.push_back(v); frontier.push_back(v);
         }
-        D.ring_end[r] = (int32_t)ext.size();
-      }
-      D.n_ext = (int32_t)ext.size();
-      // a tile whose halo swallowed nothing (isolated component) behaves like depth 0
-      D.n_upd = depth == 0 ? D.n_ext : D.ring_end[depth - 1];
-      if (D.n_ext > 65535) { ok = false; break; }
-      D.vmap_off = (int32_t)P.t_vmap.size();
-      for (int32_t k = 0; k < D.n_ext; ++k) P.t_vmap.push_back(ext[k]);
-      // local edges: visit each ext vertex's outgoing (source-role) incidences
-      les.clear();
-      for (int32_t lv = 0; lv < D.n_ext; ++lv) {
-        const int32_t v = ext[lv];
-        for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s) {
-          if (P.ginc[s] < 0) continue;  // v is the target; the source adds it
-          const int32_t k = P.ginc[s];
-          const int32_t u = P.eij[k].y;
-          if (stamp[u] != t) continue;
-          const int32_t lvl = std::max(ring[v], ring[u]);
-          if (depth > 0 && std::min(ring[v], ring[u]) >= depth) continue;  // feeds no updated vertex
-          les.push_back({lvl, ring[v] == 0 ? 0 : 1, P.e_i2o[k], k});
+        D.ring_end[0] = (int32_t)ext.size();
+        for (int r = 1; r <= kMaxDepth; ++r) {
+          if (r <= depth) {
+            next.clear();
+            for (int32_t v : frontier)
+              for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s) {
+                const int32_t k = P.ginc[s] & 0x7fffffff;
+                const int32_t u = (P.ginc[s] < 0) ? P.eij[k].x : P.eij[k].y;
+                if (stamp[u] != t) { stamp[u] = t; ring[u] = r; next.push_back(u); }
+              }
+            // inside a ring the order is free: by degree (lanes of a wave walk similar lists)
+            std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) {
+              const int32_t da = P.grow[a + 1] - P.grow[a], db = P.grow[b + 1] - P.grow[b];
+              return da != db ? da > db : a < b;
+            });
+            for (int32_t u : next) { lidx[u] = (int32_t)ext.size(); ext.push_back(u); }
+            frontier.swap(next);
+          }
+          D.ring_end[r] = (int32_t)ext.size();
         }
-      }
-      std::sort(les.begin(), les.end(), [](const LE& a, const LE& b) {
-        if (a.level != b.level) return a.level < b.level;
-        if (a.level <= 1 && a.notown != b.notown) return a.notown < b.notown;
-        return a.orig < b.orig;
-      });
-      D.e_loc = (int32_t)les.size();
-      D.estart = estart[t];
-      D.e_own = estart[t + 1] - estart[t];
-      // owned edges must be exactly the prefix and in internal order
-      for (int32_t le = 0; le < D.e_own; ++le)
-        if (le >= D.e_loc || les[le].k != D.estart + le) { ok = false; P.note = "edge order invariant"; }
-      if (!ok) break;
-      {
-        int32_t le = 0;
-        for (int l = 0; l <= kMaxDepth; ++l) {
-          while (le < D.e_loc && les[le].level <= l) ++le;
-          D.level_end[l] = le;
+        D.n_ext = (int32_t)ext.size();
+        D.n_upd = depth == 0 ? D.n_ext : D.ring_end[depth - 1];
+        if (D.n_ext > 65535) { O.ok = false; continue; }
+        O.vmap.assign(ext.begin(), ext.end());
+        // local edges: each ext vertex contributes its outgoing (source-role) incidences;
+        // sort key = (level, not-owned, original id) packed in 64 bits
+        keys.clear();
+        for (int32_t lv = 0; lv < D.n_ext; ++lv) {
+          const int32_t v = ext[lv];
+          for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s) {
+            if (P.ginc[s] < 0) continue;  // v is the target; the source adds it
+            const int32_t k = P.ginc[s];
+            const int32_t u = P.eij[k].y;
+            if (stamp[u] != t) continue;
+            const int32_t lvl = std::max(ring[v], ring[u]);
+            if (depth > 0 && std::min(ring[v], ring[u]) >= depth) continue;  // feeds no updated vertex
+            const uint64_t notown = (lvl <= 1 && ring[v] != 0) ? 1 : 0;
+            keys.push_back(((uint64_t)lvl << 40) | (notown << 39) | (uint64_t)(uint32_t)P.e_i2o[k]);
+          }
         }
-      }
-      D.emap_off = (int32_t)P.t_emap.size();
-      for (int32_t le = 0; le < D.e_loc; ++le) P.t_emap.push_back(les[le].k);
-      // incidence slots of updated vertices, ascending original edge id
-      D.srow_off = (int32_t)P.t_srow.size();
-      // slot assignment: walk updated vertices, their ginc lists are already in original order
-      std::vector<uint16_t> slot_src(D.e_loc, 0xffff), slot_dst(D.e_loc, 0xffff);
-      {
-        // map internal edge id -> local id through a small sorted table
-        std::vector<std::pair<int32_t, int32_t>> tab(D.e_loc);
-        for (int32_t le = 0; le < D.e_loc; ++le) tab[le] = {les[le].k, le};
-        std::sort(tab.begin(), tab.end());
+        std::sort(keys.begin(), keys.end());
+        D.e_loc = (int32_t)keys.size();
+        D.estart = estart[t];
+        D.e_own = estart[t + 1] - estart[t];
+        lk.resize(D.e_loc);
+        for (int32_t le = 0; le < D.e_loc; ++le) {
+          const int32_t k = P.e_o2i[(int32_t)(keys[le] & 0xffffffffu)];
+          lk[le] = k;
+          estamp[k] = t;
+          eloc[k] = le;
+        }
+        // owned edges must be exactly the prefix and in internal order
+        for (int32_t le = 0; le < D.e_own; ++le)
+          if (le >= D.e_loc || lk[le] != D.estart + le) { O.ok = false; O.note = "edge order invariant"; }
+        if (!O.ok) continue;
+        {
+          int32_t le = 0;
+          for (int l = 0; l <= kMaxDepth; ++l) {
+            while (le < D.e_loc && (int)(keys[le] >> 40) <= l) ++le;
+            D.level_end[l] = le;
+          }
+        }
+        O.emap.assign(lk.begin(), lk.end());
         // Transposed incidence slots: the 64 vertices a wave updates together form a group; the
         // j-th incidence of lane l lives at base + 64 j + l, so phase P reads are conflict-free.
+        // Within a vertex the incidences keep ascending original edge id (ginc order).
+        slot_src.assign(D.e_loc, 0xffff);
+        slot_dst.assign(D.e_loc, 0xffff);
+        O.srow.clear();
         int32_t base = 0;
-        for (int32_t g0 = 0; g0 < D.n_upd && ok; g0 += 64) {
+        for (int32_t g0 = 0; g0 < D.n_upd && O.ok; g0 += 64) {
           const int32_t g1 = std::min(g0 + 64, D.n_upd);
           int32_t width = 0;
           for (int32_t lv = g0; lv < g1; ++lv) width = std::max(width, P.grow[ext[lv] + 1] - P.grow[ext[lv]]);
-          if (base + 64 * width + kDummySlots > 65535) { ok = false; break; }
-          for (int32_t lv = g0; lv < g1; ++lv) {
+          if (base + 64 * width + kDummySlots > 65535) { O.ok = false; break; }
+          for (int32_t lv = g0; lv < g1 && O.ok; ++lv) {
             const int32_t v = ext[lv];
             const int32_t deg = P.grow[v + 1] - P.grow[v];
             const int32_t s0 = base + (lv - g0);
-            P.t_srow.push_back((uint32_t)s0 | ((uint32_t)deg << 16));
+            O.srow.push_back((uint32_t)s0 | ((uint32_t)deg << 16));
             int32_t j = 0;
             for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s, ++j) {
               const int32_t k = P.ginc[s] & 0x7fffffff;
-              auto it = std::lower_bound(tab.begin(), tab.end(), std::make_pair(k, (int32_t)-1));
-              if (it == tab.end() || it->first != k) { ok = false; P.note = "halo closure invariant"; break; }
+              if (estamp[k] != t) { O.ok = false; O.note = "halo closure invariant"; break; }
               const uint16_t slot = (uint16_t)(s0 + 64 * j);
-              if (P.ginc[s] < 0) slot_dst[it->second] = slot; else slot_src[it->second] = slot;
+              if (P.ginc[s] < 0) slot_dst[eloc[k]] = slot; else slot_src[eloc[k]] = slot;
             }
-            if (!ok) break;
           }
           base += 64 * width;
         }
         D.nslots = base;
+        if (!O.ok) continue;
+        O.eij.resize(D.e_loc);
+        O.ew.resize(D.e_loc);
+        for (int32_t le = 0; le < D.e_loc; ++le) {
+          const int32_t k = lk[le];
+          const uint32_t li = (uint32_t)lidx[P.eij[k].x], lj = (uint32_t)lidx[P.eij[k].y];
+          O.eij[le] = {li | (lj << 16), (uint32_t)slot_src[le] | ((uint32_t)slot_dst[le] << 16)};
+          O.ew[le] = P.ew[k];
+        }
       }
-      if (!ok) break;
-      D.erec_off = (int32_t)P.t_eij.size();
-      for (int32_t le = 0; le < D.e_loc; ++le) {
-        const int32_t k = les[le].k;
-        const uint32_t li = (uint32_t)lidx[P.eij[k].x], lj = (uint32_t)lidx[P.eij[k].y];
-        P.t_eij.push_back({li | (lj << 16), (uint32_t)slot_src[le] | ((uint32_t)slot_dst[le] << 16)});
-        P.t_ew.push_back(P.ew[k]);
-      }
-      e_max = std::max(e_max, D.e_loc);
-      upd_max = std::max(upd_max, D.n_ext);  // every local vertex gets a register slot
-      lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots) * 12);
+    };
+    lap("tiles setup");
+    if (nthreads <= 1) {
+      build_range(0, 0, ntiles);
+    } else {
+      std::vector<std::thread> th;
+      for (int i = 0; i < nthreads; ++i)
+        th.emplace_back(build_range, i, (int)((int64_t)ntiles * i / nthreads),
+                        (int)((int64_t)ntiles * (i + 1) / nthreads));
+      for (auto& x : th) x.join();
     }
+    lap("tiles(par)");
+    {
+      size_t nv = 0, ne = 0, ns = 0;
+      for (int t = 0; t < ntiles && ok; ++t) {
+        TileDesc& D = P.tiles[t];
+        TileOut& O = outs[t];
+        if (!O.ok) { ok = false; if (O.note) P.note = O.note; break; }
+        D.vmap_off = (int32_t)nv; D.emap_off = (int32_t)ne; D.erec_off = (int32_t)ne; D.srow_off = (int32_t)ns;
+        nv += O.vmap.size(); ne += O.emap.size(); ns += O.srow.size();
+        e_max = std::max(e_max, D.e_loc);
+        upd_max = std::max(upd_max, D.n_ext);  // every local vertex gets a register slot
+        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots) * 12);
+      }
+      if (ok) {
+        P.t_vmap.resize(nv); P.t_emap.resize(ne); P.t_eij.resize(ne); P.t_ew.resize(ne); P.t_srow.resize(ns);
+        for (int t = 0; t < ntiles; ++t) {
+          const TileDesc& D = P.tiles[t];
+          const TileOut& O = outs[t];
+          std::copy(O.vmap.begin(), O.vmap.end(), P.t_vmap.begin() + D.vmap_off);
+          std::copy(O.emap.begin(), O.emap.end(), P.t_emap.begin() + D.emap_off);
+          std::copy(O.eij.begin(), O.eij.end(), P.t_eij.begin() + D.erec_off);
+          std::copy(O.ew.begin(), O.ew.end(), P.t_ew.begin() + D.erec_off);
+          std::copy(O.srow.begin(), O.srow.end(), P.t_srow.begin() + D.srow_off);
+        }
+      }
+    }
+    lap("concat");
     TileCfg cfg{};
     if (ok && lds_max > lds_cap) ok = false;
     if (ok && !pick_cfg(opt.tile_threads, e_max, upd_max, &cfg)) ok = false;

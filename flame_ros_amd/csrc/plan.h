@@ -19,11 +19,28 @@ struct PlanOptions {
   int tile_depth = 0;    // halo depth (0 = auto)
   int tile_threads = 0;  // workgroup size (0 = auto)
   int64_t lds_bytes = 160 * 1024;
+  int host_threads = 0;  // plan-build threads (0 = up to 8)
 };
 
 struct Float4 { float x, y, z, w; };
 struct Int2 { int32_t x, y; };
 struct UInt2 { uint32_t x, y; };
+
+// Per-tile and per-thread build buffers.  They live in the Plan so that a handle re-uploaded every
+// frame keeps their capacity (no page faults / allocator traffic after the first frame).
+struct TileBuild {
+  std::vector<int32_t> vmap, emap;
+  std::vector<UInt2> eij;
+  std::vector<Float4> ew;
+  std::vector<uint32_t> srow;
+  bool ok = true;
+  const char* note = nullptr;
+};
+struct ThreadScratch {
+  std::vector<int32_t> stamp, ring, lidx, estamp, eloc, ext, frontier, next, lk;
+  std::vector<uint64_t> keys;
+  std::vector<uint16_t> slot_src, slot_dst;
+};
 
 struct Plan {
   int32_t V = 0, E = 0, T = 0;
@@ -46,6 +63,11 @@ struct Plan {
   std::vector<Float4> t_ew;
   std::vector<uint32_t> t_srow;
   std::string note;  // why the tile path was not built, if so
+  // build buffers (persistent capacity)
+  std::vector<TileBuild> tile_build;
+  std::vector<ThreadScratch> scratch;
+  std::vector<int32_t> b_idx, b_leaf, b_tile_of, b_deg, b_estart, b_fill;
+  std::vector<int64_t> b_keys;
 };
 
 // Builds the plan.  Returns 0 or a FLAME_HIP_ERR_* code (bad indices).
