@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_primal(int32_t V, const int32_t* __rest
 // Tile path.  One workgroup = one subdomain (own vertices + depth-D halo) resident in LDS and
 // registers for `iters` PD iterations; see common.h TileDesc and DESIGN.md.
 //   registers : per-thread EPT edges {ids, slots, alpha, beta, dx, dy, q1..3}, VPT vertices
-//   LDS       : bar[n_ext] float4 {xb,w1b,w2b,-}; c0/c1/c2[nslots] per-incidence -K^T q terms
+//   LDS       : bar[n_ext] float4 {xb,w1b,w2b,-}; cs[nslots] float4 per-incidence -K^T q terms
 // Phase D (edge threads) gathers bar[] of both endpoints, ascends q, scatters the two endpoint
 // contributions into the endpoints' incidence slots; phase P (vertex threads) sums its slots in
 // slot order (= ascending original edge id => deterministic and oracle-exact), prox,
@@ -120,7 +120,7 @@ __device__ __forceinline__ int wave_max(int v) {
 
 // Phase D on the first K of this thread's edges: every gather is issued before the first use.
 template <int K, int EPT>
-__device__ __forceinline__ void tile_phase_d(const float4* bar, float* c0, float* c1, float* c2,
+__device__ __forceinline__ void tile_phase_d(const float4* bar, float4* cs,
                                              const uint32_t (&eij)[EPT], const uint32_t (&ess)[EPT],
                                              const uint32_t (&esd)[EPT], const float4 (&ew)[EPT],
                                              float (&q1)[EPT], float (&q2)[EPT], float (&q3)[EPT],
@@ -135,30 +135,27 @@ __device__ __forceinline__ void tile_phase_d(const float4* bar, float* c0, float
   for (int k = 0; k < K; ++k) {
     dual_edge(bi[k], bj[k], ew[k], sigma, q1[k], q2[k], q3[k]);
     const float aq = ew[k].x * q1[k], b2 = ew[k].y * q2[k], b3 = ew[k].y * q3[k];
-    c0[ess[k]] = aq;
-    c1[ess[k]] = fmaf(-ew[k].z, aq, b2);
-    c2[ess[k]] = fmaf(-ew[k].w, aq, b3);
-    c0[esd[k]] = -aq;
-    c1[esd[k]] = -b2;
-    c2[esd[k]] = -b3;
+    // one 16-byte store per endpoint (ds_write_b128) instead of three scattered dwords
+    cs[ess[k]] = make_float4(aq, fmaf(-ew[k].z, aq, b2), fmaf(-ew[k].w, aq, b3), 0.0f);
+    cs[esd[k]] = make_float4(-aq, -b2, -b3, 0.0f);
   }
 }
 
 // nk (number of active edge blocks) is wave-uniform: dispatch to the matching unrolled body
 template <int K, int EPT>
 struct PhaseD {
-  static __device__ __forceinline__ void run(int nk, const float4* bar, float* c0, float* c1,
-                                             float* c2, const uint32_t (&eij)[EPT],
+  static __device__ __forceinline__ void run(int nk, const float4* bar, float4* cs,
+                                             const uint32_t (&eij)[EPT],
                                              const uint32_t (&ess)[EPT], const uint32_t (&esd)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
                                              float (&q2)[EPT], float (&q3)[EPT], float sigma) {
-    if (nk == K) tile_phase_d<K, EPT>(bar, c0, c1, c2, eij, ess, esd, ew, q1, q2, q3, sigma);
-    else PhaseD<K - 1, EPT>::run(nk, bar, c0, c1, c2, eij, ess, esd, ew, q1, q2, q3, sigma);
+    if (nk == K) tile_phase_d<K, EPT>(bar, cs, eij, ess, esd, ew, q1, q2, q3, sigma);
+    else PhaseD<K - 1, EPT>::run(nk, bar, cs, eij, ess, esd, ew, q1, q2, q3, sigma);
   }
 };
 template <int EPT>
 struct PhaseD<0, EPT> {
-  static __device__ __forceinline__ void run(int, const float4*, float*, float*, float*,
+  static __device__ __forceinline__ void run(int, const float4*, float4*,
                                              const uint32_t (&)[EPT], const uint32_t (&)[EPT],
                                              const uint32_t (&)[EPT], const float4 (&)[EPT],
                                              float (&)[EPT], float (&)[EPT], float (&)[EPT], float) {}
@@ -173,11 +170,8 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   const int n_own = D.n_own, n_ext = D.n_ext, n_upd = D.n_upd;
   const int e_own = D.e_own, e_loc = D.e_loc, depth = D.depth;
   if (n_ext == 0) return;  // empty tile (more tiles than vertices)
-  const int cstride = D.nslots + kDummySlots;
   float4* bar = reinterpret_cast<float4*>(smem);
-  float* c0 = reinterpret_cast<float*>(smem + (size_t)n_ext * 16);
-  float* c1 = c0 + cstride;
-  float* c2 = c1 + cstride;
+  float4* cs = bar + n_ext;  // D.nslots + kDummySlots incidence slots
   const int lane = tid & 63;
   const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
   const uint32_t dummy = (uint32_t)(D.nslots + lane);  // per-lane trash slot: inert writes/reads
@@ -256,7 +250,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     // wave-uniform: this wave's k-th edge block covers local edges [k NT + wbase, +64)
     const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
     // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
-    PhaseD<EPT, EPT>::run(nk, bar, c0, c1, c2, eij, ess, esd, ew, q1, q2, q3, sigma);
+    PhaseD<EPT, EPT>::run(nk, bar, cs, eij, ess, esd, ew, q1, q2, q3, sigma);
     __syncthreads();
     if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it] = __builtin_readcyclecounter();
     // ---- phase P: primal descent (slot order = ascending original edge id), prox, extra-grad ----
@@ -270,18 +264,15 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
         // transposed slots: incidence j of this lane is at sb + 64 j (conflict-free across lanes);
         // the group is padded to the wave's max degree, so reads past deg stay in bounds
         for (int j = 0; j < wdeg[k]; j += 4) {  // wave-uniform trip count
-          float t0[4], t1[4], t2[4];
+          float4 t[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int s = sb + 64 * min(j + u, wdeg[k] - 1);
-            t0[u] = c0[s]; t1[u] = c1[s]; t2[u] = c2[s];
-          }
+          for (int u = 0; u < 4; ++u) t[u] = lds_read4(cs + sb + 64 * min(j + u, wdeg[k] - 1));
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const bool on = (j + u) < deg;
-            x = on ? fmaf(ntau, t0[u], x) : x;
-            w1 = on ? fmaf(ntau, t1[u], w1) : w1;
-            w2 = on ? fmaf(ntau, t2[u], w2) : w2;
+            x = on ? fmaf(ntau, t[u].x, x) : x;
+            w1 = on ? fmaf(ntau, t[u].y, w1) : w1;
+            w2 = on ? fmaf(ntau, t[u].z, w2) : w2;
           }
         }
         x = prox_l1(x, vz[k], vt[k], x_min, x_max);

@@ -127,7 +127,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   // ---- tile sizing ----
   const int64_t lds_cap = opt.lds_bytes;
   // an isolated single tile holds the whole graph when it fits the largest kernel config
-  const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 24) <= lds_cap;
+  const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 32) <= lds_cap;
   // Auto sizing (measured on MI355X, DESIGN.md "Tile sizing"): one tile per CU when the graph
   // allows it (256 CUs), never below 32 own vertices (halo overhead) or above 196 (LDS / threads);
   // when there are more tiles than CUs prefer the shallower halo whose tiles co-reside on a CU.
@@ -380,7 +380,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         nv += O.vmap.size(); ne += O.emap.size(); ns += O.srow.size();
         e_max = std::max(e_max, D.e_loc);
         upd_max = std::max(upd_max, D.n_ext);  // every local vertex gets a register slot
-        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots) * 12);
+        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots) * 16);
       }
       if (ok) {
         P.t_vmap.resize(nv); P.t_emap.resize(ne); P.t_eij.resize(ne); P.t_ew.resize(ne); P.t_srow.resize(ns);
