@@ -97,6 +97,19 @@ class COracle:
             raise MemoryError("nltgv2_solve")
         return self.x
 
+    def solve_threads(self, params, num_iters, num_threads):
+        """OpenMP variant (bit-identical to solve); used by bench.py's threaded cpu_baseline legs."""
+        if not hasattr(self, "_row"):
+            self._row = np.empty(self.V + 1, np.int32)
+            self._inc = np.empty(2 * self.E, np.int32)
+            g = self._g()
+            _load().nltgv2_build_incidence(C.byref(g), self._row.ctypes.data_as(C.c_void_p),
+                                           self._inc.ctypes.data_as(C.c_void_p))
+        g = self._g()
+        _load().nltgv2_solve_omp(C.byref(params), C.byref(g), self._row.ctypes.data_as(C.c_void_p),
+                                 self._inc.ctypes.data_as(C.c_void_p), int(num_iters), int(num_threads))
+        return self.x
+
     def dual_step(self, params):
         g = self._g()
         _load().nltgv2_dual_step(C.byref(params), C.byref(g))

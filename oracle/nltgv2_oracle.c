@@ -258,3 +258,78 @@ void nltgv2_triangles(const nltgv2_tri_params* tp, const float Kinv[9], int32_t 
     }
   }
 }
+
+/* ---- multi-threaded CPU variant (for the cpu_baseline legs (ii)/(iii) of BASELINE.md only):
+ * edge-parallel dual + vertex-parallel CSR primal under OpenMP, the shape the reference's own
+ * OpenMP loops have (reference cfg/flame_offline_tum.yaml:70-71: 4 threads, chunk 1024).  Same
+ * arithmetic and the same per-vertex summation order as the sequential functions above, so its
+ * result is bit-identical; `inc` lists, per vertex, the incident edges in ascending edge id with
+ * bit 31 set when the vertex is the target (built by nltgv2_build_incidence). ---- */
+void nltgv2_build_incidence(const nltgv2_graph* g, int32_t* row /* V+1 */, int32_t* inc /* 2E */) {
+  memset(row, 0, sizeof(int32_t) * ((size_t)g->V + 1));
+  for (int32_t e = 0; e < g->E; ++e) { row[g->edges[2 * e] + 1]++; row[g->edges[2 * e + 1] + 1]++; }
+  for (int32_t v = 0; v < g->V; ++v) row[v + 1] += row[v];
+  int32_t* fill = (int32_t*)malloc(sizeof(int32_t) * (size_t)(g->V > 0 ? g->V : 1));
+  memcpy(fill, row, sizeof(int32_t) * (size_t)g->V);
+  for (int32_t e = 0; e < g->E; ++e) {
+    inc[fill[g->edges[2 * e]]++] = e;
+    inc[fill[g->edges[2 * e + 1]]++] = e | (int32_t)0x80000000;
+  }
+  free(fill);
+}
+
+int nltgv2_solve_omp(const nltgv2_params* p, nltgv2_graph* g, const int32_t* row,
+                     const int32_t* inc, int num_iters, int num_threads) {
+  const float sigma = p->step_q, tau = p->step_x, th = p->theta, tl = p->step_x * p->data_factor;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(num_threads)
+#endif
+  for (int it = 0; it < num_iters; ++it) {
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int32_t e = 0; e < g->E; ++e) {
+      const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+      const float dx = g->pos[2 * i] - g->pos[2 * j], dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+      float t = g->xb[i] - g->xb[j];
+      t = fmaf(-g->w1b[i], dx, t);
+      t = fmaf(-g->w2b[i], dy, t);
+      float* q = g->q + 3 * e;
+      q[0] = proj_unit(fmaf(sigma, g->alpha[e] * t, q[0]));
+      q[1] = proj_unit(fmaf(sigma, g->beta[e] * (g->w1b[i] - g->w1b[j]), q[1]));
+      q[2] = proj_unit(fmaf(sigma, g->beta[e] * (g->w2b[i] - g->w2b[j]), q[2]));
+    }
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int32_t v = 0; v < g->V; ++v) {
+      const float xp = g->x[v], w1p = g->w1[v], w2p = g->w2[v];
+      float x = xp, w1 = w1p, w2 = w2p;
+      for (int32_t s = row[v]; s < row[v + 1]; ++s) {
+        const int32_t e = inc[s] & 0x7fffffff;
+        const int32_t i = g->edges[2 * e], j = g->edges[2 * e + 1];
+        const float dx = g->pos[2 * i] - g->pos[2 * j], dy = g->pos[2 * i + 1] - g->pos[2 * j + 1];
+        const float* q = g->q + 3 * e;
+        const float aq = g->alpha[e] * q[0], b2 = g->beta[e] * q[1], b3 = g->beta[e] * q[2];
+        if (inc[s] >= 0) {
+          x = fmaf(-tau, aq, x);
+          w1 = fmaf(-tau, fmaf(-dx, aq, b2), w1);
+          w2 = fmaf(-tau, fmaf(-dy, aq, b3), w2);
+        } else {
+          x = fmaf(-tau, -aq, x);
+          w1 = fmaf(-tau, -b2, w1);
+          w2 = fmaf(-tau, -b3, w2);
+        }
+      }
+      const float t = tl * g->wgt[v], z = g->z[v], r = x - z;
+      float xn = (r > t) ? (x - t) : ((r < -t) ? (x + t) : z);
+      xn = fminf(fmaxf(xn, p->x_min), p->x_max);
+      g->x[v] = xn; g->w1[v] = w1; g->w2[v] = w2;
+      g->xb[v] = fmaf(th, xn - xp, xn);
+      g->w1b[v] = fmaf(th, w1 - w1p, w1);
+      g->w2b[v] = fmaf(th, w2 - w2p, w2);
+    }
+  }
+  (void)num_threads;
+  return 0;
+}

@@ -68,6 +68,12 @@ void nltgv2_apply_K(const nltgv2_graph* g, const float* x, const float* w1, cons
                     float* Ku);
 void nltgv2_apply_KT(const nltgv2_graph* g, const float* q, float* kx, float* kw1, float* kw2);
 
+/* Multi-threaded variant for the threaded cpu_baseline legs:
+ * bit-identical to nltgv2_solve.  row V+1 / inc 2E from nltgv2_build_incidence. */
+void nltgv2_build_incidence(const nltgv2_graph* g, int32_t* row, int32_t* inc);
+int nltgv2_solve_omp(const nltgv2_params* p, nltgv2_graph* g, const int32_t* row,
+                     const int32_t* inc, int num_iters, int num_threads);
+
 /* ---- per-triangle stage ---- */
 typedef struct {
   int32_t do_oblique_triangle_filter; /* cfg/flame_offline_tum.yaml:40 */

@@ -214,6 +214,18 @@ def test_step_is_dual_primal_extragradient(g5k):
     assert_bit_equal(o1.q, o2.q, "q")
 
 
+def test_threaded_variant_is_bit_identical(g5k):
+    """The OpenMP baseline variant (edge-parallel dual + CSR primal) equals the sequential step."""
+    o1, o2 = orc(g5k), orc(g5k)
+    st = random_state(g5k, 11)
+    for o in (o1, o2):
+        o.set_state(**st)
+    o1.solve(default_params(), 25)
+    o2.solve_threads(default_params(), 25, 3)
+    for a in ("x", "w1", "w2", "xb", "w1b", "w2b", "q"):
+        assert_bit_equal(getattr(o2, a), getattr(o1, a), a)
+
+
 def test_edge_cases():
     p = default_params()
     o = COracle(np.zeros((0, 2)), np.zeros((0, 2), np.int32), [], [], [], [])
