@@ -93,6 +93,10 @@ def main():
                     help="N>1: independent frames per GPU (default) or ONE graph cut into N "
                          "subdomains with RCCL halo exchange")
     ap.add_argument("--halo-depth", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames axis: B independent feature-grid graphs (640x480, one feature per "
+                         "--batch-win cell) per step in ONE handle, one LDS tile per frame")
+    ap.add_argument("--batch-win", type=int, default=16)
     args = ap.parse_args()
 
     import torch
@@ -109,7 +113,16 @@ def main():
     from flame_ros_amd.regularizer import GraphRegularizer, default_params
 
     partition = args.mode == "partition" and world > 1
-    g, cfg_iters = graphgen.named(args.workload, seed=0 if partition else rank)
+    if args.batch:
+        frames = [graphgen.dataset_shaped(640, 480, args.batch_win, seed=1000 * rank + b)
+                  for b in range(args.batch)]
+
+        class _G:  # concatenated view, for the byte/size accounting below
+            V = sum(f.V for f in frames)
+            E = sum(f.E for f in frames)
+        g, cfg_iters = _G, 200
+    else:
+        g, cfg_iters = graphgen.named(args.workload, seed=0 if partition else rank)
     iters = args.iters or cfg_iters
     opts = {}
     if args.path: opts["path"] = args.path
@@ -136,6 +149,8 @@ def main():
             def info(self, k):
                 return ps.solver.reg.info(k)
         r = _R()
+    elif args.batch:
+        r = GraphRegularizer.from_batch(frames, device=local_rank, **opts)
     else:
         r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris,
                              device=local_rank, **opts)
@@ -177,7 +192,7 @@ def main():
     # PCIe-inclusive frame rate (never `value`): host graph in -> plan build + H2D -> iterations
     # -> D2H of x and the triangle stage, a fresh handle per frame as a real frame stream would do
     frame_ms = None
-    if not partition:
+    if not partition and not args.batch:
         ts = []
         import ctypes as C
         rf = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris,
@@ -196,7 +211,8 @@ def main():
         frame_ms = sorted(ts)[1]
 
     if rank == 0:
-        total_iters = (1 if partition else world) * args.steps * iters
+        nfr = max(args.batch, 1)
+        total_iters = (1 if partition else world) * args.steps * iters * nfr
         alg_bytes_iter = 84 * g.E + 60 * g.V
         path = r.info("path")
         iters_per_launch = iters / max(launches, 1)
@@ -214,7 +230,7 @@ def main():
                        "path": {1: "global", 2: "tile"}[path], "num_tiles": r.info("num_tiles"),
                        "tile_depth": r.info("tile_depth"), "tile_threads": r.info("tile_threads"),
                        "hipgraph": not args.no_graph},
-            "frames_per_s": (1 if partition else world) * args.steps / elapsed,
+            "frames_per_s": (1 if partition else world) * args.steps * nfr / elapsed,
             "us_per_iteration": elapsed / (args.steps * iters) * 1e6,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -235,8 +251,14 @@ def main():
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
+        if args.batch:
+            out["metric"] = "primal-dual iterations/sec over a batch of %d independent %d-vertex graphs" % (
+                args.batch, frames[0].V)
+            out["config"]["workload"] = "batch of %d feature-grid graphs (640x480, win %d), %d PD iterations each" % (
+                args.batch, args.batch_win, iters)
+            out["roofline"]["note"] += " Batch mode: value counts frame-iterations."
         if not args.no_cpu:
-            cb = cpu_baseline(g, iters, args.cpu_budget)
+            cb = cpu_baseline(frames[0] if args.batch else g, iters, args.cpu_budget)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1thread"] = out["value"] / (1 if partition else world) / cb["value"]
         print(json.dumps(out))

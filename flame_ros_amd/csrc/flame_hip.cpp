@@ -246,6 +246,20 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   return 0;
 }
 
+int flame_hip_graph_upload_batch(flame_hip_graph* g, int32_t num_graphs, const int32_t* voff,
+                                 const float* pos, const int32_t* edges, const float* alpha,
+                                 const float* beta, const float* z, const float* wgt,
+                                 const float* x0, const int32_t* tris) {
+  if (!g || num_graphs < 1 || !voff) return FLAME_HIP_ERR_ARG;
+  g->opt.batch_voff.assign(voff, voff + num_graphs + 1);
+  const int saved_path = g->opt.path;
+  g->opt.path = FLAME_HIP_PATH_TILE;
+  int rc = flame_hip_graph_upload(g, pos, edges, alpha, beta, z, wgt, x0, tris);
+  g->opt.path = saved_path;
+  g->opt.batch_voff.clear();
+  return rc;
+}
+
 int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* edges,
                            const float* alpha, const float* beta, const float* z,
                            const float* wgt, const float* x0, const int32_t* tris) {

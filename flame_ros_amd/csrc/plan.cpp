@@ -137,17 +137,32 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
   bool single = (opt.tile_own <= 0 || opt.tile_own >= V) && single_fits;
   if (single) { tile_own = std::max(V, 1); depth = 0; }
+  const bool batch = !opt.batch_voff.empty();
+  if (batch) {  // every graph of the batch is one isolated tile; edges must not cross graphs
+    const std::vector<int32_t>& vo = opt.batch_voff;
+    if (vo.front() != 0 || vo.back() != V) return FLAME_HIP_ERR_ARG;
+    for (size_t b = 0; b + 1 < vo.size(); ++b)
+      if (vo[b + 1] < vo[b]) return FLAME_HIP_ERR_ARG;
+    for (int32_t e = 0; e < E; ++e) {
+      const int32_t i = edges[2 * e], j = edges[2 * e + 1];
+      const size_t b = std::upper_bound(vo.begin(), vo.end(), i) - vo.begin() - 1;
+      if (j < vo[b] || j >= vo[b + 1]) return FLAME_HIP_ERR_ARG;
+    }
+    single = false;
+    depth = 0;
+  }
 
   std::vector<int32_t> deg_o(V, 0);
   for (int32_t e = 0; e < E; ++e) { deg_o[edges[2 * e]]++; deg_o[edges[2 * e + 1]]++; }
 
-  for (int attempt = 0; attempt < 6; ++attempt) {
-    const int ntiles = V == 0 ? 0 : (V + tile_own - 1) / tile_own;
+  for (int attempt = 0; attempt < (batch ? 1 : 6); ++attempt) {
+    const int ntiles = batch ? (int)opt.batch_voff.size() - 1 : (V == 0 ? 0 : (V + tile_own - 1) / tile_own);
     // ---- vertex order: RCB leaves = tiles ----
     std::vector<int32_t> idx(V);
     std::iota(idx.begin(), idx.end(), 0);
     std::vector<int32_t> leaf_start;
-    if (V > 0) rcb_par(pos, idx, 0, V, ntiles, &leaf_start, opt.host_threads == 1 ? 0 : 3);
+    if (batch) leaf_start.assign(opt.batch_voff.begin(), opt.batch_voff.end() - 1);
+    else if (V > 0) rcb_par(pos, idx, 0, V, ntiles, &leaf_start, opt.host_threads == 1 ? 0 : 3);
     leaf_start.push_back(V);
     // inside a tile the order is free (everything lives in LDS): sort by degree so the lanes of a
     // wave walk incidence lists of similar length

@@ -34,7 +34,23 @@ def _ptr(a):
 class GraphRegularizer:
     """One Delaunay vertex graph resident on one GPU (a `flame_hip_graph` handle)."""
 
-    def __init__(self, pos, edges, alpha, beta, z, wgt, x0=None, tris=None, device=0, **options):
+    @classmethod
+    def from_batch(cls, graphs, device=0, **options):
+        """Frames axis: independent graphs (objects with pos/edges/alpha/beta/z/wgt/tris) in ONE
+        handle, one LDS tile (= one workgroup) per graph, all iterations in one launch."""
+        voff = np.zeros(len(graphs) + 1, np.int32)
+        voff[1:] = np.cumsum([len(g.z) for g in graphs])
+        toff = np.cumsum([0] + [len(g.tris) for g in graphs])
+        cat = lambda name: np.concatenate([np.asarray(getattr(g, name)) for g in graphs])  # noqa: E731
+        edges = np.concatenate([np.asarray(g.edges, np.int32) + voff[b] for b, g in enumerate(graphs)])
+        tris = np.concatenate([np.asarray(g.tris, np.int32) + voff[b] for b, g in enumerate(graphs)])
+        self = cls(cat("pos"), edges, cat("alpha"), cat("beta"), cat("z"), cat("wgt"), tris=tris,
+                   device=device, _batch_voff=voff, **options)
+        self.voff, self.toff = voff, toff
+        return self
+
+    def __init__(self, pos, edges, alpha, beta, z, wgt, x0=None, tris=None, device=0,
+                 _batch_voff=None, **options):
         self._lib = _l.load()
         self._h = C.c_void_p()
         pos = _f32(pos).reshape(-1, 2)
@@ -54,9 +70,15 @@ class GraphRegularizer:
             for k, v in options.items():
                 _l.check(self._lib.flame_hip_set_option(self._h, k.encode(), int(v)),
                          "flame_hip_set_option(%s)" % k)
-            _l.check(self._lib.flame_hip_graph_upload(self._h, _ptr(pos), _ptr(edges), _ptr(alpha),
-                                                      _ptr(beta), _ptr(z), _ptr(wgt), _ptr(x0),
-                                                      _ptr(tris)), "flame_hip_graph_upload")
+            if _batch_voff is not None:
+                vo = np.ascontiguousarray(_batch_voff, np.int32)
+                _l.check(self._lib.flame_hip_graph_upload_batch(
+                    self._h, len(vo) - 1, _ptr(vo), _ptr(pos), _ptr(edges), _ptr(alpha), _ptr(beta),
+                    _ptr(z), _ptr(wgt), _ptr(x0), _ptr(tris)), "flame_hip_graph_upload_batch")
+            else:
+                _l.check(self._lib.flame_hip_graph_upload(self._h, _ptr(pos), _ptr(edges), _ptr(alpha),
+                                                          _ptr(beta), _ptr(z), _ptr(wgt), _ptr(x0),
+                                                          _ptr(tris)), "flame_hip_graph_upload")
         except Exception:
             self.close()
             raise

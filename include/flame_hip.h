@@ -84,6 +84,17 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
                            const float* alpha, const float* beta, const float* z,
                            const float* wgt, const float* x0, const int32_t* tris);
 
+/* Frames axis: a batch of `num_graphs` INDEPENDENT graphs in one handle (block-diagonal): graph b
+ * owns the vertices [voff[b], voff[b+1]) (voff has num_graphs+1 entries, voff[0] = 0,
+ * voff[num_graphs] = V); edge endpoints are vertex ids of the concatenated arrays and must stay
+ * inside one graph.  Every graph becomes one LDS-resident tile, so one launch runs ALL iterations
+ * of ALL frames (one workgroup per frame); a graph too large for one tile -> FLAME_HIP_ERR_ARG.
+ * Same array conventions as flame_hip_graph_upload. */
+int flame_hip_graph_upload_batch(flame_hip_graph* g, int32_t num_graphs, const int32_t* voff,
+                                 const float* pos, const int32_t* edges, const float* alpha,
+                                 const float* beta, const float* z, const float* wgt,
+                                 const float* x0, const int32_t* tris);
+
 /* Overwrite solver state (any pointer may be NULL = keep).  q is 3E interleaved. */
 int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, const float* w2,
                         const float* xb, const float* w1b, const float* w2b, const float* q);

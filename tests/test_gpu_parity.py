@@ -131,3 +131,24 @@ def test_edge_cases(gpu):
     for opts in (dict(path=1), dict(path=2), dict(path=2, tile_own=8, tile_depth=3)):
         o, r = run_both(g, opts, 33, state_seed=8)
         compare_state(o, r, "tiny %s" % opts)
+
+
+def test_batch_of_frames(gpu):
+    """Frames axis: a batch of independent feature graphs in one handle (one LDS tile = one
+    workgroup per frame, every iteration in a single launch); each frame equals its own oracle."""
+    gs = [graphgen.dataset_shaped(640, 480, 16, seed=s) for s in range(6)] + \
+         [graphgen.synthetic(300, seed=9), graphgen.dataset_shaped(320, 240, 8, seed=4)]
+    r = GraphRegularizer.from_batch(gs)
+    assert r.info("num_tiles") == len(gs) and r.info("tile_depth") == 0
+    r.step(default_params(), 150)
+    ms, launches = r.last_solve_ms()
+    assert launches == 1
+    x, w1, w2, q = r.download()
+    eoff = np.cumsum([0] + [g.E for g in gs])
+    for b, g in enumerate(gs):
+        o = make_oracle(g)
+        o.solve(oracle_params(), 150)
+        sl = slice(r.voff[b], r.voff[b + 1])
+        assert_bit_equal(x[sl], o.x, "frame %d x" % b)
+        assert_bit_equal(w1[sl], o.w1, "frame %d w1" % b)
+        assert_bit_equal(q[eoff[b]:eoff[b + 1]], o.q, "frame %d q" % b)

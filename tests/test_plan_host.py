@@ -210,3 +210,25 @@ def test_global_path_and_fallbacks():
     # empty graph
     r = GraphRegularizer(np.zeros((0, 2)), np.zeros((0, 2), np.int32), [], [], [], [], device=-1)
     assert r.info("V") == 0
+
+
+def test_batch_plan():
+    gs = [graphgen.dataset_shaped(640, 480, 16, seed=s) for s in range(3)] + [graphgen.synthetic(200, seed=1)]
+    r = GraphRegularizer.from_batch(gs, device=-1)
+    tiles = tiles_of(r)
+    assert len(tiles) == 4 and r.info("tile_depth") == 0
+    for b, T in enumerate(tiles):
+        assert (T.vstart, T.n_own, T.n_ext, T.e_own, T.e_loc) == (r.voff[b], gs[b].V, gs[b].V, gs[b].E, gs[b].E)
+    # an edge crossing two frames, and a frame too large for one tile, are argument errors
+    g0, g1 = gs[0], gs[3]
+    voff = np.array([0, g0.V, g0.V + g1.V], np.int32)
+    edges = np.concatenate([g0.edges, g1.edges + g0.V]).astype(np.int32)
+    edges[0, 1] = g0.V + 1
+    cat = lambda n: np.concatenate([getattr(g0, n), getattr(g1, n)])  # noqa: E731
+    with pytest.raises(lib.FlameHipError) as e:
+        GraphRegularizer(cat("pos"), edges, cat("alpha"), cat("beta"), cat("z"), cat("wgt"), device=-1,
+                         _batch_voff=voff)
+    assert e.value.code == lib.ERR_ARG
+    with pytest.raises(lib.FlameHipError) as e:
+        GraphRegularizer.from_batch([graphgen.synthetic(5000, seed=2)], device=-1)
+    assert e.value.code == lib.ERR_ARG
