@@ -99,6 +99,9 @@ struct flame_hip_graph {
   float4* tri_normals = nullptr;
   float4* vtx_normals = nullptr;
   uint8_t* tri_valid = nullptr;
+  // mesh output (row f1)
+  float4* mesh_pts = nullptr;
+  int32_t* v_i2o_dev = nullptr;
   // costs
   double* partials = nullptr;
   // halo exchange lists (internal ids), see flame_hip_halo_register
@@ -120,7 +123,7 @@ struct flame_hip_graph {
     execs.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
                     t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
-                    tri_valid, partials, prof, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
+                    tri_valid, partials, prof, mesh_pts, v_i2o_dev, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
@@ -129,6 +132,7 @@ struct flame_hip_graph {
     tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
     partials = nullptr;
     prof = nullptr;
+    mesh_pts = nullptr; v_i2o_dev = nullptr;
     halo_send_v = halo_send_e = halo_recv_v = halo_recv_e = nullptr;
     n_send_v = n_send_e = n_recv_v = n_recv_e = 0;
   }
@@ -339,6 +343,9 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
       return rc;
   }
   if ((rc = dev_alloc(&g->vtx_normals, (size_t)V))) return rc;
+  if ((rc = dev_alloc(&g->mesh_pts, 3 * (size_t)V)) || (rc = dev_alloc(&g->v_i2o_dev, (size_t)V)) ||
+      (rc = h2d(g->v_i2o_dev, P.v_i2o)))
+    return rc;
   if ((rc = dev_alloc(&g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
   if (g->profile && P.has_tiles) {
     if ((rc = dev_alloc(&g->prof, P.tiles.size() * kProfWords))) return rc;
@@ -520,6 +527,8 @@ int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smoot
   return 0;
 }
 
+static void fill_tri_params(const float Kinv[9], const flame_hip_tri_params* tp, TriParamsDev* d);
+
 int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
                         float* vtx_normals, uint8_t* tri_valid, float* tri_normals) {
   int rc = require_device(g);
@@ -529,16 +538,7 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
   if ((rc = flame_hip_sync(g))) return rc;
   const int32_t V = g->V, T = g->plan.T;
   TriParamsDev d;
-  d.do_oblique = tp->do_oblique_triangle_filter;
-  d.do_edge = tp->do_edge_length_filter;
-  d.do_idepth = tp->do_idepth_triangle_filter;
-  d.cos_thresh = (float)std::cos((double)tp->oblique_normal_thresh);
-  d.diff_factor = tp->oblique_idepth_diff_factor;
-  d.diff_abs = tp->oblique_idepth_diff_abs;
-  const float max_len = tp->edge_length_thresh * (float)tp->width;
-  d.max_len2 = max_len * max_len;
-  d.min_idepth = tp->min_triangle_idepth;
-  for (int k = 0; k < 9; ++k) d.Kinv[k] = Kinv[k];
+  fill_tri_params(Kinv, tp, &d);
   HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
                           g->tri_normals, g->tri_valid, g->vtx_normals));
   HIPCHK(hipStreamSynchronize(g->stream));
@@ -560,6 +560,55 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
       tri_normals[3 * t] = h[t].x; tri_normals[3 * t + 1] = h[t].y; tri_normals[3 * t + 2] = h[t].z;
     }
   }
+  return 0;
+}
+
+static void fill_tri_params(const float Kinv[9], const flame_hip_tri_params* tp, TriParamsDev* d) {
+  d->do_oblique = tp->do_oblique_triangle_filter;
+  d->do_edge = tp->do_edge_length_filter;
+  d->do_idepth = tp->do_idepth_triangle_filter;
+  d->cos_thresh = (float)std::cos((double)tp->oblique_normal_thresh);
+  d->diff_factor = tp->oblique_idepth_diff_factor;
+  d->diff_abs = tp->oblique_idepth_diff_abs;
+  const float max_len = tp->edge_length_thresh * (float)tp->width;
+  d->max_len2 = max_len * max_len;
+  d->min_idepth = tp->min_triangle_idepth;
+  for (int k = 0; k < 9; ++k) d->Kinv[k] = Kinv[k];
+}
+
+int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
+                   float* points, int32_t* faces, int32_t* num_faces) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!Kinv || !tp || tp->width < 2 || tp->height < 2) return FLAME_HIP_ERR_ARG;
+  if (g->plan.T <= 0 && g->T > 0) return FLAME_HIP_ERR_STATE;
+  if ((rc = flame_hip_sync(g))) return rc;
+  const int32_t V = g->V, T = g->plan.T;
+  const Plan& P = g->plan;
+  TriParamsDev d;
+  fill_tri_params(Kinv, tp, &d);
+  HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
+                          g->tri_normals, g->tri_valid, g->vtx_normals));
+  HIPCHK(launch_mesh(g->stream, V, g->pos, g->A[g->cur], g->vtx_normals, g->v_i2o_dev, d, tp->width,
+                     tp->height, g->mesh_pts));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  if (points && V > 0)
+    HIPCHK(hipMemcpy(points, g->mesh_pts, sizeof(float4) * 3 * (size_t)V, hipMemcpyDeviceToHost));
+  int32_t nf = 0;
+  if (T > 0 && (faces || num_faces)) {
+    std::vector<uint8_t> valid(T);
+    HIPCHK(hipMemcpy(valid.data(), g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
+    for (int32_t t = 0; t < T; ++t)
+      if (valid[t]) {
+        if (faces) {  // reversed winding, caller's vertex ids (reference src/utils.cc:224-226)
+          faces[3 * nf] = P.v_i2o[P.tris[3 * t + 2]];
+          faces[3 * nf + 1] = P.v_i2o[P.tris[3 * t + 1]];
+          faces[3 * nf + 2] = P.v_i2o[P.tris[3 * t]];
+        }
+        ++nf;
+      }
+  }
+  if (num_faces) *num_faces = nf;
   return 0;
 }
 

@@ -61,4 +61,9 @@ hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* p
                             const int32_t* tinc, TriParamsDev tp, float4* tri_normals,
                             uint8_t* tri_valid, float4* vtx_normals);
 
+// ---- row f1: mesh vertices in PointNormalUV layout (3 float4 per vertex, caller's order) ----
+hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4* A,
+                       const float4* vtx_normals, const int32_t* i2o, TriParamsDev tp, int32_t width,
+                       int32_t height, float4* out);
+
 }  // namespace flamehip

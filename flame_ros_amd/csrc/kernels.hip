@@ -449,6 +449,37 @@ __global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* _
 }
 
 // ------------------------------------------------------------------------------------------
+// "Next" row f1: mesh vertices in flame_ros::PointNormalUV layout (reference src/utils.h:47-53,
+// packed at src/utils.cc:184-209): 3 float4 per vertex {p,0 | n,0 | u,v,0,0}; NaN xyz when the
+// idepth is not a positive finite number.  Written in the CALLER's vertex order (i2o).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mesh(int32_t V, const float2* __restrict__ pos,
+                                              const float4* __restrict__ A,
+                                              const float4* __restrict__ vtx_normals,
+                                              const int32_t* __restrict__ i2o, TriParamsDev tp,
+                                              float wm1, float hm1, float4* __restrict__ out) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const float id = A[v].x;
+  const float2 uv = pos[v];
+  float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0;
+  if (!isnan(id) && id > 0.0f) {
+    const float q0 = uv.x / id, q1 = uv.y / id, q2 = 1.0f / id;
+    o0.x = (tp.Kinv[0] * q0 + tp.Kinv[1] * q1) + tp.Kinv[2] * q2;
+    o0.y = (tp.Kinv[3] * q0 + tp.Kinv[4] * q1) + tp.Kinv[5] * q2;
+    o0.z = (tp.Kinv[6] * q0 + tp.Kinv[7] * q1) + tp.Kinv[8] * q2;
+    const float4 n = vtx_normals[v];
+    o1 = make_float4(n.x, n.y, n.z, 0.f);
+    o2.x = uv.x / wm1;
+    o2.y = uv.y / hm1;
+  } else {
+    o0.x = o0.y = o0.z = __builtin_nanf("");
+  }
+  float4* o = out + 3 * (size_t)i2o[v];
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+
+// ------------------------------------------------------------------------------------------
 // Halo exchange (multi-GPU subdomains): gather the full state of listed own
 // vertices / edges into a contiguous send buffer, scatter a received buffer into halo entries.
 // Layout: nv x {A, B} float4 pairs, then ne x q float4.
@@ -487,6 +518,15 @@ __global__ __launch_bounds__(256) void k_halo_unpack(int32_t nv, int32_t ne,
 }
 
 }  // namespace
+
+hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4* A,
+                       const float4* vtx_normals, const int32_t* i2o, TriParamsDev tp, int32_t width,
+                       int32_t height, float4* out) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_mesh, dim3((V + 255) / 256), dim3(256), 0, s, V, pos, A, vtx_normals, i2o, tp,
+                     (float)(width - 1), (float)(height - 1), out);
+  return hipGetLastError();
+}
 
 hipError_t launch_halo_pack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
                             const int32_t* eidx, const float4* A, const float4* B, const float4* q,

@@ -176,3 +176,13 @@ class GraphRegularizer:
         _l.check(self._lib.flame_hip_triangles(self._h, _ptr(Kinv), C.byref(tri_params), _ptr(vn),
                                                _ptr(tv), _ptr(tn)), "flame_hip_triangles")
         return tn, tv, vn
+
+    def mesh(self, Kinv, tri_params):
+        """Row f1: (points[V,12] PointNormalUV layout, faces[F,3] reversed winding)."""
+        Kinv = _f32(Kinv).reshape(9)
+        pts = np.empty((self.V, 12), np.float32)
+        faces = np.empty((max(self.T, 1), 3), np.int32)
+        nf = C.c_int32()
+        _l.check(self._lib.flame_hip_mesh(self._h, _ptr(Kinv), C.byref(tri_params), _ptr(pts),
+                                          _ptr(faces), C.byref(nf)), "flame_hip_mesh")
+        return pts, faces[:nf.value]

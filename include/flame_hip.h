@@ -117,6 +117,15 @@ int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smoot
 int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
                         float* vtx_normals, uint8_t* tri_valid, float* tri_normals);
 
+/* "Next" row f1: the mesh as flame_ros publishes it on /flame/mesh.  Replaces the
+ * vertex loop and face loop of publishDepthMesh (reference src/utils.cc:184-230): points = V x 12
+ * floats in flame_ros::PointNormalUV layout {x,y,z,0 | nx,ny,nz,0 | u/(W-1), v/(H-1), 0, 0}
+ * (reference src/utils.h:47-53), NaN xyz for vertices whose idepth is NaN or <= 0; faces = valid
+ * triangles with reversed winding, 3 vertex ids each (capacity 3T), *num_faces of them.  Runs the
+ * triangle stage first.  Any output pointer may be NULL.  Synchronises. */
+int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
+                   float* points, int32_t* faces, int32_t* num_faces);
+
 /* Results out (any pointer may be NULL).  Caller's vertex/edge order.  Synchronises. */
 int flame_hip_download(flame_hip_graph* g, float* x, float* w1, float* w2, float* q);
 int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b);

@@ -163,3 +163,21 @@ def triangles(tri_params, Kinv, pos, x, tris):
     _load().nltgv2_triangles(C.byref(tri_params), vp(Kinv), C.c_int32(V), C.c_int32(T), vp(pos),
                              vp(x), vp(tris), vp(tn), vp(tv), vp(vn))
     return tn, tv, vn
+
+
+def mesh(Kinv, pos, x, vtx_normals, tris, tri_valid, width, height):
+    """Row f1: (points[V,12] in PointNormalUV layout, faces[F,3] reversed winding)."""
+    pos = _f32(pos).reshape(-1, 2)
+    x, vn = _f32(x), _f32(vtx_normals).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    tv = np.ascontiguousarray(tri_valid, dtype=np.uint8)
+    Kinv = _f32(Kinv).reshape(9)
+    pts = np.empty((len(x), 12), np.float32)
+    faces = np.empty((len(tris), 3), np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L = _load()
+    L.nltgv2_mesh_points(vp(Kinv), C.c_int32(len(x)), vp(pos), vp(x), vp(vn), C.c_int32(width),
+                         C.c_int32(height), vp(pts))
+    L.nltgv2_mesh_faces.restype = C.c_int32
+    n = L.nltgv2_mesh_faces(C.c_int32(len(tris)), vp(tris), vp(tv), vp(faces))
+    return pts, faces[:n]

@@ -333,3 +333,40 @@ int nltgv2_solve_omp(const nltgv2_params* p, nltgv2_graph* g, const int32_t* row
   (void)num_threads;
   return 0;
 }
+
+/* ---- "next" row f1: mesh vertices as flame_ros packs them for /flame/mesh.
+ * Restates reference src/utils.cc:184-209 (publishDepthMesh): valid iff idepth is not NaN and
+ * > 0; uhom = (u, v, 1) / id; p = Kinv * uhom; texture coords u / (cols-1), v / (rows-1); invalid
+ * vertices get NaN xyz and nothing else.  Layout = flame_ros::PointNormalUV (reference
+ * src/utils.h:47-53: PCL_ADD_POINT4D, PCL_ADD_NORMAL4D, u, v, 16-byte aligned = 12 floats).  Faces
+ * (reference src/utils.cc:216-230): valid triangles, winding reversed.  The matrix-vector product
+ * is evaluated (K0*q0 + K1*q1) + K2*q2 without contraction (Eigen's own order is not pinned:
+ * PARITY UNPINNED applies to the last ulp here too). */
+void nltgv2_mesh_points(const float Kinv[9], int32_t V, const float* pos, const float* x,
+                        const float* vtx_normals, int32_t width, int32_t height, float* out12) {
+  const float wm1 = (float)(width - 1), hm1 = (float)(height - 1);
+  for (int32_t v = 0; v < V; ++v) {
+    float* o = out12 + 12 * (size_t)v;
+    for (int k = 0; k < 12; ++k) o[k] = 0.0f;
+    const float id = x[v];
+    if (!isnan(id) && id > 0.0f) {
+      const float q0 = pos[2 * v] / id, q1 = pos[2 * v + 1] / id, q2 = 1.0f / id;
+      for (int r = 0; r < 3; ++r) o[r] = (Kinv[3 * r] * q0 + Kinv[3 * r + 1] * q1) + Kinv[3 * r + 2] * q2;
+      o[4] = vtx_normals[3 * v]; o[5] = vtx_normals[3 * v + 1]; o[6] = vtx_normals[3 * v + 2];
+      o[8] = pos[2 * v] / wm1;
+      o[9] = pos[2 * v + 1] / hm1;
+    } else {
+      o[0] = o[1] = o[2] = NAN;
+    }
+  }
+}
+
+int32_t nltgv2_mesh_faces(int32_t T, const int32_t* tris, const uint8_t* tri_valid, int32_t* faces) {
+  int32_t n = 0;
+  for (int32_t t = 0; t < T; ++t)
+    if (tri_valid[t]) {
+      faces[3 * n] = tris[3 * t + 2]; faces[3 * n + 1] = tris[3 * t + 1]; faces[3 * n + 2] = tris[3 * t];
+      ++n;
+    }
+  return n;
+}

@@ -92,6 +92,12 @@ void nltgv2_triangles(const nltgv2_tri_params* tp, const float Kinv[9], int32_t 
                       const float* pos, const float* x, const int32_t* tris, float* tri_normals,
                       uint8_t* tri_valid, float* vtx_normals);
 
+/* "next" row f1: mesh vertices in flame_ros::PointNormalUV layout (12 floats) and faces with
+ * reversed winding (reference src/utils.cc:184-230).  Returns the number of faces. */
+void nltgv2_mesh_points(const float Kinv[9], int32_t V, const float* pos, const float* x,
+                        const float* vtx_normals, int32_t width, int32_t height, float* out12);
+int32_t nltgv2_mesh_faces(int32_t T, const int32_t* tris, const uint8_t* tri_valid, int32_t* faces);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_tri_params
-from oracle.cbind import triangles as oracle_triangles, TriParams as OTri
+from oracle.cbind import mesh as oracle_mesh, triangles as oracle_triangles, TriParams as OTri
 from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params, random_state
 
 pytestmark = pytest.mark.gpu
@@ -152,3 +152,27 @@ def test_batch_of_frames(gpu):
         assert_bit_equal(x[sl], o.x, "frame %d x" % b)
         assert_bit_equal(w1[sl], o.w1, "frame %d w1" % b)
         assert_bit_equal(q[eoff[b]:eoff[b + 1]], o.q, "frame %d q" % b)
+
+
+def test_mesh_points_and_faces(gpu):
+    """Row f1: PointNormalUV vertices + reversed-winding faces, incl. invalid (NaN) vertices."""
+    g = graphgen.synthetic(4000, seed=6)
+    o, r = run_both(g, {}, 30)
+    bad = np.arange(0, g.V, 97)
+    x = o.x.copy()
+    x[bad[::2]] = np.nan
+    x[bad[1::2]] = -0.5
+    o.set_state(x=x)
+    r.set_state(x=x)
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    tp = default_tri_params(640, 480)
+    otp = OTri(*[getattr(tp, f[0]) for f in tp._fields_])
+    _, tv_o, vn_o = oracle_triangles(otp, Kinv, g.pos, o.x, g.tris)
+    pts_o, faces_o = oracle_mesh(Kinv, g.pos, o.x, vn_o, g.tris, tv_o, 640, 480)
+    pts, faces = r.mesh(Kinv, tp)
+    assert np.array_equal(faces, faces_o) and 0 < len(faces) < g.T
+    assert np.array_equal(np.isnan(pts), np.isnan(pts_o)) and np.isnan(pts[bad, :3]).all()
+    ok = ~np.isnan(pts_o)
+    assert_bit_equal(pts[ok], pts_o[ok], "mesh points")
+    assert np.all(pts[bad, 3:] == 0)
