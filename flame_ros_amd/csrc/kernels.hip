@@ -161,6 +161,11 @@ struct PhaseD<0, EPT> {
                                              float (&)[EPT], float (&)[EPT], float (&)[EPT], float) {}
 };
 
+#ifndef FLAME_P_ROUND
+#define FLAME_P_ROUND 4
+#endif
+constexpr int kPRound = FLAME_P_ROUND;  // incidence slots read per round of phase P
+
 template <int NT, int EPT, int VPT>
 __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -263,12 +268,12 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
         float x = xp, w1 = w1p, w2 = w2p;
         // transposed slots: incidence j of this lane is at sb + 64 j (conflict-free across lanes);
         // the group is padded to the wave's max degree, so reads past deg stay in bounds
-        for (int j = 0; j < wdeg[k]; j += 4) {  // wave-uniform trip count
-          float4 t[4];
+        for (int j = 0; j < wdeg[k]; j += kPRound) {  // wave-uniform trip count
+          float4 t[kPRound];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) t[u] = lds_read4(cs + sb + 64 * min(j + u, wdeg[k] - 1));
+          for (int u = 0; u < kPRound; ++u) t[u] = lds_read4(cs + sb + 64 * min(j + u, wdeg[k] - 1));
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < kPRound; ++u) {
             const bool on = (j + u) < deg;
             x = on ? fmaf(ntau, t[u].x, x) : x;
             w1 = on ? fmaf(ntau, t[u].y, w1) : w1;
