@@ -99,6 +99,12 @@ struct flame_hip_graph {
   float4* tri_normals = nullptr;
   float4* vtx_normals = nullptr;
   uint8_t* tri_valid = nullptr;
+  // dense maps (row f2), allocated on first use for the requested image size
+  int64_t map_pixels = 0;
+  uint32_t* map_owner = nullptr;
+  float* map_idm = nullptr;
+  float* map_dm = nullptr;
+  float* map_cloud = nullptr;
   // mesh output (row f1)
   float4* mesh_pts = nullptr;
   int32_t* v_i2o_dev = nullptr;
@@ -123,7 +129,7 @@ struct flame_hip_graph {
     execs.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
                     t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
-                    tri_valid, partials, prof, mesh_pts, v_i2o_dev, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
+                    tri_valid, partials, prof, mesh_pts, v_i2o_dev, map_owner, map_idm, map_dm, map_cloud, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
@@ -133,6 +139,7 @@ struct flame_hip_graph {
     partials = nullptr;
     prof = nullptr;
     mesh_pts = nullptr; v_i2o_dev = nullptr;
+    map_owner = nullptr; map_idm = map_dm = map_cloud = nullptr; map_pixels = 0;
     halo_send_v = halo_send_e = halo_recv_v = halo_recv_e = nullptr;
     n_send_v = n_send_e = n_recv_v = n_recv_e = 0;
   }
@@ -609,6 +616,39 @@ int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_
       }
   }
   if (num_faces) *num_faces = nf;
+  return 0;
+}
+
+int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
+                        int32_t filtered, float min_depth, float max_depth, float* idepthmap,
+                        float* depthmap, float* cloud) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!Kinv || !tp || tp->width < 1 || tp->height < 1) return FLAME_HIP_ERR_ARG;
+  if (g->plan.T <= 0 && g->T > 0) return FLAME_HIP_ERR_STATE;
+  if ((rc = flame_hip_sync(g))) return rc;
+  const int32_t V = g->V, T = g->plan.T;
+  const int64_t npix = (int64_t)tp->width * tp->height;
+  if (npix != g->map_pixels) {
+    for (void* p : {(void*)g->map_owner, (void*)g->map_idm, (void*)g->map_dm, (void*)g->map_cloud})
+      if (p) (void)hipFree(p);
+    g->map_owner = nullptr; g->map_idm = g->map_dm = g->map_cloud = nullptr; g->map_pixels = 0;
+    if ((rc = dev_alloc(&g->map_owner, (size_t)npix)) || (rc = dev_alloc(&g->map_idm, (size_t)npix)) ||
+        (rc = dev_alloc(&g->map_dm, (size_t)npix)) || (rc = dev_alloc(&g->map_cloud, 3 * (size_t)npix)))
+      return rc;
+    g->map_pixels = npix;
+  }
+  TriParamsDev d;
+  fill_tri_params(Kinv, tp, &d);
+  HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
+                          g->tri_normals, g->tri_valid, g->vtx_normals));
+  HIPCHK(launch_raster(g->stream, T, tp->width, tp->height, g->pos, g->A[g->cur], g->tris,
+                       g->tri_valid, filtered, d, min_depth, max_depth, g->map_owner, g->map_idm,
+                       depthmap || cloud ? g->map_dm : nullptr, cloud ? g->map_cloud : nullptr));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  if (idepthmap) HIPCHK(hipMemcpy(idepthmap, g->map_idm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
+  if (depthmap) HIPCHK(hipMemcpy(depthmap, g->map_dm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
+  if (cloud) HIPCHK(hipMemcpy(cloud, g->map_cloud, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -66,4 +66,10 @@ hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4
                        const float4* vtx_normals, const int32_t* i2o, TriParamsDev tp, int32_t width,
                        int32_t height, float4* out);
 
+// ---- row f2: dense idepthmap (owner pass + fill pass), depth map, point cloud ----
+hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height, const float2* pos,
+                         const float4* A, const int32_t* tris, const uint8_t* tri_valid,
+                         int32_t filtered, TriParamsDev tp, float min_depth, float max_depth,
+                         uint32_t* owner, float* idm, float* dm, float* cloud);
+
 }  // namespace flamehip

@@ -485,6 +485,86 @@ __global__ __launch_bounds__(256) void k_mesh(int32_t V, const float2* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// "Next" row f2: dense idepthmap / depthmap / point cloud.  Pass 1 (one wave per triangle, lanes
+// stride over the bounding box): atomicMin of the triangle id into a per-pixel owner map, so the
+// LOWEST covering triangle wins deterministically.  Pass 2 (one thread per pixel): barycentric
+// idepth of the owner triangle, depth = 1/idepth (reference src/flame_offline_tum.cc:650-661),
+// cloud = Kinv (jj d, ii d, d) within [min_depth, max_depth] (reference src/utils.cc:290-312).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+  return fmaf(bx - ax, py - ay, -((by - ay) * (px - ax)));
+}
+
+__global__ __launch_bounds__(256) void k_raster_owner(int32_t T, int32_t width, int32_t height,
+                                                      const float2* __restrict__ pos,
+                                                      const int32_t* __restrict__ tris,
+                                                      const uint8_t* __restrict__ tri_valid,
+                                                      int32_t filtered, uint32_t* __restrict__ owner) {
+  const int32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (t >= T) return;
+  if (filtered && !tri_valid[t]) return;
+  const float2 A = pos[tris[3 * t]], B = pos[tris[3 * t + 1]], Cc = pos[tris[3 * t + 2]];
+  const float area = edge_fn(A.x, A.y, B.x, B.y, Cc.x, Cc.y);
+  if (!(area != 0.0f)) return;
+  int x0 = (int)ceilf(fminf(A.x, fminf(B.x, Cc.x))), x1 = (int)floorf(fmaxf(A.x, fmaxf(B.x, Cc.x)));
+  int y0 = (int)ceilf(fminf(A.y, fminf(B.y, Cc.y))), y1 = (int)floorf(fmaxf(A.y, fmaxf(B.y, Cc.y)));
+  x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, width - 1); y1 = min(y1, height - 1);
+  const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+  if (bw <= 0 || bh <= 0) return;
+  for (int k = lane; k < bw * bh; k += 64) {
+    const int jj = x0 + k % bw, ii = y0 + k / bw;
+    const float px = (float)jj, py = (float)ii;
+    const float wa = edge_fn(B.x, B.y, Cc.x, Cc.y, px, py);
+    const float wb = edge_fn(Cc.x, Cc.y, A.x, A.y, px, py);
+    const float wc = edge_fn(A.x, A.y, B.x, B.y, px, py);
+    const bool in = (wa >= 0.f && wb >= 0.f && wc >= 0.f) || (wa <= 0.f && wb <= 0.f && wc <= 0.f);
+    if (in) atomicMin(owner + (size_t)ii * width + jj, (uint32_t)t);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_raster_fill(int32_t width, int32_t height,
+                                                     const float2* __restrict__ pos,
+                                                     const float4* __restrict__ A,
+                                                     const int32_t* __restrict__ tris,
+                                                     const uint32_t* __restrict__ owner,
+                                                     TriParamsDev tp, float min_depth, float max_depth,
+                                                     float* __restrict__ idm, float* __restrict__ dm,
+                                                     float* __restrict__ cloud) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)width * height) return;
+  const int jj = (int)(k % width), ii = (int)(k / width);
+  const uint32_t t = owner[k];
+  float id = __builtin_nanf("");
+  if (t != 0xffffffffu) {
+    const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+    const float2 Pa = pos[a], Pb = pos[b], Pc = pos[c];
+    const float px = (float)jj, py = (float)ii;
+    const float wa = edge_fn(Pb.x, Pb.y, Pc.x, Pc.y, px, py);
+    const float wb = edge_fn(Pc.x, Pc.y, Pa.x, Pa.y, px, py);
+    const float wc = edge_fn(Pa.x, Pa.y, Pb.x, Pb.y, px, py);
+    const float num = fmaf(wc, A[c].x, fmaf(wb, A[b].x, wa * A[a].x));
+    id = num / ((wa + wb) + wc);
+  }
+  idm[k] = id;
+  float depth = __builtin_nanf("");
+  if (!isnan(id) && id > 0.0f) depth = 1.0f / id;
+  if (dm) dm[k] = depth;
+  if (cloud) {
+    float ox, oy, oz;
+    if (isnan(depth) || depth < min_depth || depth > max_depth) {
+      ox = oy = oz = __builtin_nanf("");
+    } else {
+      const float q0 = (float)jj * depth, q1 = (float)ii * depth, q2 = depth;
+      ox = (tp.Kinv[0] * q0 + tp.Kinv[1] * q1) + tp.Kinv[2] * q2;
+      oy = (tp.Kinv[3] * q0 + tp.Kinv[4] * q1) + tp.Kinv[5] * q2;
+      oz = (tp.Kinv[6] * q0 + tp.Kinv[7] * q1) + tp.Kinv[8] * q2;
+    }
+    cloud[3 * k] = ox; cloud[3 * k + 1] = oy; cloud[3 * k + 2] = oz;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Halo exchange (multi-GPU subdomains): gather the full state of listed own
 // vertices / edges into a contiguous send buffer, scatter a received buffer into halo entries.
 // Layout: nv x {A, B} float4 pairs, then ne x q float4.
@@ -530,6 +610,24 @@ hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4
   if (V <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_mesh, dim3((V + 255) / 256), dim3(256), 0, s, V, pos, A, vtx_normals, i2o, tp,
                      (float)(width - 1), (float)(height - 1), out);
+  return hipGetLastError();
+}
+
+hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height, const float2* pos,
+                         const float4* A, const int32_t* tris, const uint8_t* tri_valid,
+                         int32_t filtered, TriParamsDev tp, float min_depth, float max_depth,
+                         uint32_t* owner, float* idm, float* dm, float* cloud) {
+  const int64_t npix = (int64_t)width * height;
+  if (npix <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(owner, 0xff, sizeof(uint32_t) * (size_t)npix, s);
+  if (e != hipSuccess) return e;
+  if (T > 0) {
+    hipLaunchKernelGGL(k_raster_owner, dim3((T + 3) / 4), dim3(256), 0, s, T, width, height, pos, tris,
+                       tri_valid, filtered, owner);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_raster_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, width, height,
+                     pos, A, tris, owner, tp, min_depth, max_depth, idm, dm, cloud);
   return hipGetLastError();
 }
 

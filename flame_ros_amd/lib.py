@@ -52,6 +52,7 @@ SYMBOLS = {
     "flame_hip_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flame_hip_triangles": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _VP, _VP, _VP]),
     "flame_hip_mesh": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _VP, _VP, C.POINTER(_I32)]),
+    "flame_hip_depthmaps": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _I32, C.c_float, C.c_float, _VP, _VP, _VP]),
     "flame_hip_download": (C.c_int, [_VP] + [_VP] * 4),
     "flame_hip_download_bar": (C.c_int, [_VP] + [_VP] * 3),
     "flame_hip_halo_register": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _VP, _I32, _VP]),

@@ -186,3 +186,14 @@ class GraphRegularizer:
         _l.check(self._lib.flame_hip_mesh(self._h, _ptr(Kinv), C.byref(tri_params), _ptr(pts),
                                           _ptr(faces), C.byref(nf)), "flame_hip_mesh")
         return pts, faces[:nf.value]
+
+    def depthmaps(self, Kinv, tri_params, filtered=True, min_depth=0.1, max_depth=100.0, cloud=True):
+        """Row f2: (idepthmap[H,W], depthmap[H,W], cloud[H,W,3] or None)."""
+        Kinv = _f32(Kinv).reshape(9)
+        H, W = tri_params.height, tri_params.width
+        idm, dm = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+        cl = np.empty((H, W, 3), np.float32) if cloud else None
+        _l.check(self._lib.flame_hip_depthmaps(self._h, _ptr(Kinv), C.byref(tri_params), int(filtered),
+                                               min_depth, max_depth, _ptr(idm), _ptr(dm), _ptr(cl)),
+                 "flame_hip_depthmaps")
+        return idm, dm, cl

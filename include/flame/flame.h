@@ -190,12 +190,79 @@ class Flame {
     if (var) *var = var_;
   }
 
+  // Dense maps (row f2).  Upstream returns cv::Mat1f (reference src/flame_offline_tum.cc:643,
+  // src/flame_nodelet.cc:688); here a row-major width() x height() float vector, NaN where the
+  // mesh does not cover the pixel (cv::Mat1f overloads below when OpenCV is present).
+  bool getFilteredInverseDepthMap(std::vector<float>* idepthmap) const { return maps(1, idepthmap, nullptr, nullptr, 0.f, 0.f); }
+  bool getInverseDepthMap(std::vector<float>* idepthmap) const { return maps(0, idepthmap, nullptr, nullptr, 0.f, 0.f); }
+  // idepth -> depth inversion and point cloud of flame_ros (reference
+  // src/flame_offline_tum.cc:650-661, src/utils.cc:290-312), computed on the GPU as well.
+  bool getDepthMapAndCloud(std::vector<float>* depthmap, std::vector<float>* cloud_xyz,
+                           float min_depth, float max_depth) const {
+    return maps(1, nullptr, depthmap, cloud_xyz, min_depth, max_depth);
+  }
+#ifdef FLAME_HAVE_OPENCV
+  void getFilteredInverseDepthMap(cv::Mat1f* idepthmap) const {
+    std::vector<float> v;
+    idepthmap->create(height_, width_);
+    if (getFilteredInverseDepthMap(&v)) std::copy(v.begin(), v.end(), idepthmap->ptr<float>());
+  }
+  cv::Mat1f getInverseDepthMap() const {
+    std::vector<float> v;
+    cv::Mat1f m(height_, width_);
+    if (getInverseDepthMap(&v)) std::copy(v.begin(), v.end(), m.ptr<float>());
+    return m;
+  }
+#endif
+  // Mesh as flame_ros publishes it (row f1; reference src/utils.cc:184-230): 12 floats per
+  // vertex in flame_ros::PointNormalUV layout and reversed-winding faces of the valid triangles.
+  bool getMeshPointNormalUV(std::vector<float>* points, std::vector<int32_t>* faces) const {
+    std::lock_guard<std::mutex> lock(mtx_);
+    if (!graph_.valid()) return false;
+    const flame_hip_tri_params tp = triParams();
+    points->assign(12 * vtx_.size(), 0.f);
+    faces->assign(3 * tris_.size(), 0);
+    int32_t nf = 0;
+    if (flame_hip_mesh(graph_.handle(), Kinv_, &tp, points->data(), faces->data(), &nf)) return false;
+    faces->resize(3 * static_cast<size_t>(nf));
+    return true;
+  }
+
   const utils::StatsTracker& stats() const { return stats_; }
   const Params& params() const { return params_; }
   int width() const { return width_; }
   int height() const { return height_; }
 
  private:
+  flame_hip_tri_params triParams() const {
+    flame_hip_tri_params tp;
+    tp.do_oblique_triangle_filter = params_.do_oblique_triangle_filter;
+    tp.oblique_normal_thresh = params_.oblique_normal_thresh;
+    tp.oblique_idepth_diff_factor = params_.oblique_idepth_diff_factor;
+    tp.oblique_idepth_diff_abs = params_.oblique_idepth_diff_abs;
+    tp.do_edge_length_filter = params_.do_edge_length_filter;
+    tp.edge_length_thresh = params_.edge_length_thresh;
+    tp.do_idepth_triangle_filter = params_.do_idepth_triangle_filter;
+    tp.min_triangle_idepth = params_.min_triangle_idepth;
+    tp.width = width_;
+    tp.height = height_;
+    return tp;
+  }
+  // NOTE: with rescale_data the device state is in rescaled units; the dense maps are only
+  // offered for rescale_data = false (the reference default, cfg/flame_offline_tum.yaml:90).
+  bool maps(int filtered, std::vector<float>* idm, std::vector<float>* dm, std::vector<float>* cloud,
+            float min_depth, float max_depth) const {
+    std::lock_guard<std::mutex> lock(mtx_);
+    if (!graph_.valid() || params_.rescale_data) return false;
+    const flame_hip_tri_params tp = triParams();
+    const size_t n = static_cast<size_t>(width_) * height_;
+    if (idm) idm->assign(n, 0.f);
+    if (dm) dm->assign(n, 0.f);
+    if (cloud) cloud->assign(3 * n, 0.f);
+    return flame_hip_depthmaps(graph_.handle(), Kinv_, &tp, filtered, min_depth, max_depth,
+                               idm ? idm->data() : nullptr, dm ? dm->data() : nullptr,
+                               cloud ? cloud->data() : nullptr) == 0;
+  }
   bool fail(int code) {
     stats_.set("hip_error", code);
     stats_.tock("update");

@@ -126,6 +126,18 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
 int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
                    float* points, int32_t* faces, int32_t* num_faces);
 
+/* "Next" row f2: dense maps at tp->width x tp->height (row-major, any output may
+ * be NULL).  idepthmap replaces getInverseDepthMap() (filtered = 0, reference
+ * src/flame_nodelet.cc:688) / getFilteredInverseDepthMap() (filtered = 1: only valid triangles,
+ * reference src/flame_offline_tum.cc:643): barycentric idepth of the lowest-index covering
+ * triangle, NaN where uncovered.  depthmap replaces the OpenMP inversion loop (reference
+ * src/flame_offline_tum.cc:650-661): 1/idepth where idepth is not NaN and > 0, else NaN.  cloud
+ * (3 floats per pixel) replaces publishPointCloud's loop (reference src/utils.cc:290-312): NaN if
+ * depth is NaN or outside [min_depth, max_depth], else Kinv (jj d, ii d, d).  Synchronises. */
+int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
+                        int32_t filtered, float min_depth, float max_depth, float* idepthmap,
+                        float* depthmap, float* cloud);
+
 /* Results out (any pointer may be NULL).  Caller's vertex/edge order.  Synchronises. */
 int flame_hip_download(flame_hip_graph* g, float* x, float* w1, float* w2, float* q);
 int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b);

@@ -181,3 +181,22 @@ def mesh(Kinv, pos, x, vtx_normals, tris, tri_valid, width, height):
     L.nltgv2_mesh_faces.restype = C.c_int32
     n = L.nltgv2_mesh_faces(C.c_int32(len(tris)), vp(tris), vp(tv), vp(faces))
     return pts, faces[:n]
+
+
+def depthmaps(width, height, pos, x, tris, tri_valid, filtered, Kinv, min_depth, max_depth):
+    """Row f2: (idepthmap[H,W], depthmap[H,W], cloud[H,W,3])."""
+    pos = _f32(pos).reshape(-1, 2)
+    x = _f32(x)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    tv = np.ascontiguousarray(tri_valid, dtype=np.uint8)
+    Kinv = _f32(Kinv).reshape(9)
+    idm = np.empty((height, width), np.float32)
+    dm = np.empty((height, width), np.float32)
+    cl = np.empty((height, width, 3), np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L = _load()
+    L.nltgv2_idepthmap(C.c_int32(width), C.c_int32(height), C.c_int32(len(tris)), vp(pos), vp(x),
+                       vp(tris), vp(tv), C.c_int32(int(filtered)), vp(idm))
+    L.nltgv2_depth_and_cloud(C.c_int32(width), C.c_int32(height), vp(idm), vp(Kinv),
+                             C.c_float(min_depth), C.c_float(max_depth), vp(dm), vp(cl))
+    return idm, dm, cl

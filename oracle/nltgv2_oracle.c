@@ -370,3 +370,69 @@ int32_t nltgv2_mesh_faces(int32_t T, const int32_t* tris, const uint8_t* tri_val
     }
   return n;
 }
+
+/* ---- "next" row f2: dense inverse-depth map, depth map and point cloud.
+ * (i) rasterisation of the mesh (upstream getInverseDepthMap / getFilteredInverseDepthMap,
+ * reference src/flame_offline_tum.cc:643, src/flame_nodelet.cc:688; the upstream rasteriser is
+ * not in the reference tree, so this is the build's own precise rule): a pixel centre (jj, ii)
+ * belongs to the LOWEST-index triangle whose three edge functions have one sign (zero included);
+ * its idepth is the barycentric interpolation of the vertex idepths; uncovered pixels are NaN;
+ * `filtered` keeps only triangles with tri_valid != 0.  (ii) depth = 1/idepth where idepth is not
+ * NaN and > 0, else NaN: reference src/flame_offline_tum.cc:650-661.  (iii) cloud: NaN if depth is
+ * NaN or outside [min_depth, max_depth], else Kinv * (jj*depth, ii*depth, depth): reference
+ * src/utils.cc:290-312. ---- */
+static inline float edge_fn(float ax, float ay, float bx, float by, float px, float py) {
+  return fmaf(bx - ax, py - ay, -((by - ay) * (px - ax)));
+}
+
+void nltgv2_idepthmap(int32_t width, int32_t height, int32_t T, const float* pos, const float* x,
+                      const int32_t* tris, const uint8_t* tri_valid, int32_t filtered,
+                      float* idepthmap) {
+  for (int64_t k = 0; k < (int64_t)width * height; ++k) idepthmap[k] = NAN;
+  for (int32_t t = T - 1; t >= 0; --t) { /* descending, so the lowest index wins overlaps */
+    if (filtered && !tri_valid[t]) continue;
+    const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+    const float ax = pos[2 * a], ay = pos[2 * a + 1], bx = pos[2 * b], by = pos[2 * b + 1];
+    const float cx = pos[2 * c], cy = pos[2 * c + 1];
+    const float area = edge_fn(ax, ay, bx, by, cx, cy);
+    if (!(area != 0.0f)) continue;
+    int32_t x0 = (int32_t)ceilf(fminf(ax, fminf(bx, cx))), x1 = (int32_t)floorf(fmaxf(ax, fmaxf(bx, cx)));
+    int32_t y0 = (int32_t)ceilf(fminf(ay, fminf(by, cy))), y1 = (int32_t)floorf(fmaxf(ay, fmaxf(by, cy)));
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > width - 1) x1 = width - 1;
+    if (y1 > height - 1) y1 = height - 1;
+    for (int32_t ii = y0; ii <= y1; ++ii)
+      for (int32_t jj = x0; jj <= x1; ++jj) {
+        const float px = (float)jj, py = (float)ii;
+        const float wa = edge_fn(bx, by, cx, cy, px, py);
+        const float wb = edge_fn(cx, cy, ax, ay, px, py);
+        const float wc = edge_fn(ax, ay, bx, by, px, py);
+        const int in = (wa >= 0.0f && wb >= 0.0f && wc >= 0.0f) || (wa <= 0.0f && wb <= 0.0f && wc <= 0.0f);
+        if (!in) continue;
+        const float num = fmaf(wc, x[c], fmaf(wb, x[b], wa * x[a]));
+        idepthmap[(int64_t)ii * width + jj] = num / ((wa + wb) + wc);
+      }
+  }
+}
+
+void nltgv2_depth_and_cloud(int32_t width, int32_t height, const float* idepthmap,
+                            const float Kinv[9], float min_depth, float max_depth,
+                            float* depthmap, float* cloud /* 3 per pixel or NULL */) {
+  for (int32_t ii = 0; ii < height; ++ii)
+    for (int32_t jj = 0; jj < width; ++jj) {
+      const int64_t k = (int64_t)ii * width + jj;
+      const float id = idepthmap[k];
+      float depth = NAN;
+      if (!isnan(id) && id > 0.0f) depth = 1.0f / id;
+      depthmap[k] = depth;
+      if (!cloud) continue;
+      float* o = cloud + 3 * k;
+      if (isnan(depth) || depth < min_depth || depth > max_depth) {
+        o[0] = o[1] = o[2] = NAN;
+      } else {
+        const float q0 = (float)jj * depth, q1 = (float)ii * depth, q2 = depth;
+        for (int r = 0; r < 3; ++r) o[r] = (Kinv[3 * r] * q0 + Kinv[3 * r + 1] * q1) + Kinv[3 * r + 2] * q2;
+      }
+    }
+}

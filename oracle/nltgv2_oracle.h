@@ -98,6 +98,15 @@ void nltgv2_mesh_points(const float Kinv[9], int32_t V, const float* pos, const 
                         const float* vtx_normals, int32_t width, int32_t height, float* out12);
 int32_t nltgv2_mesh_faces(int32_t T, const int32_t* tris, const uint8_t* tri_valid, int32_t* faces);
 
+/* "next" row f2: dense idepthmap (lowest-index covering triangle, barycentric), depth = 1/idepth
+ * (reference src/flame_offline_tum.cc:650-661) and point cloud (reference src/utils.cc:290-312). */
+void nltgv2_idepthmap(int32_t width, int32_t height, int32_t T, const float* pos, const float* x,
+                      const int32_t* tris, const uint8_t* tri_valid, int32_t filtered,
+                      float* idepthmap);
+void nltgv2_depth_and_cloud(int32_t width, int32_t height, const float* idepthmap,
+                            const float Kinv[9], float min_depth, float max_depth,
+                            float* depthmap, float* cloud);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,17 @@ int main(int argc, char** argv) {
   const auto& st = sensor->stats().stats();
   if (st.find("nltgv2_total_smoothness_cost") == st.end() || st.find("num_edges") == st.end()) return 14;
 
+  // rows f1 / f2 through the facade (reference src/flame_offline_tum.cc:636-661)
+  std::vector<float> idm, dm, cloud, pts;
+  std::vector<int32_t> faces;
+  if (!sensor->getFilteredInverseDepthMap(&idm) || !sensor->getDepthMapAndCloud(&dm, &cloud, 0.1f, 100.f) ||
+      !sensor->getMeshPointNormalUV(&pts, &faces))
+    return 17;
+  if (idm.size() != 640u * 480u || cloud.size() != 3u * idm.size() || pts.size() != 12u * V) return 18;
+  size_t nvalid = 0;
+  for (size_t k = 0; k < validity.size(); ++k) nvalid += validity[k] ? 1 : 0;
+  if (faces.size() != 3 * nvalid) return 19;
+
   FILE* f = std::fopen(argv[2], "wb");
   if (!f) return 15;
   std::fwrite(oid.data(), 4, V, f);

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_tri_params
-from oracle.cbind import mesh as oracle_mesh, triangles as oracle_triangles, TriParams as OTri
+from oracle.cbind import depthmaps as oracle_depthmaps, mesh as oracle_mesh, triangles as oracle_triangles, TriParams as OTri
 from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params, random_state
 
 pytestmark = pytest.mark.gpu
@@ -176,3 +176,30 @@ def test_mesh_points_and_faces(gpu):
     ok = ~np.isnan(pts_o)
     assert_bit_equal(pts[ok], pts_o[ok], "mesh points")
     assert np.all(pts[bad, 3:] == 0)
+
+
+@pytest.mark.parametrize("filtered", [True, False])
+def test_dense_maps(gpu, filtered):
+    """Row f2: idepthmap rasterisation, idepth -> depth inversion, point cloud."""
+    g = graphgen.dataset_shaped(640, 480, 16, seed=7)
+    o, r = run_both(g, {}, 40)
+    x = o.x.copy()
+    x[::53] = np.nan
+    x[7::61] = -1.0
+    o.set_state(x=x)
+    r.set_state(x=x)
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    tp = default_tri_params(640, 480)
+    otp = OTri(*[getattr(tp, f[0]) for f in tp._fields_])
+    _, tv_o, _ = oracle_triangles(otp, Kinv, g.pos, o.x, g.tris)
+    idm_o, dm_o, cl_o = oracle_depthmaps(640, 480, g.pos, o.x, g.tris, tv_o, filtered, Kinv, 0.1, 100.0)
+    idm, dm, cl = r.depthmaps(Kinv, tp, filtered=filtered, min_depth=0.1, max_depth=100.0)
+    for got, want, name in ((idm, idm_o, "idepthmap"), (dm, dm_o, "depthmap"), (cl, cl_o, "cloud")):
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        ok = ~np.isnan(want)
+        assert_bit_equal(got[ok], want[ok], name)
+    cover = 1.0 - np.isnan(idm).mean()
+    assert 0.5 < cover <= 1.0 and (np.isnan(dm).sum() >= np.isnan(idm).sum())
+    if filtered:
+        assert np.isnan(idm).sum() > np.isnan(r.depthmaps(Kinv, tp, filtered=False, cloud=False)[0]).sum()
