@@ -41,8 +41,11 @@ def cpu_baseline(g, iters, budget_s=12.0):
     # BASELINE.md section 2 legs (ii)/(iii): the OpenMP variant (edge-parallel dual + CSR primal,
     # bit-identical) at the reference's default 4 threads and on all host cores; informational
     threaded = {}
-    ncpu = os.cpu_count() or 1
-    for nt in sorted({min(4, ncpu), ncpu}):
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    for nt in sorted({min(4, ncpu), min(16, ncpu)}):  # >16 threads only adds barrier overhead
         o.solve_threads(p, 5, nt)
         d2, t0 = 0, time.perf_counter()
         while True:

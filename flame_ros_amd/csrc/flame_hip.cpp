@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
@@ -37,13 +38,24 @@ struct GraphExecEntry {
   int launches;
 };
 
+// Device buffers are owned by the handle and keep their capacity across uploads (a frame stream
+// re-uploads a similar graph every frame: no hipMalloc/hipFree after the first few frames).
+// `caps` maps the address of the pointer member to its capacity in bytes.
+typedef std::unordered_map<void*, size_t> CapMap;
+
 template <class T>
-int dev_alloc(T** p, size_t n) {
-  *p = nullptr;
+int dev_alloc(CapMap& caps, T** p, size_t n) {
   n += 1;  // one pad element: kernels clamp indices of empty lists to element 0
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+  const size_t bytes = n * sizeof(T);
+  auto it = caps.find((void*)p);
+  if (*p && it != caps.end() && it->second >= bytes) return 0;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  const size_t want = bytes + bytes / 4;  // slack for the next, slightly larger frame
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), want);
   if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
   if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
+  caps[(void*)p] = want;
   return 0;
 }
 
@@ -121,12 +133,19 @@ struct flame_hip_graph {
   unsigned long long* prof = nullptr;
 
   std::vector<GraphExecEntry> execs;
+  CapMap caps;
+  int solves_since_upload = 0;
+
+  void drop_execs() {
+    for (auto& e : execs) (void)hipGraphExecDestroy(e.exec);
+    execs.clear();
+  }
 
   void free_device() {
     if (device < 0) return;
     (void)hipSetDevice(device);
-    for (auto& e : execs) (void)hipGraphExecDestroy(e.exec);
-    execs.clear();
+    drop_execs();
+    caps.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
                     t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
                     tri_valid, partials, prof, mesh_pts, v_i2o_dev, map_owner, map_idm, map_dm, map_cloud, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
@@ -294,7 +313,8 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   }
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(hipStreamSynchronize(g->stream));
-  g->free_device();
+  g->drop_execs();  // captured launches hold the old grid / pointers
+  g->solves_since_upload = 0;
   if (P.has_tiles) {
     if (!tile_config_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return FLAME_HIP_ERR_STATE;
     HIPCHK(prepare_tile(P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes));
@@ -311,16 +331,16 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     hpos[k] = make_float2(pos[2 * o], pos[2 * o + 1]);
   }
   for (int b = 0; b < 2; ++b) {
-    if ((rc = dev_alloc(&g->A[b], V))) return rc;
-    if ((rc = dev_alloc(&g->B[b], V))) return rc;
-    if ((rc = dev_alloc(&g->q[b], E))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->A[b], V))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->B[b], V))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->q[b], E))) return rc;
     HIPCHK(hipMemset(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1)));
   }
   g->cur = 0;
   if ((rc = h2d(g->A[0], hA)) || (rc = h2d(g->B[0], hB))) return rc;
-  if ((rc = dev_alloc(&g->pos, V)) || (rc = h2d(g->pos, hpos))) return rc;
-  if ((rc = dev_alloc(&g->eij, E)) || (rc = dev_alloc(&g->ew, E)) ||
-      (rc = dev_alloc(&g->grow, (size_t)V + 1)) || (rc = dev_alloc(&g->ginc, 2 * (size_t)E)))
+  if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d(g->pos, hpos))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->eij, E)) || (rc = dev_alloc(g->caps, &g->ew, E)) ||
+      (rc = dev_alloc(g->caps, &g->grow, (size_t)V + 1)) || (rc = dev_alloc(g->caps, &g->ginc, 2 * (size_t)E)))
     return rc;
   static_assert(sizeof(Int2) == sizeof(int2) && sizeof(Float4) == sizeof(float4) &&
                     sizeof(UInt2) == sizeof(uint2), "layout");
@@ -331,11 +351,11 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   }
   HIPCHK(hipMemcpy(g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
   if (P.has_tiles) {
-    if ((rc = dev_alloc(&g->tiles, P.tiles.size())) || (rc = h2d(g->tiles, P.tiles)) ||
-        (rc = dev_alloc(&g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->t_vmap, P.t_vmap)) ||
-        (rc = dev_alloc(&g->t_emap, P.t_emap.size())) || (rc = h2d(g->t_emap, P.t_emap)) ||
-        (rc = dev_alloc(&g->t_srow, P.t_srow.size())) || (rc = h2d(g->t_srow, P.t_srow)) ||
-        (rc = dev_alloc(&g->t_eij, P.t_eij.size())) || (rc = dev_alloc(&g->t_ew, P.t_ew.size())))
+    if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d(g->tiles, P.tiles)) ||
+        (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->t_vmap, P.t_vmap)) ||
+        (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->t_emap, P.t_emap)) ||
+        (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->t_srow, P.t_srow)) ||
+        (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ew, P.t_ew.size())))
       return rc;
     if (!P.t_eij.empty()) {
       HIPCHK(hipMemcpy(g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
@@ -343,19 +363,19 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     }
   }
   if (P.T > 0) {
-    if ((rc = dev_alloc(&g->tris, P.tris.size())) || (rc = h2d(g->tris, P.tris)) ||
-        (rc = dev_alloc(&g->trow, P.trow.size())) || (rc = h2d(g->trow, P.trow)) ||
-        (rc = dev_alloc(&g->tinc, P.tinc.size())) || (rc = h2d(g->tinc, P.tinc)) ||
-        (rc = dev_alloc(&g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(&g->tri_valid, (size_t)P.T)))
+    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->tris, P.tris)) ||
+        (rc = dev_alloc(g->caps, &g->trow, P.trow.size())) || (rc = h2d(g->trow, P.trow)) ||
+        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->tinc, P.tinc)) ||
+        (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
       return rc;
   }
-  if ((rc = dev_alloc(&g->vtx_normals, (size_t)V))) return rc;
-  if ((rc = dev_alloc(&g->mesh_pts, 3 * (size_t)V)) || (rc = dev_alloc(&g->v_i2o_dev, (size_t)V)) ||
+  if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) ||
       (rc = h2d(g->v_i2o_dev, P.v_i2o)))
     return rc;
-  if ((rc = dev_alloc(&g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
   if (g->profile && P.has_tiles) {
-    if ((rc = dev_alloc(&g->prof, P.tiles.size() * kProfWords))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->prof, P.tiles.size() * kProfWords))) return rc;
     HIPCHK(hipMemset(g->prof, 0, sizeof(unsigned long long) * P.tiles.size() * kProfWords));
   }
   g->uploaded = true;
@@ -456,7 +476,8 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   HIPCHK(hipEventRecord(g->ev0, s));
   int launches = 0, cur_out = g->cur;
   if (num_iters > 0 && g->V > 0) {
-    if (g->use_graph && s == g->stream) {
+    if (g->use_graph && s == g->stream && g->solves_since_upload > 0) {  // a frame stream that
+      // re-uploads before every solve never pays capture + instantiate
       GraphExecEntry* hit = nullptr;
       for (auto& e : g->execs)
         if (e.iters == num_iters && e.cur == g->cur && std::memcmp(&e.p, &sp, sizeof(sp)) == 0) hit = &e;
@@ -489,6 +510,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   }
   g->cur = cur_out;
   g->last_launches = launches;
+  g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
   g->timed = true;
   return 0;
@@ -630,11 +652,8 @@ int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip
   const int32_t V = g->V, T = g->plan.T;
   const int64_t npix = (int64_t)tp->width * tp->height;
   if (npix != g->map_pixels) {
-    for (void* p : {(void*)g->map_owner, (void*)g->map_idm, (void*)g->map_dm, (void*)g->map_cloud})
-      if (p) (void)hipFree(p);
-    g->map_owner = nullptr; g->map_idm = g->map_dm = g->map_cloud = nullptr; g->map_pixels = 0;
-    if ((rc = dev_alloc(&g->map_owner, (size_t)npix)) || (rc = dev_alloc(&g->map_idm, (size_t)npix)) ||
-        (rc = dev_alloc(&g->map_dm, (size_t)npix)) || (rc = dev_alloc(&g->map_cloud, 3 * (size_t)npix)))
+    if ((rc = dev_alloc(g->caps, &g->map_owner, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->map_idm, (size_t)npix)) ||
+        (rc = dev_alloc(g->caps, &g->map_dm, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->map_cloud, 3 * (size_t)npix)))
       return rc;
     g->map_pixels = npix;
   }
@@ -688,15 +707,14 @@ int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b
   return download_impl(g, true, xb, w1b, w2b, nullptr);
 }
 
-static int upload_index_list(const std::vector<int32_t>& map, int32_t limit, int32_t n,
+static int upload_index_list(CapMap& caps, const std::vector<int32_t>& map, int32_t limit, int32_t n,
                              const int32_t* ids, int32_t** dev) {
   std::vector<int32_t> h((size_t)(n > 0 ? n : 0));
   for (int32_t k = 0; k < n; ++k) {
     if (ids[k] < 0 || ids[k] >= limit) return FLAME_HIP_ERR_ARG;
     h[k] = map[ids[k]];
   }
-  if (*dev) { (void)hipFree(*dev); *dev = nullptr; }
-  int rc = dev_alloc(dev, h.size());
+  int rc = dev_alloc(caps, dev, h.size());
   if (rc) return rc;
   return h2d(*dev, h);
 }
@@ -712,10 +730,10 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(hipStreamSynchronize(g->stream));
   const Plan& P = g->plan;
-  if ((rc = upload_index_list(P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
-      (rc = upload_index_list(P.e_o2i, g->E, n_send_e, send_e, &g->halo_send_e)) ||
-      (rc = upload_index_list(P.v_o2i, g->V, n_recv_v, recv_v, &g->halo_recv_v)) ||
-      (rc = upload_index_list(P.e_o2i, g->E, n_recv_e, recv_e, &g->halo_recv_e)))
+  if ((rc = upload_index_list(g->caps, P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
+      (rc = upload_index_list(g->caps, P.e_o2i, g->E, n_send_e, send_e, &g->halo_send_e)) ||
+      (rc = upload_index_list(g->caps, P.v_o2i, g->V, n_recv_v, recv_v, &g->halo_recv_v)) ||
+      (rc = upload_index_list(g->caps, P.e_o2i, g->E, n_recv_e, recv_e, &g->halo_recv_e)))
     return rc;
   g->n_send_v = n_send_v; g->n_send_e = n_send_e; g->n_recv_v = n_recv_v; g->n_recv_e = n_recv_e;
   return 0;
