@@ -260,7 +260,7 @@ def main():
             out["config"]["workload"] = "batch of %d feature-grid graphs (640x480, win %d), %d PD iterations each" % (
                 args.batch, args.batch_win, iters)
             out["roofline"]["note"] += " Batch mode: value counts frame-iterations."
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # contract: rank 0 at N=1 only
             cb = cpu_baseline(frames[0] if args.batch else g, iters, args.cpu_budget)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1thread"] = out["value"] / (1 if partition else world) / cb["value"]
