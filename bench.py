@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--tile-depth", type=int, default=0)
     ap.add_argument("--tile-threads", type=int, default=0)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-balance", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "partition"],
@@ -133,6 +134,7 @@ def main():
     if args.tile_depth: opts["tile_depth"] = args.tile_depth
     if args.tile_threads: opts["tile_threads"] = args.tile_threads
     if args.no_graph: opts["use_graph"] = 0
+    if args.no_balance: opts["balance"] = 0
     p = default_params()
     if partition:
         from flame_ros_amd import dist as fdist

@@ -240,6 +240,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->opt.tile_threads = value;
   } else if (k == "use_graph") {
     g->use_graph = value != 0;
+  } else if (k == "balance") {
+    g->opt.balance = value != 0;
   } else if (k == "host_threads") {
     if (value < 0) return FLAME_HIP_ERR_ARG;
     g->opt.host_threads = value;

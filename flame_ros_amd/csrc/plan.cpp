@@ -14,9 +14,36 @@
 namespace flamehip {
 namespace {
 
-// Recursive coordinate bisection of idx[lo,hi) into `leaves` parts of near-equal size; parts are
-// emitted in recursion order, which keeps spatial neighbours close in the tile order.
-void rcb(const float* pos, std::vector<int32_t>& idx, int lo, int hi, int leaves,
+// Split position of idx[lo,hi) along `axis` for l1 of `leaves` parts.  Unweighted: equal counts
+// (nth_element).  Weighted (w != nullptr): sort along the axis and cut where the cumulative
+// weight reaches l1/leaves of the total, so parts get equal COST rather than equal size.
+int split_range(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, int hi,
+                int axis, int l1, int leaves) {
+  auto less = [&](int32_t a, int32_t b) {
+    const float pa = pos[2 * a + axis], pb = pos[2 * b + axis];
+    return pa < pb || (pa == pb && a < b);
+  };
+  if (!w) {
+    const int mid = lo + (int)(((int64_t)(hi - lo) * l1) / leaves);
+    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, less);
+    return mid;
+  }
+  std::sort(idx.begin() + lo, idx.begin() + hi, less);
+  double total = 0.0;
+  for (int k = lo; k < hi; ++k) total += w[idx[k]];
+  const double target = total * l1 / leaves;
+  double acc = 0.0;
+  int mid = lo;
+  while (mid < hi && acc + 0.5 * w[idx[mid]] < target) acc += w[idx[mid++]];
+  // every part keeps at least one vertex per leaf it must still produce
+  mid = std::max(lo + l1, std::min(mid, hi - (leaves - l1)));
+  return std::max(lo, std::min(mid, hi));
+}
+
+// Recursive coordinate bisection of idx[lo,hi) into `leaves` parts of near-equal size (or cost,
+// when weights are given); parts are emitted in recursion order, which keeps spatial neighbours
+// close in the tile order.
+void rcb(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, int hi, int leaves,
          std::vector<int32_t>* leaf_start) {
   if (leaves <= 1 || hi - lo <= 1) {
     leaf_start->push_back(lo);
@@ -32,22 +59,17 @@ void rcb(const float* pos, std::vector<int32_t>& idx, int lo, int hi, int leaves
     }
   const int axis = (mx[1] - mn[1] > mx[0] - mn[0]) ? 1 : 0;
   const int l1 = leaves / 2, l2 = leaves - l1;
-  const int mid = lo + (int)(((int64_t)(hi - lo) * l1) / leaves);
-  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
-                   [&](int32_t a, int32_t b) {
-                     const float pa = pos[2 * a + axis], pb = pos[2 * b + axis];
-                     return pa < pb || (pa == pb && a < b);
-                   });
-  rcb(pos, idx, lo, mid, l1, leaf_start);
-  rcb(pos, idx, mid, hi, l2, leaf_start);
+  const int mid = split_range(pos, w, idx, lo, hi, axis, l1, leaves);
+  rcb(pos, w, idx, lo, mid, l1, leaf_start);
+  rcb(pos, w, idx, mid, hi, l2, leaf_start);
 }
 
 // Same bisection, but the two halves of the top `par_levels` levels run on separate threads; each
 // half appends its leaves to its own list, concatenated in order (identical result).
-void rcb_par(const float* pos, std::vector<int32_t>& idx, int lo, int hi, int leaves,
-             std::vector<int32_t>* leaf_start, int par_levels) {
+void rcb_par(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, int hi,
+             int leaves, std::vector<int32_t>* leaf_start, int par_levels) {
   if (par_levels <= 0 || leaves <= 1 || hi - lo <= 4096) {
-    rcb(pos, idx, lo, hi, leaves, leaf_start);
+    rcb(pos, w, idx, lo, hi, leaves, leaf_start);
     return;
   }
   float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
@@ -59,15 +81,10 @@ void rcb_par(const float* pos, std::vector<int32_t>& idx, int lo, int hi, int le
     }
   const int axis = (mx[1] - mn[1] > mx[0] - mn[0]) ? 1 : 0;
   const int l1 = leaves / 2, l2 = leaves - l1;
-  const int mid = lo + (int)(((int64_t)(hi - lo) * l1) / leaves);
-  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
-                   [&](int32_t a, int32_t b) {
-                     const float pa = pos[2 * a + axis], pb = pos[2 * b + axis];
-                     return pa < pb || (pa == pb && a < b);
-                   });
+  const int mid = split_range(pos, w, idx, lo, hi, axis, l1, leaves);
   std::vector<int32_t> right;
-  std::thread th([&] { rcb_par(pos, idx, mid, hi, l2, &right, par_levels - 1); });
-  rcb_par(pos, idx, lo, mid, l1, leaf_start, par_levels - 1);
+  std::thread th([&] { rcb_par(pos, w, idx, mid, hi, l2, &right, par_levels - 1); });
+  rcb_par(pos, w, idx, lo, mid, l1, leaf_start, par_levels - 1);
   th.join();
   leaf_start->insert(leaf_start->end(), right.begin(), right.end());
 }
@@ -81,12 +98,14 @@ const TileCfg kCfgs[] = {
 };
 
 bool pick_cfg(int want_nt, int e_max, int upd_max, TileCfg* out) {
-  // first pass: the smallest workgroup that keeps <= 4 edges per thread (no spills, short serial
-  // chains); second pass: anything that fits
-  for (int pass = 0; pass < 2; ++pass)
+  // pass 0: one vertex and <= 3 edges per thread (most waves to hide LDS latency; measured:
+  // 1024 x 2 x 1 beats 512 x 4 x 2 by 4 % at 50 k); pass 1: <= 4 edges per thread (no spills);
+  // pass 2: anything that fits.  Within a pass the smallest workgroup wins.
+  for (int pass = 0; pass < 3; ++pass)
     for (const TileCfg& c : kCfgs) {
       if (want_nt && c.nt != want_nt) continue;
-      if (pass == 0 && c.ept > 4) continue;
+      if (pass == 0 && (c.ept > 3 || c.vpt > 1)) continue;
+      if (pass == 1 && c.ept > 4) continue;
       if ((int64_t)c.nt * c.ept >= e_max && (int64_t)c.nt * c.vpt >= upd_max) {
         *out = c;
         return true;
@@ -159,14 +178,21 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   std::vector<int32_t> deg_o(V, 0);
   for (int32_t e = 0; e < E; ++e) { deg_o[edges[2 * e]]++; deg_o[edges[2 * e + 1]]++; }
 
-  for (int attempt = 0; attempt < (batch ? 1 : 6); ++attempt) {
+  // Cost balancing (second pass): tiles at the image border have much larger halos (long hull
+  // edges of the triangulation), and a launch lasts as long as its slowest tile.  After a first
+  // unweighted partition every vertex gets the cost density of its tile and the bisection is
+  // redone on cost instead of count.
+  std::vector<float> vweight;
+  bool balanced = false;
+  for (int attempt = 0; attempt < (batch ? 1 : 7); ++attempt) {
     const int ntiles = batch ? (int)opt.batch_voff.size() - 1 : (V == 0 ? 0 : (V + tile_own - 1) / tile_own);
     // ---- vertex order: RCB leaves = tiles ----
     std::vector<int32_t> idx(V);
     std::iota(idx.begin(), idx.end(), 0);
     std::vector<int32_t> leaf_start;
     if (batch) leaf_start.assign(opt.batch_voff.begin(), opt.batch_voff.end() - 1);
-    else if (V > 0) rcb_par(pos, idx, 0, V, ntiles, &leaf_start, opt.host_threads == 1 ? 0 : 3);
+    else if (V > 0) rcb_par(pos, vweight.empty() ? nullptr : vweight.data(), idx, 0, V, ntiles, &leaf_start,
+                            opt.host_threads == 1 ? 0 : 3);
     leaf_start.push_back(V);
     // inside a tile the order is free (everything lives in LDS): sort by degree so the lanes of a
     // wave walk incidence lists of similar length
@@ -418,6 +444,18 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     TileCfg cfg{};
     if (ok && lds_max > lds_cap) ok = false;
     if (ok && !pick_cfg(opt.tile_threads, e_max, upd_max, &cfg)) ok = false;
+    if (ok && opt.balance && !balanced && !batch && !single && ntiles >= 16) {
+      balanced = true;
+      vweight.assign(V, 1.0f);
+      for (int t = 0; t < ntiles; ++t) {
+        const TileDesc& D = P.tiles[t];
+        const float cost = (float)D.e_loc + 2.0f * (float)D.n_ext;
+        for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k)
+          vweight[P.v_i2o[k]] = cost / (float)std::max(D.n_own, 1);
+      }
+      lap("balance weights");
+      continue;  // rebuild with weighted bisection (same tile count)
+    }
     if (ok) {
       P.has_tiles = true;
       P.tile_threads = cfg.nt; P.tile_ept = cfg.ept; P.tile_vpt = cfg.vpt;
@@ -425,6 +463,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       P.tile_lds_bytes = lds_max;
       return 0;
     }
+    vweight.clear();  // a failed weighted pass falls back to plain bisection with smaller tiles
     // did not fit: shrink the tiles (a single tile becomes a halo'd partition) and retry
     P.tiles.clear();
     if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }

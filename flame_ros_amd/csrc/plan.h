@@ -20,6 +20,7 @@ struct PlanOptions {
   int tile_threads = 0;  // workgroup size (0 = auto)
   int64_t lds_bytes = 160 * 1024;
   int host_threads = 0;  // plan-build threads (0 = up to 8)
+  int balance = 1;       // second, cost-weighted bisection pass (equalises tile cost)
   // batch of independent graphs (frames axis): nb + 1 vertex offsets; graph b = one isolated tile
   std::vector<int32_t> batch_voff;
 };
