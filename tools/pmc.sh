@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev helper (gpurun): PMC counters of the tile kernel.  usage: scripts_pmc.sh <tag> <bench args...>
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 tag=$1; shift
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES"; do
   n=$(echo $set | cut -d' ' -f1)

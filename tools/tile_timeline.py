@@ -1,6 +1,6 @@
 """dev helper: in-kernel timeline of the tile kernel (cycles) per tile."""
-import sys, numpy as np
-sys.path.insert(0, '.')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flame_ros_amd import graphgen
 from flame_ros_amd.regularizer import GraphRegularizer, default_params
 import argparse
