@@ -39,7 +39,7 @@ struct TileDesc {
   int32_t emap_off;   // into t_emap: e_loc internal edge ids (gather list of q, owned first)
   int32_t erec_off;   // into t_eij / t_ew: e_loc records
   int32_t srow_off;   // into t_srow: n_upd packed {slot of incidence 0 | degree << 16}
-  int32_t nslots;     // incidence slots (transposed per 64-vertex group: slot(j) = slot0 + 64 j)
+  int32_t nslots;     // incidence slots (one row per vertex, odd pitch per 64-vertex group)
   int32_t ring_end[kMaxDepth + 1];   // ring_end[r] = #local vertices with ring <= r
   int32_t level_end[kMaxDepth + 1];  // level_end[l] = #local edges with level <= l
 };

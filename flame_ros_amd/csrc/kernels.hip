@@ -266,12 +266,12 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
         const int sb = (int)(vs[k] & 0xffffu), deg = (int)(vs[k] >> 16);
         const float xp = vx[k], w1p = vw1[k], w2p = vw2[k];
         float x = xp, w1 = w1p, w2 = w2p;
-        // transposed slots: incidence j of this lane is at sb + 64 j (conflict-free across lanes);
-        // the group is padded to the wave's max degree, so reads past deg stay in bounds
+        // incidence j of this lane is at sb + j; rows have an odd pitch >= the wave's max degree, so
+        // a column read is conflict-free across lanes and reads past deg stay inside the row
         for (int j = 0; j < wdeg[k]; j += kPRound) {  // wave-uniform trip count
           float4 t[kPRound];
 #pragma unroll
-          for (int u = 0; u < kPRound; ++u) t[u] = lds_read4(cs + sb + 64 * min(j + u, wdeg[k] - 1));
+          for (int u = 0; u < kPRound; ++u) t[u] = lds_read4(cs + sb + min(j + u, wdeg[k] - 1));
 #pragma unroll
           for (int u = 0; u < kPRound; ++u) {
             const bool on = (j + u) < deg;

@@ -207,12 +207,20 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     for (int t = 0; t < ntiles; ++t)
       for (int k = leaf_start[t]; k < leaf_start[t + 1]; ++k) tile_of[k] = t;
 
-    // ---- edge order: (owner tile of the source, level 0 before level 1, original id) ----
-    // counting sort over the 2 * ntiles buckets; visiting e in ascending original id keeps each
-    // bucket in original order
+    // ---- edge order: (owner tile of the source, level 0 before level 1, source vertex,
+    // original id).  Edges of one source are adjacent, so the lanes of a wave gather the same or
+    // consecutive `bar` entries (broadcast / conflict-free) and write consecutive incidence slots.
+    // Two stable counting sorts: by source internal id, then by the 2 * ntiles (tile, level)
+    // buckets.
     std::vector<int32_t> eorder(E);
     {
       std::vector<int32_t>& cnt = P.b_fill;
+      std::vector<int32_t>& by_src = P.b_estart;
+      by_src.resize(E);
+      cnt.assign((size_t)V + 1, 0);
+      for (int32_t e = 0; e < E; ++e) cnt[P.v_o2i[edges[2 * e]] + 1]++;
+      for (int32_t v = 0; v < V; ++v) cnt[v + 1] += cnt[v];
+      for (int32_t e = 0; e < E; ++e) by_src[cnt[P.v_o2i[edges[2 * e]]]++] = e;
       cnt.assign(2 * (size_t)ntiles + 1, 0);
       auto bucket = [&](int32_t e) {
         const int32_t ti = tile_of[P.v_o2i[edges[2 * e]]], tj = tile_of[P.v_o2i[edges[2 * e + 1]]];
@@ -220,7 +228,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       };
       for (int32_t e = 0; e < E; ++e) cnt[bucket(e) + 1]++;
       for (size_t b = 0; b + 1 < cnt.size(); ++b) cnt[b + 1] += cnt[b];
-      for (int32_t e = 0; e < E; ++e) eorder[cnt[bucket(e)]++] = e;
+      for (int32_t k = 0; k < E; ++k) { const int32_t e = by_src[k]; eorder[cnt[bucket(e)]++] = e; }
     }
     P.e_i2o = eorder;
     P.e_o2i.assign(E, 0);
@@ -327,7 +335,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         if (D.n_ext > 65535) { O.ok = false; continue; }
         O.vmap.assign(ext.begin(), ext.end());
         // local edges: each ext vertex contributes its outgoing (source-role) incidences;
-        // sort key = (level, not-owned, original id) packed in 64 bits
+        // sort key = (level, not-owned, source local id, original id) packed in 64 bits
         keys.clear();
         for (int32_t lv = 0; lv < D.n_ext; ++lv) {
           const int32_t v = ext[lv];
@@ -339,7 +347,9 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
             const int32_t lvl = std::max(ring[v], ring[u]);
             if (depth > 0 && std::min(ring[v], ring[u]) >= depth) continue;  // feeds no updated vertex
             const uint64_t notown = (lvl <= 1 && ring[v] != 0) ? 1 : 0;
-            keys.push_back(((uint64_t)lvl << 40) | (notown << 39) | (uint64_t)(uint32_t)P.e_i2o[k]);
+            // [level:5][not owned:1][source local id:16][original id:32]
+            keys.push_back(((uint64_t)lvl << 49) | (notown << 48) | ((uint64_t)(uint32_t)lv << 32) |
+                           (uint64_t)(uint32_t)P.e_i2o[k]);
           }
         }
         std::sort(keys.begin(), keys.end());
@@ -360,33 +370,36 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         {
           int32_t le = 0;
           for (int l = 0; l <= kMaxDepth; ++l) {
-            while (le < D.e_loc && (int)(keys[le] >> 40) <= l) ++le;
+            while (le < D.e_loc && (int)(keys[le] >> 49) <= l) ++le;
             D.level_end[l] = le;
           }
         }
         O.emap.assign(lk.begin(), lk.end());
-        // Transposed incidence slots: the 64 vertices a wave updates together form a group; the
-        // j-th incidence of lane l lives at base + 64 j + l, so phase P reads are conflict-free.
-        // Within a vertex the incidences keep ascending original edge id (ginc order).
+        // Incidence slots, one row per vertex with an ODD pitch W per 64-vertex group (the 64
+        // vertices a wave updates together): slot(lv, j) = base + (lv - g0) W + j.  Phase P reads
+        // column j across lanes (stride W, odd => conflict-free ds_read_b128); phase D writes the
+        // consecutive incidences of one source from consecutive lanes.  Within a vertex the
+        // incidences keep ascending original edge id (ginc order).
         slot_src.assign(D.e_loc, 0xffff);
         slot_dst.assign(D.e_loc, 0xffff);
         O.srow.clear();
         int32_t base = 0;
         for (int32_t g0 = 0; g0 < D.n_upd && O.ok; g0 += 64) {
           const int32_t g1 = std::min(g0 + 64, D.n_upd);
-          int32_t width = 0;
+          int32_t width = 1;
           for (int32_t lv = g0; lv < g1; ++lv) width = std::max(width, P.grow[ext[lv] + 1] - P.grow[ext[lv]]);
+          width |= 1;
           if (base + 64 * width + kDummySlots > 65535) { O.ok = false; break; }
           for (int32_t lv = g0; lv < g1 && O.ok; ++lv) {
             const int32_t v = ext[lv];
             const int32_t deg = P.grow[v + 1] - P.grow[v];
-            const int32_t s0 = base + (lv - g0);
+            const int32_t s0 = base + (lv - g0) * width;
             O.srow.push_back((uint32_t)s0 | ((uint32_t)deg << 16));
             int32_t j = 0;
             for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s, ++j) {
               const int32_t k = P.ginc[s] & 0x7fffffff;
               if (estamp[k] != t) { O.ok = false; O.note = "halo closure invariant"; break; }
-              const uint16_t slot = (uint16_t)(s0 + 64 * j);
+              const uint16_t slot = (uint16_t)(s0 + j);
               if (P.ginc[s] < 0) slot_dst[eloc[k]] = slot; else slot_src[eloc[k]] = slot;
             }
           }

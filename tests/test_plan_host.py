@@ -141,11 +141,13 @@ def test_plan_invariants(V, opts):
             assert np.all(np.isin(nb, ext))
         level = np.maximum(ring[li], ring[lj])
         assert np.all(np.diff(level) >= 0)
+        own_e = slice(0, T.e_own)  # owned edges: grouped by source (adjacent lanes share gathers)
+        assert np.all(np.diff(li[own_e].astype(np.int64))[level[own_e][1:] == level[own_e][:-1]] >= 0)
         for l in range(depth + 1):
             assert level_end[l] == int((level <= l).sum())
         assert T.n_upd == (T.n_ext if depth == 0 else ring_end[depth - 1])
         # incidence slots: every (updated vertex, incidence) is hit by exactly one edge endpoint,
-        # at position = rank of the edge's original id in the vertex's list; transposed by 64
+        # at position = rank of the edge's original id in the vertex's list (row-major, odd pitch)
         sr = srow[T.srow_off:T.srow_off + T.n_upd]
         s0, dg = (sr & 0xffff).astype(np.int64), (sr >> 16).astype(np.int64)
         assert np.array_equal(dg, deg[ext[:T.n_upd]])
@@ -154,8 +156,8 @@ def test_plan_invariants(V, opts):
         for e in range(T.e_loc):
             for lv, slot in ((li[e], ss[e]), (lj[e], sd[e])):
                 if lv < T.n_upd:
-                    assert slot != 0xffff and (slot - s0[lv]) % 64 == 0 and slot < T.nslots
-                    used.setdefault(int(lv), []).append(((slot - s0[lv]) // 64, e_i2o[loc_e[e]]))
+                    assert slot != 0xffff and 0 <= slot - s0[lv] < dg[lv] and slot < T.nslots
+                    used.setdefault(int(lv), []).append((slot - s0[lv], e_i2o[loc_e[e]]))
                 else:
                     assert slot == 0xffff
         for lv, lst in used.items():
