@@ -104,13 +104,11 @@ __global__ __launch_bounds__(256) void k_primal(int32_t V, const int32_t* __rest
 // slot order (= ascending original edge id => deterministic and oracle-exact), prox,
 // extra-gradient, publishes the new bar[].  Two workgroup barriers per iteration, no atomics.
 // ------------------------------------------------------------------------------------------
-// LDS float4 read that keeps all four lanes live, so the compiler emits ds_read_b128 (4 LDS cycles
-// per wave) instead of ds_read_b96 (8 cycles) when only x,y,z are consumed.
-__device__ __forceinline__ float4 lds_read4(const float4* p) {
-  float4 v = *p;
-  asm volatile("" ::"v"(v.w));
-  return v;
-}
+// Keeps the unused 4th component of an LDS float4 read live, so the compiler emits ds_read_b128
+// (4 LDS cycles per wave) instead of ds_read_b96 (8 cycles) when only x,y,z are consumed.  Call
+// it AFTER a whole batch of reads has been issued: the empty asm makes the compiler wait for its
+// operand, so touching each value right after its own load would serialise the batch.
+__device__ __forceinline__ void keep_w(const float4& v) { asm volatile("" ::"v"(v.w)); }
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -128,9 +126,11 @@ __device__ __forceinline__ void tile_phase_d(const float4* bar, float4* cs,
   float4 bi[K], bj[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    bi[k] = lds_read4(bar + (eij[k] & 0xffffu));
-    bj[k] = lds_read4(bar + (eij[k] >> 16));
+    bi[k] = bar[eij[k] & 0xffffu];
+    bj[k] = bar[eij[k] >> 16];
   }
+#pragma unroll
+  for (int k = 0; k < K; ++k) { keep_w(bi[k]); keep_w(bj[k]); }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     dual_edge(bi[k], bj[k], ew[k], sigma, q1[k], q2[k], q3[k]);
@@ -271,7 +271,9 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
         for (int j = 0; j < wdeg[k]; j += kPRound) {  // wave-uniform trip count
           float4 t[kPRound];
 #pragma unroll
-          for (int u = 0; u < kPRound; ++u) t[u] = lds_read4(cs + sb + min(j + u, wdeg[k] - 1));
+          for (int u = 0; u < kPRound; ++u) t[u] = cs[sb + min(j + u, wdeg[k] - 1)];
+#pragma unroll
+          for (int u = 0; u < kPRound; ++u) keep_w(t[u]);
 #pragma unroll
           for (int u = 0; u < kPRound; ++u) {
             const bool on = (j + u) < deg;
