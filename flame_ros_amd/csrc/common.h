@@ -19,7 +19,9 @@ namespace flamehip {
 
 constexpr int kMaxDepth = 16;    // max halo depth (iterations per tile launch)
 constexpr int kProfWords = 2 * kMaxDepth + 4;  // debug timeline words per tile
-constexpr int kDummySlots = 64;  // per-lane trash slots behind the incidence slots (inert writes)
+constexpr int kSlotRound = 4;    // incidence slots summed per round of phase P
+constexpr int kDummySlots = 64;  // per-lane trash slots behind the incidence slots (inert writes);
+                                 // one more, always +0, follows them (reads past a vertex's degree)
 
 struct SolveParams {
   float lambda, tau, sigma, theta, x_min, x_max;

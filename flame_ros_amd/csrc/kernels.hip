@@ -161,10 +161,7 @@ struct PhaseD<0, EPT> {
                                              float (&)[EPT], float (&)[EPT], float (&)[EPT], float) {}
 };
 
-#ifndef FLAME_P_ROUND
-#define FLAME_P_ROUND 4
-#endif
-constexpr int kPRound = FLAME_P_ROUND;  // incidence slots read per round of phase P
+constexpr int kPRound = kSlotRound;  // incidence slots read per round of phase P
 
 template <int NT, int EPT, int VPT>
 __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
@@ -184,6 +181,9 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   // active-set cutoffs live in lanes: lane l < 32 holds ring_end[l], lane 32+l holds level_end[l]
   int cut = 0;
   if ((lane & 31) <= kMaxDepth) cut = (lane < 32) ? D.ring_end[lane & 31] : D.level_end[lane & 31];
+
+  const int zslot = D.nslots + kDummySlots;  // the always-zero slot
+  if (tid == 0) cs[zslot] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- global loads: index lists first, then every dependent gather, nothing waited between ----
   int gi[VPT];
@@ -266,20 +266,21 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
         const int sb = (int)(vs[k] & 0xffffu), deg = (int)(vs[k] >> 16);
         const float xp = vx[k], w1p = vw1[k], w2p = vw2[k];
         float x = xp, w1 = w1p, w2 = w2p;
-        // incidence j of this lane is at sb + j; rows have an odd pitch >= the wave's max degree, so
-        // a column read is conflict-free across lanes and reads past deg stay inside the row
+        // incidence j of this lane is at sb + j (rows have an odd pitch: a column read is
+        // conflict-free across lanes).  Past the vertex's degree the lane reads the shared +0
+        // slot instead: fmaf(-tau, +0, x) == x bit-for-bit, so the dependent fma chain carries
+        // no select (the select is on the address, ahead of the load).
         for (int j = 0; j < wdeg[k]; j += kPRound) {  // wave-uniform trip count
           float4 t[kPRound];
 #pragma unroll
-          for (int u = 0; u < kPRound; ++u) t[u] = cs[sb + min(j + u, wdeg[k] - 1)];
+          for (int u = 0; u < kPRound; ++u) t[u] = cs[(j + u < deg) ? (sb + j + u) : zslot];
 #pragma unroll
           for (int u = 0; u < kPRound; ++u) keep_w(t[u]);
 #pragma unroll
           for (int u = 0; u < kPRound; ++u) {
-            const bool on = (j + u) < deg;
-            x = on ? fmaf(ntau, t[u].x, x) : x;
-            w1 = on ? fmaf(ntau, t[u].y, w1) : w1;
-            w2 = on ? fmaf(ntau, t[u].z, w2) : w2;
+            x = fmaf(ntau, t[u].x, x);
+            w1 = fmaf(ntau, t[u].y, w1);
+            w2 = fmaf(ntau, t[u].z, w2);
           }
         }
         x = prox_l1(x, vz[k], vt[k], x_min, x_max);
