@@ -19,7 +19,10 @@ namespace flamehip {
 
 constexpr int kMaxDepth = 16;    // max halo depth (iterations per tile launch)
 constexpr int kProfWords = 2 * kMaxDepth + 4;  // debug timeline words per tile
-constexpr int kSlotRound = 4;    // incidence slots summed per round of phase P
+#ifndef FLAME_SLOT_ROUND
+#define FLAME_SLOT_ROUND 6
+#endif
+constexpr int kSlotRound = FLAME_SLOT_ROUND;    // incidence slots summed per round of phase P
 constexpr int kDummySlots = 64;  // per-lane trash slots behind the incidence slots (inert writes);
                                  // one more, always +0, follows them (reads past a vertex's degree)
 
