@@ -203,3 +203,36 @@ def test_dense_maps(gpu, filtered):
     assert 0.5 < cover <= 1.0 and (np.isnan(dm).sum() >= np.isnan(idm).sum())
     if filtered:
         assert np.isnan(idm).sum() > np.isnan(r.depthmaps(Kinv, tp, filtered=False, cloud=False)[0]).sum()
+
+
+def test_irregular_graphs(gpu):
+    """Degree distributions no Delaunay graph has: a 3000-leaf star (one incidence list too long
+    for any LDS tile -> automatic global path), a path, parallel edges and both orientations."""
+    rng = np.random.default_rng(3)
+
+    class G:
+        pass
+
+    def mk(pos, edges):
+        g = G()
+        g.pos = np.asarray(pos, np.float32)
+        g.edges = np.asarray(edges, np.int32)
+        g.V, g.E = len(g.pos), len(g.edges)
+        d = g.pos[g.edges[:, 0]] - g.pos[g.edges[:, 1]]
+        g.alpha = (1.0 / np.maximum(np.sqrt((d ** 2).sum(1)), 1.0)).astype(np.float32)
+        g.beta = g.alpha.copy()
+        g.z = (0.5 + 0.3 * rng.random(g.V)).astype(np.float32)
+        g.wgt = np.ones(g.V, np.float32)
+        g.tris = None
+        return g
+
+    n = 3000
+    star = mk(np.c_[rng.uniform(0, 640, n + 1), rng.uniform(0, 480, n + 1)],
+              [(0, k) if k % 2 else (k, 0) for k in range(1, n + 1)])
+    path = mk(np.c_[np.arange(4000) * 3.0, np.zeros(4000)], [(k, k + 1) for k in range(3999)])
+    multi = mk(rng.uniform(0, 100, (50, 2)),
+               [(a, b) for a in range(50) for b in range(a + 1, 50) if (a + b) % 7 == 0] * 2)
+    for name, g, want_path in (("star", star, 1), ("path", path, 2), ("multi", multi, 2)):
+        o, r = run_both(g, {}, 60, state_seed=12)
+        assert r.info("path") == want_path, name
+        compare_state(o, r, name)
