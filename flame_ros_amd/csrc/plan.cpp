@@ -28,13 +28,36 @@ int split_range(const float* pos, const float* w, std::vector<int32_t>& idx, int
     std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, less);
     return mid;
   }
-  std::sort(idx.begin() + lo, idx.begin() + hi, less);
+  // weighted quickselect (expected O(n)): narrow [a,b) until the prefix weight reaches `target`
   double total = 0.0;
   for (int k = lo; k < hi; ++k) total += w[idx[k]];
-  const double target = total * l1 / leaves;
-  double acc = 0.0;
-  int mid = lo;
-  while (mid < hi && acc + 0.5 * w[idx[mid]] < target) acc += w[idx[mid++]];
+  double target = total * l1 / leaves;
+  // invariant: [lo,a) < [a,b) < [b,hi) along the axis; `target` = weight still to take from a on
+  int a = lo, b = hi;
+  while (b - a > 32) {
+    const int32_t c0 = idx[a], c1 = idx[a + (b - a) / 2], c2 = idx[b - 1];
+    const int32_t piv = less(c0, c1) ? (less(c1, c2) ? c1 : (less(c0, c2) ? c2 : c0))
+                                     : (less(c0, c2) ? c0 : (less(c1, c2) ? c2 : c1));
+    const int mi = (int)(std::partition(idx.begin() + a, idx.begin() + b,
+                                        [&](int32_t v) { return less(v, piv); }) - idx.begin());
+    if (mi == a) {  // the pivot is the minimum of the range: settle it at position a
+      std::iter_swap(idx.begin() + a, std::find(idx.begin() + a, idx.begin() + b, piv));
+      if (target <= 0.5 * w[piv]) { b = a; break; }
+      target -= w[piv];
+      ++a;
+      continue;
+    }
+    double lw = 0.0;
+    for (int k = a; k < mi; ++k) lw += w[idx[k]];
+    if (lw >= target) b = mi;
+    else { target -= lw; a = mi; }
+  }
+  std::sort(idx.begin() + a, idx.begin() + b, less);
+  int mid = a;
+  {
+    double acc = 0.0;
+    while (mid < b && acc + 0.5 * w[idx[mid]] < target) acc += w[idx[mid++]];
+  }
   // every part keeps at least one vertex per leaf it must still produce
   mid = std::max(lo + l1, std::min(mid, hi - (leaves - l1)));
   return std::max(lo, std::min(mid, hi));
