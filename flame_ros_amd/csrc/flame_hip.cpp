@@ -59,10 +59,20 @@ int dev_alloc(CapMap& caps, T** p, size_t n) {
   return 0;
 }
 
+// All copies go through the handle's own non-blocking stream (hipMemcpyAsync + stream sync),
+// never the legacy stream: a legacy-stream copy in one host thread collides with a stream capture
+// running in another thread (hipErrorStreamCaptureImplicit), and distinct handles must be usable
+// from distinct threads.
+inline hipError_t memcpy_sync(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+
 template <class T>
-int h2d(T* dst, const std::vector<T>& src) {
+int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
   if (src.empty()) return 0;
-  HIPCHK(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(s, dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -336,49 +346,49 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     if ((rc = dev_alloc(g->caps, &g->A[b], V))) return rc;
     if ((rc = dev_alloc(g->caps, &g->B[b], V))) return rc;
     if ((rc = dev_alloc(g->caps, &g->q[b], E))) return rc;
-    HIPCHK(hipMemset(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1)));
+    HIPCHK(hipMemsetAsync(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
   }
   g->cur = 0;
-  if ((rc = h2d(g->A[0], hA)) || (rc = h2d(g->B[0], hB))) return rc;
-  if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d(g->pos, hpos))) return rc;
+  if ((rc = h2d(g->stream, g->A[0], hA)) || (rc = h2d(g->stream, g->B[0], hB))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d(g->stream, g->pos, hpos))) return rc;
   if ((rc = dev_alloc(g->caps, &g->eij, E)) || (rc = dev_alloc(g->caps, &g->ew, E)) ||
       (rc = dev_alloc(g->caps, &g->grow, (size_t)V + 1)) || (rc = dev_alloc(g->caps, &g->ginc, 2 * (size_t)E)))
     return rc;
   static_assert(sizeof(Int2) == sizeof(int2) && sizeof(Float4) == sizeof(float4) &&
                     sizeof(UInt2) == sizeof(uint2), "layout");
   if (E > 0) {
-    HIPCHK(hipMemcpy(g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice));
+    HIPCHK(memcpy_sync(g->stream, g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice));
+    HIPCHK(memcpy_sync(g->stream, g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice));
+    HIPCHK(memcpy_sync(g->stream, g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice));
   }
-  HIPCHK(hipMemcpy(g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
+  HIPCHK(memcpy_sync(g->stream, g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
   if (P.has_tiles) {
-    if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d(g->tiles, P.tiles)) ||
-        (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->t_vmap, P.t_vmap)) ||
-        (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->t_emap, P.t_emap)) ||
-        (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->t_srow, P.t_srow)) ||
+    if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d(g->stream, g->tiles, P.tiles)) ||
+        (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->stream, g->t_vmap, P.t_vmap)) ||
+        (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->stream, g->t_emap, P.t_emap)) ||
+        (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->stream, g->t_srow, P.t_srow)) ||
         (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ew, P.t_ew.size())))
       return rc;
     if (!P.t_eij.empty()) {
-      HIPCHK(hipMemcpy(g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
+      HIPCHK(memcpy_sync(g->stream, g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
+      HIPCHK(memcpy_sync(g->stream, g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
     }
   }
   if (P.T > 0) {
-    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->tris, P.tris)) ||
-        (rc = dev_alloc(g->caps, &g->trow, P.trow.size())) || (rc = h2d(g->trow, P.trow)) ||
-        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->tinc, P.tinc)) ||
+    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->stream, g->tris, P.tris)) ||
+        (rc = dev_alloc(g->caps, &g->trow, P.trow.size())) || (rc = h2d(g->stream, g->trow, P.trow)) ||
+        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->stream, g->tinc, P.tinc)) ||
         (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
       return rc;
   }
   if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
   if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) ||
-      (rc = h2d(g->v_i2o_dev, P.v_i2o)))
+      (rc = h2d(g->stream, g->v_i2o_dev, P.v_i2o)))
     return rc;
   if ((rc = dev_alloc(g->caps, &g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
   if (g->profile && P.has_tiles) {
     if ((rc = dev_alloc(g->caps, &g->prof, P.tiles.size() * kProfWords))) return rc;
-    HIPCHK(hipMemset(g->prof, 0, sizeof(unsigned long long) * P.tiles.size() * kProfWords));
+    HIPCHK(hipMemsetAsync(g->prof, 0, sizeof(unsigned long long) * P.tiles.size() * kProfWords, g->stream));
   }
   g->uploaded = true;
   g->timed = false;
@@ -403,8 +413,8 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
   if (x || w1 || w2 || xb || w1b || w2b) {
     std::vector<float4> hA(V), hB(V);
     if (V > 0) {
-      HIPCHK(hipMemcpy(hA.data(), g->A[g->cur], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(hB.data(), g->B[g->cur], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
+      HIPCHK(memcpy_sync(g->stream, hA.data(), g->A[g->cur], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
+      HIPCHK(memcpy_sync(g->stream, hB.data(), g->B[g->cur], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
     }
     for (int32_t k = 0; k < V; ++k) {
       const int32_t o = P.v_i2o[k];
@@ -415,7 +425,7 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
       if (w1b) hB[k].y = w1b[o];
       if (w2b) hB[k].z = w2b[o];
     }
-    if ((rc = h2d(g->A[g->cur], hA)) || (rc = h2d(g->B[g->cur], hB))) return rc;
+    if ((rc = h2d(g->stream, g->A[g->cur], hA)) || (rc = h2d(g->stream, g->B[g->cur], hB))) return rc;
   }
   if (q && E > 0) {
     std::vector<float4> hq(E);
@@ -423,7 +433,7 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
       const int32_t o = P.e_i2o[k];
       hq[k] = make_float4(q[3 * o], q[3 * o + 1], q[3 * o + 2], 0.f);
     }
-    if ((rc = h2d(g->q[g->cur], hq))) return rc;
+    if ((rc = h2d(g->stream, g->q[g->cur], hq))) return rc;
   }
   return 0;
 }
@@ -485,7 +495,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
         if (e.iters == num_iters && e.cur == g->cur && std::memcmp(&e.p, &sp, sizeof(sp)) == 0) hit = &e;
       if (!hit) {
         hipGraph_t graph = nullptr;
-        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
         rc = enqueue_iterations(g, sp, num_iters, s, g->cur, &cur_out, &launches);
         hipError_t ee = hipStreamEndCapture(s, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -576,17 +586,17 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
   const Plan& P = g->plan;
   if (vtx_normals && V > 0) {
     std::vector<float4> h(V);
-    HIPCHK(hipMemcpy(h.data(), g->vtx_normals, sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(g->stream, h.data(), g->vtx_normals, sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
     for (int32_t k = 0; k < V; ++k) {
       const int32_t o = P.v_i2o[k];
       vtx_normals[3 * o] = h[k].x; vtx_normals[3 * o + 1] = h[k].y; vtx_normals[3 * o + 2] = h[k].z;
     }
   }
   if (tri_valid && T > 0)
-    HIPCHK(hipMemcpy(tri_valid, g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(g->stream, tri_valid, g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
   if (tri_normals && T > 0) {
     std::vector<float4> h(T);
-    HIPCHK(hipMemcpy(h.data(), g->tri_normals, sizeof(float4) * (size_t)T, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(g->stream, h.data(), g->tri_normals, sizeof(float4) * (size_t)T, hipMemcpyDeviceToHost));
     for (int32_t t = 0; t < T; ++t) {
       tri_normals[3 * t] = h[t].x; tri_normals[3 * t + 1] = h[t].y; tri_normals[3 * t + 2] = h[t].z;
     }
@@ -624,11 +634,11 @@ int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_
                      tp->height, g->mesh_pts));
   HIPCHK(hipStreamSynchronize(g->stream));
   if (points && V > 0)
-    HIPCHK(hipMemcpy(points, g->mesh_pts, sizeof(float4) * 3 * (size_t)V, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(g->stream, points, g->mesh_pts, sizeof(float4) * 3 * (size_t)V, hipMemcpyDeviceToHost));
   int32_t nf = 0;
   if (T > 0 && (faces || num_faces)) {
     std::vector<uint8_t> valid(T);
-    HIPCHK(hipMemcpy(valid.data(), g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(g->stream, valid.data(), g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
     for (int32_t t = 0; t < T; ++t)
       if (valid[t]) {
         if (faces) {  // reversed winding, caller's vertex ids (reference src/utils.cc:224-226)
@@ -667,9 +677,9 @@ int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip
                        g->tri_valid, filtered, d, min_depth, max_depth, g->map_owner, g->map_idm,
                        depthmap || cloud ? g->map_dm : nullptr, cloud ? g->map_cloud : nullptr));
   HIPCHK(hipStreamSynchronize(g->stream));
-  if (idepthmap) HIPCHK(hipMemcpy(idepthmap, g->map_idm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
-  if (depthmap) HIPCHK(hipMemcpy(depthmap, g->map_dm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
-  if (cloud) HIPCHK(hipMemcpy(cloud, g->map_cloud, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost));
+  if (idepthmap) HIPCHK(memcpy_sync(g->stream, idepthmap, g->map_idm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
+  if (depthmap) HIPCHK(memcpy_sync(g->stream, depthmap, g->map_dm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
+  if (cloud) HIPCHK(memcpy_sync(g->stream, cloud, g->map_cloud, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -681,7 +691,7 @@ static int download_impl(flame_hip_graph* g, bool bar, float* a0, float* a1, flo
   const Plan& P = g->plan;
   if ((a0 || a1 || a2) && V > 0) {
     std::vector<float4> h(V);
-    HIPCHK(hipMemcpy(h.data(), bar ? g->B[g->cur] : g->A[g->cur], sizeof(float4) * (size_t)V,
+    HIPCHK(memcpy_sync(g->stream, h.data(), bar ? g->B[g->cur] : g->A[g->cur], sizeof(float4) * (size_t)V,
                      hipMemcpyDeviceToHost));
     for (int32_t k = 0; k < V; ++k) {
       const int32_t o = P.v_i2o[k];
@@ -692,7 +702,7 @@ static int download_impl(flame_hip_graph* g, bool bar, float* a0, float* a1, flo
   }
   if (q && E > 0) {
     std::vector<float4> h(E);
-    HIPCHK(hipMemcpy(h.data(), g->q[g->cur], sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost));
+    HIPCHK(memcpy_sync(g->stream, h.data(), g->q[g->cur], sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost));
     for (int32_t k = 0; k < E; ++k) {
       const int32_t o = P.e_i2o[k];
       q[3 * o] = h[k].x; q[3 * o + 1] = h[k].y; q[3 * o + 2] = h[k].z;
@@ -709,8 +719,8 @@ int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b
   return download_impl(g, true, xb, w1b, w2b, nullptr);
 }
 
-static int upload_index_list(CapMap& caps, const std::vector<int32_t>& map, int32_t limit, int32_t n,
-                             const int32_t* ids, int32_t** dev) {
+static int upload_index_list(hipStream_t s, CapMap& caps, const std::vector<int32_t>& map,
+                             int32_t limit, int32_t n, const int32_t* ids, int32_t** dev) {
   std::vector<int32_t> h((size_t)(n > 0 ? n : 0));
   for (int32_t k = 0; k < n; ++k) {
     if (ids[k] < 0 || ids[k] >= limit) return FLAME_HIP_ERR_ARG;
@@ -718,7 +728,7 @@ static int upload_index_list(CapMap& caps, const std::vector<int32_t>& map, int3
   }
   int rc = dev_alloc(caps, dev, h.size());
   if (rc) return rc;
-  return h2d(*dev, h);
+  return h2d(s, *dev, h);
 }
 
 int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t* send_v,
@@ -732,10 +742,10 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(hipStreamSynchronize(g->stream));
   const Plan& P = g->plan;
-  if ((rc = upload_index_list(g->caps, P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
-      (rc = upload_index_list(g->caps, P.e_o2i, g->E, n_send_e, send_e, &g->halo_send_e)) ||
-      (rc = upload_index_list(g->caps, P.v_o2i, g->V, n_recv_v, recv_v, &g->halo_recv_v)) ||
-      (rc = upload_index_list(g->caps, P.e_o2i, g->E, n_recv_e, recv_e, &g->halo_recv_e)))
+  if ((rc = upload_index_list(g->stream, g->caps, P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
+      (rc = upload_index_list(g->stream, g->caps, P.e_o2i, g->E, n_send_e, send_e, &g->halo_send_e)) ||
+      (rc = upload_index_list(g->stream, g->caps, P.v_o2i, g->V, n_recv_v, recv_v, &g->halo_recv_v)) ||
+      (rc = upload_index_list(g->stream, g->caps, P.e_o2i, g->E, n_recv_e, recv_e, &g->halo_recv_e)))
     return rc;
   g->n_send_v = n_send_v; g->n_send_e = n_send_e; g->n_recv_v = n_recv_v; g->n_recv_e = n_recv_e;
   return 0;
@@ -796,7 +806,7 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
     n = (int64_t)P.tiles.size() * kProfWords; esz = 8;
     if (buf && cap_bytes > 0) {
       if (hipDeviceSynchronize() != hipSuccess) return FLAME_HIP_ERR_HIP;
-      if (hipMemcpy(buf, g->prof, (size_t)std::min<int64_t>(cap_bytes, n * esz), hipMemcpyDeviceToHost) != hipSuccess)
+      if (memcpy_sync(g->stream, buf, g->prof, (size_t)std::min<int64_t>(cap_bytes, n * esz), hipMemcpyDeviceToHost) != hipSuccess)
         return FLAME_HIP_ERR_HIP;
     }
     return n;

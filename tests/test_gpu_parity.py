@@ -236,3 +236,38 @@ def test_irregular_graphs(gpu):
         o, r = run_both(g, {}, 60, state_seed=12)
         assert r.info("path") == want_path, name
         compare_state(o, r, name)
+
+
+def test_distinct_handles_are_thread_safe_and_deterministic(gpu):
+    """include/flame_hip.h: one handle is not thread-safe, distinct handles are.  Four host
+    threads drive four handles concurrently (ctypes drops the GIL); every result equals the
+    oracle, and a repeated solve reproduces the same bits."""
+    import threading
+    gs = [graphgen.synthetic(4000 + 500 * k, seed=30 + k) for k in range(4)]
+    want = []
+    for g in gs:
+        o = make_oracle(g)
+        o.solve(oracle_params(), 90)
+        want.append(o.x.copy())
+    got, errs = [None] * 4, []
+
+    def work(k):
+        try:
+            xs = []
+            for rep in range(2):
+                with GraphRegularizer(gs[k].pos, gs[k].edges, gs[k].alpha, gs[k].beta, gs[k].z,
+                                      gs[k].wgt, tile_own=48 if rep else 0) as r:
+                    for n in (30, 30, 30):
+                        r.step(default_params(), n)
+                    xs.append(r.download()[0])
+            assert np.array_equal(xs[0].view(np.uint32), xs[1].view(np.uint32))
+            got[k] = xs[0]
+        except Exception as e:  # noqa
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k in range(4):
+        assert_bit_equal(got[k], want[k], "thread %d" % k)
