@@ -169,7 +169,7 @@ def main():
     for _ in range(args.warmup):
         r.step(p, iters, sync=False)
     barrier()
-    dev_ms, launches = 0.0, 0
+    launches = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r.step(p, iters, sync=False)

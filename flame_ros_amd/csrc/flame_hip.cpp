@@ -127,6 +127,8 @@ struct flame_hip_graph {
   float* map_idm = nullptr;
   float* map_dm = nullptr;
   float* map_cloud = nullptr;
+  // graph filter scratch (row a9)
+  float* filter_tmp = nullptr;
   // mesh output (row f1)
   float4* mesh_pts = nullptr;
   int32_t* v_i2o_dev = nullptr;
@@ -158,7 +160,7 @@ struct flame_hip_graph {
     caps.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
                     t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
-                    tri_valid, partials, prof, mesh_pts, v_i2o_dev, map_owner, map_idm, map_dm, map_cloud, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
+                    tri_valid, partials, prof, filter_tmp, mesh_pts, v_i2o_dev, map_owner, map_idm, map_dm, map_cloud, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
@@ -167,7 +169,7 @@ struct flame_hip_graph {
     tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
     partials = nullptr;
     prof = nullptr;
-    mesh_pts = nullptr; v_i2o_dev = nullptr;
+    mesh_pts = nullptr; v_i2o_dev = nullptr; filter_tmp = nullptr;
     map_owner = nullptr; map_idm = map_dm = map_cloud = nullptr; map_pixels = 0;
     halo_send_v = halo_send_e = halo_recv_v = halo_recv_e = nullptr;
     n_send_v = n_send_e = n_recv_v = n_recv_e = 0;
@@ -650,6 +652,18 @@ int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_
       }
   }
   if (num_faces) *num_faces = nf;
+  return 0;
+}
+
+int flame_hip_graph_filter(flame_hip_graph* g, int32_t kind, int32_t passes) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if ((kind != 0 && kind != 1) || passes < 0) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(g->device));
+  if ((rc = dev_alloc(g->caps, &g->filter_tmp, (size_t)g->V))) return rc;
+  for (int32_t k = 0; k < passes; ++k)
+    HIPCHK(launch_graph_filter(g->stream, g->V, kind, g->grow, g->ginc, g->eij, g->A[g->cur],
+                               g->B[g->cur], g->filter_tmp));
   return 0;
 }
 

@@ -61,6 +61,10 @@ hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* p
                             const int32_t* tinc, TriParamsDev tp, float4* tri_normals,
                             uint8_t* tri_valid, float4* vtx_normals);
 
+// ---- row a9: graph median (kind 0) / low-pass (kind 1) filter, one Jacobi pass ----
+hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int32_t* grow,
+                               const int32_t* ginc, const int2* eij, float4* A, float4* B, float* tmp);
+
 // ---- row f1: mesh vertices in PointNormalUV layout (3 float4 per vertex, caller's order) ----
 hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4* A,
                        const float4* vtx_normals, const int32_t* i2o, TriParamsDev tp, int32_t width,

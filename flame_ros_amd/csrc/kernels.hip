@@ -457,6 +457,54 @@ __global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* _
 }
 
 // ------------------------------------------------------------------------------------------
+// Row a9: optional graph median / low-pass filter of the vertex idepths (Jacobi pass over the
+// incidence CSR; see oracle/nltgv2_oracle.c nltgv2_graph_filter for the exact rule).  The median
+// is found by rank counting (O(deg^2) compares, no per-thread arrays).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_graph_filter(int32_t V, int32_t kind,
+                                                      const int32_t* __restrict__ grow,
+                                                      const int32_t* __restrict__ ginc,
+                                                      const int2* __restrict__ eij,
+                                                      const float4* __restrict__ A,
+                                                      float* __restrict__ out) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const int32_t s0 = grow[v], n = grow[v + 1] - s0 + 1;
+  auto val = [&](int32_t k) -> float {
+    if (k == 0) return A[v].x;
+    const int32_t ent = ginc[s0 + k - 1];
+    const int2 ij = eij[ent & 0x7fffffff];
+    return A[ent < 0 ? ij.x : ij.y].x;
+  };
+  if (kind == 0) {
+    float med = A[v].x;
+    for (int32_t i = 0; i < n; ++i) {
+      const float xi = val(i);
+      int32_t rank = 0;
+      for (int32_t j = 0; j < n; ++j) {
+        const float xj = val(j);
+        rank += (xj < xi) || (xj == xi && j < i);
+      }
+      if (rank == (n - 1) / 2) med = xi;
+    }
+    out[v] = med;
+  } else {
+    float sum = A[v].x;
+    for (int32_t k = 1; k < n; ++k) sum += val(k);
+    out[v] = sum / (float)n;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_graph_filter_commit(int32_t V, const float* __restrict__ in,
+                                                             float4* __restrict__ A,
+                                                             float4* __restrict__ B) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  A[v].x = in[v];
+  B[v].x = in[v];
+}
+
+// ------------------------------------------------------------------------------------------
 // "Next" row f1: mesh vertices in flame_ros::PointNormalUV layout (reference src/utils.h:47-53,
 // packed at src/utils.cc:184-209): 3 float4 per vertex {p,0 | n,0 | u,v,0,0}; NaN xyz when the
 // idepth is not a positive finite number.  Written in the CALLER's vertex order (i2o).
@@ -606,6 +654,16 @@ __global__ __launch_bounds__(256) void k_halo_unpack(int32_t nv, int32_t ne,
 }
 
 }  // namespace
+
+hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int32_t* grow,
+                               const int32_t* ginc, const int2* eij, float4* A, float4* B, float* tmp) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_graph_filter, dim3((V + 255) / 256), dim3(256), 0, s, V, kind, grow, ginc, eij, A, tmp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_graph_filter_commit, dim3((V + 255) / 256), dim3(256), 0, s, V, tmp, A, B);
+  return hipGetLastError();
+}
 
 hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4* A,
                        const float4* vtx_normals, const int32_t* i2o, TriParamsDev tp, int32_t width,

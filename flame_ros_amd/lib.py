@@ -47,6 +47,7 @@ SYMBOLS = {
     "flame_hip_graph_upload_batch": (C.c_int, [_VP, _I32, _VP] + [_VP] * 8),
     "flame_hip_set_state": (C.c_int, [_VP] + [_VP] * 7),
     "flame_hip_solve": (C.c_int, [_VP, C.POINTER(Params), _I32, _VP]),
+    "flame_hip_graph_filter": (C.c_int, [_VP, _I32, _I32]),
     "flame_hip_sync": (C.c_int, [_VP]),
     "flame_hip_last_solve_ms": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),
     "flame_hip_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -197,3 +197,8 @@ class GraphRegularizer:
                                                min_depth, max_depth, _ptr(idm), _ptr(dm), _ptr(cl)),
                  "flame_hip_depthmaps")
         return idm, dm, cl
+
+    def graph_filter(self, kind, passes=1):
+        """Row a9: median (kind 0) / low-pass (kind 1) filter of the vertex idepths."""
+        _l.check(self._lib.flame_hip_graph_filter(self._h, int(kind), int(passes)), "flame_hip_graph_filter")
+        self.sync()

@@ -108,6 +108,13 @@ int flame_hip_sync(flame_hip_graph* g);
  * number of kernel launches it made.  Synchronises. */
 int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches);
 
+/* Row a9: the optional graph filters applied to the vertex idepths (upstream options
+ * regularization/do_median_filter, do_lowpass_filter, reference cfg/flame_offline_tum.yaml:85-86;
+ * timing keys median_filter / lowpass_filter, msg/FlameStats.msg:45-46).  kind 0 = median of the
+ * vertex and its neighbours (lower median), kind 1 = plain average of the vertex and its
+ * neighbours; `passes` Jacobi passes; sets x and x_bar.  Asynchronous on the handle's stream. */
+int flame_hip_graph_filter(flame_hip_graph* g, int32_t kind, int32_t passes);
+
 /* Replaces: smoothnessCost()/dataCost() behind the stat keys nltgv2_total_smoothness_cost and
  * nltgv2_total_data_cost (reference src/utils.cc:131-136).  Synchronises. */
 int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smooth, double* data);

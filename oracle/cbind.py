@@ -110,6 +110,20 @@ class COracle:
                                  self._inc.ctypes.data_as(C.c_void_p), int(num_iters), int(num_threads))
         return self.x
 
+    def graph_filter(self, kind):
+        """Row a9: one Jacobi pass of the median (kind 0) or low-pass (kind 1) graph filter."""
+        if not hasattr(self, "_row"):
+            self._row = np.empty(self.V + 1, np.int32)
+            self._inc = np.empty(2 * self.E, np.int32)
+            g = self._g()
+            _load().nltgv2_build_incidence(C.byref(g), self._row.ctypes.data_as(C.c_void_p),
+                                           self._inc.ctypes.data_as(C.c_void_p))
+        g = self._g()
+        scratch = np.empty(max(self.V, 1), np.float32)
+        _load().nltgv2_graph_filter(C.byref(g), self._row.ctypes.data_as(C.c_void_p),
+                                    self._inc.ctypes.data_as(C.c_void_p), C.c_int32(kind),
+                                    scratch.ctypes.data_as(C.c_void_p))
+
     def dual_step(self, params):
         g = self._g()
         _load().nltgv2_dual_step(C.byref(params), C.byref(g))

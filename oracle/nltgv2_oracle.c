@@ -436,3 +436,42 @@ void nltgv2_depth_and_cloud(int32_t width, int32_t height, const float* idepthma
       }
     }
 }
+
+/* ---- row a9: optional graph median / low-pass filters of the vertex idepths.
+ * Evidence that they exist: timing stat keys median_filter / lowpass_filter (reference
+ * msg/FlameStats.msg:45-46, src/utils.cc:155-156) and YAML keys regularization/do_median_filter,
+ * do_lowpass_filter (cfg/flame_offline_tum.yaml:85-86, never read by flame_ros => upstream default,
+ * off).  Upstream's arithmetic is not in the reference tree; this is the build's precise rule,
+ * Jacobi style (all vertices read the pre-filter values):
+ *   median : x_v <- lower median of {x_v} U {x_u : u adjacent to v}  (element (n-1)/2 of the
+ *            ascending order; ties broken by position: self first, then incidence order)
+ *   lowpass: x_v <- (x_v + sum_u x_u) / (1 + deg v), summed self first then in ascending edge id
+ * Afterwards the extrapolated value x_bar is set to the filtered x. ---- */
+void nltgv2_graph_filter(nltgv2_graph* g, const int32_t* row, const int32_t* inc, int32_t kind,
+                         float* scratch /* V */) {
+  for (int32_t v = 0; v < g->V; ++v) {
+    const int32_t n = row[v + 1] - row[v] + 1;
+    /* value k of the multiset: k = 0 is the vertex itself, k >= 1 its (k-1)-th incidence */
+#define NB_VAL(k) ((k) == 0 ? g->x[v] : g->x[(inc[row[v] + (k) - 1] < 0) ? g->edges[2 * (inc[row[v] + (k) - 1] & 0x7fffffff)] \
+                                                                           : g->edges[2 * inc[row[v] + (k) - 1] + 1]])
+    if (kind == 0) {
+      float med = g->x[v];
+      for (int32_t i = 0; i < n; ++i) {
+        const float xi = NB_VAL(i);
+        int32_t rank = 0;
+        for (int32_t j = 0; j < n; ++j) {
+          const float xj = NB_VAL(j);
+          rank += (xj < xi) || (xj == xi && j < i);
+        }
+        if (rank == (n - 1) / 2) med = xi;
+      }
+      scratch[v] = med;
+    } else {
+      float sum = g->x[v];
+      for (int32_t k = 1; k < n; ++k) sum += NB_VAL(k);
+      scratch[v] = sum / (float)n;
+    }
+#undef NB_VAL
+  }
+  for (int32_t v = 0; v < g->V; ++v) { g->x[v] = scratch[v]; g->xb[v] = scratch[v]; }
+}

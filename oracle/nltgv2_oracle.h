@@ -92,6 +92,11 @@ void nltgv2_triangles(const nltgv2_tri_params* tp, const float Kinv[9], int32_t 
                       const float* pos, const float* x, const int32_t* tris, float* tri_normals,
                       uint8_t* tri_valid, float* vtx_normals);
 
+/* row a9: graph median (kind 0) / low-pass (kind 1) filter of the vertex idepths, one Jacobi pass;
+ * row/inc from nltgv2_build_incidence, scratch V floats.  Sets x and x_bar. */
+void nltgv2_graph_filter(nltgv2_graph* g, const int32_t* row, const int32_t* inc, int32_t kind,
+                         float* scratch);
+
 /* "next" row f1: mesh vertices in flame_ros::PointNormalUV layout (12 floats) and faces with
  * reversed winding (reference src/utils.cc:184-230).  Returns the number of faces. */
 void nltgv2_mesh_points(const float Kinv[9], int32_t V, const float* pos, const float* x,

@@ -271,3 +271,20 @@ def test_distinct_handles_are_thread_safe_and_deterministic(gpu):
     assert not errs, errs
     for k in range(4):
         assert_bit_equal(got[k], want[k], "thread %d" % k)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_graph_filters(gpu, kind):
+    """Row a9: median / low-pass graph filter, also followed by the regulariser."""
+    g = graphgen.synthetic(5000, seed=8)
+    o, r = run_both(g, {}, 0)
+    for _ in range(2):
+        o.graph_filter(kind)
+    r.graph_filter(kind, passes=2)
+    x, xb = r.download()[0], r.download_bar()[0]
+    assert_bit_equal(x, o.x, "filtered x")
+    assert_bit_equal(xb, o.xb, "filtered x_bar")
+    assert np.abs(x - g.z).max() > 1e-3  # it did something: the 5 % outliers are pulled in
+    o.solve(oracle_params(), 20)
+    r.step(default_params(), 20)
+    compare_state(o, r, "after filter kind %d" % kind)

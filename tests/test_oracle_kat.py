@@ -226,6 +226,17 @@ def test_threaded_variant_is_bit_identical(g5k):
         assert_bit_equal(getattr(o2, a), getattr(o1, a), a)
 
 
+def test_graph_filters_known_answers():
+    """Row a9 on a 4-vertex path 0-1-2-3 with values (1, 5, 2, 9)."""
+    o = COracle([[0, 0], [1, 0], [2, 0], [3, 0]], [[0, 1], [1, 2], [2, 3]], [1, 1, 1], [1, 1, 1],
+                [1.0, 5.0, 2.0, 9.0], [1, 1, 1, 1])
+    o.graph_filter(0)  # lower medians of {1,5} {5,1,2} {2,5,9} {9,2}
+    assert o.x.tolist() == [1.0, 2.0, 5.0, 2.0] and o.xb.tolist() == o.x.tolist()
+    o.set_state(x=[1.0, 5.0, 2.0, 9.0])
+    o.graph_filter(1)  # plain averages
+    assert np.allclose(o.x, [3.0, 8.0 / 3.0, 16.0 / 3.0, 5.5], rtol=1e-6)
+
+
 def test_edge_cases():
     p = default_params()
     o = COracle(np.zeros((0, 2)), np.zeros((0, 2), np.int32), [], [], [], [])
