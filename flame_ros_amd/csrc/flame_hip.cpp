@@ -112,7 +112,7 @@ struct flame_hip_graph {
   int32_t* t_vmap = nullptr;
   int32_t* t_emap = nullptr;
   uint2* t_eij = nullptr;
-  float2* t_ab = nullptr;
+  float4* t_ew = nullptr;
   uint32_t* t_srow = nullptr;
   // triangles
   int32_t* tris = nullptr;
@@ -159,13 +159,13 @@ struct flame_hip_graph {
     drop_execs();
     caps.clear();
     void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
-                    t_emap, t_eij, t_ab, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
+                    t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
                     tri_valid, partials, prof, filter_tmp, mesh_pts, v_i2o_dev, map_owner, map_idm, map_dm, map_cloud, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
     for (void* p : ptrs)
       if (p) (void)hipFree(p);
     A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
     eij = nullptr; ew = nullptr; grow = ginc = nullptr; pos = nullptr; tiles = nullptr;
-    t_vmap = t_emap = nullptr; t_eij = nullptr; t_ab = nullptr; t_srow = nullptr;
+    t_vmap = t_emap = nullptr; t_eij = nullptr; t_ew = nullptr; t_srow = nullptr;
     tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
     partials = nullptr;
     prof = nullptr;
@@ -369,13 +369,11 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
         (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->stream, g->t_vmap, P.t_vmap)) ||
         (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->stream, g->t_emap, P.t_emap)) ||
         (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->stream, g->t_srow, P.t_srow)) ||
-        (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ab, P.t_ew.size())))
+        (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ew, P.t_ew.size())))
       return rc;
     if (!P.t_eij.empty()) {
       HIPCHK(memcpy_sync(g->stream, g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
-      std::vector<float2> hab(P.t_ew.size());  // the kernel recomputes dx, dy from the positions
-      for (size_t k = 0; k < hab.size(); ++k) hab[k] = make_float2(P.t_ew[k].x, P.t_ew[k].y);
-      HIPCHK(memcpy_sync(g->stream, g->t_ab, hab.data(), sizeof(float2) * hab.size(), hipMemcpyHostToDevice));
+      HIPCHK(memcpy_sync(g->stream, g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
     }
   }
   if (P.T > 0) {
@@ -451,7 +449,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
   if (g->path == FLAME_HIP_PATH_TILE) {
     TileArgs a;
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
-    a.t_ab = g->t_ab; a.pos = g->pos; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
+    a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
     const int per = P.tile_depth > 0 ? P.tile_depth : num_iters;
     for (int32_t done = 0; done < num_iters;) {

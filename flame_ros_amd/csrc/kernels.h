@@ -11,8 +11,7 @@ struct TileArgs {
   const int32_t* t_vmap;
   const int32_t* t_emap;
   const uint2* t_eij;
-  const float2* t_ab;   // local edge {alpha, beta}
-  const float2* pos;    // vertex pixel positions (internal order): dx, dy are recomputed per launch
+  const float4* t_ew;
   const uint32_t* t_srow;
   const float4* A_src;
   const float4* B_src;

@@ -183,43 +183,30 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   if ((lane & 31) <= kMaxDepth) cut = (lane < 32) ? D.ring_end[lane & 31] : D.level_end[lane & 31];
 
   const int zslot = D.nslots + kDummySlots;  // the always-zero slot
+  if (tid == 0) cs[zslot] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // ---- global loads: index lists first, then every dependent gather, nothing waited between.
-  // Bytes matter here (the load phase runs at the fabric's burst rate, ~67 cycles per KB per
-  // tile): own vertices / owned edges need no index, the outermost ring needs no primal state, and
-  // dx, dy are recomputed from the vertex positions instead of being stored per edge. ----
+  // ---- global loads: index lists first, then every dependent gather, nothing waited between ----
   int gi[VPT];
   uint32_t vs[VPT];
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
-    gi[k] = D.vstart + min(lv, n_own - 1);
-    if (lv >= n_own && lv < n_ext) gi[k] = a.t_vmap[D.vmap_off + lv];
-    vs[k] = 0;  // outermost ring / padding lanes: no incidence slots
-    if (lv < n_upd) vs[k] = a.t_srow[D.srow_off + lv];
+    gi[k] = a.t_vmap[D.vmap_off + min(lv, n_ext - 1)];
+    vs[k] = a.t_srow[D.srow_off + min(lv, n_upd - 1)];
   }
   uint2 er[EPT];
-  float2 eab[EPT];
+  float4 ew[EPT];
   int qi[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
-    const int le = k * NT + tid;
-    const int lec = min(le, max(e_loc - 1, 0));  // arrays carry one pad element
+    const int lec = min(k * NT + tid, max(e_loc - 1, 0));  // arrays carry one pad element
     er[k] = a.t_eij[D.erec_off + lec];
-    eab[k] = a.t_ab[D.erec_off + lec];
-    qi[k] = D.estart + min(le, max(e_own - 1, 0));
-    if (le >= e_own && le < e_loc) qi[k] = a.t_emap[D.emap_off + le];
+    ew[k] = a.t_ew[D.erec_off + lec];
+    qi[k] = a.t_emap[D.emap_off + lec];
   }
   float4 vA[VPT], vB[VPT];
-  float2 vpos[VPT];
 #pragma unroll
-  for (int k = 0; k < VPT; ++k) {
-    const int lv = k * NT + tid;
-    vA[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lv < n_upd) vA[k] = a.A_src[gi[k]];
-    vB[k] = a.B_src[gi[k]];
-    vpos[k] = a.pos[gi[k]];
-  }
+  for (int k = 0; k < VPT; ++k) { vA[k] = a.A_src[gi[k]]; vB[k] = a.B_src[gi[k]]; }
   float q1[EPT], q2[EPT], q3[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
@@ -230,14 +217,14 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   float vx[VPT], vw1[VPT], vw2[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT], vw1b[VPT], vw2b[VPT];
   int wdeg[VPT];
   const float tl = a.p.tl;
-  float2* ps = reinterpret_cast<float2*>(cs);  // positions staged in the (still unused) slot area
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     vx[k] = vA[k].x; vw1[k] = vA[k].y; vw2[k] = vA[k].z; vz[k] = vA[k].w;
     vxb[k] = vB[k].x; vw1b[k] = vB[k].y; vw2b[k] = vB[k].z; vwgt[k] = vB[k].w;
     vt[k] = tl * vwgt[k];
-    if (lv < n_ext) { bar[lv] = vB[k]; ps[lv] = vpos[k]; }
+    if (lv >= n_upd) vs[k] = 0;  // outermost ring / padding lanes: no incidence slots
+    if (lv < n_ext) bar[lv] = vB[k];
     wdeg[k] = wave_max((int)(vs[k] >> 16));
   }
   uint32_t eij[EPT], ess[EPT], esd[EPT];
@@ -249,16 +236,6 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     ess[k] = (real && ss != 0xffffu) ? ss : dummy;
     esd[k] = (real && sd != 0xffffu) ? sd : dummy;
   }
-  __syncthreads();
-  // d = pos_source - pos_target, the same float subtraction the host / oracle performs
-  float4 ew[EPT];
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) {
-    const float2 pi = ps[eij[k] & 0xffffu], pj = ps[eij[k] >> 16];
-    ew[k] = make_float4(eab[k].x, eab[k].y, pi.x - pj.x, pi.y - pj.y);
-  }
-  __syncthreads();  // the slot area is reused from here on
-  if (tid == 0) cs[zslot] = make_float4(0.f, 0.f, 0.f, 0.f);  // visible to phase P after the D->P barrier
   __syncthreads();
   // optional in-kernel timeline (debug): [tile][0]=start, [1]=loaded, [2it]=after phase D of
   // iteration it, [2it+1]=after phase P, [kProfWords-1]=end

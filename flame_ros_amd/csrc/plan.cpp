@@ -461,9 +461,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         nv += O.vmap.size(); ne += O.emap.size(); ns += O.srow.size();
         e_max = std::max(e_max, D.e_loc);
         upd_max = std::max(upd_max, D.n_ext);  // every local vertex gets a register slot
-        // bar + max(incidence slots incl. trash/zero slots, position staging at load time)
-        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 +
-                                                 std::max<int64_t>((int64_t)(D.nslots + kDummySlots + 1) * 16, (int64_t)D.n_ext * 8));
+        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots + 1) * 16);
       }
       if (ok) {
         P.t_vmap.resize(nv); P.t_emap.resize(ne); P.t_eij.resize(ne); P.t_ew.resize(ne); P.t_srow.resize(ns);
