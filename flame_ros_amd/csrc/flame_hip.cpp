@@ -252,6 +252,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->opt.tile_threads = value;
   } else if (k == "use_graph") {
     g->use_graph = value != 0;
+  } else if (k == "order_mode") {
+    if (value < 0 || value > 1) return FLAME_HIP_ERR_ARG;
+    g->opt.order_mode = value;
   } else if (k == "balance") {
     g->opt.balance = value != 0;
   } else if (k == "host_threads") {

@@ -217,11 +217,31 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     else if (V > 0) rcb_par(pos, vweight.empty() ? nullptr : vweight.data(), idx, 0, V, ntiles, &leaf_start,
                             opt.host_threads == 1 ? 0 : 3);
     leaf_start.push_back(V);
-    // inside a tile the order is free (everything lives in LDS): sort by degree so the lanes of a
-    // wave walk incidence lists of similar length
-    for (int t = 0; t < ntiles; ++t)
-      std::sort(idx.begin() + leaf_start[t], idx.begin() + leaf_start[t + 1],
-                [&](int32_t a, int32_t b) { return deg_o[a] != deg_o[b] ? deg_o[a] > deg_o[b] : a < b; });
+    // Inside a tile the order is free.  order_mode 0: by degree (lanes of a wave walk incidence
+    // lists of similar length); 1: Morton order of the pixel position, so the vertices another
+    // tile needs as halo (a strip along the shared border) are contiguous runs in memory and its
+    // 16-byte gathers share 64-byte sectors.
+    if (opt.order_mode == 1 && V > 0) {
+      float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
+      for (int32_t v = 0; v < V; ++v)
+        for (int a = 0; a < 2; ++a) { mn[a] = std::min(mn[a], pos[2 * v + a]); mx[a] = std::max(mx[a], pos[2 * v + a]); }
+      std::vector<uint32_t>& code = P.b_code;
+      code.resize(V);
+      auto spread = [](uint32_t x) { x &= 0xffff; x = (x | (x << 8)) & 0x00ff00ff; x = (x | (x << 4)) & 0x0f0f0f0f;
+                                     x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; };
+      for (int32_t v = 0; v < V; ++v) {
+        const uint32_t qx = (uint32_t)(65535.0f * (pos[2 * v] - mn[0]) / std::max(mx[0] - mn[0], 1e-20f));
+        const uint32_t qy = (uint32_t)(65535.0f * (pos[2 * v + 1] - mn[1]) / std::max(mx[1] - mn[1], 1e-20f));
+        code[v] = spread(qx) | (spread(qy) << 1);
+      }
+      for (int t = 0; t < ntiles; ++t)
+        std::sort(idx.begin() + leaf_start[t], idx.begin() + leaf_start[t + 1],
+                  [&](int32_t a, int32_t b) { return code[a] != code[b] ? code[a] < code[b] : a < b; });
+    } else {
+      for (int t = 0; t < ntiles; ++t)
+        std::sort(idx.begin() + leaf_start[t], idx.begin() + leaf_start[t + 1],
+                  [&](int32_t a, int32_t b) { return deg_o[a] != deg_o[b] ? deg_o[a] > deg_o[b] : a < b; });
+    }
     lap("rcb+degsort");
     P.v_i2o = idx;
     P.v_o2i.assign(V, 0);
@@ -343,11 +363,14 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
                 const int32_t u = (P.ginc[s] < 0) ? P.eij[k].x : P.eij[k].y;
                 if (stamp[u] != t) { stamp[u] = t; ring[u] = r; next.push_back(u); }
               }
-            // inside a ring the order is free: by degree (lanes of a wave walk similar lists)
-            std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) {
-              const int32_t da = P.grow[a + 1] - P.grow[a], db = P.grow[b + 1] - P.grow[b];
-              return da != db ? da > db : a < b;
-            });
+            // inside a ring the order is free: by degree (lanes of a wave walk similar lists),
+            // or by internal id (monotone gather addresses: adjacent lanes share sectors)
+            if (opt.order_mode == 1) std::sort(next.begin(), next.end());
+            else
+              std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) {
+                const int32_t da = P.grow[a + 1] - P.grow[a], db = P.grow[b + 1] - P.grow[b];
+                return da != db ? da > db : a < b;
+              });
             for (int32_t u : next) { lidx[u] = (int32_t)ext.size(); ext.push_back(u); }
             frontier.swap(next);
           }

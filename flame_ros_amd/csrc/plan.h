@@ -21,6 +21,7 @@ struct PlanOptions {
   int64_t lds_bytes = 160 * 1024;
   int host_threads = 0;  // plan-build threads (0 = up to 8)
   int balance = 1;       // second, cost-weighted bisection pass (equalises tile cost)
+  int order_mode = 1;    // vertex order inside tiles / rings: 0 by degree, 1 spatial (gather locality)
   // batch of independent graphs (frames axis): nb + 1 vertex offsets; graph b = one isolated tile
   std::vector<int32_t> batch_voff;
 };
@@ -71,6 +72,7 @@ struct Plan {
   std::vector<ThreadScratch> scratch;
   std::vector<int32_t> b_idx, b_leaf, b_tile_of, b_deg, b_estart, b_fill;
   std::vector<int64_t> b_keys;
+  std::vector<uint32_t> b_code;
 };
 
 // Builds the plan.  Returns 0 or a FLAME_HIP_ERR_* code (bad indices).

@@ -4,13 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flame_ros_amd import graphgen
 from flame_ros_amd.regularizer import GraphRegularizer, default_params
 import argparse
-ap = argparse.ArgumentParser(); ap.add_argument('--workload', default='50k'); ap.add_argument('--own', type=int, default=0); ap.add_argument('--depth', type=int, default=0); ap.add_argument('--nt', type=int, default=0)
+ap = argparse.ArgumentParser(); ap.add_argument('--workload', default='50k'); ap.add_argument('--own', type=int, default=0); ap.add_argument('--depth', type=int, default=0); ap.add_argument('--nt', type=int, default=0); ap.add_argument('--order', type=int, default=-1)
 a = ap.parse_args()
 g, iters = graphgen.named(a.workload)
 opts = dict(profile=1, use_graph=0)
 if a.own: opts['tile_own'] = a.own
 if a.depth: opts['tile_depth'] = a.depth
 if a.nt: opts['tile_threads'] = a.nt
+if a.order >= 0: opts['order_mode'] = a.order
 r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, **opts)
 p = default_params()
 r.step(p, iters); r.step(p, iters)
