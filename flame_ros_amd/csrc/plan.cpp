@@ -221,7 +221,10 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     // lists of similar length); 1: Morton order of the pixel position, so the vertices another
     // tile needs as halo (a strip along the shared border) are contiguous runs in memory and its
     // 16-byte gathers share 64-byte sectors.
-    if (opt.order_mode == 1 && V > 0) {
+    // Isolated tiles (single-tile graphs, batch frames) gather nothing from other tiles: they keep
+    // the degree order, whose tighter incidence rows let ~1.2 k-vertex graphs fit one tile's LDS.
+    const bool spatial = opt.order_mode == 1 && !single && !batch;
+    if (spatial && V > 0) {
       float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
       for (int32_t v = 0; v < V; ++v)
         for (int a = 0; a < 2; ++a) { mn[a] = std::min(mn[a], pos[2 * v + a]); mx[a] = std::max(mx[a], pos[2 * v + a]); }
@@ -365,7 +368,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
               }
             // inside a ring the order is free: by degree (lanes of a wave walk similar lists),
             // or by internal id (monotone gather addresses: adjacent lanes share sectors)
-            if (opt.order_mode == 1) std::sort(next.begin(), next.end());
+            if (spatial) std::sort(next.begin(), next.end());
             else
               std::sort(next.begin(), next.end(), [&](int32_t a, int32_t b) {
                 const int32_t da = P.grow[a + 1] - P.grow[a], db = P.grow[b + 1] - P.grow[b];
