@@ -400,6 +400,32 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   return 0;
 }
 
+static int require_device(const flame_hip_graph* g);
+
+// New data terms on an unchanged topology: resets the solver state (x = x0 or z, w = 0,
+// x_bar = x, q = 0) without rebuilding the host plan or touching the graph arrays.
+int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float* wgt, const float* x0) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  const int32_t V = g->V, E = g->E;
+  if (V > 0 && (!z || !wgt)) return FLAME_HIP_ERR_ARG;
+  if (!all_finite(z, V) || !all_finite(wgt, V) || (x0 && !all_finite(x0, V))) return FLAME_HIP_ERR_NAN;
+  HIPCHK(hipSetDevice(g->device));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  const Plan& P = g->plan;
+  std::vector<float4> hA(V), hB(V);
+  for (int32_t k = 0; k < V; ++k) {
+    const int32_t o = P.v_i2o[k];
+    const float xi = x0 ? x0[o] : z[o];
+    hA[k] = make_float4(xi, 0.f, 0.f, z[o]);
+    hB[k] = make_float4(xi, 0.f, 0.f, wgt[o]);
+  }
+  if ((rc = h2d(g->stream, g->A[g->cur], hA)) || (rc = h2d(g->stream, g->B[g->cur], hB))) return rc;
+  HIPCHK(hipMemsetAsync(g->q[g->cur], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
+  HIPCHK(hipStreamSynchronize(g->stream));
+  return 0;
+}
+
 static int require_device(const flame_hip_graph* g) {
   if (!g) return FLAME_HIP_ERR_ARG;
   if (!g->uploaded) return FLAME_HIP_ERR_STATE;

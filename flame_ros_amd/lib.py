@@ -44,6 +44,7 @@ SYMBOLS = {
     "flame_hip_set_option": (C.c_int, [_VP, C.c_char_p, _I32]),
     "flame_hip_get_info": (C.c_int, [_VP, C.c_char_p, C.POINTER(_I64)]),
     "flame_hip_graph_upload": (C.c_int, [_VP] + [_VP] * 8),
+    "flame_hip_graph_update_data": (C.c_int, [_VP, _VP, _VP, _VP]),
     "flame_hip_graph_upload_batch": (C.c_int, [_VP, _I32, _VP] + [_VP] * 8),
     "flame_hip_set_state": (C.c_int, [_VP] + [_VP] * 7),
     "flame_hip_solve": (C.c_int, [_VP, C.POINTER(Params), _I32, _VP]),

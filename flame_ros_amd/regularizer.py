@@ -202,3 +202,10 @@ class GraphRegularizer:
         """Row a9: median (kind 0) / low-pass (kind 1) filter of the vertex idepths."""
         _l.check(self._lib.flame_hip_graph_filter(self._h, int(kind), int(passes)), "flame_hip_graph_filter")
         self.sync()
+
+    def update_data(self, z, wgt, x0=None):
+        """New data terms on the same topology: state reset without rebuilding the plan."""
+        z, wgt = _f32(z), _f32(wgt)
+        x0 = None if x0 is None else _f32(x0)
+        _l.check(self._lib.flame_hip_graph_update_data(self._h, _ptr(z), _ptr(wgt), _ptr(x0)),
+                 "flame_hip_graph_update_data")

@@ -84,6 +84,12 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
                            const float* alpha, const float* beta, const float* z,
                            const float* wgt, const float* x0, const int32_t* tris);
 
+/* New frame on an UNCHANGED topology (same vertices, edges, weights): only the data terms, data
+ * weights and the initial x change.  Resets the state exactly like flame_hip_graph_upload but
+ * keeps the host plan, the device graph arrays and the captured launch graphs.  z/wgt V, x0 V or
+ * NULL (= z). */
+int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float* wgt, const float* x0);
+
 /* Frames axis: a batch of `num_graphs` INDEPENDENT graphs in one handle (block-diagonal): graph b
  * owns the vertices [voff[b], voff[b+1]) (voff has num_graphs+1 entries, voff[0] = 0,
  * voff[num_graphs] = V); edge endpoints are vertex ids of the concatenated arrays and must stay

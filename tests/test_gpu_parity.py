@@ -288,3 +288,21 @@ def test_graph_filters(gpu, kind):
     o.solve(oracle_params(), 20)
     r.step(default_params(), 20)
     compare_state(o, r, "after filter kind %d" % kind)
+
+
+def test_update_data_keeps_topology(gpu):
+    """flame_hip_graph_update_data: new z / weights / x0 on the same graph == a fresh upload."""
+    g = graphgen.synthetic(3000, seed=13)
+    rng = np.random.default_rng(14)
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    r.step(default_params(), 37)  # dirty state, odd number of ping-pong flips
+    for x0 in (None, (g.z + 0.01).astype(np.float32)):
+        z2 = (g.z + rng.normal(0, 0.05, g.V)).clip(0.01).astype(np.float32)
+        w2 = rng.uniform(0.5, 2.0, g.V).astype(np.float32)
+        r.update_data(z2, w2, x0)
+        r.step(default_params(), 41)
+        o = make_oracle(g)
+        o.z[:], o.wgt[:] = z2, w2
+        o.set_state(x=z2 if x0 is None else x0, xb=z2 if x0 is None else x0)
+        o.solve(oracle_params(), 41)
+        compare_state(o, r, "update_data")
