@@ -60,6 +60,28 @@ def cpu_baseline(g, iters, budget_s=12.0):
     return out
 
 
+def parity_check(g, iters, device, opts):
+    """Accuracy line of SURVEY.md 8(d): the GPU result of one frame (fresh state, `iters`
+    iterations) against the oracle on the same inputs -- the oracle as checker, not as product."""
+    import numpy as np
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+    from oracle import COracle
+    from oracle.cbind import default_params as oparams
+    o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    o.solve(oparams(), iters)
+    with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=device, **opts) as r:
+        r.step(default_params(), iters)
+        x = r.download(with_q=False)[0]
+        smooth, data = r.costs(default_params())
+    d = x.astype(np.float64) - o.x
+    so, do = o.costs(oparams())
+    return {"rms_idepth": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.abs(d).max()),
+            "bit_exact": bool(np.array_equal(x.view(np.uint32), o.x.view(np.uint32))),
+            "tolerance_rms": 1e-4, "iterations": iters,
+            "smoothness_cost": smooth, "data_cost": data,
+            "oracle_smoothness_cost": so, "oracle_data_cost": do}
+
+
 def profiled_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
     collect.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH x2 gfx950 correction).  PMC counters
@@ -272,6 +294,8 @@ def main():
         if not args.no_cpu and world == 1:  # contract: rank 0 at N=1 only
             cb = cpu_baseline(frames[0] if args.batch else g, iters, args.cpu_budget)
             out["cpu_baseline"] = cb
+            if not args.batch:
+                out["parity_vs_oracle"] = parity_check(g, iters, local_rank, opts)
             out["speedup_vs_cpu_1thread"] = out["value"] / (1 if partition else world) / cb["value"]
         print(json.dumps(out))
     if world > 1:
