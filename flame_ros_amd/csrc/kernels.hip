@@ -166,7 +166,12 @@ constexpr int kPRound = kSlotRound;  // incidence slots read per round of phase 
 template <int NT, int EPT, int VPT>
 __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileDesc& D = a.tiles[blockIdx.x];
+  // XCD-aware block -> tile map (speed only): block b runs on XCD b % 8, tiles are numbered in
+  // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
+  // makes tiles that share halo vertices / edges share one L2.  Bijective for any tile count.
+  const int nt_all = a.ntiles, xq = nt_all >> 3, xr = nt_all & 7, xcd = blockIdx.x & 7;
+  const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const TileDesc& D = a.tiles[tile_id];
   const int tid = threadIdx.x;
   const unsigned long long t_start = __builtin_readcyclecounter();
   const int n_own = D.n_own, n_ext = D.n_ext, n_upd = D.n_upd;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   __syncthreads();
   // optional in-kernel timeline (debug): [tile][0]=start, [1]=loaded, [2it]=after phase D of
   // iteration it, [2it+1]=after phase P, [kProfWords-1]=end
-  unsigned long long* prof = a.prof ? a.prof + (size_t)blockIdx.x * kProfWords : nullptr;
+  unsigned long long* prof = a.prof ? a.prof + (size_t)tile_id * kProfWords : nullptr;
   if (prof && tid == 0) { prof[0] = t_start; prof[1] = __builtin_readcyclecounter(); }
 
   const float sigma = a.p.sigma, ntau = -a.p.tau, theta = a.p.theta;
