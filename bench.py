@@ -281,7 +281,8 @@ def main():
                                      "iterations_per_s": iters * 1e3 / frame_ms,
                                      "note": "host arrays in -> plan build (CPU) + H2D + solve + D2H, "
                                              "one handle re-uploaded per frame; informational, never `value`"}
-        tr = profiled_traffic(args.workload, "k_tile" if path == 2 else "k_primal")
+        tr = profiled_traffic("batch%d" % args.batch if args.batch else args.workload,
+                              "k_tile" if path == 2 else "k_primal")
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
             out["roofline"]["traffic_source"] = tr["source"]
