@@ -181,7 +181,11 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   const int auto_depth = one_round ? 4 : 3;
   int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
   int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
-  bool single = (opt.tile_own <= 0 || opt.tile_own >= V) && single_fits;
+  // Auto: a lone graph is one isolated tile only when it is small (<= 512 vertices): above that a
+  // few dozen depth-4 tiles on as many CUs finish sooner than one CU iterating alone (TUM-sized
+  // 1.2 k vertices: 0.33 ms vs 0.43 ms per 200 iterations).  tile_own >= V forces the single tile;
+  // batch frames are always single tiles (throughput, one CU per frame).
+  bool single = single_fits && (opt.tile_own >= V || (opt.tile_own <= 0 && V <= 512));
   if (single) { tile_own = std::max(V, 1); depth = 0; }
   const bool batch = !opt.batch_voff.empty();
   if (batch) {  // every graph of the batch is one isolated tile; edges must not cross graphs

@@ -75,6 +75,10 @@ def test_dataset_shaped_graphs(gpu):
         g = graphgen.dataset_shaped(w, h, win)
         o, r = run_both(g, {}, iters)
         compare_state(o, r, "win%d" % win)
+    g = graphgen.dataset_shaped(640, 480, 16)  # the same frame forced into one isolated LDS tile
+    o, r = run_both(g, dict(tile_own=g.V), 200)
+    assert r.info("num_tiles") == 1
+    compare_state(o, r, "single tile")
 
 
 def test_costs_match_oracle(gpu):

@@ -206,8 +206,13 @@ def test_global_path_and_fallbacks():
     r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, path=1)
     assert r.info("path") == lib.PATH_GLOBAL and r.info("num_tiles") == 0
     # a graph that fits one LDS tile is a single isolated tile (depth 0: any iterations/launch)
-    g = graphgen.dataset_shaped(640, 480, 16)
+    g = graphgen.dataset_shaped(320, 240, 16)  # 300 vertices: small enough to be one tile by default
     r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1)
+    assert r.info("num_tiles") == 1 and r.info("tile_depth") == 0
+    g = graphgen.dataset_shaped(640, 480, 16)  # 1200 vertices: tiles by default, one tile on request
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1)
+    assert r.info("num_tiles") > 1 and r.info("tile_depth") == 4
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, tile_own=g.V)
     assert r.info("num_tiles") == 1 and r.info("tile_depth") == 0
     # empty graph
     r = GraphRegularizer(np.zeros((0, 2)), np.zeros((0, 2), np.int32), [], [], [], [], device=-1)
