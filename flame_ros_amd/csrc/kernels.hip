@@ -211,7 +211,13 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   }
   float4 vA[VPT], vB[VPT];
 #pragma unroll
-  for (int k = 0; k < VPT; ++k) { vA[k] = a.A_src[gi[k]]; vB[k] = a.B_src[gi[k]]; }
+  for (int k = 0; k < VPT; ++k) {
+    // the outermost ring is read-only: it needs x_bar (B) but not the primal state (A); fewer
+    // active lanes = fewer cache lines for the vector-memory unit to walk
+    vA[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k * NT + tid < n_upd) vA[k] = a.A_src[gi[k]];
+    vB[k] = a.B_src[gi[k]];
+  }
   float q1[EPT], q2[EPT], q3[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
