@@ -310,3 +310,27 @@ def test_update_data_keeps_topology(gpu):
         o.set_state(x=z2 if x0 is None else x0, xb=z2 if x0 is None else x0)
         o.solve(oracle_params(), 41)
         compare_state(o, r, "update_data")
+
+
+@pytest.mark.parametrize("kw", [
+    dict(data_factor=0.1, step_x=2e-3, step_q=60.0, theta=0.5),       # cfg comment: "0.1 for lvl5"
+    dict(data_factor=0.25, step_x=5e-4, step_q=250.0, theta=0.0),     # "0.25 for lvl3", no extrapolation
+    dict(data_factor=0.15, step_x=1e-3, step_q=125.0, theta=1.0, x_min=0.3, x_max=0.9),  # active clamp
+])
+def test_parameter_and_weight_variants(gpu, kw):
+    """Other regulariser parameters (reference cfg/flame_offline_tum.yaml:93-96 comments), adaptive
+    data weights (1/var, yaml :89) incl. zero-weight vertices, and x initialised from a prediction
+    (init_with_prediction, yaml :91) instead of the data term."""
+    from flame_ros_amd.regularizer import default_params as gp
+    g = graphgen.synthetic(4000, seed=15)
+    rng = np.random.default_rng(16)
+    wgt = (1.0 / rng.uniform(1e-3, 1e-2, g.V)).astype(np.float32)
+    wgt[::17] = 0.0
+    x0 = (g.z + rng.normal(0, 0.03, g.V)).clip(0.01).astype(np.float32)
+    for opts in (dict(path=1), dict(path=2), dict(path=2, tile_own=40, tile_depth=3)):
+        o = make_oracle(g, x0=x0)
+        o.wgt[:] = wgt
+        r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, wgt, x0=x0, **opts)
+        o.solve(oracle_params(**kw), 77)
+        r.step(gp(**kw), 77)
+        compare_state(o, r, "%s %s" % (kw, opts))
