@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="50k", choices=["5k", "50k", "200k"])
+    ap.add_argument("--workload", default="50k", choices=["5k", "50k", "200k", "tum", "euroc"])
     ap.add_argument("--iters", type=int, default=0, help="PD iterations per step (0 = config)")
     ap.add_argument("--path", type=int, default=0)
     ap.add_argument("--tile-own", type=int, default=0)
@@ -258,8 +258,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if partition else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic %s-vertex Delaunay graph, %d PD iterations per frame, "
-                                   "one frame per GPU" % (args.workload, iters),
+            "config": {"workload": ("synthetic %s-vertex Delaunay graph" % args.workload if args.workload[0].isdigit()
+                                    else "%s-shaped feature-grid graph (%d vertices)" % (args.workload, g.V)) +
+                                   ", %d PD iterations per frame, one frame per GPU" % iters,
                        "V": g.V, "E": g.E, "iters_per_step": iters, "parallelism": ("partition%d_halo%d" % (world, args.halo_depth)) if partition else "replicas%d" % world,
                        "path": {1: "global", 2: "tile"}[path], "num_tiles": r.info("num_tiles"),
                        "tile_depth": r.info("tile_depth"), "tile_threads": r.info("tile_threads"),

@@ -93,6 +93,17 @@ NAMED = {
 }
 
 
+# dataset-shaped stand-ins for BASELINE configs 1 and 3 (the datasets themselves are not available:
+# no network, no image decoder): one jittered feature per detection cell
+GRID = {
+    "tum": dict(width=640, height=480, win=16, iters=200),     # fr3/structure_texture_far, V = 1200
+    "euroc": dict(width=752, height=480, win=6, iters=200),    # V1_01, "~10k vertices": V = 10000
+}
+
+
 def named(name, seed=0):
+    if name in GRID:
+        c = GRID[name]
+        return dataset_shaped(c["width"], c["height"], c["win"], seed), c["iters"]
     c = NAMED[name]
     return synthetic(c["num_vertices"], c["width"], c["height"], seed), c["iters"]
