@@ -135,6 +135,17 @@ def test_edge_cases(gpu):
     for opts in (dict(path=1), dict(path=2), dict(path=2, tile_own=8, tile_depth=3)):
         o, r = run_both(g, opts, 33, state_seed=8)
         compare_state(o, r, "tiny %s" % opts)
+    # mostly isolated vertices (degree 0) around a small connected part, several tiles
+    g = graphgen.synthetic(120, seed=9)
+    rng = np.random.default_rng(10)
+    extra = 1500
+    g.pos = np.concatenate([g.pos, rng.uniform(0, 640, (extra, 2)).astype(np.float32)])
+    g.z = np.concatenate([g.z, rng.uniform(0.2, 1.0, extra).astype(np.float32)])
+    g.wgt = np.ones(len(g.z), np.float32)
+    g.tris = None
+    for opts in (dict(path=1), dict(path=2, tile_own=50, tile_depth=3), dict(path=2, tile_own=10 ** 6)):
+        o, r = run_both(g, opts, 21, state_seed=11)
+        compare_state(o, r, "isolated %s" % opts)
 
 
 def test_batch_of_frames(gpu):
