@@ -214,6 +214,24 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   // redone on cost instead of count.
   std::vector<float> vweight;
   bool balanced = false;
+  auto grid_cell = [&](const float* pp) {
+    int c[2];
+    for (int a = 0; a < 2; ++a) {
+      const float f = (pp[a] - P.wgrid_mn[a]) / std::max(P.wgrid_mx[a] - P.wgrid_mn[a], 1e-20f);
+      c[a] = std::max(0, std::min(Plan::kGrid - 1, (int)(f * Plan::kGrid)));
+    }
+    return c[1] * Plan::kGrid + c[0];
+  };
+  {
+    // frame stream: reuse the cost-density field of the previous frame (same tile count) so the
+    // weighted bisection is the only pass
+    const int want_tiles = (V + tile_own - 1) / std::max(tile_own, 1);
+    if (opt.balance && !batch && !single && !P.wgrid.empty() && P.wgrid_tiles == want_tiles && want_tiles >= 16) {
+      vweight.resize(V);
+      for (int32_t v = 0; v < V; ++v) vweight[v] = P.wgrid[grid_cell(pos + 2 * v)];
+      balanced = true;
+    }
+  }
   for (int attempt = 0; attempt < (batch ? 1 : 7); ++attempt) {
     const int ntiles = batch ? (int)opt.batch_voff.size() - 1 : (V == 0 ? 0 : (V + tile_own - 1) / tile_own);
     // ---- vertex order: RCB leaves = tiles ----
@@ -530,9 +548,33 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       P.tile_threads = cfg.nt; P.tile_ept = cfg.ept; P.tile_vpt = cfg.vpt;
       P.tile_depth = depth;
       P.tile_lds_bytes = lds_max;
+      if (opt.balance && !batch && !single && ntiles >= 16) {  // remember the cost-density field
+        for (int a = 0; a < 2; ++a) { P.wgrid_mn[a] = INFINITY; P.wgrid_mx[a] = -INFINITY; }
+        for (int32_t v = 0; v < V; ++v)
+          for (int a = 0; a < 2; ++a) {
+            P.wgrid_mn[a] = std::min(P.wgrid_mn[a], pos[2 * v + a]);
+            P.wgrid_mx[a] = std::max(P.wgrid_mx[a], pos[2 * v + a]);
+          }
+        std::vector<float> sum(Plan::kGrid * Plan::kGrid, 0.f), cnt(Plan::kGrid * Plan::kGrid, 0.f);
+        double total = 0.0;
+        for (int t = 0; t < ntiles; ++t) {
+          const TileDesc& D = P.tiles[t];
+          const float dens = ((float)D.e_loc + 2.0f * (float)D.n_ext) / (float)std::max(D.n_own, 1);
+          for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k) {
+            const int c = grid_cell(pos + 2 * P.v_i2o[k]);
+            sum[c] += dens; cnt[c] += 1.f;
+          }
+          total += (double)dens * D.n_own;
+        }
+        const float mean = V > 0 ? (float)(total / V) : 1.0f;
+        P.wgrid.resize(sum.size());
+        for (size_t c = 0; c < sum.size(); ++c) P.wgrid[c] = cnt[c] > 0.f ? sum[c] / cnt[c] : mean;
+        P.wgrid_tiles = ntiles;
+      }
       return 0;
     }
     vweight.clear();  // a failed weighted pass falls back to plain bisection with smaller tiles
+    P.wgrid.clear();
     // did not fit: shrink the tiles (a single tile becomes a halo'd partition) and retry
     P.tiles.clear();
     if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }

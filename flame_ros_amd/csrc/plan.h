@@ -73,6 +73,12 @@ struct Plan {
   std::vector<int32_t> b_idx, b_leaf, b_tile_of, b_deg, b_estart, b_fill;
   std::vector<int64_t> b_keys;
   std::vector<uint32_t> b_code;
+  // cost-density field of the last balanced partition on a coarse pixel grid: a handle that is
+  // re-uploaded every frame balances the next frame in ONE weighted pass instead of two
+  static constexpr int kGrid = 32;
+  std::vector<float> wgrid;  // kGrid * kGrid, empty = none yet
+  float wgrid_mn[2] = {0.f, 0.f}, wgrid_mx[2] = {1.f, 1.f};
+  int32_t wgrid_tiles = 0;   // tile count the field was built for
 };
 
 // Builds the plan.  Returns 0 or a FLAME_HIP_ERR_* code (bad indices).
