@@ -345,3 +345,29 @@ def test_parameter_and_weight_variants(gpu, kw):
         o.solve(oracle_params(**kw), 77)
         r.step(gp(**kw), 77)
         compare_state(o, r, "%s %s" % (kw, opts))
+
+
+def test_fuzz_sizes_and_tile_options(gpu):
+    """Random graph sizes, tile sizes, halo depths, workgroup sizes and launch splits (incl. tile
+    counts that are not multiples of 8 for the XCD-aware block map, tiles with very few own
+    vertices, and more tiles than the halo can separate): always the oracle's bits."""
+    rng = np.random.default_rng(2026)
+    for trial in range(24):
+        V = int(rng.integers(3, 2500))
+        g = graphgen.synthetic(V, seed=100 + trial) if V >= 4 else None
+        if g is None:
+            continue
+        own = int(rng.integers(4, max(5, V // 2)))
+        depth = int(rng.integers(1, 9))
+        opts = dict(path=2, tile_own=own, tile_depth=depth, balance=int(rng.integers(0, 2)),
+                    order_mode=int(rng.integers(0, 2)), use_graph=int(rng.integers(0, 2)))
+        if rng.random() < 0.3:
+            opts["tile_threads"] = int(rng.choice([256, 512, 1024]))
+        chunks = [int(c) for c in rng.integers(0, 12, size=3)]
+        try:
+            o, r = run_both(g, opts, None, state_seed=trial, chunks=chunks)
+        except Exception as e:  # a forced workgroup size may not fit: then the error must be clean
+            from flame_ros_amd.lib import FlameHipError
+            assert isinstance(e, FlameHipError) and e.code == -1 and "tile_threads" in opts, (opts, e)
+            continue
+        compare_state(o, r, "fuzz V=%d %s %s" % (V, opts, chunks))
