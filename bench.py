@@ -132,6 +132,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    if local_rank >= torch.cuda.device_count():  # launcher restricted visibility to one GPU per rank
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
