@@ -19,6 +19,7 @@
 
 #include "kernels.h"
 #include "plan.h"
+#include "sync.h"
 
 using namespace flamehip;
 
@@ -91,6 +92,8 @@ struct flame_hip_graph {
   PlanOptions opt;
   int use_graph = 1;
   Plan plan;
+  SyncOut sync;          // inputs derived by flame_hip_graph_sync (kept for flame_hip_graph_edges)
+  bool synced = false;   // the current graph came from flame_hip_graph_sync
   int path = 0;  // resolved path after upload
 
   hipStream_t stream = nullptr;
@@ -178,7 +181,7 @@ struct flame_hip_graph {
 
 extern "C" {
 
-int flame_hip_version(void) { return 100; }
+int flame_hip_version(void) { return 200; }
 
 const char* flame_hip_strerror(int code) {
   switch (code) {
@@ -233,6 +236,27 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
     if (g->stream) (void)hipStreamDestroy(g->stream);
   }
   delete g;
+}
+
+// A solve may have been enqueued on a caller-supplied stream: everything that rewrites the solver
+// state from the host waits for its end event first (the handle's own stream is synchronised by
+// the callers themselves).
+static hipError_t wait_last_solve(flame_hip_graph* g) {
+  if (g->device < 0 || !g->timed) return hipSuccess;
+  return hipEventSynchronize(g->ev1);
+}
+
+int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T) {
+  if (!g || V < 0 || E < 0 || T < 0) return FLAME_HIP_ERR_ARG;
+  if (g->device >= 0) {
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(wait_last_solve(g));
+    HIPCHK(hipStreamSynchronize(g->stream));
+  }
+  g->V = V; g->E = E; g->T = T;
+  g->uploaded = false;
+  g->n_send_v = g->n_send_e = g->n_recv_v = g->n_recv_e = 0;  // halo lists index the old graph
+  return 0;
 }
 
 int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
@@ -312,6 +336,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
                            const float* wgt, const float* x0, const int32_t* tris) {
   if (!g) return FLAME_HIP_ERR_ARG;
   const int32_t V = g->V, E = g->E;
+  if (edges != g->sync.edges.data()) g->synced = false;
   if ((V > 0 && (!pos || !z || !wgt)) || (E > 0 && (!edges || !alpha || !beta)))
     return FLAME_HIP_ERR_ARG;
   if (!all_finite(pos, 2 * (size_t)V) || !all_finite(z, V) || !all_finite(wgt, V) ||
@@ -329,6 +354,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     return 0;
   }
   HIPCHK(hipSetDevice(g->device));
+  HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
   g->drop_execs();  // captured launches hold the old grid / pointers
   g->solves_since_upload = 0;
@@ -379,13 +405,15 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
       HIPCHK(memcpy_sync(g->stream, g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
     }
   }
-  if (P.T > 0) {
-    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->stream, g->tris, P.tris)) ||
-        (rc = dev_alloc(g->caps, &g->trow, P.trow.size())) || (rc = h2d(g->stream, g->trow, P.trow)) ||
-        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->stream, g->tinc, P.tinc)) ||
-        (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
-      return rc;
-  }
+  // the triangle arrays always exist: with T == 0 the vertex -> triangle CSR is all-empty rows, so
+  // the triangle stage, mesh and dense maps run (degenerate normals, nothing covered)
+  if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->stream, g->tris, P.tris)) ||
+      (rc = dev_alloc(g->caps, &g->trow, (size_t)V + 1)) ||
+      (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->stream, g->tinc, P.tinc)) ||
+      (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
+    return rc;
+  if (P.T > 0) { if ((rc = h2d(g->stream, g->trow, P.trow))) return rc; }
+  else HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), g->stream));
   if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
   if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) ||
       (rc = h2d(g->stream, g->v_i2o_dev, P.v_i2o)))
@@ -402,6 +430,44 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
 
 static int require_device(const flame_hip_graph* g);
 
+int32_t flame_hip_feature_gate(int32_t n, const float* idepth_var, float var_max, uint8_t* keep) {
+  if (n < 0 || (n > 0 && (!idepth_var || !keep))) return FLAME_HIP_ERR_ARG;
+  int32_t cnt = 0;
+  for (int32_t v = 0; v < n; ++v) { keep[v] = idepth_var[v] < var_max ? 1 : 0; cnt += keep[v]; }
+  return cnt;
+}
+
+int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, int32_t V, int32_t T,
+                         const float* pos, const float* idepth_mu, const float* idepth_var,
+                         const int32_t* tris, const float* prediction, float* scale) {
+  if (!g || !sp || V < 0 || T < 0) return FLAME_HIP_ERR_ARG;
+  if ((V > 0 && (!pos || !idepth_mu || !idepth_var)) || (T > 0 && !tris)) return FLAME_HIP_ERR_ARG;
+  if (!all_finite(pos, 2 * (size_t)V) || !all_finite(idepth_mu, V)) return FLAME_HIP_ERR_NAN;
+  for (int32_t v = 0; v < V; ++v) {
+    if (std::isnan(idepth_var[v])) return FLAME_HIP_ERR_NAN;
+    if (!(idepth_var[v] < sp->idepth_var_max_graph)) return FLAME_HIP_ERR_ARG;  // fails the gate
+  }
+  int rc = graph_sync_host(*sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, &g->sync);
+  if (rc) return rc;
+  const int32_t E = (int32_t)(g->sync.edges.size() / 2);
+  if ((rc = flame_hip_graph_resize(g, V, E, T))) return rc;
+  const SyncOut& S = g->sync;
+  rc = flame_hip_graph_upload(g, pos, S.edges.data(), S.alpha.data(), S.alpha.data(), S.z.data(),
+                              S.wgt.data(), S.x0.data(), T > 0 ? tris : nullptr);
+  if (rc) return rc;
+  g->synced = true;
+  if (scale) *scale = S.scale;
+  return 0;
+}
+
+int flame_hip_graph_edges(const flame_hip_graph* g, int32_t* edges) {
+  if (!g || !g->uploaded) return FLAME_HIP_ERR_STATE;
+  if (!g->synced) return FLAME_HIP_ERR_STATE;  // the caller supplied the edge list itself
+  if (g->E > 0 && !edges) return FLAME_HIP_ERR_ARG;
+  std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)g->E);
+  return 0;
+}
+
 // New data terms on an unchanged topology: resets the solver state (x = x0 or z, w = 0,
 // x_bar = x, q = 0) without rebuilding the host plan or touching the graph arrays.
 int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float* wgt, const float* x0) {
@@ -411,6 +477,7 @@ int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float*
   if (V > 0 && (!z || !wgt)) return FLAME_HIP_ERR_ARG;
   if (!all_finite(z, V) || !all_finite(wgt, V) || (x0 && !all_finite(x0, V))) return FLAME_HIP_ERR_NAN;
   HIPCHK(hipSetDevice(g->device));
+  HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
   const Plan& P = g->plan;
   std::vector<float4> hA(V), hB(V);
@@ -440,6 +507,7 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
   const int32_t V = g->V, E = g->E;
   const Plan& P = g->plan;
   HIPCHK(hipSetDevice(g->device));
+  HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
   if (x || w1 || w2 || xb || w1b || w2b) {
     std::vector<float4> hA(V), hB(V);
@@ -690,9 +758,20 @@ int flame_hip_graph_filter(flame_hip_graph* g, int32_t kind, int32_t passes) {
   if ((kind != 0 && kind != 1) || passes < 0) return FLAME_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(g->device));
   if ((rc = dev_alloc(g->caps, &g->filter_tmp, (size_t)g->V))) return rc;
+  if (g->timed) HIPCHK(hipStreamWaitEvent(g->stream, g->ev1, 0));
   for (int32_t k = 0; k < passes; ++k)
     HIPCHK(launch_graph_filter(g->stream, g->V, kind, g->grow, g->ginc, g->eij, g->A[g->cur],
                                g->B[g->cur], g->filter_tmp));
+  return 0;
+}
+
+int flame_hip_scale_state(flame_hip_graph* g, float s) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!std::isfinite(s)) return FLAME_HIP_ERR_NAN;
+  HIPCHK(hipSetDevice(g->device));
+  if (g->timed) HIPCHK(hipStreamWaitEvent(g->stream, g->ev1, 0));
+  HIPCHK(launch_scale_state(g->stream, g->V, g->A[g->cur], g->B[g->cur], s));
   return 0;
 }
 
@@ -783,6 +862,7 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
   if ((n_send_v && !send_v) || (n_send_e && !send_e) || (n_recv_v && !recv_v) || (n_recv_e && !recv_e))
     return FLAME_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(g->device));
+  HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
   const Plan& P = g->plan;
   if ((rc = upload_index_list(g->stream, g->caps, P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
@@ -844,6 +924,11 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
   else if (k == "t_emap") { src = P.t_emap.data(); n = (int64_t)P.t_emap.size(); }
   else if (k == "t_eij") { src = P.t_eij.data(); n = (int64_t)P.t_eij.size(); esz = 8; }
   else if (k == "t_srow") { src = P.t_srow.data(); n = (int64_t)P.t_srow.size(); }
+  else if (k == "sync_edges") { src = g->sync.edges.data(); n = (int64_t)g->sync.edges.size(); }
+  else if (k == "sync_alpha") { src = g->sync.alpha.data(); n = (int64_t)g->sync.alpha.size(); }
+  else if (k == "sync_z") { src = g->sync.z.data(); n = (int64_t)g->sync.z.size(); }
+  else if (k == "sync_wgt") { src = g->sync.wgt.data(); n = (int64_t)g->sync.wgt.size(); }
+  else if (k == "sync_x0") { src = g->sync.x0.data(); n = (int64_t)g->sync.x0.size(); }
   else if (k == "profile") {  // device timeline of the LAST tile launch (set_option profile=1)
     if (!g->prof) return FLAME_HIP_ERR_STATE;
     n = (int64_t)P.tiles.size() * kProfWords; esz = 8;

@@ -65,6 +65,9 @@ hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* p
 hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int32_t* grow,
                                const int32_t* ginc, const int2* eij, float4* A, float4* B, float* tmp);
 
+// ---- row a7 epilogue: x, w, x_bar, w_bar, z *= scale (state back in the caller's units) ----
+hipError_t launch_scale_state(hipStream_t s, int32_t V, float4* A, float4* B, float scale);
+
 // ---- row f1: mesh vertices in PointNormalUV layout (3 float4 per vertex, caller's order) ----
 hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4* A,
                        const float4* vtx_normals, const int32_t* i2o, TriParamsDev tp, int32_t width,

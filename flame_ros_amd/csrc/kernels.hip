@@ -515,6 +515,18 @@ __global__ __launch_bounds__(256) void k_graph_filter_commit(int32_t V, const fl
   B[v].x = in[v];
 }
 
+// Row a7 epilogue: back to the caller's units after a solve on rescaled data (rescale_data,
+// reference cfg/flame_offline_tum.yaml:90): primal state and data term times s.
+__global__ __launch_bounds__(256) void k_scale_state(int32_t V, float4* __restrict__ A,
+                                                     float4* __restrict__ B, float s) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  float4 a = A[v], b = B[v];
+  a.x *= s; a.y *= s; a.z *= s; a.w *= s;
+  b.x *= s; b.y *= s; b.z *= s;
+  A[v] = a; B[v] = b;
+}
+
 // ------------------------------------------------------------------------------------------
 // "Next" row f1: mesh vertices in flame_ros::PointNormalUV layout (reference src/utils.h:47-53,
 // packed at src/utils.cc:184-209): 3 float4 per vertex {p,0 | n,0 | u,v,0,0}; NaN xyz when the
@@ -673,6 +685,12 @@ hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_graph_filter_commit, dim3((V + 255) / 256), dim3(256), 0, s, V, tmp, A, B);
+  return hipGetLastError();
+}
+
+hipError_t launch_scale_state(hipStream_t s, int32_t V, float4* A, float4* B, float scale) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scale_state, dim3((V + 255) / 256), dim3(256), 0, s, V, A, B, scale);
   return hipGetLastError();
 }
 

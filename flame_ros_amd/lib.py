@@ -28,6 +28,12 @@ class TriParams(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class SyncParams(C.Structure):
+    """flame_hip_sync_params (reference src/flame_offline_tum.cc:234-249, yaml :89-92)."""
+    _fields_ = [("adaptive_data_weights", C.c_int32), ("rescale_data", C.c_int32),
+                ("init_with_prediction", C.c_int32), ("idepth_var_max_graph", C.c_float)]
+
+
 class TileDesc(C.Structure):
     """Mirror of flamehip::TileDesc (csrc/common.h) for the plan debug hook."""
     _fields_ = [(n, C.c_int32) for n in
@@ -41,9 +47,14 @@ _VP, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 SYMBOLS = {
     "flame_hip_graph_create": (C.c_int, [C.POINTER(_VP), C.c_int, _I32, _I32, _I32]),
     "flame_hip_graph_destroy": (None, [_VP]),
+    "flame_hip_graph_resize": (C.c_int, [_VP, _I32, _I32, _I32]),
     "flame_hip_set_option": (C.c_int, [_VP, C.c_char_p, _I32]),
     "flame_hip_get_info": (C.c_int, [_VP, C.c_char_p, C.POINTER(_I64)]),
     "flame_hip_graph_upload": (C.c_int, [_VP] + [_VP] * 8),
+    "flame_hip_graph_sync": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_float)]),
+    "flame_hip_feature_gate": (_I32, [_I32, _VP, C.c_float, _VP]),
+    "flame_hip_graph_edges": (C.c_int, [_VP, _VP]),
+    "flame_hip_scale_state": (C.c_int, [_VP, C.c_float]),
     "flame_hip_graph_update_data": (C.c_int, [_VP, _VP, _VP, _VP]),
     "flame_hip_graph_upload_batch": (C.c_int, [_VP, _I32, _VP] + [_VP] * 8),
     "flame_hip_set_state": (C.c_int, [_VP] + [_VP] * 7),

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _l
-from .lib import Params, TriParams, FlameHipError  # noqa: F401
+from .lib import Params, SyncParams, TriParams, FlameHipError  # noqa: F401
 
 
 def default_params(data_factor=0.15, step_x=1e-3, step_q=125.0, theta=0.25, x_min=0.0, x_max=10.0):
@@ -21,6 +21,23 @@ def default_params(data_factor=0.15, step_x=1e-3, step_q=125.0, theta=0.25, x_mi
 def default_tri_params(width=640, height=480):
     """Defaults of cfg/flame_offline_tum.yaml:38-53 (reference)."""
     return TriParams(1, 1.57, 0.35, 0.1, 1, 0.333, 1, 0.01, width, height)
+
+
+def default_sync_params(adaptive_data_weights=False, rescale_data=False, init_with_prediction=True,
+                        idepth_var_max_graph=0.01):
+    """Defaults of cfg/flame_offline_tum.yaml:89-92 (reference)."""
+    return SyncParams(int(adaptive_data_weights), int(rescale_data), int(init_with_prediction),
+                      idepth_var_max_graph)
+
+
+def feature_gate(idepth_var, var_max):
+    """Row a7 gate: which tracked features may enter the graph (var < idepth_var_max_graph)."""
+    var = _f32(idepth_var)
+    keep = np.empty(len(var), np.uint8)
+    n = _l.load().flame_hip_feature_gate(len(var), _ptr(var), var_max, _ptr(keep))
+    if n < 0:
+        raise FlameHipError(int(n), "flame_hip_feature_gate")
+    return keep.astype(bool)
 
 
 def _f32(a):
@@ -82,6 +99,62 @@ class GraphRegularizer:
         except Exception:
             self.close()
             raise
+
+    @classmethod
+    def empty(cls, device=0, **options):
+        """A handle with no graph yet (frame streams: sync_features() / reupload() per frame)."""
+        self = cls.__new__(cls)
+        self._lib = _l.load()
+        self._h = C.c_void_p()
+        self.V = self.E = self.T = 0
+        _l.check(self._lib.flame_hip_graph_create(C.byref(self._h), device, 0, 0, 0), "flame_hip_graph_create")
+        for k, v in options.items():
+            _l.check(self._lib.flame_hip_set_option(self._h, k.encode(), int(v)), "flame_hip_set_option(%s)" % k)
+        return self
+
+    def sync_features(self, pos, idepth_mu, idepth_var, tris, sync_params, prediction=None):
+        """Row a7 (graph sync): tracked features + their Delaunay triangulation -> edges, weights,
+        data terms, initial x; resizes this handle and uploads.  Returns the data scale."""
+        pos = _f32(pos).reshape(-1, 2)
+        mu, var = _f32(idepth_mu), _f32(idepth_var)
+        tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        pred = None if prediction is None else _f32(prediction)
+        scale = C.c_float()
+        _l.check(self._lib.flame_hip_graph_sync(self._h, C.byref(sync_params), len(mu), len(tris), _ptr(pos),
+                                                _ptr(mu), _ptr(var), _ptr(tris) if len(tris) else None,
+                                                _ptr(pred), C.byref(scale)), "flame_hip_graph_sync")
+        self.V, self.T, self.E = len(mu), len(tris), self.info("E")
+        return scale.value
+
+    def edges(self):
+        """The edge list derived by sync_features ([E,2] int32, i < j, lexicographic)."""
+        e = np.empty((self.E, 2), np.int32)
+        _l.check(self._lib.flame_hip_graph_edges(self._h, _ptr(e)), "flame_hip_graph_edges")
+        return e
+
+    def scale_state(self, s, sync=True):
+        _l.check(self._lib.flame_hip_scale_state(self._h, float(s)), "flame_hip_scale_state")
+        if sync:
+            self.sync()
+
+    def reupload(self, pos, edges, alpha, beta, z, wgt, x0=None, tris=None):
+        """Next frame of a stream on the SAME handle (flame_hip_graph_resize + upload): a new
+        graph of any size; stream, events, device buffers and plan buffers are kept."""
+        pos = _f32(pos).reshape(-1, 2)
+        edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        alpha, beta, z, wgt = _f32(alpha), _f32(beta), _f32(z), _f32(wgt)
+        V, E = pos.shape[0], edges.shape[0]
+        if alpha.shape != (E,) or beta.shape != (E,) or z.shape != (V,) or wgt.shape != (V,):
+            raise ValueError("array shapes do not match V/E")
+        x0 = None if x0 is None else _f32(x0)
+        if tris is not None:
+            tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        T = 0 if tris is None else tris.shape[0]
+        _l.check(self._lib.flame_hip_graph_resize(self._h, V, E, T), "flame_hip_graph_resize")
+        self.V, self.E, self.T = V, E, T
+        _l.check(self._lib.flame_hip_graph_upload(self._h, _ptr(pos), _ptr(edges), _ptr(alpha),
+                                                  _ptr(beta), _ptr(z), _ptr(wgt), _ptr(x0),
+                                                  _ptr(tris)), "flame_hip_graph_upload")
 
     # -- lifetime --
     def close(self):

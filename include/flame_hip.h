@@ -71,6 +71,13 @@ enum {
 int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t E, int32_t T);
 void flame_hip_graph_destroy(flame_hip_graph* g);
 
+/* One handle serves a frame STREAM: every frame of FLaME is a new graph (reference
+ * src/flame_offline_tum.cc:578: update() re-triangulates per image).  Sets the sizes of the NEXT
+ * flame_hip_graph_upload*; the handle keeps its stream, events, device buffers (capacity), host
+ * plan buffers and the tile cost-density grid.  Registered halo lists are dropped.  Waits for any
+ * solve still in flight. */
+int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
+
 /* Options are set BEFORE upload.  Keys: "path" (enum above), "tile_own" (target own vertices
  * per tile), "tile_depth" (halo depth = iterations per launch), "tile_threads", "use_graph"
  * (replay launches from a hipGraph).  Unknown key -> FLAME_HIP_ERR_ARG. */
@@ -83,6 +90,31 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
 int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* edges,
                            const float* alpha, const float* beta, const float* z,
                            const float* wgt, const float* x0, const int32_t* tris);
+
+/* Replaces: graph sync inside Flame::update (row a7) when the caller has the tracked features and
+ * their Delaunay triangulation rather than a ready edge list: derives the unique undirected edges
+ * (i < j, lexicographic), alpha = beta = 1/|pos_i - pos_j|, the data terms z = mu / scale with
+ * scale = mean(mu) under rescale_data, the data weights (1 or 1/var) and the initial x (prediction
+ * / scale where init_with_prediction and the prediction is finite, else z), resizes the handle to
+ * (V, E, T) and uploads.  Parameters: reference src/flame_offline_tum.cc:234-249,
+ * cfg/flame_offline_tum.yaml:87-92.  Every feature must pass the gate var < idepth_var_max_graph
+ * (FLAME_HIP_ERR_ARG otherwise; flame_hip_feature_gate selects them BEFORE triangulation).
+ * The solve then runs in rescaled units; flame_hip_scale_state(g, scale) brings the state back. */
+typedef struct {
+  int32_t adaptive_data_weights; /* regularization/nltgv2/adaptive_data_weights */
+  int32_t rescale_data;          /* .../rescale_data */
+  int32_t init_with_prediction;  /* .../init_with_prediction */
+  float idepth_var_max_graph;    /* .../idepth_var_max */
+} flame_hip_sync_params;
+int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, int32_t V, int32_t T,
+                         const float* pos, const float* idepth_mu, const float* idepth_var,
+                         const int32_t* tris, const float* prediction, float* scale);
+/* keep[v] = var[v] < var_max; returns the number kept (or a negative error).  No device needed. */
+int32_t flame_hip_feature_gate(int32_t n, const float* idepth_var, float var_max, uint8_t* keep);
+/* The edge list flame_hip_graph_sync derived (2E ints; E from flame_hip_get_info "E"). */
+int flame_hip_graph_edges(const flame_hip_graph* g, int32_t* edges);
+/* x, w, x_bar, w_bar and z times s (asynchronous on the handle's stream). */
+int flame_hip_scale_state(flame_hip_graph* g, float s);
 
 /* New frame on an UNCHANGED topology (same vertices, edges, weights): only the data terms, data
  * weights and the initial x change.  Resets the state exactly like flame_hip_graph_upload but

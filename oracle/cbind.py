@@ -124,6 +124,12 @@ class COracle:
                                     self._inc.ctypes.data_as(C.c_void_p), C.c_int32(kind),
                                     scratch.ctypes.data_as(C.c_void_p))
 
+    def scale_state(self, s):
+        """Row a7 epilogue: state and data term back to the caller's units (x *= s, ...)."""
+        self.z = self.z.copy()  # may alias the caller's array
+        g = self._g()
+        _load().nltgv2_scale_state(C.byref(g), self.z.ctypes.data_as(C.c_void_p), C.c_float(s))
+
     def dual_step(self, params):
         g = self._g()
         _load().nltgv2_dual_step(C.byref(params), C.byref(g))
@@ -161,6 +167,44 @@ class COracle:
         vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         _load().nltgv2_apply_KT(C.byref(g), vp(q), vp(out[0]), vp(out[1]), vp(out[2]))
         return out
+
+
+class SyncParams(C.Structure):
+    """nltgv2_sync_params (reference cfg/flame_offline_tum.yaml:89-92)."""
+    _fields_ = [("adaptive_data_weights", C.c_int32), ("rescale_data", C.c_int32),
+                ("init_with_prediction", C.c_int32), ("idepth_var_max_graph", C.c_float)]
+
+
+def feature_gate(var, var_max):
+    var = _f32(var)
+    keep = np.empty(len(var), np.uint8)
+    L = _load()
+    L.nltgv2_feature_gate.restype = C.c_int32
+    n = L.nltgv2_feature_gate(C.c_int32(len(var)), var.ctypes.data_as(C.c_void_p), C.c_float(var_max),
+                              keep.ctypes.data_as(C.c_void_p))
+    assert n == int(keep.sum())
+    return keep.astype(bool)
+
+
+def graph_sync(sp, pos, mu, var, tris, prediction=None):
+    """Row a7.  Returns dict(edges[E,2], alpha, beta, z, wgt, x0, scale)."""
+    pos = _f32(pos).reshape(-1, 2)
+    mu, var = _f32(mu), _f32(var)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    V, T = len(mu), len(tris)
+    pred = None if prediction is None else _f32(prediction)
+    edges = np.empty((3 * max(T, 1), 2), np.int32)
+    alpha, beta = np.empty(3 * max(T, 1), np.float32), np.empty(3 * max(T, 1), np.float32)
+    z, wgt, x0 = (np.empty(V, np.float32) for _ in range(3))
+    scale = C.c_float()
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L = _load()
+    L.nltgv2_graph_sync.restype = C.c_int32
+    E = L.nltgv2_graph_sync(C.byref(sp), C.c_int32(V), C.c_int32(T), vp(pos), vp(mu), vp(var), vp(tris),
+                            vp(pred), vp(edges), vp(alpha), vp(beta), vp(z), vp(wgt), vp(x0),
+                            C.byref(scale))
+    return dict(edges=edges[:E].copy(), alpha=alpha[:E].copy(), beta=beta[:E].copy(), z=z, wgt=wgt,
+                x0=x0, scale=scale.value)
 
 
 def triangles(tri_params, Kinv, pos, x, tris):

@@ -475,3 +475,84 @@ void nltgv2_graph_filter(nltgv2_graph* g, const int32_t* row, const int32_t* inc
   }
   for (int32_t v = 0; v < g->V; ++v) { g->x[v] = scratch[v]; g->xb[v] = scratch[v]; }
 }
+
+/* ---- row a7: graph sync -- what Flame::update() does between the Delaunay
+ * triangulation and the first regulariser step.  The parameters cross the boundary at reference
+ * src/flame_offline_tum.cc:234-249 with the meanings stated in cfg/flame_offline_tum.yaml:87-92:
+ *   idepth_var_max_graph  "Maximum idepth var before feature can be added to graph" (:92)
+ *   adaptive_data_weights "Set vertex data weights to inverse idepth variance"       (:89)
+ *   rescale_data          "Rescale data to have mean 1"                              (:90)
+ *   init_with_prediction  "Initialize vertex idepths with predicted value from dense idepthmap" (:91)
+ * Upstream's code for it is not in the reference tree; this is the build's precise statement:
+ *   gate    : feature v may enter the graph iff var_v < idepth_var_max_graph (strict)
+ *   edges   : the unique undirected edges of the triangulation, oriented i < j, in lexicographic
+ *             order of (i, j); alpha_e = beta_e = 1 / sqrt(dx^2 + dy^2) in float32, dx^2 + dy^2 NOT
+ *             fused ([UPSTREAM-RECALL] reciprocal pixel edge length)
+ *   scale   : rescale_data ? (float)(sum_v (double)mu_v / V) : 1; a scale that is not > 0 reads 1
+ *   z_v     = mu_v / scale;  wgt_v = adaptive ? 1 / var_v : 1
+ *   x0_v    = (init_with_prediction && prediction && isfinite(prediction_v)) ? prediction_v / scale
+ *                                                                             : z_v
+ * Returns E. ---- */
+int32_t nltgv2_feature_gate(int32_t n, const float* var, float var_max, uint8_t* keep) {
+  int32_t cnt = 0;
+  for (int32_t v = 0; v < n; ++v) { keep[v] = var[v] < var_max ? 1 : 0; cnt += keep[v]; }
+  return cnt;
+}
+
+static int cmp_pair(const void* a, const void* b) {
+  const int32_t* x = (const int32_t*)a; const int32_t* y = (const int32_t*)b;
+  if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+  if (x[1] != y[1]) return x[1] < y[1] ? -1 : 1;
+  return 0;
+}
+
+int32_t nltgv2_graph_sync(const nltgv2_sync_params* sp, int32_t V, int32_t T, const float* pos,
+                          const float* mu, const float* var, const int32_t* tris,
+                          const float* prediction, int32_t* edges /* cap 2*3T */, float* alpha,
+                          float* beta, float* z, float* wgt, float* x0, float* scale_out) {
+  int32_t n = 0;
+  for (int32_t t = 0; t < T; ++t)
+    for (int k = 0; k < 3; ++k) {
+      const int32_t a = tris[3 * t + k], b = tris[3 * t + (k + 1) % 3];
+      edges[2 * n] = a < b ? a : b;
+      edges[2 * n + 1] = a < b ? b : a;
+      ++n;
+    }
+  qsort(edges, (size_t)n, 2 * sizeof(int32_t), cmp_pair);
+  int32_t E = 0;
+  for (int32_t k = 0; k < n; ++k)
+    if (E == 0 || edges[2 * k] != edges[2 * E - 2] || edges[2 * k + 1] != edges[2 * E - 1]) {
+      edges[2 * E] = edges[2 * k]; edges[2 * E + 1] = edges[2 * k + 1]; ++E;
+    }
+  for (int32_t e = 0; e < E; ++e) {
+    const int32_t i = edges[2 * e], j = edges[2 * e + 1];
+    const float dx = pos[2 * i] - pos[2 * j], dy = pos[2 * i + 1] - pos[2 * j + 1];
+    const float len = sqrtf(dx * dx + dy * dy);
+    alpha[e] = 1.0f / len;
+    beta[e] = alpha[e];
+  }
+  float scale = 1.0f;
+  if (sp->rescale_data && V > 0) {
+    double s = 0.0;
+    for (int32_t v = 0; v < V; ++v) s += (double)mu[v];
+    scale = (float)(s / (double)V);
+    if (!(scale > 0.0f)) scale = 1.0f;
+  }
+  for (int32_t v = 0; v < V; ++v) {
+    z[v] = mu[v] / scale;
+    wgt[v] = sp->adaptive_data_weights ? 1.0f / var[v] : 1.0f;
+    x0[v] = (sp->init_with_prediction && prediction && isfinite(prediction[v])) ? prediction[v] / scale : z[v];
+  }
+  if (scale_out) *scale_out = scale;
+  return E;
+}
+
+/* Back to the caller's units after a rescaled solve: primal state and data term times s (the dual
+ * state is scale free).  One float32 multiply per value. */
+void nltgv2_scale_state(nltgv2_graph* g, float* z_mut, float s) {
+  for (int32_t v = 0; v < g->V; ++v) {
+    g->x[v] *= s; g->w1[v] *= s; g->w2[v] *= s;
+    g->xb[v] *= s; g->w1b[v] *= s; g->w2b[v] *= s;
+    if (z_mut) z_mut[v] *= s;
+  }
+}

@@ -97,6 +97,22 @@ void nltgv2_triangles(const nltgv2_tri_params* tp, const float Kinv[9], int32_t 
 void nltgv2_graph_filter(nltgv2_graph* g, const int32_t* row, const int32_t* inc, int32_t kind,
                          float* scratch);
 
+/* ---- row a7: graph sync (gate, edges of the triangulation, alpha/beta, rescale, adaptive weights,
+ * prediction init); see the statement above nltgv2_graph_sync in nltgv2_oracle.c ---- */
+typedef struct {
+  int32_t adaptive_data_weights; /* cfg/flame_offline_tum.yaml:89 */
+  int32_t rescale_data;          /* :90 */
+  int32_t init_with_prediction;  /* :91 */
+  float idepth_var_max_graph;    /* :92 */
+} nltgv2_sync_params;
+int32_t nltgv2_feature_gate(int32_t n, const float* var, float var_max, uint8_t* keep);
+/* edges capacity 2*3T ints, alpha/beta capacity 3T; returns E */
+int32_t nltgv2_graph_sync(const nltgv2_sync_params* sp, int32_t V, int32_t T, const float* pos,
+                          const float* mu, const float* var, const int32_t* tris,
+                          const float* prediction, int32_t* edges, float* alpha, float* beta,
+                          float* z, float* wgt, float* x0, float* scale_out);
+void nltgv2_scale_state(nltgv2_graph* g, float* z_mut, float s);
+
 /* "next" row f1: mesh vertices in flame_ros::PointNormalUV layout (12 floats) and faces with
  * reversed winding (reference src/utils.cc:184-230).  Returns the number of faces. */
 void nltgv2_mesh_points(const float Kinv[9], int32_t V, const float* pos, const float* x,

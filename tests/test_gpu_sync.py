@@ -1,0 +1,53 @@
+"""-m gpu: row a7 end to end on the device: graph sync -> solve -> (un-scale) -> triangle stage,
+against the oracle's statements of each (bit-exact), for every combination of the sync switches
+(reference cfg/flame_offline_tum.yaml:89-92)."""
+import numpy as np
+import pytest
+
+from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_sync_params, default_tri_params
+from oracle import COracle
+from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync, triangles as oracle_triangles, TriParams as OTri
+from tests.test_graph_sync import features
+from tests.util import assert_bit_equal, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("adaptive,rescale,init_pred", [(0, 0, 1), (1, 0, 1), (0, 1, 0), (1, 1, 1)])
+def test_sync_solve_unscale_triangles(gpu, adaptive, rescale, init_pred):
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    tp = default_tri_params(640, 480)
+    otp = OTri(*[getattr(tp, f[0]) for f in tp._fields_])
+    r = GraphRegularizer.empty(device=0)
+    for frame, V in enumerate((6000, 2500)):  # two frames of a stream on one handle
+        g, var, pred = features(V, 20 + frame)
+        # adaptive weights 1/var reach 1e5: keep the data step tau*lambda*w inside the clamp range
+        if adaptive:
+            var = np.maximum(var, np.float32(2e-3))
+        sp = default_sync_params(adaptive, rescale, init_pred, 0.01)
+        s = oracle_sync(OSync(adaptive, rescale, init_pred, 0.01), g.pos, g.z, var, g.tris, pred)
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+        scale = r.sync_features(g.pos, g.z, var, g.tris, sp, prediction=pred)
+        assert np.float32(scale) == np.float32(s["scale"])
+        o.solve(oracle_params(), 150)
+        r.step(default_params(), 150)
+        so, do = o.costs(oracle_params())
+        sg, dg = r.costs(default_params())
+        assert abs(sg - so) <= 1e-9 * so and abs(dg - do) <= 1e-9 * max(do, 1e-30)
+        o.scale_state(scale)
+        r.scale_state(scale)
+        x, w1, w2, q = r.download()
+        xb, _, _ = r.download_bar()
+        assert_bit_equal(x, o.x, "x")
+        assert_bit_equal(w1, o.w1, "w1")
+        assert_bit_equal(w2, o.w2, "w2")
+        assert_bit_equal(xb, o.xb, "xb")
+        assert_bit_equal(q, o.q, "q")
+        if rescale:  # back in the caller's units: close to the measured idepths again
+            assert abs(float(np.mean(x)) - float(np.mean(g.z))) < 0.02
+        tn_o, tv_o, vn_o = oracle_triangles(otp, Kinv, g.pos, o.x, g.tris)
+        tn, tv, vn = r.triangles(Kinv, tp)
+        assert np.array_equal(tv, tv_o)
+        assert_bit_equal(vn, vn_o, "vertex normals")
+    r.close()
