@@ -1,22 +1,37 @@
-// include/flame/flame.h -- flame::Flame, reduced to the regulariser path, on MI355X.
+// include/flame/flame.h -- flame::Flame as flame_ros consumes it, with the regulariser path on
+// MI355X (libflame_hip.so).
 //
-// What flame_ros calls: the constructor (reference src/flame_offline_tum.cc:
-// 408-412), update() (:578-579), getInverseDepthMesh() (:628-635), getRawIDepths() (:680-682),
-// stats() (:706-707).  Upstream's update() = feature detection + epipolar idepth filtering +
-// Delaunay triangulation (OpenCV/Sophus code, out of scope here) followed by the part this class
-// implements on the GPU: graph sync (row a7), N x nltgv2 step (a2-a5), costs (a6), per-triangle
-// stage (a8).  That tail is exposed as updateGraph(); INTEGRATION.md shows the three-line change
-// that makes upstream's update() call it.
+// Every member flame_ros calls is declared here with the signature of its call site:
+//   constructor                              reference src/flame_offline_tum.cc:408-412, src/flame_nodelet.cc:523-527
+//   update(time, img_id, pose, gray, is_pf)  src/flame_offline_tum.cc:578-579, src/flame_nodelet.cc:634-635
+//   update(..., idepths_true)                src/flame_offline_tum.cc:593-594
+//   getInverseDepthMesh                      :628-635
+//   getFilteredInverseDepthMap(cv::Mat1f*)   :643;  getInverseDepthMap()  src/flame_nodelet.cc:688
+//   getRawIDepths                            :680-682
+//   getDebugImage{Wireframe,Features,Detections,Matches,Normals,InverseDepthMap}   :731-766
+//   stats()                                  :706-707
+//   updatePoseFramePoses / prunePoseFrames   src/flame_nodelet.cc:474-475
 //
-// Conventions kept from the reference: update*() returns false on failure and the caller skips
-// the frame (src/flame_offline_tum.cc:597-601); every other method is void with caller-owned
-// output vectors; nothing throws; an internal mutex serialises update against the pose-frame
-// mutators the nodelet calls from another thread (src/flame_nodelet.cc:474-475).
+// Upstream's update() = feature detection + epipolar idepth filtering + Delaunay triangulation
+// (OpenCV/Sophus code upstream of the hot path, SURVEY.md 2 "OUT OF SCOPE") followed by the part
+// this class runs on the GPU: graph sync (row a7), N x nltgv2 step (a2-a5), costs (a6), the
+// per-triangle stage (a8), dense maps / mesh (f1, f2).  The feature pipeline plugs in through
+// FrontEnd (two callbacks: tracked features of the frame; triangulation of the gated features);
+// update() returns false when none is registered, exactly like any other failed update (the
+// frontends warn and skip the frame, src/flame_offline_tum.cc:597-601).  updateGraph() is the GPU
+// tail on its own, for callers that already hold features + triangulation.
+//
+// Conventions kept from the reference: update*() returns false on failure; every other method is
+// void / returns an image with caller-owned outputs; nothing throws; an internal mutex serialises
+// update against the pose-frame mutators the nodelet calls from another thread
+// (src/flame_nodelet.cc:474-475; stat key update_locking, msg/FlameStats.msg:34).
 #pragma once
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <functional>
+#include <limits>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -25,9 +40,40 @@
 #include "optimizers/nltgv2_l1_graph_regularizer.h"
 #include "params.h"
 #include "types.h"
+#include "utils/assert.h"
+#include "utils/image_utils.h"
 #include "utils/stats_tracker.h"
+#include "utils/visualization.h"
 
 namespace flame {
+
+// One camera frame as update() receives it.
+struct FrameInput {
+  double time = 0.0;
+  uint32_t img_id = 0;
+  SE3f pose;
+  const Image1b* img = nullptr;
+  bool is_poseframe = false;
+  const Image1f* idepths_true = nullptr;  // analysis/pass_in_truth (src/flame_offline_tum.cc:577-595)
+};
+
+// Everything the feature pipeline knows about the tracked features of a frame.
+struct FeatureSet {
+  std::vector<Point2f> vtx;
+  std::vector<float> idepth_mu, idepth_var;
+  std::vector<float> prediction;  // empty, or one value per feature (NaN = none)
+};
+
+// The part of upstream's Flame::update() that is NOT on the hot path, as callbacks.
+struct FrontEnd {
+  // detection + tracking + epipolar idepth filtering: all features tracked in this frame
+  std::function<bool(const FrameInput&, FeatureSet*)> track;
+  // Delaunay triangulation of the features that passed the variance gate
+  std::function<bool(const std::vector<Point2f>&, std::vector<Triangle>*)> triangulate;
+  // pose-frame bookkeeping (optional)
+  std::function<void(const std::vector<uint32_t>&, const std::vector<SE3f>&)> updatePoseFramePoses;
+  std::function<void(const std::vector<uint32_t>&)> prunePoseFrames;
+};
 
 class Flame {
  public:
@@ -36,133 +82,54 @@ class Flame {
       : width_(width), height_(height), params_(params) {
     toRowMajor(K, K_);
     toRowMajor(Kinv, Kinv_);
+    const Vec3b black(0, 0, 0);
+    debug_wireframe_ = Image3b(height, width, black);
+    debug_features_ = Image3b(height, width, black);
+    debug_detections_ = Image3b(height, width, black);
+    debug_matches_ = Image3b(height, width, black);
+    debug_normals_ = Image3b(height, width, black);
+    debug_idepthmap_ = Image3b(height, width, black);
   }
   Flame(const Flame&) = delete;
   Flame& operator=(const Flame&) = delete;
 
-  // The tail of upstream's update(): `vtx` are the tracked features that passed the variance gate
-  // (idepth_var_max_graph), `idepth_mu` / `idepth_var` their filtered inverse depths,
-  // `triangles` their Delaunay triangulation; `prediction` (optional) initialises x when
-  // init_with_prediction is set.  Returns false on any error (stats key "hip_error" holds the
-  // flame_hip code).
+  void setFrontEnd(const FrontEnd& fe) {
+    std::lock_guard<std::mutex> lock(mtx_);
+    frontend_ = fe;
+  }
+
+  // reference src/flame_offline_tum.cc:578-579, src/flame_nodelet.cc:634-635
+  bool update(double time, uint32_t img_id, const SE3f& pose, const Image1b& img, bool is_poseframe) {
+    FrameInput in;
+    in.time = time; in.img_id = img_id; in.pose = pose; in.img = &img; in.is_poseframe = is_poseframe;
+    return updateFrame(in);
+  }
+  // reference src/flame_offline_tum.cc:593-594 (ground-truth idepths passed in)
+  bool update(double time, uint32_t img_id, const SE3f& pose, const Image1b& img, bool is_poseframe,
+              const Image1f& idepths_true) {
+    FrameInput in;
+    in.time = time; in.img_id = img_id; in.pose = pose; in.img = &img; in.is_poseframe = is_poseframe;
+    in.idepths_true = &idepths_true;
+    return updateFrame(in);
+  }
+
+  // The GPU tail of update(): `vtx` are the features that passed the variance gate
+  // (idepth_var_max_graph; a feature that fails it makes the update fail), `idepth_mu` /
+  // `idepth_var` their filtered inverse depths, `triangles` their Delaunay triangulation;
+  // `prediction` (optional, NaN = none) initialises x when init_with_prediction is set.  Returns
+  // false on any error (stats key "hip_error" holds the flame_hip code); the results of the last
+  // successful update stay readable.
   bool updateGraph(double time, uint32_t img_id, const std::vector<Point2f>& vtx,
                    const std::vector<float>& idepth_mu, const std::vector<float>& idepth_var,
                    const std::vector<Triangle>& triangles,
                    const std::vector<float>* prediction = nullptr) {
-    namespace reg = optimizers::nltgv2_l1_graph_regularizer;
     stats_.tick("update_locking");
     std::lock_guard<std::mutex> lock(mtx_);
     stats_.tock("update_locking");
     stats_.tick("update");
-    (void)time;
-    (void)img_id;
-    const int32_t V = static_cast<int32_t>(vtx.size()), T = static_cast<int32_t>(triangles.size());
-    if (idepth_mu.size() != vtx.size() || idepth_var.size() != vtx.size() ||
-        (prediction && prediction->size() != vtx.size()))
-      return fail(FLAME_HIP_ERR_ARG);
-
-    // ---- graph sync (row a7) ----
-    stats_.tick("sync_graph");
-    vtx_ = vtx;
-    mu_ = idepth_mu;
-    var_ = idepth_var;
-    tris_ = triangles;
-    std::vector<std::pair<int32_t, int32_t> > und;
-    und.reserve(3 * static_cast<size_t>(T));
-    for (int32_t t = 0; t < T; ++t)
-      for (int k = 0; k < 3; ++k) {
-        int32_t a = triangles[t][k], b = triangles[t][(k + 1) % 3];
-        if (a < 0 || b < 0 || a >= V || b >= V || a == b) return fail(FLAME_HIP_ERR_ARG);
-        und.push_back(a < b ? std::make_pair(a, b) : std::make_pair(b, a));
-      }
-    std::sort(und.begin(), und.end());
-    und.erase(std::unique(und.begin(), und.end()), und.end());
-    const int32_t E = static_cast<int32_t>(und.size());
-    edges_.resize(E);
-    std::vector<float> pos(2 * static_cast<size_t>(V)), alpha(E), z(V), wgt(V), x0(V);
-    std::vector<int32_t> eidx(2 * static_cast<size_t>(E)), tidx(3 * static_cast<size_t>(T));
-    for (int32_t v = 0; v < V; ++v) { pos[2 * v] = vtx[v].x; pos[2 * v + 1] = vtx[v].y; }
-    for (int32_t e = 0; e < E; ++e) {
-      edges_[e] = Edge(und[e].first, und[e].second);
-      eidx[2 * e] = und[e].first;
-      eidx[2 * e + 1] = und[e].second;
-      const float dx = pos[2 * und[e].first] - pos[2 * und[e].second];
-      const float dy = pos[2 * und[e].first + 1] - pos[2 * und[e].second + 1];
-      alpha[e] = 1.0f / std::sqrt(dx * dx + dy * dy);  // [UPSTREAM-RECALL] reciprocal edge length
-    }
-    for (int32_t t = 0; t < T; ++t)
-      for (int k = 0; k < 3; ++k) tidx[3 * t + k] = triangles[t][k];
-    float scale = 1.0f;
-    if (params_.rescale_data && V > 0) {  // "Rescale data to have mean 1" (yaml :90)
-      double s = 0.0;
-      for (int32_t v = 0; v < V; ++v) s += idepth_mu[v];
-      scale = static_cast<float>(s / V);
-      if (!(scale > 0.0f)) scale = 1.0f;
-    }
-    for (int32_t v = 0; v < V; ++v) {
-      z[v] = idepth_mu[v] / scale;
-      wgt[v] = params_.adaptive_data_weights ? 1.0f / idepth_var[v] : 1.0f;  // yaml :89
-      x0[v] = (params_.init_with_prediction && prediction) ? (*prediction)[v] / scale : z[v];
-    }
-    int rc = graph_.build(params_.hip_device, V, E, T, pos.data(), eidx.data(), alpha.data(),
-                          alpha.data(), z.data(), wgt.data(), x0.data(), T ? tidx.data() : nullptr);
-    stats_.tock("sync_graph");
-    if (rc) return fail(rc);
-
-    // ---- regulariser (rows a2-a6) ----
-    stats_.tick("nltgv2");
-    if (params_.do_nltgv2) {
-      rc = reg::step(params_.rparams, &graph_, params_.nltgv2_iterations);
-      if (rc) return fail(rc);
-    }
-    stats_.tock("nltgv2");
-    idepths_.assign(V, 0.0f);
-    rc = flame_hip_download(graph_.handle(), idepths_.data(), nullptr, nullptr, nullptr);
-    if (rc) return fail(rc);
-    const flame_hip_params cp = reg::toC(params_.rparams);
-    double smooth = 0.0, data = 0.0;
-    rc = flame_hip_costs(graph_.handle(), &cp, &smooth, &data);
-    if (rc) return fail(rc);
-
-    // ---- per-triangle stage (row a8) ----
-    stats_.tick("interpolate");
-    normals_flat_.assign(3 * static_cast<size_t>(V), 0.0f);
-    tri_valid_.assign(T, 0);
-    flame_hip_tri_params tp;
-    tp.do_oblique_triangle_filter = params_.do_oblique_triangle_filter;
-    tp.oblique_normal_thresh = params_.oblique_normal_thresh;
-    tp.oblique_idepth_diff_factor = params_.oblique_idepth_diff_factor;
-    tp.oblique_idepth_diff_abs = params_.oblique_idepth_diff_abs;
-    tp.do_edge_length_filter = params_.do_edge_length_filter;
-    tp.edge_length_thresh = params_.edge_length_thresh;
-    tp.do_idepth_triangle_filter = params_.do_idepth_triangle_filter;
-    tp.min_triangle_idepth = params_.min_triangle_idepth / scale;
-    tp.width = width_;
-    tp.height = height_;
-    if (T > 0) {
-      rc = flame_hip_triangles(graph_.handle(), Kinv_, &tp, normals_flat_.data(), tri_valid_.data(), nullptr);
-      if (rc) return fail(rc);
-    }
-    stats_.tock("interpolate");
-    for (int32_t v = 0; v < V; ++v) idepths_[v] *= scale;
-
-    // ---- stats (keys read at reference src/utils.cc:117-156) ----
-    stats_.set("num_feats", V);
-    stats_.set("num_vtx", V);
-    stats_.set("num_tris", T);
-    stats_.set("num_edges", E);
-    stats_.set("nltgv2_total_smoothness_cost", smooth);
-    stats_.set("nltgv2_avg_smoothness_cost", V ? smooth / V : 0.0);
-    stats_.set("nltgv2_total_data_cost", data);
-    stats_.set("nltgv2_avg_data_cost", V ? data / V : 0.0);
-    stats_.set("nltgv2_iters", params_.do_nltgv2 ? params_.nltgv2_iterations : 0);
-    stats_.set("hip_error", 0);
-    float ms = 0.f;
-    int32_t launches = 0;
-    if (params_.do_nltgv2 && flame_hip_last_solve_ms(graph_.handle(), &ms, &launches) == 0)
-      stats_.setTiming("nltgv2_device", ms);
+    const bool ok = updateGraphLocked(time, img_id, vtx, idepth_mu, idepth_var, triangles, prediction, nullptr);
     stats_.tock("update");
-    return true;
+    return ok;
   }
 
   // Caller owns the vectors (reference src/flame_offline_tum.cc:628-635).
@@ -182,17 +149,23 @@ class Flame {
     if (edges) *edges = edges_;
   }
 
-  // reference src/flame_offline_tum.cc:680-682
+  // reference src/flame_offline_tum.cc:680-682: every tracked feature, before the variance gate
   void getRawIDepths(std::vector<Point2f>* vtx, std::vector<float>* mu, std::vector<float>* var) const {
     std::lock_guard<std::mutex> lock(mtx_);
-    if (vtx) *vtx = vtx_;
-    if (mu) *mu = mu_;
-    if (var) *var = var_;
+    if (vtx) *vtx = raw_vtx_;
+    if (mu) *mu = raw_mu_;
+    if (var) *var = raw_var_;
   }
 
-  // Dense maps (row f2).  Upstream returns cv::Mat1f (reference src/flame_offline_tum.cc:643,
-  // src/flame_nodelet.cc:688); here a row-major width() x height() float vector, NaN where the
-  // mesh does not cover the pixel (cv::Mat1f overloads below when OpenCV is present).
+  // Dense maps (row f2), NaN where the mesh does not cover the pixel.  The Image1f forms are the
+  // reference's (cv::Mat1f when OpenCV is present: src/flame_offline_tum.cc:643,
+  // src/flame_nodelet.cc:688); on failure the image is all NaN.
+  void getFilteredInverseDepthMap(Image1f* idepthmap) const { mapImage(1, idepthmap); }
+  Image1f getInverseDepthMap() const {
+    Image1f m;
+    mapImage(0, &m);
+    return m;
+  }
   bool getFilteredInverseDepthMap(std::vector<float>* idepthmap) const { return maps(1, idepthmap, nullptr, nullptr, 0.f, 0.f); }
   bool getInverseDepthMap(std::vector<float>* idepthmap) const { return maps(0, idepthmap, nullptr, nullptr, 0.f, 0.f); }
   // idepth -> depth inversion and point cloud of flame_ros (reference
@@ -201,24 +174,11 @@ class Flame {
                            float min_depth, float max_depth) const {
     return maps(1, nullptr, depthmap, cloud_xyz, min_depth, max_depth);
   }
-#ifdef FLAME_HAVE_OPENCV
-  void getFilteredInverseDepthMap(cv::Mat1f* idepthmap) const {
-    std::vector<float> v;
-    idepthmap->create(height_, width_);
-    if (getFilteredInverseDepthMap(&v)) std::copy(v.begin(), v.end(), idepthmap->ptr<float>());
-  }
-  cv::Mat1f getInverseDepthMap() const {
-    std::vector<float> v;
-    cv::Mat1f m(height_, width_);
-    if (getInverseDepthMap(&v)) std::copy(v.begin(), v.end(), m.ptr<float>());
-    return m;
-  }
-#endif
   // Mesh as flame_ros publishes it (row f1; reference src/utils.cc:184-230): 12 floats per
   // vertex in flame_ros::PointNormalUV layout and reversed-winding faces of the valid triangles.
   bool getMeshPointNormalUV(std::vector<float>* points, std::vector<int32_t>* faces) const {
     std::lock_guard<std::mutex> lock(mtx_);
-    if (!graph_.valid()) return false;
+    if (!device_frame_valid_) return false;
     const flame_hip_tri_params tp = triParams();
     points->assign(12 * vtx_.size(), 0.f);
     faces->assign(3 * tris_.size(), 0);
@@ -228,12 +188,171 @@ class Flame {
     return true;
   }
 
+  // Debug images, BGR8, width x height (reference src/flame_offline_tum.cc:731-766).  Wireframe:
+  // edges of the valid triangles coloured by idepth; Features: the raw features coloured by
+  // idepth; InverseDepthMap: jet colormap of the filtered dense idepthmap; all three on black
+  // (the input image is not kept).  Detections / Matches / Normals belong to the feature
+  // pipeline / are not drawn here: black images of the right size.
+  const Image3b& getDebugImageWireframe() const { return debug_wireframe_; }
+  const Image3b& getDebugImageFeatures() const { return debug_features_; }
+  const Image3b& getDebugImageDetections() const { return debug_detections_; }
+  const Image3b& getDebugImageMatches() const { return debug_matches_; }
+  const Image3b& getDebugImageNormals() const { return debug_normals_; }
+  const Image3b& getDebugImageInverseDepthMap() const { return debug_idepthmap_; }
+
+  // reference src/flame_nodelet.cc:474-475 (called from the ROS callback thread): forwarded to the
+  // front end under the same mutex update() holds.
+  void updatePoseFramePoses(const std::vector<uint32_t>& pf_ids, const std::vector<SE3f>& pf_poses) {
+    std::lock_guard<std::mutex> lock(mtx_);
+    if (frontend_.updatePoseFramePoses) frontend_.updatePoseFramePoses(pf_ids, pf_poses);
+  }
+  void prunePoseFrames(const std::vector<uint32_t>& pf_ids) {
+    std::lock_guard<std::mutex> lock(mtx_);
+    if (frontend_.prunePoseFrames) frontend_.prunePoseFrames(pf_ids);
+  }
+
   const utils::StatsTracker& stats() const { return stats_; }
   const Params& params() const { return params_; }
   int width() const { return width_; }
   int height() const { return height_; }
 
  private:
+  bool updateFrame(const FrameInput& in) {
+    stats_.tick("update_locking");
+    std::lock_guard<std::mutex> lock(mtx_);
+    stats_.tock("update_locking");
+    stats_.tick("update");
+    bool ok = false;
+    if (!frontend_.track || !frontend_.triangulate) {
+      stats_.set("hip_error", FLAME_HIP_ERR_STATE);  // no feature pipeline registered
+    } else {
+      FeatureSet fs;
+      stats_.tick("update_idepths");
+      ok = frontend_.track(in, &fs) && fs.idepth_mu.size() == fs.vtx.size() &&
+           fs.idepth_var.size() == fs.vtx.size() &&
+           (fs.prediction.empty() || fs.prediction.size() == fs.vtx.size());
+      stats_.tock("update_idepths");
+      if (ok) {
+        // variance gate (row a7): "Maximum idepth var before feature can be added to graph"
+        // (reference cfg/flame_offline_tum.yaml:92)
+        const int32_t n = static_cast<int32_t>(fs.vtx.size());
+        std::vector<uint8_t> keep(fs.vtx.size());
+        const int32_t nk = flame_hip_feature_gate(n, fs.idepth_var.data(), params_.idepth_var_max_graph, keep.data());
+        ok = nk >= 0;
+        FeatureSet g;
+        for (int32_t v = 0; ok && v < n; ++v)
+          if (keep[v]) {
+            g.vtx.push_back(fs.vtx[v]);
+            g.idepth_mu.push_back(fs.idepth_mu[v]);
+            g.idepth_var.push_back(fs.idepth_var[v]);
+            if (!fs.prediction.empty()) g.prediction.push_back(fs.prediction[v]);
+          }
+        std::vector<Triangle> tris;
+        if (ok) {
+          stats_.tick("triangulate");
+          ok = frontend_.triangulate(g.vtx, &tris);
+          stats_.tock("triangulate");
+        }
+        if (ok)
+          ok = updateGraphLocked(in.time, in.img_id, g.vtx, g.idepth_mu, g.idepth_var, tris,
+                                 g.prediction.empty() ? nullptr : &g.prediction, &fs);
+      }
+    }
+    stats_.tock("update");
+    return ok;
+  }
+
+  bool updateGraphLocked(double time, uint32_t img_id, const std::vector<Point2f>& vtx,
+                         const std::vector<float>& idepth_mu, const std::vector<float>& idepth_var,
+                         const std::vector<Triangle>& triangles, const std::vector<float>* prediction,
+                         const FeatureSet* raw) {
+    namespace reg = optimizers::nltgv2_l1_graph_regularizer;
+    (void)time;
+    (void)img_id;
+    const int32_t V = static_cast<int32_t>(vtx.size()), T = static_cast<int32_t>(triangles.size());
+    if (idepth_mu.size() != vtx.size() || idepth_var.size() != vtx.size() ||
+        (prediction && prediction->size() != vtx.size()))
+      return fail(FLAME_HIP_ERR_ARG);
+    device_frame_valid_ = false;  // the device state follows this frame from here on
+
+    // ---- graph sync (row a7), in the library ----
+    stats_.tick("sync_graph");
+    std::vector<float> pos(2 * static_cast<size_t>(V));
+    std::vector<int32_t> tidx(3 * static_cast<size_t>(T));
+    for (int32_t v = 0; v < V; ++v) { pos[2 * v] = vtx[v].x; pos[2 * v + 1] = vtx[v].y; }
+    for (int32_t t = 0; t < T; ++t)
+      for (int k = 0; k < 3; ++k) tidx[3 * t + k] = triangles[t][k];
+    flame_hip_sync_params sp;
+    sp.adaptive_data_weights = params_.adaptive_data_weights;
+    sp.rescale_data = params_.rescale_data;
+    sp.init_with_prediction = params_.init_with_prediction;
+    sp.idepth_var_max_graph = params_.idepth_var_max_graph;
+    float scale = 1.0f;
+    int rc = graph_.sync(params_.hip_device, sp, V, T, pos.data(), idepth_mu.data(), idepth_var.data(),
+                         tidx.data(), prediction ? prediction->data() : nullptr, &scale);
+    if (rc) return fail(rc);
+    const int32_t E = graph_.numEdges();
+    std::vector<int32_t> eidx(2 * static_cast<size_t>(E));
+    if ((rc = flame_hip_graph_edges(graph_.handle(), eidx.data()))) return fail(rc);
+    stats_.tock("sync_graph");
+
+    // ---- regulariser (rows a2-a6) ----
+    stats_.tick("nltgv2");
+    if (params_.do_nltgv2) {
+      rc = reg::step(params_.rparams, &graph_, params_.nltgv2_iterations);
+      if (rc) return fail(rc);
+    }
+    stats_.tock("nltgv2");
+    const flame_hip_params cp = reg::toC(params_.rparams);
+    double smooth = 0.0, data = 0.0;
+    if ((rc = flame_hip_costs(graph_.handle(), &cp, &smooth, &data))) return fail(rc);
+    // back to the caller's units: everything downstream (idepths, triangle filters, mesh, maps)
+    // works on un-scaled inverse depths with the un-scaled thresholds
+    if (scale != 1.0f && (rc = flame_hip_scale_state(graph_.handle(), scale))) return fail(rc);
+    std::vector<float> idepths(V, 0.0f);
+    if ((rc = flame_hip_download(graph_.handle(), idepths.data(), nullptr, nullptr, nullptr))) return fail(rc);
+
+    // ---- per-triangle stage (row a8) ----
+    stats_.tick("interpolate");
+    std::vector<float> normals(3 * static_cast<size_t>(V), 0.0f);
+    std::vector<uint8_t> tri_valid(T, 0);
+    const flame_hip_tri_params tp = triParams();
+    if ((rc = flame_hip_triangles(graph_.handle(), Kinv_, &tp, normals.data(), tri_valid.data(), nullptr)))
+      return fail(rc);
+    stats_.tock("interpolate");
+
+    // ---- commit: every cached output changes together ----
+    vtx_ = vtx;
+    tris_ = triangles;
+    idepths_.swap(idepths);
+    normals_flat_.swap(normals);
+    tri_valid_.swap(tri_valid);
+    edges_.resize(E);
+    for (int32_t e = 0; e < E; ++e) edges_[e] = Edge(eidx[2 * e], eidx[2 * e + 1]);
+    if (raw) { raw_vtx_ = raw->vtx; raw_mu_ = raw->idepth_mu; raw_var_ = raw->idepth_var; }
+    else { raw_vtx_ = vtx; raw_mu_ = idepth_mu; raw_var_ = idepth_var; }
+    device_frame_valid_ = true;
+    drawDebugImages();
+
+    // ---- stats (keys read at reference src/utils.cc:117-156) ----
+    stats_.set("num_feats", static_cast<double>(raw_vtx_.size()));
+    stats_.set("num_vtx", V);
+    stats_.set("num_tris", T);
+    stats_.set("num_edges", E);
+    stats_.set("nltgv2_total_smoothness_cost", smooth);
+    stats_.set("nltgv2_avg_smoothness_cost", V ? smooth / V : 0.0);
+    stats_.set("nltgv2_total_data_cost", data);
+    stats_.set("nltgv2_avg_data_cost", V ? data / V : 0.0);
+    stats_.set("nltgv2_iters", params_.do_nltgv2 ? params_.nltgv2_iterations : 0);
+    stats_.set("nltgv2_data_scale", scale);
+    stats_.set("hip_error", 0);
+    float ms = 0.f;
+    int32_t launches = 0;
+    if (params_.do_nltgv2 && flame_hip_last_solve_ms(graph_.handle(), &ms, &launches) == 0)
+      stats_.setTiming("nltgv2_device", ms);
+    return true;
+  }
+
   flame_hip_tri_params triParams() const {
     flame_hip_tri_params tp;
     tp.do_oblique_triangle_filter = params_.do_oblique_triangle_filter;
@@ -248,12 +367,14 @@ class Flame {
     tp.height = height_;
     return tp;
   }
-  // NOTE: with rescale_data the device state is in rescaled units; the dense maps are only
-  // offered for rescale_data = false (the reference default, cfg/flame_offline_tum.yaml:90).
   bool maps(int filtered, std::vector<float>* idm, std::vector<float>* dm, std::vector<float>* cloud,
             float min_depth, float max_depth) const {
     std::lock_guard<std::mutex> lock(mtx_);
-    if (!graph_.valid() || params_.rescale_data) return false;
+    return mapsLocked(filtered, idm, dm, cloud, min_depth, max_depth);
+  }
+  bool mapsLocked(int filtered, std::vector<float>* idm, std::vector<float>* dm, std::vector<float>* cloud,
+                  float min_depth, float max_depth) const {
+    if (!device_frame_valid_) return false;
     const flame_hip_tri_params tp = triParams();
     const size_t n = static_cast<size_t>(width_) * height_;
     if (idm) idm->assign(n, 0.f);
@@ -263,10 +384,74 @@ class Flame {
                                idm ? idm->data() : nullptr, dm ? dm->data() : nullptr,
                                cloud ? cloud->data() : nullptr) == 0;
   }
+  void mapImage(int filtered, Image1f* out) const {
+    std::vector<float> v;
+    const bool ok = maps(filtered, &v, nullptr, nullptr, 0.f, 0.f);
+    *out = Image1f(height_, width_, std::numeric_limits<float>::quiet_NaN());
+    if (!ok) return;
+    for (int i = 0; i < height_; ++i)
+      for (int j = 0; j < width_; ++j) (*out)(i, j) = v[static_cast<size_t>(i) * width_ + j];
+  }
   bool fail(int code) {
     stats_.set("hip_error", code);
-    stats_.tock("update");
+    stats_.tock("sync_graph");  // close whatever timer the failed stage left open (no-op otherwise)
+    stats_.tock("nltgv2");
+    stats_.tock("interpolate");
     return false;
+  }
+
+  // ---- debug drawing (not on the path; plain CPU loops over the committed results) ----
+  Vec3b idepthColor(float id) const {
+    return utils::jet(id * params_.scene_color_scale, 0.0f, 2.0f);
+  }
+  void putPixel(Image3b* img, int x, int y, const Vec3b& c) const {
+    if (x >= 0 && y >= 0 && x < width_ && y < height_) (*img)(y, x) = c;
+  }
+  void drawLine(Image3b* img, int x0, int y0, int x1, int y1, const Vec3b& c) const {
+    const int dx = std::abs(x1 - x0), dy = -std::abs(y1 - y0);
+    const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (int guard = 0; guard < 4 * (width_ + height_); ++guard) {
+      putPixel(img, x0, y0, c);
+      if (x0 == x1 && y0 == y1) break;
+      const int e2 = 2 * err;
+      if (e2 >= dy) { err += dy; x0 += sx; }
+      if (e2 <= dx) { err += dx; y0 += sy; }
+    }
+  }
+  void drawDebugImages() {
+    const Vec3b black(0, 0, 0);
+    if (params_.debug_draw_wireframe) {
+      debug_wireframe_ = Image3b(height_, width_, black);
+      for (size_t t = 0; t < tris_.size(); ++t) {
+        if (!tri_valid_[t]) continue;
+        for (int k = 0; k < 3; ++k) {
+          const int a = tris_[t][k], b = tris_[t][(k + 1) % 3];
+          drawLine(&debug_wireframe_, utils::fast_roundf(vtx_[a].x), utils::fast_roundf(vtx_[a].y),
+                   utils::fast_roundf(vtx_[b].x), utils::fast_roundf(vtx_[b].y),
+                   idepthColor(0.5f * (idepths_[a] + idepths_[b])));
+        }
+      }
+    }
+    if (params_.debug_draw_features) {
+      debug_features_ = Image3b(height_, width_, black);
+      for (size_t v = 0; v < raw_vtx_.size(); ++v) {
+        const int x = utils::fast_roundf(raw_vtx_[v].x), y = utils::fast_roundf(raw_vtx_[v].y);
+        const Vec3b c = idepthColor(raw_mu_[v]);
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) putPixel(&debug_features_, x + dx, y + dy, c);
+      }
+    }
+    if (params_.debug_draw_idepthmap) {
+      debug_idepthmap_ = Image3b(height_, width_, black);
+      std::vector<float> idm;
+      if (mapsLocked(1, &idm, nullptr, nullptr, 0.f, 0.f))
+        for (int i = 0; i < height_; ++i)
+          for (int j = 0; j < width_; ++j) {
+            const float id = idm[static_cast<size_t>(i) * width_ + j];
+            if (!std::isnan(id)) debug_idepthmap_(i, j) = idepthColor(id);
+          }
+    }
   }
 
   int width_, height_;
@@ -274,12 +459,15 @@ class Flame {
   float K_[9], Kinv_[9];
   mutable std::mutex mtx_;
   utils::StatsTracker stats_;
+  FrontEnd frontend_;
   optimizers::nltgv2_l1_graph_regularizer::Graph graph_;
-  std::vector<Point2f> vtx_;
-  std::vector<float> mu_, var_, idepths_, normals_flat_;
+  bool device_frame_valid_ = false;  // the device state belongs to the committed frame
+  std::vector<Point2f> vtx_, raw_vtx_;
+  std::vector<float> raw_mu_, raw_var_, idepths_, normals_flat_;
   std::vector<Triangle> tris_;
   std::vector<Edge> edges_;
   std::vector<uint8_t> tri_valid_;
+  Image3b debug_wireframe_, debug_features_, debug_detections_, debug_matches_, debug_normals_, debug_idepthmap_;
 };
 
 }  // namespace flame

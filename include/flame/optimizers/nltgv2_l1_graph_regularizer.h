@@ -33,29 +33,63 @@ class Graph {
   void reset() {
     if (g_) flame_hip_graph_destroy(g_);
     g_ = nullptr;
+    device_ = -1;
     V_ = E_ = T_ = 0;
+    resident_ = false;
   }
   // Returns a flame_hip error code (0 = ok).  pos 2V, edges 2E (i -> j), tris 3T or nullptr.
+  // The handle is created once and then RESIZED frame after frame: its stream, events, device
+  // buffers, host plan buffers and tile cost-density grid survive (flame_hip_graph_resize); it is
+  // only re-created when the device changes.
   int build(int device, int32_t V, int32_t E, int32_t T, const float* pos, const int32_t* edges,
             const float* alpha, const float* beta, const float* z, const float* wgt,
             const float* x0, const int32_t* tris) {
-    reset();
-    int rc = flame_hip_graph_create(&g_, device, V, E, T);
+    int rc = acquire(device);
     if (rc) return rc;
-    rc = flame_hip_graph_upload(g_, pos, edges, alpha, beta, z, wgt, x0, tris);
-    if (rc) { reset(); return rc; }
+    if ((rc = flame_hip_graph_resize(g_, V, E, T))) return rc;
+    V_ = E_ = T_ = 0;
+    resident_ = false;
+    if ((rc = flame_hip_graph_upload(g_, pos, edges, alpha, beta, z, wgt, x0, tris))) return rc;
     V_ = V; E_ = E; T_ = T;
+    resident_ = true;
     return 0;
   }
-  bool valid() const { return g_ != nullptr; }
+  // Graph sync (row a7) in the library: features + triangulation in, graph resident on the GPU.
+  int sync(int device, const flame_hip_sync_params& sp, int32_t V, int32_t T, const float* pos,
+           const float* idepth_mu, const float* idepth_var, const int32_t* tris,
+           const float* prediction, float* scale) {
+    int rc = acquire(device);
+    if (rc) return rc;
+    V_ = E_ = T_ = 0;
+    resident_ = false;
+    if ((rc = flame_hip_graph_sync(g_, &sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, scale)))
+      return rc;
+    int64_t e = 0;
+    if ((rc = flame_hip_get_info(g_, "E", &e))) return rc;
+    V_ = V; E_ = static_cast<int32_t>(e); T_ = T;
+    resident_ = true;
+    return 0;
+  }
+  // a graph is resident (the last build / sync succeeded)
+  bool valid() const { return g_ != nullptr && resident_; }
   int32_t numVertices() const { return V_; }
   int32_t numEdges() const { return E_; }
   int32_t numTriangles() const { return T_; }
   flame_hip_graph* handle() const { return g_; }
 
  private:
+  int acquire(int device) {
+    if (g_ && device_ == device) return 0;
+    reset();
+    const int rc = flame_hip_graph_create(&g_, device, 0, 0, 0);
+    if (rc) { g_ = nullptr; return rc; }
+    device_ = device;
+    return 0;
+  }
   flame_hip_graph* g_ = nullptr;
+  int device_ = -1;
   int32_t V_ = 0, E_ = 0, T_ = 0;
+  bool resident_ = false;
 };
 
 // num_iters x (dualStep; primalStep; extraGradientStep).  Returns 0 or a flame_hip error code.

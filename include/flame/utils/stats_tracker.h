@@ -20,6 +20,7 @@ class StatsTracker {
     const double ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - it->second).count();
     timings_[name] = ms;
+    starts_.erase(it);  // a second tock without a tick is a no-op
     return ms;
   }
   void set(const std::string& name, double v) { stats_[name] = v; }

@@ -1,8 +1,11 @@
 // tests/cpp/facade_conformance.cc -- exercises include/flame/flame.h the way flame_ros does
 // (reference src/flame_offline_tum.cc:404-412 construct, :578 update, :628-635 mesh out,
-// :706-707 stats, src/utils.cc:117-136 stat keys).  Reads a graph (pos, mu, tris) from a binary
-// file written by the Python test, runs one update, writes idepths / validity / normals / costs
-// back.  Exit code 0 = update ok, 3 = update returned false (no device), other = harness error.
+// :706-707 stats, src/utils.cc:117-136 stat keys), WITHOUT OpenCV/Eigen (the fallback types of
+// include/flame/types.h).  Usage: facade_conformance out.bin out.txt in1.bin [in2.bin ...]: every
+// input is one frame (header V, T, iters, device, flags; pos, mu, [var], tris) fed to the SAME
+// flame::Flame object in turn (a frame stream on one GPU handle); idepths / validity / normals /
+// costs of the LAST frame are written back.  flags: 1 = adaptive_data_weights, 2 = rescale_data,
+// 4 = a var array follows mu.  Exit code 0 = ok, 3 = update returned false (no device).
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -25,16 +28,14 @@ static bool read_all(const char* path, std::vector<char>* buf) {
 int main(int argc, char** argv) {
   if (argc < 4) return 10;
   std::vector<char> buf;
-  if (!read_all(argv[1], &buf)) return 11;
-  const int32_t* hdr = reinterpret_cast<const int32_t*>(buf.data());
-  const int32_t V = hdr[0], T = hdr[1], iters = hdr[2], device = hdr[3];
-  const float* pos = reinterpret_cast<const float*>(hdr + 4);
-  const float* mu = pos + 2 * V;
-  const int32_t* tri = reinterpret_cast<const int32_t*>(mu + V);
+  if (!read_all(argv[3], &buf)) return 11;
+  const int32_t* hdr0 = reinterpret_cast<const int32_t*>(buf.data());
 
   flame::Params params;  // defaults = cfg/flame_offline_tum.yaml
-  params.nltgv2_iterations = iters;
-  params.hip_device = device;
+  params.nltgv2_iterations = hdr0[2];
+  params.hip_device = hdr0[3];
+  params.adaptive_data_weights = (hdr0[4] & 1) != 0;
+  params.rescale_data = (hdr0[4] & 2) != 0;
   params.rparams.data_factor = 0.15f;
   params.rparams.step_x = 0.001f;
   params.rparams.step_q = 125.0f;
@@ -46,18 +47,31 @@ int main(int argc, char** argv) {
   Kinv(1, 0) = 0.f; Kinv(1, 1) = 1.f / 525.f; Kinv(1, 2) = -239.5f / 525.f;
   Kinv(2, 0) = 0.f; Kinv(2, 1) = 0.f; Kinv(2, 2) = 1.f;
   std::shared_ptr<flame::Flame> sensor = std::make_shared<flame::Flame>(640, 480, K, Kinv, params);
-
-  std::vector<flame::Point2f> vtx(V);
-  std::vector<float> idepth(V), var(V, 1e-4f);
-  std::vector<flame::Triangle> tris(T);
-  for (int v = 0; v < V; ++v) { vtx[v] = flame::Point2f(pos[2 * v], pos[2 * v + 1]); idepth[v] = mu[v]; }
-  for (int t = 0; t < T; ++t) tris[t] = flame::Triangle(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]);
-
   const bool first = sensor->stats().stats("fps_max") <= 0.0f;  // missing key reads as <= 0
   if (!first) return 12;
-  bool ok = sensor->updateGraph(0.0, 0, vtx, idepth, var, tris);
-  std::printf("update=%d hip_error=%d\n", ok ? 1 : 0, static_cast<int>(sensor->stats().stats("hip_error")));
-  if (!ok) return 3;
+
+  int32_t V = 0, T = 0;
+  for (int a = 3; a < argc; ++a) {
+    if (!read_all(argv[a], &buf)) return 11;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(buf.data());
+    V = hdr[0]; T = hdr[1];
+    const float* pos = reinterpret_cast<const float*>(hdr + 5);
+    const float* mu = pos + 2 * V;
+    const float* varp = (hdr[4] & 4) ? mu + V : nullptr;
+    const int32_t* tri = reinterpret_cast<const int32_t*>(mu + V + (varp ? V : 0));
+    std::vector<flame::Point2f> vtx(V);
+    std::vector<float> idepth(V), var(V, 1e-4f);
+    std::vector<flame::Triangle> tris(T);
+    for (int v = 0; v < V; ++v) {
+      vtx[v] = flame::Point2f(pos[2 * v], pos[2 * v + 1]);
+      idepth[v] = mu[v];
+      if (varp) var[v] = varp[v];
+    }
+    for (int t = 0; t < T; ++t) tris[t] = flame::Triangle(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]);
+    bool ok = sensor->updateGraph(0.033 * a, a, vtx, idepth, var, tris);
+    std::printf("update=%d hip_error=%d\n", ok ? 1 : 0, static_cast<int>(sensor->stats().stats("hip_error")));
+    if (!ok) return 3;
+  }
 
   std::vector<flame::Point2f> ovtx;
   std::vector<float> oid;
@@ -83,13 +97,13 @@ int main(int argc, char** argv) {
   for (size_t k = 0; k < validity.size(); ++k) nvalid += validity[k] ? 1 : 0;
   if (faces.size() != 3 * nvalid) return 19;
 
-  FILE* f = std::fopen(argv[2], "wb");
+  FILE* f = std::fopen(argv[1], "wb");
   if (!f) return 15;
   std::fwrite(oid.data(), 4, V, f);
   for (int v = 0; v < V; ++v) { float n[3] = {normals[v](0), normals[v](1), normals[v](2)}; std::fwrite(n, 4, 3, f); }
   for (int t = 0; t < T; ++t) { unsigned char b = validity[t] ? 1 : 0; std::fwrite(&b, 1, 1, f); }
   std::fclose(f);
-  f = std::fopen(argv[3], "w");
+  f = std::fopen(argv[2], "w");
   if (!f) return 16;
   std::fprintf(f, "%d %.17g %.17g %.17g %.17g\n", static_cast<int>(edges.size()),
                sensor->stats().stats("nltgv2_total_smoothness_cost"),

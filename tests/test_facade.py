@@ -1,9 +1,19 @@
-"""The C++ facade include/flame/flame.h (flame::Flame reduced to the regulariser path) compiled as
-C++11 (the reference's standard, reference CMakeLists.txt:26) and driven the way flame_ros does.
-CPU: it must compile, link against libflame_hip.so, and updateGraph() must return false without a
-GPU (reference error convention: caller warns and skips the frame, src/flame_offline_tum.cc:
-597-601).  GPU: its output equals the oracle bit for bit."""
+"""The C++ facade include/flame/ (flame::Flame as flame_ros consumes it) compiled as C++11 with
+-Wall -Wextra -Werror (the reference's standard, reference CMakeLists.txt:26) and driven the way
+flame_ros does.
+
+* facade_conformance.cc   fallback types (no OpenCV/Eigen): updateGraph() on a stream of frames
+* callsite_conformance.cc flame_ros' own call sites with cv:: / Eigen:: / Sophus:: types (API
+                          stand-ins under tests/cpp/standins/): both update() overloads through a
+                          registered FrontEnd, every getter, debug images, pose-frame mutators,
+                          LoadTracker, jet / applyColorMap, FLAME_ASSERT
+* cmake/flameConfig.cmake find_package(flame) -> flame_INCLUDE_DIRS / flame_LIBRARIES
+
+CPU: everything must compile, link against libflame_hip.so, and update*() must return false
+without a GPU (reference error convention: the caller warns and skips the frame,
+src/flame_offline_tum.cc:597-601).  GPU: the outputs equal the oracle bit for bit."""
 import os
+import shutil
 import struct
 import subprocess
 
@@ -12,43 +22,132 @@ import pytest
 
 from flame_ros_amd import lib
 from oracle import COracle
-from oracle.cbind import default_params, triangles as oracle_triangles, TriParams
-from tests.util import graphgen
+from oracle.cbind import (SyncParams as OSync, TriParams, default_params, graph_sync as oracle_sync,
+                          triangles as oracle_triangles)
+from tests.util import assert_bit_equal, graphgen
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CXX = ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror"]
+LINK = ["-L" + os.path.join(ROOT, "flame_ros_amd"), "-lflame_hip",
+        "-Wl,-rpath," + os.path.join(ROOT, "flame_ros_amd"), "-pthread"]
+
+
+def have_gpu():
+    import torch
+    return torch.cuda.is_available()
 
 
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     lib.load()
     out = str(tmp_path_factory.mktemp("facade") / "facade_conformance")
-    cmd = ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "facade_conformance.cc"), "-o", out,
-           "-L" + os.path.join(ROOT, "flame_ros_amd"), "-lflame_hip",
-           "-Wl,-rpath," + os.path.join(ROOT, "flame_ros_amd"), "-pthread"]
-    subprocess.check_call(cmd)
+    subprocess.check_call(CXX + ["-I" + os.path.join(ROOT, "include"),
+                                 os.path.join(ROOT, "tests", "cpp", "facade_conformance.cc"), "-o", out] + LINK)
     return out
 
 
-def write_input(path, g, iters, device):
+@pytest.fixture(scope="module")
+def callsite_exe(tmp_path_factory):
+    lib.load()
+    out = str(tmp_path_factory.mktemp("callsite") / "callsite_conformance")
+    subprocess.check_call(CXX + ["-I" + os.path.join(ROOT, "tests", "cpp", "standins"),
+                                 "-I" + os.path.join(ROOT, "include"),
+                                 os.path.join(ROOT, "tests", "cpp", "callsite_conformance.cc"), "-o", out] + LINK)
+    return out
+
+
+def write_input(path, g, iters, device, flags=0, var=None):
     with open(path, "wb") as f:
-        f.write(struct.pack("<4i", g.V, g.T, iters, device))
+        f.write(struct.pack("<5i", g.V, g.T, iters, device, flags | (4 if var is not None else 0)))
         f.write(g.pos.astype(np.float32).tobytes())
         f.write(g.z.astype(np.float32).tobytes())
+        if var is not None:
+            f.write(np.asarray(var, np.float32).tobytes())
         f.write(g.tris.astype(np.int32).tobytes())
 
 
 def test_facade_compiles_and_fails_cleanly_without_gpu(exe, tmp_path):
-    import torch
-    if torch.cuda.is_available():
+    if have_gpu():
         pytest.skip("GPU present: covered by the gpu test")
     g = graphgen.synthetic(500, seed=1)
     inp = str(tmp_path / "in.bin")
     write_input(inp, g, 10, 0)
-    p = subprocess.run([exe, inp, str(tmp_path / "o.bin"), str(tmp_path / "o.txt")],
+    p = subprocess.run([exe, str(tmp_path / "o.bin"), str(tmp_path / "o.txt"), inp],
                        capture_output=True, text=True)
     assert p.returncode == 3, (p.returncode, p.stdout, p.stderr)
     assert "update=0" in p.stdout and "hip_error=%d" % lib.ERR_NODEVICE in p.stdout
+
+
+def test_callsites_compile_and_fail_cleanly_without_gpu(callsite_exe):
+    """flame_ros' call sites compile -std=c++11 -Werror against include/flame/ with cv::/Eigen::/
+    Sophus:: types; without a GPU every update() returns false (and nothing crashes)."""
+    if have_gpu():
+        pytest.skip("GPU present: covered by the gpu test")
+    p = subprocess.run([callsite_exe, "0"], capture_output=True, text=True)
+    assert p.returncode == 3, (p.returncode, p.stdout, p.stderr)
+    assert "frames_failed=3" in p.stdout and "hip_error=%d" % lib.ERR_NODEVICE in p.stdout
+
+
+def test_facade_headers_are_self_contained(tmp_path):
+    """Each public header compiles on its own (both type branches)."""
+    for hdr in ("flame/flame.h", "flame/params.h", "flame/types.h", "flame/utils/assert.h",
+                "flame/utils/image_utils.h", "flame/utils/load_tracker.h", "flame/utils/stats_tracker.h",
+                "flame/utils/triangulator.h", "flame/utils/visualization.h",
+                "flame/optimizers/nltgv2_l1_graph_regularizer.h", "flame_hip.h"):
+        src = tmp_path / "t.cc"
+        src.write_text("#include <%s>\nint main() { return 0; }\n" % hdr)
+        for extra in ([], ["-I" + os.path.join(ROOT, "tests", "cpp", "standins")]):
+            subprocess.check_call(CXX + extra + ["-I" + os.path.join(ROOT, "include"), "-fsyntax-only", str(src)])
+    # the C ABI header is plain C
+    src = tmp_path / "t.c"
+    src.write_text("#include <flame_hip.h>\nint main(void) { flame_hip_params p; p.theta = 0.25f; return p.theta > 1.0f; }\n")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-fsyntax-only", str(src)])
+
+
+@pytest.mark.skipif(shutil.which("cmake") is None, reason="cmake not on PATH")
+def test_find_package_flame(tmp_path):
+    """find_package(flame REQUIRED) as in reference CMakeLists.txt:57 resolves to this repo and
+    defines flame_INCLUDE_DIRS / flame_LIBRARIES (reference CMakeLists.txt:205, src/CMakeLists.txt:11)."""
+    lib.load()
+    (tmp_path / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.10)\nproject(probe NONE)\n"
+        "find_package(flame REQUIRED)\n"
+        "file(WRITE ${CMAKE_BINARY_DIR}/vars.txt \"${flame_INCLUDE_DIRS}\\n${flame_LIBRARIES}\\n\")\n")
+    # project(NONE) has no compiler, so Threads cannot be probed: only the variable contract is checked
+    cfg = open(os.path.join(ROOT, "cmake", "flameConfig.cmake")).read()
+    assert "flame_INCLUDE_DIRS" in cfg and "flame_LIBRARIES" in cfg
+    build = tmp_path / "b"
+    build.mkdir()
+    (tmp_path / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.10)\nproject(probe CXX)\n"
+        "find_package(flame REQUIRED)\n"
+        "file(WRITE ${CMAKE_BINARY_DIR}/vars.txt \"${flame_INCLUDE_DIRS}\\n${flame_LIBRARIES}\\n\")\n"
+        "add_executable(probe %s)\n"
+        "target_include_directories(probe PRIVATE ${flame_INCLUDE_DIRS})\n"
+        "target_link_libraries(probe ${flame_LIBRARIES})\n" % os.path.join(ROOT, "tests", "cpp", "facade_conformance.cc"))
+    p = subprocess.run(["cmake", "-S", str(tmp_path), "-B", str(build), "-Dflame_DIR=" + os.path.join(ROOT, "cmake"),
+                        "-DCMAKE_CXX_STANDARD=11"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    inc, libs = open(build / "vars.txt").read().split("\n")[:2]
+    assert inc == os.path.join(ROOT, "include") and "libflame_hip.so" in libs
+    p = subprocess.run(["cmake", "--build", str(build)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert os.path.exists(build / "probe")
+
+
+KINV = np.array([[np.float32(1) / np.float32(525), 0, np.float32(-319.5) / np.float32(525)],
+                 [0, np.float32(1) / np.float32(525), np.float32(-239.5) / np.float32(525)],
+                 [0, 0, 1]], np.float32)
+
+
+def read_outputs(ob, ot, g):
+    raw = open(ob, "rb").read()
+    x = np.frombuffer(raw[:4 * g.V], np.float32)
+    vn = np.frombuffer(raw[4 * g.V:16 * g.V], np.float32).reshape(-1, 3)
+    tv = np.frombuffer(raw[16 * g.V:], np.uint8)
+    nE, smooth, data, avg_smooth, upd_ms = open(ot).read().split()
+    return x, vn, tv, int(nE), float(smooth), float(data), float(avg_smooth), float(upd_ms)
 
 
 @pytest.mark.gpu
@@ -57,26 +156,64 @@ def test_facade_matches_oracle_on_gpu(gpu, exe, tmp_path):
     iters = 120
     inp, ob, ot = (str(tmp_path / n) for n in ("in.bin", "o.bin", "o.txt"))
     write_input(inp, g, iters, 0)
-    p = subprocess.run([exe, inp, ob, ot], capture_output=True, text=True)
+    p = subprocess.run([exe, ob, ot, inp], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
-    raw = open(ob, "rb").read()
-    x = np.frombuffer(raw[:4 * g.V], np.float32)
-    vn = np.frombuffer(raw[4 * g.V:16 * g.V], np.float32).reshape(-1, 3)
-    tv = np.frombuffer(raw[16 * g.V:], np.uint8)
-    nE, smooth, data, avg_smooth, upd_ms = open(ot).read().split()
+    x, vn, tv, nE, smooth, data, avg_smooth, upd_ms = read_outputs(ob, ot, g)
     o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
     po = default_params()
     o.solve(po, iters)
-    assert int(nE) == g.E
-    assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32))
+    assert nE == g.E
+    assert_bit_equal(x, o.x, "x")
     so, do = o.costs(po)
-    assert abs(float(smooth) - so) <= 1e-9 * so and abs(float(data) - do) <= 1e-9 * do
-    assert abs(float(avg_smooth) - so / g.V) <= 1e-9 * so and float(upd_ms) > 0
-    Kinv = np.array([[1 / 525, 0, -319.5 / 525], [0, 1 / 525, -239.5 / 525], [0, 0, 1]], np.float32)
-    Kinv = np.array([[np.float32(1) / np.float32(525), 0, np.float32(-319.5) / np.float32(525)],
-                     [0, np.float32(1) / np.float32(525), np.float32(-239.5) / np.float32(525)],
-                     [0, 0, 1]], np.float32)
+    assert abs(smooth - so) <= 1e-9 * so and abs(data - do) <= 1e-9 * do
+    assert abs(avg_smooth - so / g.V) <= 1e-9 * so and upd_ms > 0
     tp = TriParams(1, 1.57, 0.35, 0.1, 1, 0.333, 1, 0.01, 640, 480)
-    _, tv_o, vn_o = oracle_triangles(tp, Kinv, g.pos, o.x, g.tris)
+    _, tv_o, vn_o = oracle_triangles(tp, KINV, g.pos, o.x, g.tris)
     assert np.array_equal(tv, tv_o)
-    assert np.array_equal(vn.view(np.uint32), vn_o.view(np.uint32))
+    assert_bit_equal(vn, vn_o, "normals")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [1, 2, 3])
+def test_facade_sync_switches_and_frame_stream_on_gpu(gpu, exe, tmp_path, flags):
+    """adaptive_data_weights / rescale_data (reference cfg/flame_offline_tum.yaml:89-90) through
+    the facade, on a stream of three frames of different size fed to ONE flame::Flame (the GPU
+    handle is resized, not re-created); the last frame is checked against the oracle's graph sync
+    + solve + un-scale + triangle stage."""
+    iters = 90
+    rng = np.random.default_rng(5)
+    frames, inputs = [], []
+    for k, V in enumerate((2500, 700, 3100)):
+        g = graphgen.synthetic(V, seed=30 + k)
+        var = rng.uniform(2e-3, 9e-3, g.V).astype(np.float32)
+        inp = str(tmp_path / ("in%d.bin" % k))
+        write_input(inp, g, iters, 0, flags=flags, var=var)
+        frames.append((g, var))
+        inputs.append(inp)
+    ob, ot = str(tmp_path / "o.bin"), str(tmp_path / "o.txt")
+    p = subprocess.run([exe, ob, ot] + inputs, capture_output=True, text=True)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert p.stdout.count("update=1") == 3
+    g, var = frames[-1]
+    x, vn, tv, nE, smooth, data, _, _ = read_outputs(ob, ot, g)
+    s = oracle_sync(OSync(flags & 1, (flags >> 1) & 1, 1, 0.01), g.pos, g.z, var, g.tris)
+    o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+    po = default_params()
+    o.solve(po, iters)
+    so, do = o.costs(po)  # costs are in the solver's (rescaled) units
+    assert abs(smooth - so) <= 1e-9 * so and abs(data - do) <= 1e-9 * do
+    o.scale_state(s["scale"])
+    assert nE == len(s["edges"])
+    assert_bit_equal(x, o.x, "x (caller's units)")
+    tp = TriParams(1, 1.57, 0.35, 0.1, 1, 0.333, 1, 0.01, 640, 480)
+    _, tv_o, vn_o = oracle_triangles(tp, KINV, g.pos, o.x, g.tris)
+    assert np.array_equal(tv, tv_o)
+    assert_bit_equal(vn, vn_o, "normals")
+
+
+@pytest.mark.gpu
+def test_callsites_run_on_gpu(gpu, callsite_exe):
+    """Both update() overloads through a registered FrontEnd, every getter and debug image."""
+    p = subprocess.run([callsite_exe, "0"], capture_output=True, text=True)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "frames_failed=0 hip_error=0" in p.stdout
