@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflame_hip.so")
-SOURCES = ["kernels.hip", "flame_hip.cpp", "plan.cpp", "sync.cpp"]
-HEADERS = ["common.h", "kernels.h", "plan.h", "sync.h", os.path.join("..", "..", "include", "flame_hip.h")]
+SOURCES = ["kernels.hip", "plan_dev.hip", "flame_hip.cpp", "plan.cpp", "sync.cpp"]
+HEADERS = ["common.h", "kernels.h", "plan.h", "plan_dev.h", "sync.h", os.path.join("..", "..", "include", "flame_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-result"]
 

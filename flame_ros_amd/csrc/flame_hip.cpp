@@ -19,6 +19,7 @@
 
 #include "kernels.h"
 #include "plan.h"
+#include "plan_dev.h"
 #include "sync.h"
 
 using namespace flamehip;
@@ -134,7 +135,26 @@ struct flame_hip_graph {
   float* filter_tmp = nullptr;
   // mesh output (row f1)
   float4* mesh_pts = nullptr;
+  // permutations on the device (results leave in the caller's order without a host pass)
   int32_t* v_i2o_dev = nullptr;
+  int32_t* v_o2i_dev = nullptr;
+  int32_t* e_i2o_dev = nullptr;
+  int32_t* e_o2i_dev = nullptr;
+  float* dl_v = nullptr;  // download staging: 3V floats
+  float* dl_q = nullptr;  // 3E floats
+  // device plan builder (row f3) and the staged inputs it reads (caller's order)
+  int plan_device = 1;
+  DevPlanner planner;
+  float2* in_pos = nullptr;
+  int2* in_edges = nullptr;
+  float* in_alpha = nullptr;
+  float* in_beta = nullptr;
+  float* in_z = nullptr;
+  float* in_wgt = nullptr;
+  float* in_x0 = nullptr;
+  int32_t* in_tris = nullptr;
+  int32_t* dflags = nullptr;
+  bool host_perms = true;  // plan.v_i2o / v_o2i / e_i2o / e_o2i / tris are valid on the host
   // costs
   double* partials = nullptr;
   // halo exchange lists (internal ids), see flame_hip_halo_register
@@ -160,21 +180,14 @@ struct flame_hip_graph {
     if (device < 0) return;
     (void)hipSetDevice(device);
     drop_execs();
+    // every device buffer of the handle is registered in `caps` (key = address of the member)
+    for (auto& kv : caps) {
+      void** pp = reinterpret_cast<void**>(kv.first);
+      if (*pp) (void)hipFree(*pp);
+      *pp = nullptr;
+    }
     caps.clear();
-    void* ptrs[] = {A[0], A[1], B[0], B[1], q[0], q[1], eij, ew, grow, ginc, pos, tiles, t_vmap,
-                    t_emap, t_eij, t_ew, t_srow, tris, trow, tinc, tri_normals, vtx_normals,
-                    tri_valid, partials, prof, filter_tmp, mesh_pts, v_i2o_dev, map_owner, map_idm, map_dm, map_cloud, halo_send_v, halo_send_e, halo_recv_v, halo_recv_e};
-    for (void* p : ptrs)
-      if (p) (void)hipFree(p);
-    A[0] = A[1] = B[0] = B[1] = q[0] = q[1] = nullptr;
-    eij = nullptr; ew = nullptr; grow = ginc = nullptr; pos = nullptr; tiles = nullptr;
-    t_vmap = t_emap = nullptr; t_eij = nullptr; t_ew = nullptr; t_srow = nullptr;
-    tris = trow = tinc = nullptr; tri_normals = vtx_normals = nullptr; tri_valid = nullptr;
-    partials = nullptr;
-    prof = nullptr;
-    mesh_pts = nullptr; v_i2o_dev = nullptr; filter_tmp = nullptr;
-    map_owner = nullptr; map_idm = map_dm = map_cloud = nullptr; map_pixels = 0;
-    halo_send_v = halo_send_e = halo_recv_v = halo_recv_e = nullptr;
+    map_pixels = 0;
     n_send_v = n_send_e = n_recv_v = n_recv_e = 0;
   }
 };
@@ -284,6 +297,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "host_threads") {
     if (value < 0) return FLAME_HIP_ERR_ARG;
     g->opt.host_threads = value;
+  } else if (k == "plan_device") {
+    g->plan_device = value != 0;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -312,6 +327,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "tile_ext_vertices") { int64_t s = 0; for (auto& t : P.tiles) s += t.n_ext; *value = s; }
   else if (k == "tile_loc_edges") { int64_t s = 0; for (auto& t : P.tiles) s += t.e_loc; *value = s; }
   else if (k == "device") *value = g->device;
+  else if (k == "plan_on_device") *value = P.on_device ? 1 : 0;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else return FLAME_HIP_ERR_ARG;
   return 0;
@@ -331,6 +347,184 @@ int flame_hip_graph_upload_batch(flame_hip_graph* g, int32_t num_graphs, const i
   return rc;
 }
 
+// ---- device plan path (row f3): inputs are staged in the caller's order, the plan is built by
+// plan_dev.hip, the initial state is permuted by a kernel.  Returns 1 = done, 0 = not eligible /
+// could not be built there (the caller falls back to the host builder), < 0 = error. ----
+namespace {
+struct TileAllocCtx { flame_hip_graph* g; DevPlanArrays* A; };
+
+int alloc_tile_arrays(void* ctx, size_t ntiles, size_t nv, size_t ne, size_t ns) {
+  TileAllocCtx* c = static_cast<TileAllocCtx*>(ctx);
+  flame_hip_graph* g = c->g;
+  int rc;
+  if ((rc = dev_alloc(g->caps, &g->tiles, ntiles)) || (rc = dev_alloc(g->caps, &g->t_vmap, nv)) ||
+      (rc = dev_alloc(g->caps, &g->t_emap, ne)) || (rc = dev_alloc(g->caps, &g->t_eij, ne)) ||
+      (rc = dev_alloc(g->caps, &g->t_ew, ne)) || (rc = dev_alloc(g->caps, &g->t_srow, ns)))
+    return rc;
+  c->A->tiles = g->tiles; c->A->t_vmap = g->t_vmap; c->A->t_emap = g->t_emap;
+  c->A->t_eij = g->t_eij; c->A->t_ew = g->t_ew; c->A->t_srow = g->t_srow;
+  return 0;
+}
+}  // namespace
+
+static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_t* edges,
+                              const float* alpha, const float* beta, const float* z, const float* wgt,
+                              const float* x0, const int32_t* tris) {
+  const int32_t V = g->V, E = g->E, T = tris ? g->T : 0;
+  Plan& P = g->plan;
+  const PlanSizing sz = plan_sizing(g->opt, V, E);
+  if (!g->plan_device || g->opt.path == FLAME_HIP_PATH_GLOBAL ||
+      !DevPlanner::eligible(g->opt, V, E, T, sz.tile_own, sz.depth, sz.single, g->opt.lds_bytes))
+    return 0;
+  hipStream_t s = g->stream;
+  int rc;
+  // ---- stage the caller's arrays ----
+  if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_edges, (size_t)E)) ||
+      (rc = dev_alloc(g->caps, &g->in_alpha, (size_t)E)) || (rc = dev_alloc(g->caps, &g->in_beta, (size_t)E)) ||
+      (rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) ||
+      (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_tris, 3 * (size_t)T)) ||
+      (rc = dev_alloc(g->caps, &g->dflags, 8)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
+  if (E > 0) {
+    HIPCHK(hipMemcpyAsync(g->in_edges, edges, sizeof(int2) * (size_t)E, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->in_alpha, alpha, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->in_beta, beta, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipMemcpyAsync(g->in_z, z, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+  if (x0) HIPCHK(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+  if (T > 0) HIPCHK(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
+  // non-finite inputs are found on the device (the flag is read with the builder's first sync)
+  HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
+  HIPCHK(launch_check_finite(s, 2 * (int64_t)V, reinterpret_cast<const float*>(g->in_pos), g->dflags));
+  HIPCHK(launch_check_finite(s, V, g->in_z, g->dflags));
+  HIPCHK(launch_check_finite(s, V, g->in_wgt, g->dflags));
+  HIPCHK(launch_check_finite(s, E, g->in_alpha, g->dflags));
+  HIPCHK(launch_check_finite(s, E, g->in_beta, g->dflags));
+  if (x0) HIPCHK(launch_check_finite(s, V, g->in_x0, g->dflags));
+  // ---- plan arrays ----
+  if ((rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_o2i_dev, (size_t)V)) ||
+      (rc = dev_alloc(g->caps, &g->e_i2o_dev, (size_t)E)) || (rc = dev_alloc(g->caps, &g->e_o2i_dev, (size_t)E)) ||
+      (rc = dev_alloc(g->caps, &g->eij, (size_t)E)) || (rc = dev_alloc(g->caps, &g->ew, (size_t)E)) ||
+      (rc = dev_alloc(g->caps, &g->grow, (size_t)V + 1)) || (rc = dev_alloc(g->caps, &g->ginc, 2 * (size_t)E)) ||
+      (rc = dev_alloc(g->caps, &g->tris, 3 * (size_t)T)) || (rc = dev_alloc(g->caps, &g->trow, (size_t)V + 1)) ||
+      (rc = dev_alloc(g->caps, &g->tinc, 3 * (size_t)T)))
+    return rc;
+  DevPlanInputs in;
+  in.pos = g->in_pos; in.edges = g->in_edges; in.alpha = g->in_alpha; in.beta = g->in_beta;
+  in.tris = T > 0 ? g->in_tris : nullptr;
+  DevPlanArrays A;
+  A.v_o2i = g->v_o2i_dev; A.v_i2o = g->v_i2o_dev; A.e_o2i = g->e_o2i_dev; A.e_i2o = g->e_i2o_dev;
+  A.eij = g->eij; A.ew = g->ew; A.grow = g->grow; A.ginc = g->ginc;
+  A.tris = g->tris; A.trow = g->trow; A.tinc = g->tinc;
+  TileAllocCtx ctx{g, &A};
+
+  int tile_own = sz.tile_own;
+  const int depth = sz.depth;
+  bool balanced = false, built = false;
+  int ntiles = 0, cfg_nt = 0, cfg_ept = 0, cfg_vpt = 0;
+  int64_t lds_max = 0;
+  std::vector<TileDesc>& tiles = P.tiles;
+  for (int attempt = 0; attempt < 7 && !built; ++attempt) {
+    ntiles = (V + tile_own - 1) / tile_own;
+    if (ntiles < 2) return 0;
+    if (!balanced) {
+      if (g->opt.balance && ntiles >= 16 && g->planner.grid_tiles() == ntiles) {
+        g->planner.set_weights_from_grid();  // a frame stream balances in ONE pass
+        balanced = true;
+      } else {
+        g->planner.set_weights_none();
+      }
+    }
+    bool ok = false, index_error = false;
+    HIPCHK(g->planner.build(s, g->opt, V, E, T, ntiles, depth, in, &A, alloc_tile_arrays, &ctx, &tiles, &ok,
+                            &index_error));
+    if (attempt == 0) {  // the finite-check flag was complete at the builder's first sync
+      int32_t f = 0;
+      HIPCHK(hipMemcpyAsync(&f, g->dflags, sizeof(f), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (f & 1) return FLAME_HIP_ERR_NAN;
+    }
+    if (index_error) return FLAME_HIP_ERR_ARG;
+    if (ok) {
+      int e_max = 0, upd_max = 0;
+      lds_max = 0;
+      for (const TileDesc& D : tiles) {
+        e_max = std::max(e_max, D.e_loc);
+        upd_max = std::max(upd_max, D.n_ext);
+        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots + 1) * 16);
+      }
+      ok = lds_max <= g->opt.lds_bytes &&
+           pick_tile_config(g->opt.tile_threads, e_max, upd_max, &cfg_nt, &cfg_ept, &cfg_vpt);
+    }
+    if (ok && g->opt.balance && !balanced && ntiles >= 16) {
+      balanced = true;
+      g->planner.set_weights_from_tiles();  // second, cost-weighted pass with the same tile count
+      continue;
+    }
+    if (ok) { built = true; break; }
+    // did not fit: smaller tiles, plain bisection again
+    g->planner.drop_grid();
+    balanced = false;
+    tile_own = std::max(16, tile_own / 2);
+  }
+  if (!built) return 0;
+  if (g->opt.balance && ntiles >= 16) HIPCHK(g->planner.update_grid(s, V, ntiles, in, A));
+  // ---- host-side description of the plan ----
+  P.V = V; P.E = E; P.T = T;
+  P.on_device = true;
+  P.has_tiles = true;
+  P.tile_threads = cfg_nt; P.tile_ept = cfg_ept; P.tile_vpt = cfg_vpt;
+  P.tile_depth = depth;
+  P.tile_lds_bytes = lds_max;
+  P.note.clear();
+  P.v_o2i.clear(); P.v_i2o.clear(); P.e_o2i.clear(); P.e_i2o.clear();
+  P.eij.clear(); P.ew.clear(); P.grow.clear(); P.ginc.clear(); P.tris.clear(); P.trow.clear(); P.tinc.clear();
+  P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
+  g->host_perms = false;
+  g->path = FLAME_HIP_PATH_TILE;
+  if (!tile_config_exists(cfg_nt, cfg_ept, cfg_vpt)) return FLAME_HIP_ERR_STATE;
+  HIPCHK(prepare_tile(cfg_nt, cfg_ept, cfg_vpt, (size_t)lds_max));
+  // ---- state ----
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dev_alloc(g->caps, &g->A[b], V)) || (rc = dev_alloc(g->caps, &g->B[b], V)) ||
+        (rc = dev_alloc(g->caps, &g->q[b], E)))
+      return rc;
+    HIPCHK(hipMemsetAsync(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), s));
+  }
+  g->cur = 0;
+  if ((rc = dev_alloc(g->caps, &g->pos, V))) return rc;
+  HIPCHK(launch_init_state(s, V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, x0 ? g->in_x0 : nullptr, g->A[0],
+                           g->B[0], g->pos));
+  if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)T)))
+    return rc;
+  if (T == 0) HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
+  return 1;
+}
+
+// Host copies of the permutations of a device-built plan, fetched on demand (set_state,
+// update_data, halo lists, mesh faces, the debug hook; the per-frame path does not need them).
+static int ensure_host_perms(flame_hip_graph* g) {
+  if (g->host_perms || !g->plan.on_device) return 0;
+  Plan& P = g->plan;
+  const size_t V = (size_t)g->V, E = (size_t)g->E, T3 = 3 * (size_t)P.T;
+  P.v_i2o.resize(V); P.v_o2i.resize(V); P.e_i2o.resize(E); P.e_o2i.resize(E); P.tris.resize(T3);
+  hipStream_t s = g->stream;
+  if (V) {
+    HIPCHK(hipMemcpyAsync(P.v_i2o.data(), g->v_i2o_dev, 4 * V, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(P.v_o2i.data(), g->v_o2i_dev, 4 * V, hipMemcpyDeviceToHost, s));
+  }
+  if (E) {
+    HIPCHK(hipMemcpyAsync(P.e_i2o.data(), g->e_i2o_dev, 4 * E, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(P.e_o2i.data(), g->e_o2i_dev, 4 * E, hipMemcpyDeviceToHost, s));
+  }
+  if (T3) HIPCHK(hipMemcpyAsync(P.tris.data(), g->tris, 4 * T3, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  g->host_perms = true;
+  return 0;
+}
+
 int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* edges,
                            const float* alpha, const float* beta, const float* z,
                            const float* wgt, const float* x0, const int32_t* tris) {
@@ -339,85 +533,104 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   if (edges != g->sync.edges.data()) g->synced = false;
   if ((V > 0 && (!pos || !z || !wgt)) || (E > 0 && (!edges || !alpha || !beta)))
     return FLAME_HIP_ERR_ARG;
-  if (!all_finite(pos, 2 * (size_t)V) || !all_finite(z, V) || !all_finite(wgt, V) ||
-      !all_finite(alpha, E) || !all_finite(beta, E) || (x0 && !all_finite(x0, V)))
-    return FLAME_HIP_ERR_NAN;
   g->uploaded = false;
-  int rc = build_plan(g->opt, V, E, g->T, pos, edges, alpha, beta, tris, &g->plan);
-  if (rc != 0) return rc;
+  int rc;
+  if (g->device >= 0) {
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(wait_last_solve(g));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->drop_execs();  // captured launches hold the old grid / pointers
+    g->solves_since_upload = 0;
+    rc = upload_device_plan(g, pos, edges, alpha, beta, z, wgt, x0, tris);
+    if (rc < 0) return rc;
+  } else {
+    rc = 0;
+  }
+  const bool dev_plan = rc == 1;
+  if (!dev_plan) {
+    if (!all_finite(pos, 2 * (size_t)V) || !all_finite(z, V) || !all_finite(wgt, V) ||
+        !all_finite(alpha, E) || !all_finite(beta, E) || (x0 && !all_finite(x0, V)))
+      return FLAME_HIP_ERR_NAN;
+    g->plan.on_device = false;
+    g->host_perms = true;
+    rc = build_plan(g->opt, V, E, g->T, pos, edges, alpha, beta, tris, &g->plan);
+    if (rc != 0) return rc;
+  }
   const Plan& P = g->plan;
-  g->path = (P.has_tiles && g->opt.path != FLAME_HIP_PATH_GLOBAL) ? FLAME_HIP_PATH_TILE
-                                                                   : FLAME_HIP_PATH_GLOBAL;
-  if (g->opt.path == FLAME_HIP_PATH_TILE && !P.has_tiles) return FLAME_HIP_ERR_ARG;
+  if (!dev_plan) {
+    g->path = (P.has_tiles && g->opt.path != FLAME_HIP_PATH_GLOBAL) ? FLAME_HIP_PATH_TILE
+                                                                     : FLAME_HIP_PATH_GLOBAL;
+    if (g->opt.path == FLAME_HIP_PATH_TILE && !P.has_tiles) return FLAME_HIP_ERR_ARG;
+  }
   if (g->device < 0) {  // plan-only handle (host-logic tests): no device work
     g->uploaded = true;
     return 0;
   }
-  HIPCHK(hipSetDevice(g->device));
-  HIPCHK(wait_last_solve(g));
-  HIPCHK(hipStreamSynchronize(g->stream));
-  g->drop_execs();  // captured launches hold the old grid / pointers
-  g->solves_since_upload = 0;
-  if (P.has_tiles) {
-    if (!tile_config_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return FLAME_HIP_ERR_STATE;
-    HIPCHK(prepare_tile(P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes));
-  }
-
-  // initial state in internal order
-  std::vector<float4> hA(V), hB(V);
-  std::vector<float2> hpos(V);
-  for (int32_t k = 0; k < V; ++k) {
-    const int32_t o = P.v_i2o[k];
-    const float xi = x0 ? x0[o] : z[o];
-    hA[k] = make_float4(xi, 0.f, 0.f, z[o]);
-    hB[k] = make_float4(xi, 0.f, 0.f, wgt[o]);
-    hpos[k] = make_float2(pos[2 * o], pos[2 * o + 1]);
-  }
-  for (int b = 0; b < 2; ++b) {
-    if ((rc = dev_alloc(g->caps, &g->A[b], V))) return rc;
-    if ((rc = dev_alloc(g->caps, &g->B[b], V))) return rc;
-    if ((rc = dev_alloc(g->caps, &g->q[b], E))) return rc;
-    HIPCHK(hipMemsetAsync(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
-  }
-  g->cur = 0;
-  if ((rc = h2d(g->stream, g->A[0], hA)) || (rc = h2d(g->stream, g->B[0], hB))) return rc;
-  if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d(g->stream, g->pos, hpos))) return rc;
-  if ((rc = dev_alloc(g->caps, &g->eij, E)) || (rc = dev_alloc(g->caps, &g->ew, E)) ||
-      (rc = dev_alloc(g->caps, &g->grow, (size_t)V + 1)) || (rc = dev_alloc(g->caps, &g->ginc, 2 * (size_t)E)))
-    return rc;
-  static_assert(sizeof(Int2) == sizeof(int2) && sizeof(Float4) == sizeof(float4) &&
-                    sizeof(UInt2) == sizeof(uint2), "layout");
-  if (E > 0) {
-    HIPCHK(memcpy_sync(g->stream, g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice));
-    HIPCHK(memcpy_sync(g->stream, g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice));
-    HIPCHK(memcpy_sync(g->stream, g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice));
-  }
-  HIPCHK(memcpy_sync(g->stream, g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
-  if (P.has_tiles) {
-    if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d(g->stream, g->tiles, P.tiles)) ||
-        (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->stream, g->t_vmap, P.t_vmap)) ||
-        (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->stream, g->t_emap, P.t_emap)) ||
-        (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->stream, g->t_srow, P.t_srow)) ||
-        (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ew, P.t_ew.size())))
-      return rc;
-    if (!P.t_eij.empty()) {
-      HIPCHK(memcpy_sync(g->stream, g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
-      HIPCHK(memcpy_sync(g->stream, g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
+  if (!dev_plan) {
+    if (P.has_tiles) {
+      if (!tile_config_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return FLAME_HIP_ERR_STATE;
+      HIPCHK(prepare_tile(P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes));
     }
+    // initial state in internal order
+    std::vector<float4> hA(V), hB(V);
+    std::vector<float2> hpos(V);
+    for (int32_t k = 0; k < V; ++k) {
+      const int32_t o = P.v_i2o[k];
+      const float xi = x0 ? x0[o] : z[o];
+      hA[k] = make_float4(xi, 0.f, 0.f, z[o]);
+      hB[k] = make_float4(xi, 0.f, 0.f, wgt[o]);
+      hpos[k] = make_float2(pos[2 * o], pos[2 * o + 1]);
+    }
+    for (int b = 0; b < 2; ++b) {
+      if ((rc = dev_alloc(g->caps, &g->A[b], V))) return rc;
+      if ((rc = dev_alloc(g->caps, &g->B[b], V))) return rc;
+      if ((rc = dev_alloc(g->caps, &g->q[b], E))) return rc;
+      HIPCHK(hipMemsetAsync(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
+    }
+    g->cur = 0;
+    if ((rc = h2d(g->stream, g->A[0], hA)) || (rc = h2d(g->stream, g->B[0], hB))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d(g->stream, g->pos, hpos))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->eij, E)) || (rc = dev_alloc(g->caps, &g->ew, E)) ||
+        (rc = dev_alloc(g->caps, &g->grow, (size_t)V + 1)) || (rc = dev_alloc(g->caps, &g->ginc, 2 * (size_t)E)))
+      return rc;
+    static_assert(sizeof(Int2) == sizeof(int2) && sizeof(Float4) == sizeof(float4) &&
+                      sizeof(UInt2) == sizeof(uint2), "layout");
+    if (E > 0) {
+      HIPCHK(memcpy_sync(g->stream, g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice));
+      HIPCHK(memcpy_sync(g->stream, g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice));
+      HIPCHK(memcpy_sync(g->stream, g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice));
+    }
+    HIPCHK(memcpy_sync(g->stream, g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
+    if (P.has_tiles) {
+      if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d(g->stream, g->tiles, P.tiles)) ||
+          (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->stream, g->t_vmap, P.t_vmap)) ||
+          (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->stream, g->t_emap, P.t_emap)) ||
+          (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->stream, g->t_srow, P.t_srow)) ||
+          (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ew, P.t_ew.size())))
+        return rc;
+      if (!P.t_eij.empty()) {
+        HIPCHK(memcpy_sync(g->stream, g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
+        HIPCHK(memcpy_sync(g->stream, g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
+      }
+    }
+    // the triangle arrays always exist: with T == 0 the vertex -> triangle CSR is all-empty rows, so
+    // the triangle stage, mesh and dense maps run (degenerate normals, nothing covered)
+    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->stream, g->tris, P.tris)) ||
+        (rc = dev_alloc(g->caps, &g->trow, (size_t)V + 1)) ||
+        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->stream, g->tinc, P.tinc)) ||
+        (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
+      return rc;
+    if (P.T > 0) { if ((rc = h2d(g->stream, g->trow, P.trow))) return rc; }
+    else HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), g->stream));
+    // permutations for the device-side result paths
+    if ((rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) || (rc = h2d(g->stream, g->v_i2o_dev, P.v_i2o)) ||
+        (rc = dev_alloc(g->caps, &g->v_o2i_dev, (size_t)V)) || (rc = h2d(g->stream, g->v_o2i_dev, P.v_o2i)) ||
+        (rc = dev_alloc(g->caps, &g->e_o2i_dev, (size_t)E)) || (rc = h2d(g->stream, g->e_o2i_dev, P.e_o2i)))
+      return rc;
   }
-  // the triangle arrays always exist: with T == 0 the vertex -> triangle CSR is all-empty rows, so
-  // the triangle stage, mesh and dense maps run (degenerate normals, nothing covered)
-  if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->stream, g->tris, P.tris)) ||
-      (rc = dev_alloc(g->caps, &g->trow, (size_t)V + 1)) ||
-      (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->stream, g->tinc, P.tinc)) ||
-      (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
-    return rc;
-  if (P.T > 0) { if ((rc = h2d(g->stream, g->trow, P.trow))) return rc; }
-  else HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), g->stream));
   if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
-  if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) ||
-      (rc = h2d(g->stream, g->v_i2o_dev, P.v_i2o)))
-    return rc;
+  if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->dl_v, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->dl_q, 3 * (size_t)E))) return rc;
   if ((rc = dev_alloc(g->caps, &g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
   if (g->profile && P.has_tiles) {
     if ((rc = dev_alloc(g->caps, &g->prof, P.tiles.size() * kProfWords))) return rc;
@@ -479,15 +692,14 @@ int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float*
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
-  const Plan& P = g->plan;
-  std::vector<float4> hA(V), hB(V);
-  for (int32_t k = 0; k < V; ++k) {
-    const int32_t o = P.v_i2o[k];
-    const float xi = x0 ? x0[o] : z[o];
-    hA[k] = make_float4(xi, 0.f, 0.f, z[o]);
-    hB[k] = make_float4(xi, 0.f, 0.f, wgt[o]);
-  }
-  if ((rc = h2d(g->stream, g->A[g->cur], hA)) || (rc = h2d(g->stream, g->B[g->cur], hB))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) ||
+      (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(g->in_z, z, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream));
+  HIPCHK(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream));
+  if (x0) HIPCHK(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream));
+  HIPCHK(launch_init_state(g->stream, V, g->v_i2o_dev, nullptr, g->in_z, g->in_wgt, x0 ? g->in_x0 : nullptr,
+                           g->A[g->cur], g->B[g->cur], nullptr));
   HIPCHK(hipMemsetAsync(g->q[g->cur], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
   HIPCHK(hipStreamSynchronize(g->stream));
   return 0;
@@ -509,6 +721,7 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
+  if ((rc = ensure_host_perms(g))) return rc;
   if (x || w1 || w2 || xb || w1b || w2b) {
     std::vector<float4> hA(V), hB(V);
     if (V > 0) {
@@ -682,14 +895,9 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
   HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
                           g->tri_normals, g->tri_valid, g->vtx_normals));
   HIPCHK(hipStreamSynchronize(g->stream));
-  const Plan& P = g->plan;
   if (vtx_normals && V > 0) {
-    std::vector<float4> h(V);
-    HIPCHK(memcpy_sync(g->stream, h.data(), g->vtx_normals, sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost));
-    for (int32_t k = 0; k < V; ++k) {
-      const int32_t o = P.v_i2o[k];
-      vtx_normals[3 * o] = h[k].x; vtx_normals[3 * o + 1] = h[k].y; vtx_normals[3 * o + 2] = h[k].z;
-    }
+    HIPCHK(launch_download_rows3(g->stream, V, g->v_o2i_dev, g->vtx_normals, g->dl_v));
+    HIPCHK(memcpy_sync(g->stream, vtx_normals, g->dl_v, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToHost));
   }
   if (tri_valid && T > 0)
     HIPCHK(memcpy_sync(g->stream, tri_valid, g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
@@ -735,6 +943,7 @@ int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_
   if (points && V > 0)
     HIPCHK(memcpy_sync(g->stream, points, g->mesh_pts, sizeof(float4) * 3 * (size_t)V, hipMemcpyDeviceToHost));
   int32_t nf = 0;
+  if (T > 0 && faces && (rc = ensure_host_perms(g))) return rc;
   if (T > 0 && (faces || num_faces)) {
     std::vector<uint8_t> valid(T);
     HIPCHK(memcpy_sync(g->stream, valid.data(), g->tri_valid, (size_t)T, hipMemcpyDeviceToHost));
@@ -810,26 +1019,19 @@ static int download_impl(flame_hip_graph* g, bool bar, float* a0, float* a1, flo
   if (rc) return rc;
   if ((rc = flame_hip_sync(g))) return rc;
   const int32_t V = g->V, E = g->E;
-  const Plan& P = g->plan;
+  hipStream_t s = g->stream;
+  // results leave in the caller's order: permuted by a kernel into a staging buffer, then copied
   if ((a0 || a1 || a2) && V > 0) {
-    std::vector<float4> h(V);
-    HIPCHK(memcpy_sync(g->stream, h.data(), bar ? g->B[g->cur] : g->A[g->cur], sizeof(float4) * (size_t)V,
-                     hipMemcpyDeviceToHost));
-    for (int32_t k = 0; k < V; ++k) {
-      const int32_t o = P.v_i2o[k];
-      if (a0) a0[o] = h[k].x;
-      if (a1) a1[o] = h[k].y;
-      if (a2) a2[o] = h[k].z;
-    }
+    HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, bar ? g->B[g->cur] : g->A[g->cur], g->dl_v));
+    if (a0) HIPCHK(hipMemcpyAsync(a0, g->dl_v, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
+    if (a1) HIPCHK(hipMemcpyAsync(a1, g->dl_v + V, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
+    if (a2) HIPCHK(hipMemcpyAsync(a2, g->dl_v + 2 * (size_t)V, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
   }
   if (q && E > 0) {
-    std::vector<float4> h(E);
-    HIPCHK(memcpy_sync(g->stream, h.data(), g->q[g->cur], sizeof(float4) * (size_t)E, hipMemcpyDeviceToHost));
-    for (int32_t k = 0; k < E; ++k) {
-      const int32_t o = P.e_i2o[k];
-      q[3 * o] = h[k].x; q[3 * o + 1] = h[k].y; q[3 * o + 2] = h[k].z;
-    }
+    HIPCHK(launch_download_rows3(s, E, g->e_o2i_dev, g->q[g->cur], g->dl_q));
+    HIPCHK(hipMemcpyAsync(q, g->dl_q, sizeof(float) * 3 * (size_t)E, hipMemcpyDeviceToHost, s));
   }
+  HIPCHK(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -864,6 +1066,7 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
+  if ((rc = ensure_host_perms(g))) return rc;
   const Plan& P = g->plan;
   if ((rc = upload_index_list(g->stream, g->caps, P.v_o2i, g->V, n_send_v, send_v, &g->halo_send_v)) ||
       (rc = upload_index_list(g->stream, g->caps, P.e_o2i, g->E, n_send_e, send_e, &g->halo_send_e)) ||
@@ -912,6 +1115,36 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
   const std::string k(name);
   const void* src = nullptr;
   int64_t n = 0, esz = 4;
+  if (P.on_device && k != "tiles" && k != "profile" && k.compare(0, 5, "sync_") != 0) {
+    // device-built plan: the arrays live on the GPU, copied out on request
+    int64_t nv = 0, ne = 0, ns = 0;
+    for (const TileDesc& D : P.tiles) { nv += D.n_ext; ne += D.e_loc; ns += D.n_upd; }
+    const void* dev = nullptr;
+    const int64_t V = g->V, E = g->E;
+    if (k == "v_o2i") { dev = g->v_o2i_dev; n = V; }
+    else if (k == "v_i2o") { dev = g->v_i2o_dev; n = V; }
+    else if (k == "e_o2i") { dev = g->e_o2i_dev; n = E; }
+    else if (k == "e_i2o") { dev = g->e_i2o_dev; n = E; }
+    else if (k == "grow") { dev = g->grow; n = V + 1; }
+    else if (k == "ginc") { dev = g->ginc; n = 2 * E; }
+    else if (k == "eij") { dev = g->eij; n = E; esz = 8; }
+    else if (k == "ew") { dev = g->ew; n = E; esz = 16; }
+    else if (k == "tris") { dev = g->tris; n = 3 * (int64_t)P.T; }
+    else if (k == "trow") { dev = g->trow; n = P.T > 0 ? V + 1 : 0; }
+    else if (k == "tinc") { dev = g->tinc; n = 3 * (int64_t)P.T; }
+    else if (k == "t_vmap") { dev = g->t_vmap; n = nv; }
+    else if (k == "t_emap") { dev = g->t_emap; n = ne; }
+    else if (k == "t_eij") { dev = g->t_eij; n = ne; esz = 8; }
+    else if (k == "t_ew") { dev = g->t_ew; n = ne; esz = 16; }
+    else if (k == "t_srow") { dev = g->t_srow; n = ns; }
+    else return FLAME_HIP_ERR_ARG;
+    if (buf && cap_bytes > 0 && n > 0) {
+      if (hipSetDevice(g->device) != hipSuccess ||
+          memcpy_sync(g->stream, buf, dev, (size_t)std::min<int64_t>(cap_bytes, n * esz), hipMemcpyDeviceToHost) != hipSuccess)
+        return FLAME_HIP_ERR_HIP;
+    }
+    return n;
+  }
   if (k == "v_o2i") { src = P.v_o2i.data(); n = (int64_t)P.v_o2i.size(); }
   else if (k == "v_i2o") { src = P.v_i2o.data(); n = (int64_t)P.v_i2o.size(); }
   else if (k == "e_o2i") { src = P.e_o2i.data(); n = (int64_t)P.e_o2i.size(); }
@@ -924,6 +1157,11 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
   else if (k == "t_emap") { src = P.t_emap.data(); n = (int64_t)P.t_emap.size(); }
   else if (k == "t_eij") { src = P.t_eij.data(); n = (int64_t)P.t_eij.size(); esz = 8; }
   else if (k == "t_srow") { src = P.t_srow.data(); n = (int64_t)P.t_srow.size(); }
+  else if (k == "ew") { src = P.ew.data(); n = (int64_t)P.ew.size(); esz = 16; }
+  else if (k == "t_ew") { src = P.t_ew.data(); n = (int64_t)P.t_ew.size(); esz = 16; }
+  else if (k == "tris") { src = P.tris.data(); n = (int64_t)P.tris.size(); }
+  else if (k == "trow") { src = P.trow.data(); n = (int64_t)P.trow.size(); }
+  else if (k == "tinc") { src = P.tinc.data(); n = (int64_t)P.tinc.size(); }
   else if (k == "sync_edges") { src = g->sync.edges.data(); n = (int64_t)g->sync.edges.size(); }
   else if (k == "sync_alpha") { src = g->sync.alpha.data(); n = (int64_t)g->sync.alpha.size(); }
   else if (k == "sync_z") { src = g->sync.z.data(); n = (int64_t)g->sync.z.size(); }

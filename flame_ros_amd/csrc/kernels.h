@@ -65,6 +65,15 @@ hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* p
 hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int32_t* grow,
                                const int32_t* ginc, const int2* eij, float4* A, float4* B, float* tmp);
 
+// ---- host boundary with a device-resident plan: state init / results out in the caller's order ----
+hipError_t launch_init_state(hipStream_t s, int32_t V, const int32_t* v_i2o, const float2* pos_o, const float* z,
+                             const float* wgt, const float* x0, float4* A, float4* B, float2* pos_i);
+// out = 3 planes of V floats {x | w1 | w2} in the caller's vertex order
+hipError_t launch_download_vertex(hipStream_t s, int32_t V, const int32_t* v_o2i, const float4* S, float* out);
+// out[3 o .. 3 o + 2] = S[o2i[o]].xyz (edge duals, vertex normals)
+hipError_t launch_download_rows3(hipStream_t s, int32_t n, const int32_t* o2i, const float4* S, float* out);
+hipError_t launch_check_finite(hipStream_t s, int64_t n, const float* p, int32_t* flags);
+
 // ---- row a7 epilogue: x, w, x_bar, w_bar, z *= scale (state back in the caller's units) ----
 hipError_t launch_scale_state(hipStream_t s, int32_t V, float4* A, float4* B, float scale);
 

@@ -515,6 +515,47 @@ __global__ __launch_bounds__(256) void k_graph_filter_commit(int32_t V, const fl
   B[v].x = in[v];
 }
 
+// ------------------------------------------------------------------------------------------
+// Host boundary helpers for a plan that lives on the device (plan_dev.hip): the caller's arrays
+// arrive and leave in the CALLER's vertex / edge order, permuted here instead of on the host.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_state(int32_t V, const int32_t* __restrict__ v_i2o,
+                                                    const float2* __restrict__ pos_o,
+                                                    const float* __restrict__ z, const float* __restrict__ wgt,
+                                                    const float* __restrict__ x0, float4* __restrict__ A,
+                                                    float4* __restrict__ B, float2* __restrict__ pos_i) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= V) return;
+  const int32_t o = v_i2o[k];
+  const float zi = z[o];
+  const float xi = x0 ? x0[o] : zi;
+  A[k] = make_float4(xi, 0.f, 0.f, zi);
+  B[k] = make_float4(xi, 0.f, 0.f, wgt[o]);
+  if (pos_i) pos_i[k] = pos_o[o];
+}
+
+__global__ __launch_bounds__(256) void k_download_vertex(int32_t V, const int32_t* __restrict__ v_o2i,
+                                                         const float4* __restrict__ S, float* __restrict__ out) {
+  const int32_t o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= V) return;
+  const float4 a = S[v_o2i[o]];
+  out[o] = a.x; out[V + o] = a.y; out[2 * (size_t)V + o] = a.z;
+}
+
+__global__ __launch_bounds__(256) void k_download_rows3(int32_t n, const int32_t* __restrict__ o2i,
+                                                        const float4* __restrict__ S, float* __restrict__ out) {
+  const int32_t o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const float4 a = S[o2i[o]];
+  out[3 * (size_t)o] = a.x; out[3 * (size_t)o + 1] = a.y; out[3 * (size_t)o + 2] = a.z;
+}
+
+// flags |= 1 when any value is not finite
+__global__ __launch_bounds__(256) void k_check_finite(int64_t n, const float* __restrict__ p, int32_t* flags) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n && !isfinite(p[k])) atomicOr(flags, 1);
+}
+
 // Row a7 epilogue: back to the caller's units after a solve on rescaled data (rescale_data,
 // reference cfg/flame_offline_tum.yaml:90): primal state and data term times s.
 __global__ __launch_bounds__(256) void k_scale_state(int32_t V, float4* __restrict__ A,
@@ -685,6 +726,31 @@ hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_graph_filter_commit, dim3((V + 255) / 256), dim3(256), 0, s, V, tmp, A, B);
+  return hipGetLastError();
+}
+
+hipError_t launch_init_state(hipStream_t s, int32_t V, const int32_t* v_i2o, const float2* pos_o, const float* z,
+                             const float* wgt, const float* x0, float4* A, float4* B, float2* pos_i) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_init_state, dim3((V + 255) / 256), dim3(256), 0, s, V, v_i2o, pos_o, z, wgt, x0, A, B, pos_i);
+  return hipGetLastError();
+}
+
+hipError_t launch_download_vertex(hipStream_t s, int32_t V, const int32_t* v_o2i, const float4* S, float* out) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_download_vertex, dim3((V + 255) / 256), dim3(256), 0, s, V, v_o2i, S, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_download_rows3(hipStream_t s, int32_t n, const int32_t* o2i, const float4* S, float* out) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_download_rows3, dim3((n + 255) / 256), dim3(256), 0, s, n, o2i, S, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_check_finite(hipStream_t s, int64_t n, const float* p, int32_t* flags) {
+  if (n <= 0 || !p) return hipSuccess;
+  hipLaunchKernelGGL(k_check_finite, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, p, flags);
   return hipGetLastError();
 }
 

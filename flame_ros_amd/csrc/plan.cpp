@@ -14,10 +14,13 @@
 namespace flamehip {
 namespace {
 
-// Split position of idx[lo,hi) along `axis` for l1 of `leaves` parts.  Unweighted: equal counts
-// (nth_element).  Weighted (w != nullptr): sort along the axis and cut where the cumulative
-// weight reaches l1/leaves of the total, so parts get equal COST rather than equal size.
-int split_range(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, int hi,
+// Split position of idx[lo,hi) along `axis` for l1 of `leaves` parts.  The order along the axis is
+// the total order (coordinate, original id).  Unweighted: the first (hi-lo) l1 / leaves vertices
+// go left.  Weighted (w != nullptr, INTEGER weights so that every implementation -- this one and the
+// device builder in plan_dev.hip -- computes the same sums whatever the summation order): with
+// acc(m) = weight before position m in that order, the split is the first m with
+// (2 acc(m) + w_m) leaves >= 2 total l1, clamped so that both sides keep one vertex per leaf.
+int split_range(const float* pos, const int32_t* w, std::vector<int32_t>& idx, int lo, int hi,
                 int axis, int l1, int leaves) {
   auto less = [&](int32_t a, int32_t b) {
     const float pa = pos[2 * a + axis], pb = pos[2 * b + axis];
@@ -28,11 +31,11 @@ int split_range(const float* pos, const float* w, std::vector<int32_t>& idx, int
     std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, less);
     return mid;
   }
-  // weighted quickselect (expected O(n)): narrow [a,b) until the prefix weight reaches `target`
-  double total = 0.0;
+  // weighted quickselect (expected O(n)): narrow [a,b) keeping `before` = weight left of a
+  int64_t total = 0;
   for (int k = lo; k < hi; ++k) total += w[idx[k]];
-  double target = total * l1 / leaves;
-  // invariant: [lo,a) < [a,b) < [b,hi) along the axis; `target` = weight still to take from a on
+  const int64_t rhs = 2 * total * l1;  // compare (2 acc + w) * leaves against this
+  int64_t before = 0;
   int a = lo, b = hi;
   while (b - a > 32) {
     const int32_t c0 = idx[a], c1 = idx[a + (b - a) / 2], c2 = idx[b - 1];
@@ -42,21 +45,22 @@ int split_range(const float* pos, const float* w, std::vector<int32_t>& idx, int
                                         [&](int32_t v) { return less(v, piv); }) - idx.begin());
     if (mi == a) {  // the pivot is the minimum of the range: settle it at position a
       std::iter_swap(idx.begin() + a, std::find(idx.begin() + a, idx.begin() + b, piv));
-      if (target <= 0.5 * w[piv]) { b = a; break; }
-      target -= w[piv];
+      if ((2 * before + w[piv]) * leaves >= rhs) { b = a; break; }
+      before += w[piv];
       ++a;
       continue;
     }
-    double lw = 0.0;
+    int64_t lw = 0;
     for (int k = a; k < mi; ++k) lw += w[idx[k]];
-    if (lw >= target) b = mi;
-    else { target -= lw; a = mi; }
+    // the answer is <= mi iff acc(mi) = before + lw already reaches the target
+    if (2 * (before + lw) * leaves >= rhs) b = mi;
+    else { before += lw; a = mi; }
   }
   std::sort(idx.begin() + a, idx.begin() + b, less);
   int mid = a;
   {
-    double acc = 0.0;
-    while (mid < b && acc + 0.5 * w[idx[mid]] < target) acc += w[idx[mid++]];
+    int64_t acc = before;
+    while (mid < b && (2 * acc + w[idx[mid]]) * leaves < rhs) acc += w[idx[mid++]];
   }
   // every part keeps at least one vertex per leaf it must still produce
   mid = std::max(lo + l1, std::min(mid, hi - (leaves - l1)));
@@ -66,7 +70,7 @@ int split_range(const float* pos, const float* w, std::vector<int32_t>& idx, int
 // Recursive coordinate bisection of idx[lo,hi) into `leaves` parts of near-equal size (or cost,
 // when weights are given); parts are emitted in recursion order, which keeps spatial neighbours
 // close in the tile order.
-void rcb(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, int hi, int leaves,
+void rcb(const float* pos, const int32_t* w, std::vector<int32_t>& idx, int lo, int hi, int leaves,
          std::vector<int32_t>* leaf_start) {
   if (leaves <= 1 || hi - lo <= 1) {
     leaf_start->push_back(lo);
@@ -89,7 +93,7 @@ void rcb(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, in
 
 // Same bisection, but the two halves of the top `par_levels` levels run on separate threads; each
 // half appends its leaves to its own list, concatenated in order (identical result).
-void rcb_par(const float* pos, const float* w, std::vector<int32_t>& idx, int lo, int hi,
+void rcb_par(const float* pos, const int32_t* w, std::vector<int32_t>& idx, int lo, int hi,
              int leaves, std::vector<int32_t>* leaf_start, int par_levels) {
   if (par_levels <= 0 || leaves <= 1 || hi - lo <= 4096) {
     rcb(pos, w, idx, lo, hi, leaves, leaf_start);
@@ -110,6 +114,13 @@ void rcb_par(const float* pos, const float* w, std::vector<int32_t>& idx, int lo
   rcb_par(pos, w, idx, lo, mid, l1, leaf_start, par_levels - 1);
   th.join();
   leaf_start->insert(leaf_start->end(), right.begin(), right.end());
+}
+
+// Integer cost density of a tile (x 1024): what one own vertex of the tile "costs" a launch --
+// local edges + 2 x local vertices, per own vertex.  Integer so that sums of it are exact.
+int32_t tile_weight(const TileDesc& D) {
+  const int64_t cost = (int64_t)D.e_loc + 2 * (int64_t)D.n_ext;
+  return (int32_t)std::max<int64_t>(1, cost * 1024 / std::max(D.n_own, 1));
 }
 
 struct TileCfg { int nt, ept, vpt; };
@@ -139,6 +150,43 @@ bool pick_cfg(int want_nt, int e_max, int upd_max, TileCfg* out) {
 
 }  // namespace
 
+PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
+  const int64_t lds_cap = opt.lds_bytes;
+  // an isolated single tile holds the whole graph when it fits the largest kernel config
+  const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 32) <= lds_cap;
+  // Auto sizing (measured on MI355X, DESIGN.md "Tile sizing"): one tile per CU when the graph
+  // allows it (256 CUs), never below 32 own vertices (halo overhead) or above 196 (LDS / threads);
+  // when there are more tiles than CUs prefer the shallower halo whose tiles co-reside on a CU.
+  // Beyond one tile per CU (V > 256 * 196) two rounds of fat depth-3 tiles beat four rounds of
+  // small ones (200 k vertices: 392 own / depth 3 = 98 k it/s vs 196 / 3 = 71 k it/s).
+  const bool one_round = V <= 256 * 196;
+  const int auto_own = one_round ? std::max(32, std::min(196, (V + 255) / 256))
+                                 : std::max(196, std::min(400, (V + 511) / 512));
+  // few tiles (a small lone graph): CUs are idle anyway, so redundant halo work is free and deeper
+  // halos amortise the per-launch load (1.2 k vertices: depth 8 = 652 k it/s vs depth 4 = 573 k)
+  const int auto_tiles = (V + auto_own - 1) / std::max(auto_own, 1);
+  const int auto_depth = !one_round ? 3 : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
+  int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
+  int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
+  // Auto: a lone graph is one isolated tile only when it is small (<= 512 vertices): above that a
+  // few dozen depth-4 tiles on as many CUs finish sooner than one CU iterating alone (TUM-sized
+  // 1.2 k vertices: 0.33 ms vs 0.43 ms per 200 iterations).  tile_own >= V forces the single tile;
+  // batch frames are always single tiles (throughput, one CU per frame).
+  bool single = single_fits && (opt.tile_own >= V || (opt.tile_own <= 0 && V <= 512));
+  if (single) { tile_own = std::max(V, 1); depth = 0; }
+  PlanSizing sz;
+  sz.auto_own = auto_own; sz.auto_depth = auto_depth;
+  sz.tile_own = tile_own; sz.depth = depth; sz.single = single;
+  return sz;
+}
+
+bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt) {
+  TileCfg c{};
+  if (!pick_cfg(want_nt, e_max, upd_max, &c)) return false;
+  *nt = c.nt; *ept = c.ept; *vpt = c.vpt;
+  return true;
+}
+
 int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const float* pos,
                const int32_t* edges, const float* alpha, const float* beta, const int32_t* tris,
                Plan* out) {
@@ -167,29 +215,11 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       if (tris[3 * t + k] < 0 || tris[3 * t + k] >= V) return FLAME_HIP_ERR_ARG;
 
   // ---- tile sizing ----
+  const PlanSizing sz = plan_sizing(opt, V, E);
+  const int auto_own = sz.auto_own, auto_depth = sz.auto_depth;
+  int tile_own = sz.tile_own, depth = sz.depth;
+  bool single = sz.single;
   const int64_t lds_cap = opt.lds_bytes;
-  // an isolated single tile holds the whole graph when it fits the largest kernel config
-  const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 32) <= lds_cap;
-  // Auto sizing (measured on MI355X, DESIGN.md "Tile sizing"): one tile per CU when the graph
-  // allows it (256 CUs), never below 32 own vertices (halo overhead) or above 196 (LDS / threads);
-  // when there are more tiles than CUs prefer the shallower halo whose tiles co-reside on a CU.
-  // Beyond one tile per CU (V > 256 * 196) two rounds of fat depth-3 tiles beat four rounds of
-  // small ones (200 k vertices: 392 own / depth 3 = 98 k it/s vs 196 / 3 = 71 k it/s).
-  const bool one_round = V <= 256 * 196;
-  const int auto_own = one_round ? std::max(32, std::min(196, (V + 255) / 256))
-                                 : std::max(196, std::min(400, (V + 511) / 512));
-  // few tiles (a small lone graph): CUs are idle anyway, so redundant halo work is free and deeper
-  // halos amortise the per-launch load (1.2 k vertices: depth 8 = 652 k it/s vs depth 4 = 573 k)
-  const int auto_tiles = (V + auto_own - 1) / std::max(auto_own, 1);
-  const int auto_depth = !one_round ? 3 : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
-  int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
-  int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
-  // Auto: a lone graph is one isolated tile only when it is small (<= 512 vertices): above that a
-  // few dozen depth-4 tiles on as many CUs finish sooner than one CU iterating alone (TUM-sized
-  // 1.2 k vertices: 0.33 ms vs 0.43 ms per 200 iterations).  tile_own >= V forces the single tile;
-  // batch frames are always single tiles (throughput, one CU per frame).
-  bool single = single_fits && (opt.tile_own >= V || (opt.tile_own <= 0 && V <= 512));
-  if (single) { tile_own = std::max(V, 1); depth = 0; }
   const bool batch = !opt.batch_voff.empty();
   if (batch) {  // every graph of the batch is one isolated tile; edges must not cross graphs
     const std::vector<int32_t>& vo = opt.batch_voff;
@@ -212,7 +242,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   // edges of the triangulation), and a launch lasts as long as its slowest tile.  After a first
   // unweighted partition every vertex gets the cost density of its tile and the bisection is
   // redone on cost instead of count.
-  std::vector<float> vweight;
+  std::vector<int32_t> vweight;  // integer cost density per vertex (x 1024), see tile_weight()
   bool balanced = false;
   auto grid_cell = [&](const float* pp) {
     int c[2];
@@ -533,12 +563,11 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     if (ok && !pick_cfg(opt.tile_threads, e_max, upd_max, &cfg)) ok = false;
     if (ok && opt.balance && !balanced && !batch && !single && ntiles >= 16) {
       balanced = true;
-      vweight.assign(V, 1.0f);
+      vweight.assign(V, 1);
       for (int t = 0; t < ntiles; ++t) {
         const TileDesc& D = P.tiles[t];
-        const float cost = (float)D.e_loc + 2.0f * (float)D.n_ext;
-        for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k)
-          vweight[P.v_i2o[k]] = cost / (float)std::max(D.n_own, 1);
+        const int32_t wt = tile_weight(D);
+        for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k) vweight[P.v_i2o[k]] = wt;
       }
       lap("balance weights");
       continue;  // rebuild with weighted bisection (same tile count)
@@ -555,20 +584,21 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
             P.wgrid_mn[a] = std::min(P.wgrid_mn[a], pos[2 * v + a]);
             P.wgrid_mx[a] = std::max(P.wgrid_mx[a], pos[2 * v + a]);
           }
-        std::vector<float> sum(Plan::kGrid * Plan::kGrid, 0.f), cnt(Plan::kGrid * Plan::kGrid, 0.f);
-        double total = 0.0;
+        // integer sums: the same field whatever the accumulation order (host loop / device atomics)
+        std::vector<int64_t> sum(Plan::kGrid * Plan::kGrid, 0), cnt(Plan::kGrid * Plan::kGrid, 0);
+        int64_t total = 0;
         for (int t = 0; t < ntiles; ++t) {
           const TileDesc& D = P.tiles[t];
-          const float dens = ((float)D.e_loc + 2.0f * (float)D.n_ext) / (float)std::max(D.n_own, 1);
+          const int32_t wt = tile_weight(D);
           for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k) {
             const int c = grid_cell(pos + 2 * P.v_i2o[k]);
-            sum[c] += dens; cnt[c] += 1.f;
+            sum[c] += wt; cnt[c] += 1;
           }
-          total += (double)dens * D.n_own;
+          total += (int64_t)wt * D.n_own;
         }
-        const float mean = V > 0 ? (float)(total / V) : 1.0f;
+        const int32_t mean = V > 0 ? (int32_t)std::max<int64_t>(1, total / V) : 1024;
         P.wgrid.resize(sum.size());
-        for (size_t c = 0; c < sum.size(); ++c) P.wgrid[c] = cnt[c] > 0.f ? sum[c] / cnt[c] : mean;
+        for (size_t c = 0; c < sum.size(); ++c) P.wgrid[c] = cnt[c] > 0 ? (int32_t)(sum[c] / cnt[c]) : mean;
         P.wgrid_tiles = ntiles;
       }
       return 0;

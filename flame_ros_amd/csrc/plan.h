@@ -67,6 +67,9 @@ struct Plan {
   std::vector<Float4> t_ew;
   std::vector<uint32_t> t_srow;
   std::string note;  // why the tile path was not built, if so
+  // built by the device builder (plan_dev.hip): the arrays above live on the GPU only (the handle
+  // copies them back on demand); `tiles` and the scalars are valid on the host
+  bool on_device = false;
   // build buffers (persistent capacity)
   std::vector<TileBuild> tile_build;
   std::vector<ThreadScratch> scratch;
@@ -76,10 +79,20 @@ struct Plan {
   // cost-density field of the last balanced partition on a coarse pixel grid: a handle that is
   // re-uploaded every frame balances the next frame in ONE weighted pass instead of two
   static constexpr int kGrid = 32;
-  std::vector<float> wgrid;  // kGrid * kGrid, empty = none yet
+  std::vector<int32_t> wgrid;  // kGrid * kGrid integer cost densities (x 1024), empty = none yet
   float wgrid_mn[2] = {0.f, 0.f}, wgrid_mx[2] = {1.f, 1.f};
   int32_t wgrid_tiles = 0;   // tile count the field was built for
 };
+
+// Tile sizing shared by the host and the device builder (measured on MI355X).
+struct PlanSizing {
+  int auto_own = 0, auto_depth = 0;  // what "auto" resolves to
+  int tile_own = 0, depth = 0;       // first attempt (a single isolated tile: tile_own = V, depth 0)
+  bool single = false;
+};
+PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E);
+// smallest instantiated kernel configuration that holds e_max local edges / upd_max local vertices
+bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt);
 
 // Builds the plan.  Returns 0 or a FLAME_HIP_ERR_* code (bad indices).
 int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const float* pos,

@@ -1,0 +1,121 @@
+// flame_ros_amd/csrc/plan_dev.h -- the graph plan built ON THE GPU (graph
+// construction upstream of the regulariser; the reference budgets it per frame, stat keys
+// sync_graph / triangulate, reference msg/FlameStats.msg:43-44, because every frame is a new graph,
+// reference src/flame_offline_tum.cc:578).
+//
+// Same contract as the host builder (plan.h / plan.cpp): identical arrays, element for element --
+// the partition (recursive coordinate bisection on the total order (coordinate, id), integer cost
+// weights), the Morton order inside tiles, the edge order, the incidence CSR in ascending original
+// edge id, the per-tile halo rings, local edge order, incidence slots.  Every rule is either
+// integer arithmetic or single IEEE float operations, so host and device agree bit for bit
+// (tests/test_gpu_plan_device.py compares them array by array).
+//
+// Covers the product case: halo tiles (depth >= 1) in spatial order.  Isolated single tiles, batches
+// of frames, the degree order and graphs beyond the LDS bitmap are built by the host builder.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+#include "plan.h"
+
+namespace flamehip {
+
+// Device arrays of a plan.  Owned by the caller (the handle), sized by the caller:
+// V / E / T sized arrays before build, the tile arrays through `alloc_tiles` once their sizes are
+// known (after the first per-tile pass).
+struct DevPlanArrays {
+  int32_t* v_o2i = nullptr;   // V
+  int32_t* v_i2o = nullptr;   // V
+  int32_t* e_o2i = nullptr;   // E
+  int32_t* e_i2o = nullptr;   // E
+  int2* eij = nullptr;        // E
+  float4* ew = nullptr;       // E
+  int32_t* grow = nullptr;    // V + 1
+  int32_t* ginc = nullptr;    // 2E
+  int32_t* tris = nullptr;    // 3T internal vertex ids
+  int32_t* trow = nullptr;    // V + 1
+  int32_t* tinc = nullptr;    // 3T
+  TileDesc* tiles = nullptr;  // ntiles
+  int32_t* t_vmap = nullptr;
+  int32_t* t_emap = nullptr;
+  uint2* t_eij = nullptr;
+  float4* t_ew = nullptr;
+  uint32_t* t_srow = nullptr;
+};
+
+struct DevPlanInputs {  // device copies of the caller's arrays, ORIGINAL order
+  const float2* pos = nullptr;   // V
+  const int2* edges = nullptr;   // E
+  const float* alpha = nullptr;  // E
+  const float* beta = nullptr;   // E
+  const int32_t* tris = nullptr; // 3T or nullptr
+};
+
+class DevPlanner {
+ public:
+  DevPlanner() = default;
+  ~DevPlanner();
+  DevPlanner(const DevPlanner&) = delete;
+  DevPlanner& operator=(const DevPlanner&) = delete;
+
+  // true when this graph / option set is handled on the device
+  static bool eligible(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int tile_own, int depth,
+                       bool single, int64_t lds_bytes);
+
+  // Builds the plan for `ntiles` tiles of halo depth `depth`.  `arrays` must hold the V/E/T sized
+  // buffers; alloc_tiles(nv, ne, ns) is called once (after a stream sync) and must fill the tile
+  // array pointers of `arrays` for those element counts.  On success *tiles_host receives the tile
+  // descriptors and *ok tells whether every tile could be built (false = the caller retries with
+  // smaller tiles or falls back to the host builder).  Returns a hipError_t.
+  typedef int (*AllocTilesFn)(void* ctx, size_t ntiles, size_t nv, size_t ne, size_t ns);
+  hipError_t build(hipStream_t s, const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int ntiles,
+                   int depth, const DevPlanInputs& in, DevPlanArrays* arrays, AllocTilesFn alloc_tiles,
+                   void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error);
+
+  // weights for the next build: none / from the tiles of the last build / from the cost-density grid
+  void set_weights_none() { weight_mode_ = 0; }
+  void set_weights_from_tiles() { weight_mode_ = 1; }
+  void set_weights_from_grid() { weight_mode_ = 2; }
+  // records the cost-density grid of the last build (device side, integer); grid_tiles() then
+  // returns the tile count it was made for
+  hipError_t update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in, const DevPlanArrays& arrays);
+  int grid_tiles() const { return grid_tiles_; }
+  void drop_grid() { grid_tiles_ = 0; }
+
+ private:
+  hipError_t reserve(int32_t V, int32_t E, int32_t T, int ntiles);
+  void release();
+
+  int weight_mode_ = 0;
+  int grid_tiles_ = 0;
+  // capacities
+  int64_t capV_ = 0, capE_ = 0, capT_ = 0, capTiles_ = 0;
+  size_t cub_bytes_ = 0;
+  // scratch (device)
+  void* cub_tmp_ = nullptr;
+  uint64_t* keys_a_ = nullptr;   // max(V, 2E, 3T)
+  uint64_t* keys_b_ = nullptr;
+  uint32_t* vals_a_ = nullptr;   // 2E
+  uint32_t* vals_b_ = nullptr;
+  int32_t* seg_pos_ = nullptr;   // V
+  int32_t* tile_of_int_ = nullptr;  // V (by internal id)
+  int32_t* w_int_ = nullptr;     // V (by original id)
+  long long* wsort_ = nullptr;   // V
+  long long* wscan_ = nullptr;   // V
+  int32_t* counts_ = nullptr;    // V + 2 (degree / triangle counts)
+  int32_t* seg_tab_ = nullptr;   // segment tables + bbox + mids (see plan_dev.hip)
+  int32_t* estart_ = nullptr;    // ntiles + 1
+  int32_t* tile_ext_ = nullptr;  // ntiles * kCapExt (pass-1 vertex lists)
+  int32_t* tile_meta_ = nullptr; // ntiles * kMetaWords (pass-1 counts, ring ends, offsets)
+  int32_t* flags_ = nullptr;     // error / totals words
+  long long* grid_sum_ = nullptr;  // kGrid^2
+  int32_t* grid_cnt_ = nullptr;    // kGrid^2
+  int32_t* grid_w_ = nullptr;      // kGrid^2
+  float* grid_bounds_ = nullptr;   // mn.x mn.y mx.x mx.y of the frame the grid was made from
+  float* gbbox_ = nullptr;         // global bbox of the current frame (4 floats)
+};
+
+}  // namespace flamehip

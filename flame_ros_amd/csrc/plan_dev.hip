@@ -1,0 +1,1014 @@
+// flame_ros_amd/csrc/plan_dev.hip -- see plan_dev.h.  The graph plan built by HIP kernels
+// (SURVEY.md 8f row f3).  Stage by stage the same rules as plan.cpp, so the arrays are identical:
+//
+//   A  partition     level-synchronous recursive coordinate bisection: per level one radix sort of
+//                    (segment, ordered coordinate along the segment's longer axis, vertex id), an
+//                    int64 prefix sum of the integer cost weights, and the split rule of
+//                    plan.cpp split_range() evaluated at every position in parallel
+//   B  vertex order  radix sort of (tile, Morton code of the pixel position, vertex id)
+//   C  edge order    radix sort of (owner tile of the source x cross-tile flag, source, edge id)
+//   D  incidence CSR radix sort of (vertex, original edge id) over the 2E incidences
+//   E  triangle CSR  radix sort of (vertex, triangle id) over the 3T corners
+//   F  tiles, pass 1 one workgroup per tile: breadth-first halo rings over the CSR with an LDS bitmap
+//                    of the vertices, rings sorted by internal id, local edge count
+//   G  tiles, pass 2 local edge keys (level, owned, source, edge id) sorted in LDS, gather lists,
+//                    incidence slots (odd pitch per 64-vertex group), local edge records
+// Only hipcub's device-wide radix sort / scan are library code; everything else is written here.
+#include "plan_dev.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+
+namespace flamehip {
+namespace {
+
+constexpr int kSegCap = 1024;     // segments (= tiles) per level at most
+constexpr int kIdBits = 22;       // vertex ids in sort keys
+constexpr int kEdgeBits = 24;     // edge / triangle ids in sort keys
+constexpr int kCapExt = 2048;     // local vertices per tile (largest kernel configuration)
+constexpr int kCapEdge = 6144;    // local edges per tile (largest kernel configuration)
+constexpr int kSortPad = 8192;    // LDS sort window (keys)
+constexpr int kHash = 4096;       // LDS hash slots (global -> local vertex id)
+constexpr int kMetaWords = 32;    // per tile: 0 n_ext, 1 e_loc, 2 n_upd, 3 fail, 4..20 ring_end, 21..23 offsets
+constexpr int kP1Threads = 512, kP2Threads = 1024;
+
+#define HIPRET(expr)                   \
+  do {                                 \
+    hipError_t e__ = (expr);           \
+    if (e__ != hipSuccess) return e__; \
+  } while (0)
+
+__device__ __forceinline__ uint32_t ord_f(float f) {  // order-preserving float -> uint
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+  x &= 0xffff; x = (x | (x << 8)) & 0x00ff00ff; x = (x | (x << 4)) & 0x0f0f0f0f;
+  x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555;
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage A: recursive coordinate bisection, one level per round of kernels.
+// seg tables (int32, kSegCap each): lo, hi, leaves, first; two tables ping-pong per level.
+// ------------------------------------------------------------------------------------------
+struct SegTab { int32_t *lo, *hi, *leaves, *first; };
+
+__global__ void k_rcb_init(int32_t V, int32_t ntiles, int32_t* perm, int32_t* seg_pos, SegTab t,
+                           int32_t* nseg, uint32_t* bbox, int32_t* mid_raw) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p < V) { perm[p] = p; seg_pos[p] = 0; }
+  if (p == 0) {
+    t.lo[0] = 0; t.hi[0] = V; t.leaves[0] = ntiles; t.first[0] = 0;
+    nseg[0] = 1;
+    bbox[0] = bbox[1] = 0xffffffffu; bbox[2] = bbox[3] = 0u;
+    mid_raw[0] = V;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rcb_bbox(int32_t V, const int32_t* __restrict__ perm,
+                                                  const float2* __restrict__ pos,
+                                                  const int32_t* __restrict__ seg_pos,
+                                                  const int32_t* __restrict__ leaves, uint32_t* bbox) {
+  __shared__ int s_first, s_same;
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  int32_t s = -1;
+  uint32_t ux = 0, uy = 0;
+  if (p < V) {
+    s = seg_pos[p];
+    const float2 q = pos[perm[p]];
+    ux = ord_f(q.x); uy = ord_f(q.y);
+  }
+  if (threadIdx.x == 0) { s_first = s; s_same = 1; }
+  __syncthreads();
+  if (p < V && s != s_first) s_same = 0;
+  __syncthreads();
+  if (s_same) {  // the whole block lies in one segment: one set of atomics per wave
+    if (s_first < 0 || leaves[s_first] <= 1) return;
+    uint32_t mnx = p < V ? ux : 0xffffffffu, mny = p < V ? uy : 0xffffffffu;
+    uint32_t mxx = p < V ? ux : 0u, mxy = p < V ? uy : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, off, 64));
+      mny = min(mny, (uint32_t)__shfl_xor((int)mny, off, 64));
+      mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
+      mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&bbox[4 * s_first], mnx); atomicMin(&bbox[4 * s_first + 1], mny);
+      atomicMax(&bbox[4 * s_first + 2], mxx); atomicMax(&bbox[4 * s_first + 3], mxy);
+    }
+  } else if (p < V && leaves[s] > 1) {
+    atomicMin(&bbox[4 * s], ux); atomicMin(&bbox[4 * s + 1], uy);
+    atomicMax(&bbox[4 * s + 2], ux); atomicMax(&bbox[4 * s + 3], uy);
+  }
+}
+
+__global__ void k_save_gbbox(const uint32_t* bbox, float* gbbox) {
+  if (threadIdx.x < 4) gbbox[threadIdx.x] = unord_f(bbox[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_rcb_keys(int32_t V, const int32_t* __restrict__ perm,
+                                                  const float2* __restrict__ pos,
+                                                  const int32_t* __restrict__ seg_pos,
+                                                  const int32_t* __restrict__ leaves,
+                                                  const uint32_t* __restrict__ bbox, uint64_t* keys) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const int32_t s = seg_pos[p], v = perm[p];
+  uint32_t coord = 0;
+  if (leaves[s] > 1) {
+    const float ex = unord_f(bbox[4 * s + 2]) - unord_f(bbox[4 * s]);
+    const float ey = unord_f(bbox[4 * s + 3]) - unord_f(bbox[4 * s + 1]);
+    const float2 q = pos[v];
+    coord = ord_f(ey > ex ? q.y : q.x);
+  }
+  keys[p] = ((uint64_t)s << (32 + kIdBits)) | ((uint64_t)coord << kIdBits) | (uint64_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_rcb_post(int32_t V, const uint64_t* __restrict__ keys,
+                                                  int32_t* perm, const int32_t* __restrict__ w_int,
+                                                  long long* wsort) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const int32_t v = (int32_t)(keys[p] & ((1u << kIdBits) - 1));
+  perm[p] = v;
+  if (wsort) wsort[p] = w_int[v];
+}
+
+// first position m of the segment with (2 acc(m) + w_m) leaves >= 2 total l1 (plan.cpp split_range)
+__global__ __launch_bounds__(256) void k_rcb_mid(int32_t V, const int32_t* __restrict__ seg_pos, SegTab t,
+                                                 const long long* __restrict__ wsort,
+                                                 const long long* __restrict__ wscan, int32_t* mid_raw) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const int32_t s = seg_pos[p];
+  const int32_t L = t.leaves[s];
+  if (L <= 1) return;
+  const int32_t lo = t.lo[s], hi = t.hi[s], l1 = L / 2;
+  const long long base = lo > 0 ? wscan[lo - 1] : 0;
+  const long long total = wscan[hi - 1] - base;
+  const long long rhs = 2 * total * l1;
+  const long long w = wsort[p];
+  const long long before = wscan[p] - w - base;
+  const bool c = (2 * before + w) * L >= rhs;
+  bool cprev = false;
+  if (p > lo) {
+    const long long wp = wsort[p - 1];
+    const long long bp = wscan[p - 1] - wp - base;
+    cprev = (2 * bp + wp) * L >= rhs;
+  }
+  if (c && !cprev) mid_raw[s] = p;
+}
+
+// one block: children of every segment, next level's table, reset of the next level's bbox / mid
+__global__ __launch_bounds__(kSegCap) void k_rcb_split(const int32_t* nseg_cur, int32_t* nseg_next, SegTab cur,
+                                                        SegTab nxt, const int32_t* mid_raw_cur,
+                                                        int32_t* mid_raw_next, int weighted, int32_t* child_base,
+                                                        int32_t* mid_out, uint32_t* bbox) {
+  __shared__ int32_t sc[kSegCap];
+  const int s = threadIdx.x;
+  const int n = nseg_cur[0];
+  int32_t lo = 0, hi = 0, L = 0, first = 0, mid = 0, nchild = 0;
+  if (s < n) {
+    lo = cur.lo[s]; hi = cur.hi[s]; L = cur.leaves[s]; first = cur.first[s];
+    if (L > 1) {
+      const int32_t l1 = L / 2;
+      if (weighted) {
+        mid = mid_raw_cur[s];
+        mid = max(lo + l1, min(mid, hi - (L - l1)));
+        mid = max(lo, min(mid, hi));
+      } else {
+        mid = lo + (int32_t)(((long long)(hi - lo) * l1) / L);
+      }
+      nchild = 2;
+    } else {
+      nchild = 1;
+    }
+  }
+  sc[s] = nchild;
+  __syncthreads();
+  for (int off = 1; off < kSegCap; off <<= 1) {  // inclusive scan
+    const int32_t v = s >= off ? sc[s - off] : 0;
+    __syncthreads();
+    sc[s] += v;
+    __syncthreads();
+  }
+  const int32_t base = sc[s] - nchild;
+  if (s == kSegCap - 1) nseg_next[0] = min(sc[s], kSegCap);
+  __syncthreads();
+  if (s < n) {
+    child_base[s] = base;
+    mid_out[s] = mid;
+    if (base + nchild <= kSegCap) {
+      if (nchild == 2) {
+        const int32_t l1 = L / 2;
+        nxt.lo[base] = lo; nxt.hi[base] = mid; nxt.leaves[base] = l1; nxt.first[base] = first;
+        nxt.lo[base + 1] = mid; nxt.hi[base + 1] = hi; nxt.leaves[base + 1] = L - l1; nxt.first[base + 1] = first + l1;
+        mid_raw_next[base] = mid; mid_raw_next[base + 1] = hi;
+      } else {
+        nxt.lo[base] = lo; nxt.hi[base] = hi; nxt.leaves[base] = L; nxt.first[base] = first;
+        mid_raw_next[base] = hi;
+      }
+    }
+  }
+  // next level's boxes
+  bbox[4 * s] = bbox[4 * s + 1] = 0xffffffffu;
+  bbox[4 * s + 2] = bbox[4 * s + 3] = 0u;
+}
+
+__global__ __launch_bounds__(256) void k_rcb_assign(int32_t V, int32_t* seg_pos,
+                                                    const int32_t* __restrict__ child_base,
+                                                    const int32_t* __restrict__ mid,
+                                                    const int32_t* __restrict__ leaves) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const int32_t s = seg_pos[p];
+  seg_pos[p] = child_base[s] + ((leaves[s] > 1 && p >= mid[s]) ? 1 : 0);
+}
+
+// after the last level: every segment is one tile, in tile order
+__global__ __launch_bounds__(kSegCap) void k_rcb_check(const int32_t* nseg, SegTab t, int32_t ntiles, int32_t* flags) {
+  const int s = threadIdx.x;
+  if (s == 0 && nseg[0] != ntiles) atomicOr(&flags[0], 1);
+  if (s < ntiles && (t.leaves[s] != 1 || t.first[s] != s)) atomicOr(&flags[0], 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage B: order inside tiles = Morton code of the pixel position (plan.cpp, order_mode 1)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_keys(int32_t V, const int32_t* __restrict__ perm,
+                                                   const float2* __restrict__ pos,
+                                                   const int32_t* __restrict__ seg_pos,
+                                                   const float* __restrict__ gb, uint64_t* keys) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const int32_t v = perm[p];
+  const float2 q = pos[v];
+  const float mnx = gb[0], mny = gb[1], mxx = gb[2], mxy = gb[3];
+  const uint32_t qx = (uint32_t)(65535.0f * (q.x - mnx) / fmaxf(mxx - mnx, 1e-20f));
+  const uint32_t qy = (uint32_t)(65535.0f * (q.y - mny) / fmaxf(mxy - mny, 1e-20f));
+  const uint32_t code = spread16(qx) | (spread16(qy) << 1);
+  keys[p] = ((uint64_t)seg_pos[p] << (32 + kIdBits)) | ((uint64_t)code << kIdBits) | (uint64_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t* __restrict__ keys,
+                                                      int32_t* v_i2o, int32_t* v_o2i, int32_t* tile_of_int) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const uint64_t k = keys[p];
+  const int32_t v = (int32_t)(k & ((1u << kIdBits) - 1));
+  v_i2o[p] = v;
+  v_o2i[v] = p;
+  tile_of_int[p] = (int32_t)(k >> (32 + kIdBits));
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage C: edge order (owner tile of the source, level 0 before level 1, source, original id)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const int2* __restrict__ edges,
+                                                   const int32_t* __restrict__ v_o2i,
+                                                   const int32_t* __restrict__ tile_of_int, uint64_t* keys,
+                                                   int32_t* tile_ecnt, int32_t* flags) {
+  const int32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int2 ij = edges[e];
+  if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {  // build_plan's index check
+    atomicOr(&flags[0], 2);
+    keys[e] = (uint64_t)e;
+    return;
+  }
+  const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
+  const int32_t ti = tile_of_int[si], tj = tile_of_int[sj];
+  const uint32_t bucket = 2u * (uint32_t)ti + (ti == tj ? 0u : 1u);
+  keys[e] = ((uint64_t)bucket << (kIdBits + kEdgeBits)) | ((uint64_t)si << kEdgeBits) | (uint64_t)e;
+  atomicAdd(&tile_ecnt[ti], 1);
+}
+
+__global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint64_t* __restrict__ keys,
+                                                     const int2* __restrict__ edges,
+                                                     const float* __restrict__ alpha,
+                                                     const float* __restrict__ beta,
+                                                     const float2* __restrict__ pos,
+                                                     const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
+                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t* deg) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= E) return;
+  const int32_t e = (int32_t)(keys[k] & ((1u << kEdgeBits) - 1));
+  const int2 ij = edges[e];
+  const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
+  const float2 pi = pos[ij.x], pj = pos[ij.y];
+  e_i2o[k] = e;
+  e_o2i[e] = k;
+  eij[k] = make_int2(si, sj);
+  ew[k] = make_float4(alpha[e], beta[e], pi.x - pj.x, pi.y - pj.y);
+  atomicAdd(&deg[si], 1);
+  atomicAdd(&deg[sj], 1);
+}
+
+// exclusive scan of n <= 1024 + 1 ints in one block: out[i] = sum_{j<i} in[j], out[n] = total
+__global__ __launch_bounds__(1024) void k_scan_small(int n, const int32_t* in, int32_t* out) {
+  __shared__ int32_t sc[1024];
+  const int i = threadIdx.x;
+  const int32_t v = i < n ? in[i] : 0;
+  sc[i] = v;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int32_t u = i >= off ? sc[i - off] : 0;
+    __syncthreads();
+    sc[i] += u;
+    __syncthreads();
+  }
+  if (i < n) out[i] = sc[i] - v;
+  if (i == n - 1) out[n] = sc[i];
+  if (n == 0 && i == 0) out[0] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage D / E: incidence CSR (ascending ORIGINAL edge id per vertex), triangle CSR
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_csr_keys(int32_t E, const int2* __restrict__ eij,
+                                                  const int32_t* __restrict__ e_i2o, uint64_t* keys,
+                                                  uint32_t* vals) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= E) return;
+  const int2 ij = eij[k];
+  const uint64_t eo = (uint64_t)e_i2o[k];
+  keys[2 * k] = ((uint64_t)ij.x << kEdgeBits) | eo;
+  vals[2 * k] = (uint32_t)k;
+  keys[2 * k + 1] = ((uint64_t)ij.y << kEdgeBits) | eo;
+  vals[2 * k + 1] = (uint32_t)k | 0x80000000u;
+}
+
+__global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
+                                                  const int32_t* __restrict__ v_o2i, int32_t* tris_int,
+                                                  uint64_t* keys, int32_t* cnt, int32_t* flags) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n3) return;
+  const int32_t vo = tris[k];
+  if (vo < 0 || vo >= V) { atomicOr(&flags[0], 2); tris_int[k] = 0; keys[k] = (uint64_t)(k / 3); return; }
+  const int32_t v = v_o2i[vo];
+  tris_int[k] = v;
+  keys[k] = ((uint64_t)v << kEdgeBits) | (uint64_t)(k / 3);
+  atomicAdd(&cnt[v], 1);
+}
+
+__global__ __launch_bounds__(256) void k_low_bits(int32_t n, const uint64_t* __restrict__ keys, int32_t* out) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) out[k] = (int32_t)(keys[k] & ((1u << kEdgeBits) - 1));
+}
+
+__global__ __launch_bounds__(256) void k_zero_i32(int32_t n, int32_t* p) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) p[k] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage F / G: tiles.  One workgroup per tile.
+// ------------------------------------------------------------------------------------------
+struct TileGraph {
+  int32_t V, depth;
+  const int32_t* grow; const int32_t* ginc; const int2* eij;
+  const int32_t* e_i2o; const int32_t* e_o2i;
+};
+
+struct TileLds {
+  uint32_t* bitmap;  // (V + 31) / 32
+  int32_t* ext;      // kCapExt
+  int32_t* hkey;     // kHash   (also the ring-sort window before the hash is built)
+  int32_t* hval;     // kHash
+};
+
+__device__ __forceinline__ uint32_t hash_slot(int32_t gid) { return ((uint32_t)gid * 2654435761u) >> 20; }  // 12 bits
+
+__device__ __forceinline__ int32_t hash_lookup(const TileLds& L, int32_t gid) {
+  uint32_t h = hash_slot(gid);
+  for (int probe = 0; probe < kHash; ++probe) {
+    const int32_t k = L.hkey[h];
+    if (k == gid) return L.hval[h];
+    if (k == -1) return -1;
+    h = (h + 1) & (kHash - 1);
+  }
+  return -1;
+}
+
+template <int NTB, class T>
+__device__ void bitonic_sort(T* a, int m) {  // m a power of two, ascending
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < m; i += NTB) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const T x = a[i], y = a[ixj];
+          const bool asc = (i & k) == 0;
+          if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
+
+// breadth-first halo rings; returns through s_n / s_ring_end (shared), sets *fail on overflow
+template <int NTB>
+__device__ void tile_rings(const TileGraph& G, const TileLds& L, int32_t vstart, int32_t n_own, int* s_n,
+                           int32_t* s_ring_end, int* s_fail) {
+  const int tid = threadIdx.x;
+  const int bm_words = (G.V + 31) >> 5;
+  for (int i = tid; i < bm_words; i += NTB) L.bitmap[i] = 0u;
+  __syncthreads();
+  if (n_own > kCapExt) { if (tid == 0) *s_fail = 1; n_own = kCapExt; }
+  for (int l = tid; l < n_own; l += NTB) {
+    const int32_t v = vstart + l;
+    L.ext[l] = v;
+    atomicOr(&L.bitmap[v >> 5], 1u << (v & 31));
+  }
+  if (tid == 0) { *s_n = n_own; s_ring_end[0] = n_own; }
+  __syncthreads();
+  int prev_lo = 0, prev_hi = n_own;
+  for (int r = 1; r <= kMaxDepth; ++r) {
+    if (r <= G.depth) {
+      for (int f = prev_lo + tid; f < prev_hi; f += NTB) {
+        const int32_t v = L.ext[f];
+        for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s) {
+          const int32_t ent = G.ginc[s];
+          const int2 ij = G.eij[ent & 0x7fffffff];
+          const int32_t u = ent < 0 ? ij.x : ij.y;
+          const uint32_t bit = 1u << (u & 31);
+          const uint32_t old = atomicOr(&L.bitmap[u >> 5], bit);
+          if (!(old & bit)) {
+            const int pos = atomicAdd(s_n, 1);
+            if (pos < kCapExt) L.ext[pos] = u;
+          }
+        }
+      }
+      __syncthreads();
+      int n = *s_n;
+      if (n > kCapExt) { if (tid == 0) { *s_fail = 1; *s_n = kCapExt; } n = kCapExt; }
+      const int cnt = n - prev_hi;
+      if (cnt > 1) {  // ring vertices in ascending internal id (any append order -> same list)
+        const int m = next_pow2(cnt);
+        int32_t* win = L.hkey;  // 2 * kHash ints contiguous (hkey, hval)
+        for (int i = tid; i < m; i += NTB) win[i] = i < cnt ? L.ext[prev_hi + i] : INT_MAX;
+        __syncthreads();
+        bitonic_sort<NTB, int32_t>(win, m);
+        for (int i = tid; i < cnt; i += NTB) L.ext[prev_hi + i] = win[i];
+      }
+      __syncthreads();
+      prev_lo = prev_hi; prev_hi = n;
+    }
+    if (tid == 0) s_ring_end[r] = prev_hi;
+  }
+  __syncthreads();
+}
+
+template <int NTB>
+__device__ void tile_hash_build(const TileLds& L, int n_ext) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kHash; i += NTB) L.hkey[i] = -1;
+  __syncthreads();
+  for (int l = tid; l < n_ext; l += NTB) {
+    const int32_t gid = L.ext[l];
+    uint32_t h = hash_slot(gid);
+    for (;;) {
+      const int32_t old = atomicCAS(&L.hkey[h], -1, gid);
+      if (old == -1) { L.hval[h] = l; break; }
+      h = (h + 1) & (kHash - 1);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int ring_of(const int32_t* s_ring_end, int lv) {
+  int r = 0;
+  while (r < kMaxDepth && lv >= s_ring_end[r]) ++r;
+  return r;
+}
+
+// key of a local edge: [level:5][not owned:1][source local id:16][original edge id:32]; 0 = not local
+__device__ __forceinline__ bool local_edge_key(const TileGraph& G, const TileLds& L, const int32_t* s_ring_end,
+                                               int32_t k, int lsrc, int rsrc, int32_t dst, uint64_t* key) {
+  if (!((L.bitmap[dst >> 5] >> (dst & 31)) & 1u)) return false;
+  const int ldst = hash_lookup(L, dst);
+  const int rdst = ring_of(s_ring_end, ldst);
+  if (G.depth > 0 && min(rsrc, rdst) >= G.depth) return false;  // feeds no updated vertex
+  const uint64_t lvl = (uint64_t)max(rsrc, rdst);
+  const uint64_t notown = (lvl <= 1 && rsrc != 0) ? 1 : 0;
+  *key = (lvl << 49) | (notown << 48) | ((uint64_t)(uint32_t)lsrc << 32) | (uint64_t)(uint32_t)G.e_i2o[k];
+  return true;
+}
+
+__global__ __launch_bounds__(kP1Threads) void k_tile_pass1(TileGraph G, const int32_t* __restrict__ vstart_tab,
+                                                           const int32_t* __restrict__ vend_tab,
+                                                           int32_t* tile_ext, int32_t* meta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_n, s_fail, s_ecnt;
+  __shared__ int32_t s_ring_end[kMaxDepth + 1];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  TileLds L;
+  L.bitmap = reinterpret_cast<uint32_t*>(smem);
+  L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
+  L.hkey = L.ext + kCapExt;
+  L.hval = L.hkey + kHash;
+  if (tid == 0) { s_fail = 0; s_ecnt = 0; }
+  __syncthreads();
+  const int32_t vstart = vstart_tab[t], n_own = vend_tab[t] - vstart;
+  tile_rings<kP1Threads>(G, L, vstart, n_own, &s_n, s_ring_end, &s_fail);
+  const int n_ext = s_n;
+  tile_hash_build<kP1Threads>(L, n_ext);
+  int cnt = 0;
+  for (int lv = tid; lv < n_ext; lv += kP1Threads) {
+    const int32_t v = L.ext[lv];
+    const int rv = ring_of(s_ring_end, lv);
+    for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s) {
+      const int32_t ent = G.ginc[s];
+      if (ent < 0) continue;  // v is the target; the source adds the edge
+      uint64_t key;
+      if (local_edge_key(G, L, s_ring_end, ent, lv, rv, G.eij[ent].y, &key)) ++cnt;
+    }
+    tile_ext[(size_t)t * kCapExt + lv] = v;
+  }
+  if (cnt) atomicAdd(&s_ecnt, cnt);
+  __syncthreads();
+  if (tid == 0) {
+    int32_t* m = meta + (size_t)t * kMetaWords;
+    m[0] = n_ext;
+    m[1] = s_ecnt;
+    m[2] = G.depth == 0 ? n_ext : s_ring_end[G.depth - 1];
+    m[3] = (s_fail || s_ecnt > kCapEdge) ? 1 : 0;
+  }
+  if (tid <= kMaxDepth) meta[(size_t)t * kMetaWords + 4 + tid] = s_ring_end[tid];
+}
+
+// exclusive scans of (n_ext, e_loc, n_upd) over the tiles; totals and the fail flag
+__global__ __launch_bounds__(kSegCap) void k_tile_offsets(int ntiles, int32_t* meta, int32_t* flags) {
+  __shared__ int32_t sc[3][kSegCap];
+  const int t = threadIdx.x;
+  int32_t v[3] = {0, 0, 0};
+  if (t < ntiles) {
+    const int32_t* m = meta + (size_t)t * kMetaWords;
+    v[0] = m[0]; v[1] = m[1]; v[2] = m[2];
+    if (m[3]) atomicOr(&flags[0], 4);
+  }
+  for (int c = 0; c < 3; ++c) sc[c][t] = v[c];
+  __syncthreads();
+  for (int off = 1; off < kSegCap; off <<= 1) {
+    int32_t u[3];
+    for (int c = 0; c < 3; ++c) u[c] = t >= off ? sc[c][t - off] : 0;
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) sc[c][t] += u[c];
+    __syncthreads();
+  }
+  if (t < ntiles) {
+    int32_t* m = meta + (size_t)t * kMetaWords;
+    for (int c = 0; c < 3; ++c) m[21 + c] = sc[c][t] - v[c];
+  }
+  if (t == kSegCap - 1) { flags[1] = sc[0][t]; flags[2] = sc[1][t]; flags[3] = sc[2][t]; }
+}
+
+__global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const int32_t* __restrict__ vstart_tab,
+                                                           const int32_t* __restrict__ vend_tab,
+                                                           const int32_t* __restrict__ estart,
+                                                           const int32_t* __restrict__ tile_ext,
+                                                           const int32_t* __restrict__ meta,
+                                                           const float4* __restrict__ ew, TileDesc* tiles,
+                                                           int32_t* t_vmap, int32_t* t_emap, uint2* t_eij,
+                                                           float4* t_ew, uint32_t* t_srow, int32_t* flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_fail, s_ecnt;
+  __shared__ int32_t s_ring_end[kMaxDepth + 1], s_level_end[kMaxDepth + 1];
+  __shared__ int32_t s_gw[kCapExt / 64], s_gbase[kCapExt / 64 + 1];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  TileLds L;
+  uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
+  L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
+  L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
+  L.hkey = L.ext + kCapExt;
+  L.hval = L.hkey + kHash;
+  const int32_t* m = meta + (size_t)t * kMetaWords;
+  const int n_ext = m[0], e_loc = m[1], n_upd = m[2];
+  const int32_t voff = m[21], eoff = m[22], soff = m[23];
+  const int32_t vstart = vstart_tab[t], n_own = vend_tab[t] - vstart;
+  const int32_t es = estart[t], e_own = estart[t + 1] - es;
+  if (tid == 0) { s_fail = m[3]; s_ecnt = 0; }
+  if (tid <= kMaxDepth) { s_ring_end[tid] = m[4 + tid]; s_level_end[tid] = 0; }
+  if (tid < kCapExt / 64) s_gw[tid] = 1;
+  const int bm_words = (G.V + 31) >> 5;
+  for (int i = tid; i < bm_words; i += kP2Threads) L.bitmap[i] = 0u;
+  __syncthreads();
+  if (m[3]) {  // pass 1 already failed this tile: leave a descriptor that says so
+    if (tid == 0) { TileDesc D = {}; D.n_ext = -1; tiles[t] = D; }
+    return;
+  }
+  for (int l = tid; l < n_ext; l += kP2Threads) {
+    const int32_t v = tile_ext[(size_t)t * kCapExt + l];
+    L.ext[l] = v;
+    atomicOr(&L.bitmap[v >> 5], 1u << (v & 31));
+    t_vmap[voff + l] = v;
+  }
+  __syncthreads();
+  tile_hash_build<kP2Threads>(L, n_ext);
+  // ---- local edges: every local vertex contributes its outgoing incidences ----
+  for (int lv = tid; lv < n_ext; lv += kP2Threads) {
+    const int32_t v = L.ext[lv];
+    const int rv = ring_of(s_ring_end, lv);
+    for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s) {
+      const int32_t ent = G.ginc[s];
+      if (ent < 0) continue;
+      uint64_t key;
+      if (local_edge_key(G, L, s_ring_end, ent, lv, rv, G.eij[ent].y, &key)) {
+        const int pos = atomicAdd(&s_ecnt, 1);
+        if (pos < kSortPad) ekeys[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  if (s_ecnt != e_loc) { if (tid == 0) s_fail = 1; }
+  const int msort = next_pow2(max(e_loc, 1));
+  for (int i = e_loc + tid; i < msort; i += kP2Threads) ekeys[i] = ~0ull;
+  __syncthreads();
+  bitonic_sort<kP2Threads, uint64_t>(ekeys, msort);
+  // ---- gather lists, local records, level ends, owned prefix check ----
+  if (e_own > e_loc && tid == 0) s_fail = 1;
+  for (int le = tid; le < e_loc; le += kP2Threads) {
+    const uint64_t key = ekeys[le];
+    const int32_t k = G.e_o2i[(int32_t)(key & 0xffffffffu)];
+    const int lvl = (int)(key >> 49);
+    const int nxt = le + 1 < e_loc ? (int)(ekeys[le + 1] >> 49) : kMaxDepth + 1;
+    for (int l = lvl; l < nxt && l <= kMaxDepth; ++l) s_level_end[l] = le + 1;
+    if (le < e_own && k != es + le) s_fail = 1;  // owned edges = the prefix, in internal order
+    const uint32_t li = (uint32_t)((key >> 32) & 0xffffu);
+    const uint32_t lj = (uint32_t)hash_lookup(L, G.eij[k].y);
+    t_emap[eoff + le] = k;
+    t_eij[eoff + le] = make_uint2(li | (lj << 16), 0xffffffffu);
+    t_ew[eoff + le] = ew[k];
+  }
+  // ---- incidence slots: one row per updated vertex, odd pitch per 64-vertex group ----
+  for (int lv = tid; lv < n_upd; lv += kP2Threads) {
+    const int32_t v = L.ext[lv];
+    atomicMax(&s_gw[lv >> 6], G.grow[v + 1] - G.grow[v]);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int32_t base = 0;
+    const int ng = (n_upd + 63) >> 6;
+    for (int g = 0; g < ng; ++g) {
+      const int32_t w = s_gw[g] | 1;
+      s_gw[g] = w;
+      s_gbase[g] = base;
+      if (base + 64 * w + kDummySlots > 65535) { s_fail = 1; break; }
+      base += 64 * w;
+    }
+    s_gbase[kCapExt / 64] = base;
+  }
+  __syncthreads();
+  for (int lv = tid; lv < n_upd; lv += kP2Threads) {
+    const int32_t v = L.ext[lv];
+    const int32_t deg = G.grow[v + 1] - G.grow[v];
+    const int g = lv >> 6;
+    const int32_t s0 = s_gbase[g] + (lv - (g << 6)) * s_gw[g];
+    t_srow[soff + lv] = (uint32_t)s0 | ((uint32_t)deg << 16);
+    const int rv = ring_of(s_ring_end, lv);
+    int j = 0;
+    for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s, ++j) {
+      const int32_t ent = G.ginc[s];
+      const int32_t k = ent & 0x7fffffff;
+      const int role = ent < 0 ? 1 : 0;  // 1: v is the target
+      const int2 ij = G.eij[k];
+      uint64_t key = 0;
+      bool ok;
+      if (!role) {
+        ok = local_edge_key(G, L, s_ring_end, k, lv, rv, ij.y, &key);
+      } else {
+        ok = ((L.bitmap[ij.x >> 5] >> (ij.x & 31)) & 1u) != 0;
+        if (ok) {
+          const int ls = hash_lookup(L, ij.x);
+          const int rs = ring_of(s_ring_end, ls);
+          ok = !(G.depth > 0 && min(rs, rv) >= G.depth);
+          const uint64_t lvl = (uint64_t)max(rs, rv);
+          const uint64_t notown = (lvl <= 1 && rs != 0) ? 1 : 0;
+          key = (lvl << 49) | (notown << 48) | ((uint64_t)(uint32_t)ls << 32) | (uint64_t)(uint32_t)G.e_i2o[k];
+        }
+      }
+      int le = -1;
+      if (ok) {  // position of the edge in the tile's sorted key list
+        int lo = 0, hi = e_loc - 1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const uint64_t km = ekeys[mid];
+          if (km == key) { le = mid; break; }
+          if (km < key) lo = mid + 1; else hi = mid - 1;
+        }
+      }
+      if (le < 0) { s_fail = 1; continue; }  // halo closure invariant
+      reinterpret_cast<unsigned short*>(&t_eij[eoff + le].y)[role] = (unsigned short)(s0 + j);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    TileDesc D = {};
+    D.vstart = vstart; D.n_own = n_own; D.n_ext = n_ext;
+    D.estart = es; D.e_own = e_own; D.e_loc = e_loc;
+    D.n_upd = n_upd; D.depth = G.depth;
+    D.vmap_off = voff; D.emap_off = eoff; D.erec_off = eoff; D.srow_off = soff;
+    D.nslots = s_gbase[kCapExt / 64];
+    for (int r = 0; r <= kMaxDepth; ++r) { D.ring_end[r] = s_ring_end[r]; D.level_end[r] = s_level_end[r]; }
+    if (s_fail) { D.n_ext = -1; atomicOr(&flags[0], 8); }
+    tiles[t] = D;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cost weights: from the tiles of the previous pass, or from the cost-density grid of the
+// previous frame (plan.cpp: tile_weight(), Plan::wgrid).  All integer.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t tile_weight_dev(const TileDesc& D) {
+  const long long cost = (long long)D.e_loc + 2 * (long long)D.n_ext;
+  const long long w = cost * 1024 / max(D.n_own, 1);
+  return (int32_t)max(1ll, w);
+}
+
+__global__ __launch_bounds__(256) void k_weights_from_tiles(int32_t V, const int32_t* __restrict__ v_i2o,
+                                                            const int32_t* __restrict__ tile_of_int,
+                                                            const TileDesc* __restrict__ tiles, int32_t* w_int) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k < V) w_int[v_i2o[k]] = tile_weight_dev(tiles[tile_of_int[k]]);
+}
+
+__device__ __forceinline__ int grid_cell_dev(const float* b, float2 q) {
+  const float fx = (q.x - b[0]) / fmaxf(b[2] - b[0], 1e-20f);
+  const float fy = (q.y - b[1]) / fmaxf(b[3] - b[1], 1e-20f);
+  const int cx = max(0, min(Plan::kGrid - 1, (int)(fx * Plan::kGrid)));
+  const int cy = max(0, min(Plan::kGrid - 1, (int)(fy * Plan::kGrid)));
+  return cy * Plan::kGrid + cx;
+}
+
+__global__ __launch_bounds__(256) void k_weights_from_grid(int32_t V, const float2* __restrict__ pos,
+                                                           const float* __restrict__ bounds,
+                                                           const int32_t* __restrict__ grid_w, int32_t* w_int) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v < V) w_int[v] = grid_w[grid_cell_dev(bounds, pos[v])];
+}
+
+__global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __restrict__ pos,
+                                                    const int32_t* __restrict__ v_i2o,
+                                                    const int32_t* __restrict__ tile_of_int,
+                                                    const TileDesc* __restrict__ tiles,
+                                                    const float* __restrict__ bounds,
+                                                    unsigned long long* sum, int32_t* cnt) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= V) return;
+  const int c = grid_cell_dev(bounds, pos[v_i2o[k]]);
+  atomicAdd(&sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]]));
+  atomicAdd(&cnt[c], 1);
+}
+
+__global__ __launch_bounds__(1024) void k_grid_final(int32_t V, const unsigned long long* sum,
+                                                     const int32_t* cnt, int32_t* grid_w) {
+  __shared__ unsigned long long s_tot[1024];
+  const int c = threadIdx.x;  // kGrid * kGrid == 1024
+  s_tot[c] = sum[c];
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (c < off) s_tot[c] += s_tot[c + off];
+    __syncthreads();
+  }
+  const long long total = (long long)s_tot[0];
+  const int32_t mean = V > 0 ? (int32_t)max(1ll, total / V) : 1024;
+  grid_w[c] = cnt[c] > 0 ? (int32_t)((long long)sum[c] / cnt[c]) : mean;
+}
+
+__global__ void k_copy4(const float* src, float* dst) {
+  if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+template <class T>
+hipError_t dalloc(T** p, size_t n) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)); }
+
+inline int bits_for(int64_t n) { int b = 1; while ((1ll << b) < n) ++b; return b; }
+
+}  // namespace
+
+static_assert(Plan::kGrid * Plan::kGrid == 1024, "k_grid_final assumes a 32 x 32 grid");
+
+DevPlanner::~DevPlanner() { release(); }
+
+void DevPlanner::release() {
+  void* ptrs[] = {cub_tmp_, keys_a_, keys_b_, vals_a_, vals_b_, seg_pos_, tile_of_int_, w_int_, wsort_, wscan_,
+                  counts_, seg_tab_, estart_, tile_ext_, tile_meta_, flags_, grid_sum_, grid_cnt_, grid_w_,
+                  grid_bounds_, gbbox_};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  cub_tmp_ = nullptr; keys_a_ = keys_b_ = nullptr; vals_a_ = vals_b_ = nullptr;
+  seg_pos_ = tile_of_int_ = w_int_ = counts_ = seg_tab_ = estart_ = tile_ext_ = tile_meta_ = flags_ = nullptr;
+  wsort_ = wscan_ = nullptr; grid_sum_ = nullptr; grid_cnt_ = grid_w_ = nullptr;
+  grid_bounds_ = gbbox_ = nullptr;
+  capV_ = capE_ = capT_ = capTiles_ = 0;
+  cub_bytes_ = 0;
+}
+
+bool DevPlanner::eligible(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int tile_own, int depth,
+                          bool single, int64_t lds_bytes) {
+  if (single || !opt.batch_voff.empty() || opt.order_mode != 1 || depth < 1) return false;
+  if (V < 2 || (int64_t)V >= (1ll << kIdBits) || (int64_t)E >= (1ll << kEdgeBits) || (int64_t)T >= (1ll << kEdgeBits))
+    return false;
+  const int ntiles = (V + tile_own - 1) / std::max(tile_own, 1);
+  if (ntiles < 2 || ntiles > kSegCap) return false;
+  const int64_t lds2 = (int64_t)kSortPad * 8 + ((V + 31) / 32) * 4ll + kCapExt * 4 + kHash * 8;
+  return lds2 <= lds_bytes;
+}
+
+hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
+  const int64_t nk = std::max<int64_t>(std::max<int64_t>(V, 2 * (int64_t)E), 3 * (int64_t)T);
+  if (V > capV_ || E > capE_ || T > capT_) {
+    const int64_t v = std::max<int64_t>(V + V / 4, capV_), e = std::max<int64_t>(E + E / 4, capE_),
+                  t = std::max<int64_t>(T + T / 4, capT_);
+    const int64_t n = std::max<int64_t>(std::max<int64_t>(v, 2 * e), 3 * t);
+    HIPRET(dalloc(&keys_a_, (size_t)n)); HIPRET(dalloc(&keys_b_, (size_t)n));
+    HIPRET(dalloc(&vals_a_, (size_t)(2 * e))); HIPRET(dalloc(&vals_b_, (size_t)(2 * e)));
+    HIPRET(dalloc(&seg_pos_, (size_t)v)); HIPRET(dalloc(&tile_of_int_, (size_t)v));
+    HIPRET(dalloc(&w_int_, (size_t)v)); HIPRET(dalloc(&wsort_, (size_t)v)); HIPRET(dalloc(&wscan_, (size_t)v));
+    HIPRET(dalloc(&counts_, (size_t)v + 2));
+    capV_ = v; capE_ = e; capT_ = t;
+    // temp storage of the library sorts / scans at the largest sizes
+    size_t need = 0, b = 0;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(nullptr, b, keys_a_, keys_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)(2 * e), 0, 64, nullptr)); need = std::max(need, b);
+    HIPRET(hipcub::DeviceScan::InclusiveSum(nullptr, b, wsort_, wscan_, (int)v, nullptr)); need = std::max(need, b);
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, counts_, counts_, (int)v + 1, nullptr)); need = std::max(need, b);
+    if (need > cub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&cub_tmp_), need)); cub_bytes_ = need; }
+  }
+  (void)nk;
+  if (!seg_tab_) {
+    // 2 tables x 4 arrays, bbox (4), mid_raw x 2, child_base, mid_out, nseg x 2
+    HIPRET(dalloc(&seg_tab_, (size_t)kSegCap * 16 + 16));
+    HIPRET(dalloc(&flags_, 8));
+    HIPRET(dalloc(&grid_sum_, (size_t)Plan::kGrid * Plan::kGrid));
+    HIPRET(dalloc(&grid_cnt_, (size_t)Plan::kGrid * Plan::kGrid));
+    HIPRET(dalloc(&grid_w_, (size_t)Plan::kGrid * Plan::kGrid));
+    HIPRET(dalloc(&grid_bounds_, 4)); HIPRET(dalloc(&gbbox_, 4));
+  }
+  if (ntiles > capTiles_) {
+    const int64_t n = std::max<int64_t>(ntiles + ntiles / 4, 64);
+    HIPRET(dalloc(&estart_, (size_t)n + 2));
+    HIPRET(dalloc(&tile_ext_, (size_t)n * kCapExt));
+    HIPRET(dalloc(&tile_meta_, (size_t)n * kMetaWords));
+    capTiles_ = n;
+  }
+  return hipSuccess;
+}
+
+hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int ntiles,
+                             int depth, const DevPlanInputs& in, DevPlanArrays* A, AllocTilesFn alloc_tiles,
+                             void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error) {
+  (void)opt;
+  *ok = false;
+  *index_error = false;
+  HIPRET(reserve(V, E, T, ntiles));
+  static bool attr_set = false;
+  const size_t lds1 = ((size_t)(V + 31) / 32) * 4 + kCapExt * 4 + kHash * 8;
+  const size_t lds2 = lds1 + (size_t)kSortPad * 8;
+  if (!attr_set) {
+    HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    attr_set = true;
+  }
+  // segment tables
+  int32_t* st = seg_tab_;
+  SegTab tab[2] = {{st, st + kSegCap, st + 2 * kSegCap, st + 3 * kSegCap},
+                   {st + 4 * kSegCap, st + 5 * kSegCap, st + 6 * kSegCap, st + 7 * kSegCap}};
+  uint32_t* bbox = reinterpret_cast<uint32_t*>(st + 8 * kSegCap);  // 4 * kSegCap
+  int32_t* mid_raw[2] = {st + 12 * kSegCap, st + 13 * kSegCap};
+  int32_t* child_base = st + 14 * kSegCap;
+  int32_t* mid_out = st + 15 * kSegCap;
+  int32_t* nseg = st + 16 * kSegCap;  // [2]
+  int32_t* perm = A->v_i2o;
+  const bool weighted = weight_mode_ != 0;
+
+  HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
+  if (weight_mode_ == 2)
+    hipLaunchKernelGGL(k_weights_from_grid, grid1(V), dim3(256), 0, s, V, in.pos, grid_bounds_, grid_w_, w_int_);
+  // (weight_mode_ 1: w_int_ was filled by the previous build's tiles, see below)
+
+  // ---- stage A ----
+  hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
+  int levels = 0;
+  while ((1 << levels) < ntiles) ++levels;
+  int cur = 0;
+  for (int lev = 0; lev < levels; ++lev, cur ^= 1) {
+    hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
+    if (lev == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
+    hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox, keys_a_);
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, V, 0, std::min(64, 32 + kIdBits + lev + 1), s));
+    hipLaunchKernelGGL(k_rcb_post, grid1(V), dim3(256), 0, s, V, keys_b_, perm, w_int_, weighted ? wsort_ : nullptr);
+    if (weighted) {
+      tb = cub_bytes_;
+      HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+      hipLaunchKernelGGL(k_rcb_mid, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], wsort_, wscan_, mid_raw[cur]);
+    }
+    hipLaunchKernelGGL(k_rcb_split, dim3(1), dim3(kSegCap), 0, s, nseg + cur, nseg + (cur ^ 1), tab[cur], tab[cur ^ 1],
+                       mid_raw[cur], mid_raw[cur ^ 1], weighted ? 1 : 0, child_base, mid_out, bbox);
+    hipLaunchKernelGGL(k_rcb_assign, grid1(V), dim3(256), 0, s, V, seg_pos_, child_base, mid_out, tab[cur].leaves);
+  }
+  hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
+  const SegTab leaf = tab[cur];  // lo = vstart, hi = vstart + n_own per tile
+
+  // ---- stage B ----
+  hipLaunchKernelGGL(k_tile_keys, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, gbbox_, keys_a_);
+  {
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, V, 0, std::min(64, 32 + kIdBits + bits_for(ntiles)), s));
+  }
+  hipLaunchKernelGGL(k_vertex_order, grid1(V), dim3(256), 0, s, V, keys_b_, A->v_i2o, A->v_o2i, tile_of_int_);
+
+  // ---- stage C ----
+  hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
+  hipLaunchKernelGGL(k_zero_i32, grid1(ntiles + 2), dim3(256), 0, s, ntiles + 2, estart_);
+  if (E > 0) {
+    hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, keys_a_, estart_, flags_);
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, E, 0,
+                                             std::min(64, kEdgeBits + kIdBits + bits_for(2 * (int64_t)ntiles)), s));
+    hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, keys_b_, in.edges, in.alpha, in.beta, in.pos,
+                       A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_);
+  }
+  hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, ntiles, estart_, estart_);
+  {
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, counts_, A->grow, V + 1, s));
+  }
+  // ---- stage D ----
+  if (E > 0) {
+    hipLaunchKernelGGL(k_csr_keys, grid1(E), dim3(256), 0, s, E, A->eij, A->e_i2o, keys_a_, vals_a_);
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb, keys_a_, keys_b_, vals_a_,
+                                              reinterpret_cast<uint32_t*>(A->ginc), 2 * E, 0, kEdgeBits + kIdBits, s));
+  }
+  // ---- stage E ----
+  if (T > 0 && in.tris) {
+    hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
+    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, A->tris, keys_a_, counts_, flags_);
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, 3 * T, 0, kEdgeBits + kIdBits, s));
+    hipLaunchKernelGGL(k_low_bits, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, keys_b_, A->tinc);
+    tb = cub_bytes_;
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, counts_, A->trow, V + 1, s));
+  }
+  // ---- stage F ----
+  TileGraph G;
+  G.V = V; G.depth = depth; G.grow = A->grow; G.ginc = A->ginc; G.eij = A->eij; G.e_i2o = A->e_i2o; G.e_o2i = A->e_o2i;
+  hipLaunchKernelGGL(k_tile_pass1, dim3(ntiles), dim3(kP1Threads), lds1, s, G, leaf.lo, leaf.hi, tile_ext_, tile_meta_);
+  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_);
+  int32_t hflags[8];
+  HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
+  HIPRET(hipStreamSynchronize(s));
+  HIPRET(hipGetLastError());
+  if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
+  if (hflags[0] & 5) return hipSuccess;  // a tile does not fit (or the partition is inconsistent): not ok
+  if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)
+    return hipErrorOutOfMemory;
+  // ---- stage G ----
+  hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
+                     tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_);
+  tiles_host->resize(ntiles);
+  HIPRET(hipMemcpyAsync(tiles_host->data(), A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
+  HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
+  HIPRET(hipStreamSynchronize(s));
+  HIPRET(hipGetLastError());
+  if (hflags[0] & 8) return hipSuccess;
+  // weights for a following balanced pass come from these tiles
+  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A->v_i2o, tile_of_int_, A->tiles, w_int_);
+  *ok = true;
+  return hipGetLastError();
+}
+
+hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in,
+                                   const DevPlanArrays& A) {
+  const int n = Plan::kGrid * Plan::kGrid;
+  HIPRET(hipMemsetAsync(grid_sum_, 0, sizeof(long long) * n, s));
+  HIPRET(hipMemsetAsync(grid_cnt_, 0, sizeof(int32_t) * n, s));
+  hipLaunchKernelGGL(k_copy4, dim3(1), dim3(64), 0, s, gbbox_, grid_bounds_);
+  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, s, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, grid_bounds_,
+                     reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_);
+  hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, s, V, reinterpret_cast<unsigned long long*>(grid_sum_),
+                     grid_cnt_, grid_w_);
+  grid_tiles_ = ntiles;
+  return hipGetLastError();
+}
+
+}  // namespace flamehip

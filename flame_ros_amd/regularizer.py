@@ -180,7 +180,7 @@ class GraphRegularizer:
         _l.check(self._lib.flame_hip_get_info(self._h, key.encode(), C.byref(v)), "flame_hip_get_info")
         return v.value
 
-    _PLAN_ELEM_BYTES = {"eij": 8, "t_eij": 8, "profile": 8, "tiles": C.sizeof(_l.TileDesc)}
+    _PLAN_ELEM_BYTES = {"eij": 8, "t_eij": 8, "ew": 16, "t_ew": 16, "profile": 8, "tiles": C.sizeof(_l.TileDesc)}
 
     def plan_array(self, name, dtype):
         """Debug hook: copy of a host-side plan array (works on plan-only handles, device=-1)."""

@@ -1,0 +1,111 @@
+"""-m gpu: row f3 -- the plan built ON THE GPU (csrc/plan_dev.hip) equals the host builder's plan
+(csrc/plan.cpp) array for array: vertex / edge permutations, incidence CSR, triangle CSR, tile
+descriptors, gather lists, local edge records, incidence slots.  Also on a frame STREAM (the second
+frame balances in one pass from the integer cost-density grid kept by each builder)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from flame_ros_amd import lib as _l
+from flame_ros_amd.regularizer import GraphRegularizer, default_params
+from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = [("v_i2o", np.int32), ("v_o2i", np.int32), ("e_i2o", np.int32), ("e_o2i", np.int32),
+          ("grow", np.int32), ("ginc", np.int32), ("eij", np.int32), ("ew", np.float32),
+          ("tris", np.int32), ("trow", np.int32), ("tinc", np.int32), ("tiles", np.int32),
+          ("t_vmap", np.int32), ("t_emap", np.int32), ("t_eij", np.uint32), ("t_ew", np.float32),
+          ("t_srow", np.uint32)]
+INFO = ["path", "num_tiles", "tile_threads", "tile_ept", "tile_vpt", "tile_depth", "tile_lds_bytes"]
+
+
+def compare_plans(host, dev, what):
+    assert dev.info("plan_on_device") == 1, what
+    assert host.info("plan_on_device") == 0, what
+    for k in INFO:
+        assert host.info(k) == dev.info(k), (what, k, host.info(k), dev.info(k))
+    for name, dt in ARRAYS:
+        a, b = host.plan_array(name, dt), dev.plan_array(name, dt)
+        assert a.shape == b.shape, (what, name, a.shape, b.shape)
+        if not np.array_equal(a.view(np.uint32), b.view(np.uint32)):
+            bad = np.flatnonzero(a.view(np.uint32) != b.view(np.uint32))
+            raise AssertionError("%s: plan array %s differs at %d of %d words, first %s" % (
+                what, name, len(bad), a.size, bad[:8].tolist()))
+
+
+CASES = [
+    ("5k", dict()),
+    ("5k", dict(balance=0)),
+    ("5k", dict(tile_own=64, tile_depth=2)),
+    ("5k", dict(tile_own=300, tile_depth=6)),
+    ("tum", dict()),
+    ("euroc", dict()),
+    ("50k", dict()),
+    ("50k", dict(tile_own=100, tile_depth=3)),
+    ("200k", dict()),
+]
+
+
+@pytest.mark.parametrize("name,opts", CASES)
+def test_device_plan_equals_host_plan(gpu, name, opts):
+    g, _ = graphgen.named(name)
+    host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **opts)
+    dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, **opts)
+    compare_plans(host, dev, "%s %s" % (name, opts))
+    host.close(); dev.close()
+
+
+def test_device_plan_frame_stream(gpu):
+    """Consecutive frames of different size on ONE handle each: from the second frame on both
+    builders balance in one pass from their cost-density grid; every frame's plan is identical and
+    the solve on the device-built plan is bit-exact against the oracle."""
+    host = dev = None
+    for k, V in enumerate((20000, 20600, 19500, 20000, 5000, 5100)):
+        g = graphgen.synthetic(V, seed=40 + k)
+        if host is None:
+            host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
+            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+        else:
+            host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+            dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+        compare_plans(host, dev, "frame %d (V=%d)" % (k, V))
+        o = make_oracle(g)
+        o.solve(oracle_params(), 33)
+        dev.step(default_params(), 33)
+        x, w1, w2, q = dev.download()
+        assert_bit_equal(x, o.x, "frame %d x" % k)
+        assert_bit_equal(q, o.q, "frame %d q" % k)
+    host.close(); dev.close()
+
+
+def test_device_plan_error_conventions(gpu):
+    """Bad indices and non-finite inputs are found by the device builder's own checks."""
+    g = graphgen.synthetic(4000, seed=9)
+    bad = g.edges.copy(); bad[17, 1] = g.V
+    with pytest.raises(_l.FlameHipError) as e:
+        GraphRegularizer(g.pos, bad, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+    assert e.value.code == _l.ERR_ARG
+    bad = g.tris.copy(); bad[5, 2] = -1
+    with pytest.raises(_l.FlameHipError) as e:
+        GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=bad)
+    assert e.value.code == _l.ERR_ARG
+    z = g.z.copy(); z[100] = np.inf
+    with pytest.raises(_l.FlameHipError) as e:
+        GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, z, g.wgt, tris=g.tris)
+    assert e.value.code == _l.ERR_NAN
+    a = g.alpha.copy(); a[3] = np.nan
+    with pytest.raises(_l.FlameHipError) as e:
+        GraphRegularizer(g.pos, g.edges, a, g.beta, g.z, g.wgt, tris=g.tris)
+    assert e.value.code == _l.ERR_NAN
+
+
+def test_host_plan_still_selectable(gpu):
+    g = graphgen.synthetic(6000, seed=3)
+    o = make_oracle(g)
+    o.solve(oracle_params(), 40)
+    with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, plan_device=0) as r:
+        assert r.info("plan_on_device") == 0 and r.info("path") == 2
+        r.step(default_params(), 40)
+        assert_bit_equal(r.download(with_q=False)[0], o.x, "host plan x")
