@@ -10,7 +10,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -378,6 +381,15 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     return 0;
   hipStream_t s = g->stream;
   int rc;
+  static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[upload] %-14s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
   // ---- stage the caller's arrays ----
   if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_edges, (size_t)E)) ||
       (rc = dev_alloc(g->caps, &g->in_alpha, (size_t)E)) || (rc = dev_alloc(g->caps, &g->in_beta, (size_t)E)) ||
@@ -403,6 +415,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   HIPCHK(launch_check_finite(s, E, g->in_alpha, g->dflags));
   HIPCHK(launch_check_finite(s, E, g->in_beta, g->dflags));
   if (x0) HIPCHK(launch_check_finite(s, V, g->in_x0, g->dflags));
+  lap("stage inputs");
   // ---- plan arrays ----
   if ((rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_o2i_dev, (size_t)V)) ||
       (rc = dev_alloc(g->caps, &g->e_i2o_dev, (size_t)E)) || (rc = dev_alloc(g->caps, &g->e_o2i_dev, (size_t)E)) ||
@@ -470,6 +483,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     tile_own = std::max(16, tile_own / 2);
   }
   if (!built) return 0;
+  lap("plan build");
   if (g->opt.balance && ntiles >= 16) HIPCHK(g->planner.update_grid(s, V, ntiles, in, A));
   // ---- host-side description of the plan ----
   P.V = V; P.E = E; P.T = T;
@@ -500,6 +514,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)T)))
     return rc;
   if (T == 0) HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
+  lap("grid+state");
   return 1;
 }
 

@@ -19,8 +19,11 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 namespace flamehip {
 namespace {
@@ -114,30 +117,50 @@ __global__ void k_save_gbbox(const uint32_t* bbox, float* gbbox) {
   if (threadIdx.x < 4) gbbox[threadIdx.x] = unord_f(bbox[threadIdx.x]);
 }
 
+// Global ranks of the vertices along x and along y in the total order (coordinate, id): the order
+// of any subset along an axis is the order of these ranks, so the per-level sorts use short keys.
+__global__ __launch_bounds__(256) void k_rank_keys(int32_t V, const float2* __restrict__ pos, int axis, int vb,
+                                                   uint64_t* keys) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const float2 q = pos[v];
+  keys[v] = ((uint64_t)ord_f(axis ? q.y : q.x) << vb) | (uint64_t)v;
+}
+
+__global__ __launch_bounds__(256) void k_rank_scatter(int32_t V, const uint64_t* __restrict__ keys, int vb,
+                                                      uint32_t* rank) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p < V) rank[(uint32_t)(keys[p] & ((1ull << vb) - 1))] = (uint32_t)p;
+}
+
 __global__ __launch_bounds__(256) void k_rcb_keys(int32_t V, const int32_t* __restrict__ perm,
-                                                  const float2* __restrict__ pos,
+                                                  const uint32_t* __restrict__ rank_x,
+                                                  const uint32_t* __restrict__ rank_y,
                                                   const int32_t* __restrict__ seg_pos,
                                                   const int32_t* __restrict__ leaves,
-                                                  const uint32_t* __restrict__ bbox, uint64_t* keys) {
+                                                  const uint32_t* __restrict__ bbox, int vb, uint32_t* keys,
+                                                  uint32_t* vals) {
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= V) return;
   const int32_t s = seg_pos[p], v = perm[p];
-  uint32_t coord = 0;
+  uint32_t r = 0;
   if (leaves[s] > 1) {
     const float ex = unord_f(bbox[4 * s + 2]) - unord_f(bbox[4 * s]);
     const float ey = unord_f(bbox[4 * s + 3]) - unord_f(bbox[4 * s + 1]);
-    const float2 q = pos[v];
-    coord = ord_f(ey > ex ? q.y : q.x);
+    r = ey > ex ? rank_y[v] : rank_x[v];
+  } else {
+    r = (uint32_t)v;  // a finished segment: any fixed order
   }
-  keys[p] = ((uint64_t)s << (32 + kIdBits)) | ((uint64_t)coord << kIdBits) | (uint64_t)v;
+  keys[p] = ((uint32_t)s << vb) | r;
+  vals[p] = (uint32_t)v;
 }
 
-__global__ __launch_bounds__(256) void k_rcb_post(int32_t V, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_rcb_post(int32_t V, const uint32_t* __restrict__ vals,
                                                   int32_t* perm, const int32_t* __restrict__ w_int,
                                                   long long* wsort) {
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= V) return;
-  const int32_t v = (int32_t)(keys[p] & ((1u << kIdBits) - 1));
+  const int32_t v = (int32_t)vals[p];
   perm[p] = v;
   if (wsort) wsort[p] = w_int[v];
 }
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(kSegCap) void k_rcb_check(const int32_t* nseg, SegT
 __global__ __launch_bounds__(256) void k_tile_keys(int32_t V, const int32_t* __restrict__ perm,
                                                    const float2* __restrict__ pos,
                                                    const int32_t* __restrict__ seg_pos,
-                                                   const float* __restrict__ gb, uint64_t* keys) {
+                                                   const float* __restrict__ gb, int vb, uint64_t* keys) {
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= V) return;
   const int32_t v = perm[p];
@@ -255,18 +278,18 @@ __global__ __launch_bounds__(256) void k_tile_keys(int32_t V, const int32_t* __r
   const uint32_t qx = (uint32_t)(65535.0f * (q.x - mnx) / fmaxf(mxx - mnx, 1e-20f));
   const uint32_t qy = (uint32_t)(65535.0f * (q.y - mny) / fmaxf(mxy - mny, 1e-20f));
   const uint32_t code = spread16(qx) | (spread16(qy) << 1);
-  keys[p] = ((uint64_t)seg_pos[p] << (32 + kIdBits)) | ((uint64_t)code << kIdBits) | (uint64_t)v;
+  keys[p] = ((uint64_t)seg_pos[p] << (32 + vb)) | ((uint64_t)code << vb) | (uint64_t)v;
 }
 
-__global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t* __restrict__ keys, int vb,
                                                       int32_t* v_i2o, int32_t* v_o2i, int32_t* tile_of_int) {
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= V) return;
   const uint64_t k = keys[p];
-  const int32_t v = (int32_t)(k & ((1u << kIdBits) - 1));
+  const int32_t v = (int32_t)(k & ((1ull << vb) - 1));
   v_i2o[p] = v;
   v_o2i[v] = p;
-  tile_of_int[p] = (int32_t)(k >> (32 + kIdBits));
+  tile_of_int[p] = (int32_t)(k >> (32 + vb));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -274,8 +297,8 @@ __global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t*
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const int2* __restrict__ edges,
                                                    const int32_t* __restrict__ v_o2i,
-                                                   const int32_t* __restrict__ tile_of_int, uint64_t* keys,
-                                                   int32_t* tile_ecnt, int32_t* flags) {
+                                                   const int32_t* __restrict__ tile_of_int, int vb, int eb,
+                                                   uint64_t* keys, int32_t* tile_ecnt, int32_t* flags) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   const int2 ij = edges[e];
@@ -287,7 +310,7 @@ __global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const i
   const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
   const int32_t ti = tile_of_int[si], tj = tile_of_int[sj];
   const uint32_t bucket = 2u * (uint32_t)ti + (ti == tj ? 0u : 1u);
-  keys[e] = ((uint64_t)bucket << (kIdBits + kEdgeBits)) | ((uint64_t)si << kEdgeBits) | (uint64_t)e;
+  keys[e] = ((uint64_t)bucket << (vb + eb)) | ((uint64_t)si << eb) | (uint64_t)e;
   atomicAdd(&tile_ecnt[ti], 1);
 }
 
@@ -297,11 +320,19 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint64_t* 
                                                      const float* __restrict__ beta,
                                                      const float2* __restrict__ pos,
                                                      const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
-                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t* deg) {
+                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t* deg, int32_t V,
+                                                     int eb) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= E) return;
-  const int32_t e = (int32_t)(keys[k] & ((1u << kEdgeBits) - 1));
+  const int32_t e = (int32_t)(keys[k] & ((1ull << eb) - 1));
   const int2 ij = edges[e];
+  if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {
+    // flagged by k_edge_keys (the plan is rejected after the next sync); keep every index in range
+    e_i2o[k] = e; e_o2i[e] = k;
+    eij[k] = make_int2(0, 0);
+    ew[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
   const float2 pi = pos[ij.x], pj = pos[ij.y];
   e_i2o[k] = e;
@@ -334,20 +365,20 @@ __global__ __launch_bounds__(1024) void k_scan_small(int n, const int32_t* in, i
 // Stage D / E: incidence CSR (ascending ORIGINAL edge id per vertex), triangle CSR
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_csr_keys(int32_t E, const int2* __restrict__ eij,
-                                                  const int32_t* __restrict__ e_i2o, uint64_t* keys,
+                                                  const int32_t* __restrict__ e_i2o, int eb, uint64_t* keys,
                                                   uint32_t* vals) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= E) return;
   const int2 ij = eij[k];
   const uint64_t eo = (uint64_t)e_i2o[k];
-  keys[2 * k] = ((uint64_t)ij.x << kEdgeBits) | eo;
+  keys[2 * k] = ((uint64_t)ij.x << eb) | eo;
   vals[2 * k] = (uint32_t)k;
-  keys[2 * k + 1] = ((uint64_t)ij.y << kEdgeBits) | eo;
+  keys[2 * k + 1] = ((uint64_t)ij.y << eb) | eo;
   vals[2 * k + 1] = (uint32_t)k | 0x80000000u;
 }
 
 __global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
-                                                  const int32_t* __restrict__ v_o2i, int32_t* tris_int,
+                                                  const int32_t* __restrict__ v_o2i, int tb, int32_t* tris_int,
                                                   uint64_t* keys, int32_t* cnt, int32_t* flags) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
@@ -355,13 +386,13 @@ __global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const i
   if (vo < 0 || vo >= V) { atomicOr(&flags[0], 2); tris_int[k] = 0; keys[k] = (uint64_t)(k / 3); return; }
   const int32_t v = v_o2i[vo];
   tris_int[k] = v;
-  keys[k] = ((uint64_t)v << kEdgeBits) | (uint64_t)(k / 3);
+  keys[k] = ((uint64_t)v << tb) | (uint64_t)(k / 3);
   atomicAdd(&cnt[v], 1);
 }
 
-__global__ __launch_bounds__(256) void k_low_bits(int32_t n, const uint64_t* __restrict__ keys, int32_t* out) {
+__global__ __launch_bounds__(256) void k_low_bits(int32_t n, const uint64_t* __restrict__ keys, int bits, int32_t* out) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k < n) out[k] = (int32_t)(keys[k] & ((1u << kEdgeBits) - 1));
+  if (k < n) out[k] = (int32_t)(keys[k] & ((1ull << bits) - 1));
 }
 
 __global__ __launch_bounds__(256) void k_zero_i32(int32_t n, int32_t* p) {
@@ -839,7 +870,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
                   t = std::max<int64_t>(T + T / 4, capT_);
     const int64_t n = std::max<int64_t>(std::max<int64_t>(v, 2 * e), 3 * t);
     HIPRET(dalloc(&keys_a_, (size_t)n)); HIPRET(dalloc(&keys_b_, (size_t)n));
-    HIPRET(dalloc(&vals_a_, (size_t)(2 * e))); HIPRET(dalloc(&vals_b_, (size_t)(2 * e)));
+    HIPRET(dalloc(&vals_a_, (size_t)std::max(2 * e, 2 * v))); HIPRET(dalloc(&vals_b_, (size_t)std::max(2 * e, 2 * v)));
     HIPRET(dalloc(&seg_pos_, (size_t)v)); HIPRET(dalloc(&tile_of_int_, (size_t)v));
     HIPRET(dalloc(&w_int_, (size_t)v)); HIPRET(dalloc(&wsort_, (size_t)v)); HIPRET(dalloc(&wscan_, (size_t)v));
     HIPRET(dalloc(&counts_, (size_t)v + 2));
@@ -848,6 +879,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     size_t need = 0, b = 0;
     HIPRET(hipcub::DeviceRadixSort::SortKeys(nullptr, b, keys_a_, keys_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)(2 * e), 0, 64, nullptr)); need = std::max(need, b);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, vals_a_, vals_b_, vals_a_, vals_b_, (int)v, 0, 32, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceScan::InclusiveSum(nullptr, b, wsort_, wscan_, (int)v, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, counts_, counts_, (int)v + 1, nullptr)); need = std::max(need, b);
     if (need > cub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&cub_tmp_), need)); cub_bytes_ = need; }
@@ -878,7 +910,18 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   (void)opt;
   *ok = false;
   *index_error = false;
+  // FLAME_HIP_PLAN_TIMING=1: synchronise after every stage and print its wall time (dev aid)
+  static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+  auto tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(s);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[plan_dev] %-14s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
+    tprev = now;
+  };
   HIPRET(reserve(V, E, T, ntiles));
+  lap("reserve");
   static bool attr_set = false;
   const size_t lds1 = ((size_t)(V + 31) / 32) * 4 + kCapExt * 4 + kHash * 8;
   const size_t lds2 = lds1 + (size_t)kSortPad * 8;
@@ -898,6 +941,13 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   int32_t* nseg = st + 16 * kSegCap;  // [2]
   int32_t* perm = A->v_i2o;
   const bool weighted = weight_mode_ != 0;
+  const int vb = bits_for(V), eb = bits_for(std::max(E, 1)), tb = bits_for(std::max(T, 1));
+  uint32_t* rank_x = vals_a_;          // 2E >= V entries each (planar graphs: E >= V; reserve() sizes
+  uint32_t* rank_y = vals_a_ + capV_;  //   vals_* for max(2E, 2V))
+  uint32_t* key32_a = vals_b_;
+  uint32_t* key32_b = vals_b_ + capV_;
+  uint32_t* val32_a = reinterpret_cast<uint32_t*>(keys_a_);
+  uint32_t* val32_b = reinterpret_cast<uint32_t*>(keys_a_) + capV_;
 
   HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
   if (weight_mode_ == 2)
@@ -905,6 +955,12 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // (weight_mode_ 1: w_int_ was filled by the previous build's tiles, see below)
 
   // ---- stage A ----
+  for (int axis = 0; axis < 2; ++axis) {  // global ranks along x and y
+    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, axis, vb, keys_b_);
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_b_, keys_a_, V, 0, 32 + vb, s));
+    hipLaunchKernelGGL(k_rank_scatter, grid1(V), dim3(256), 0, s, V, keys_a_, vb, axis ? rank_y : rank_x);
+  }
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int levels = 0;
   while ((1 << levels) < ntiles) ++levels;
@@ -912,10 +968,12 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   for (int lev = 0; lev < levels; ++lev, cur ^= 1) {
     hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
     if (lev == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
-    hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox, keys_a_);
+    hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, rank_x, rank_y, seg_pos_, tab[cur].leaves, bbox,
+                       vb, key32_a, val32_a);
     size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, V, 0, std::min(64, 32 + kIdBits + lev + 1), s));
-    hipLaunchKernelGGL(k_rcb_post, grid1(V), dim3(256), 0, s, V, keys_b_, perm, w_int_, weighted ? wsort_ : nullptr);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb, key32_a, key32_b, val32_a, val32_b, V, 0,
+                                              std::min(32, vb + lev + 1), s));
+    hipLaunchKernelGGL(k_rcb_post, grid1(V), dim3(256), 0, s, V, val32_b, perm, w_int_, weighted ? wsort_ : nullptr);
     if (weighted) {
       tb = cub_bytes_;
       HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
@@ -927,48 +985,55 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   }
   hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
   const SegTab leaf = tab[cur];  // lo = vstart, hi = vstart + n_own per tile
+  lap("A rcb");
 
   // ---- stage B ----
-  hipLaunchKernelGGL(k_tile_keys, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, gbbox_, keys_a_);
+  hipLaunchKernelGGL(k_tile_keys, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, gbbox_, vb, keys_a_);
   {
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, V, 0, std::min(64, 32 + kIdBits + bits_for(ntiles)), s));
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_a_, keys_b_, V, 0, std::min(64, 32 + vb + bits_for(ntiles)), s));
   }
-  hipLaunchKernelGGL(k_vertex_order, grid1(V), dim3(256), 0, s, V, keys_b_, A->v_i2o, A->v_o2i, tile_of_int_);
+  hipLaunchKernelGGL(k_vertex_order, grid1(V), dim3(256), 0, s, V, keys_b_, vb, A->v_i2o, A->v_o2i, tile_of_int_);
 
+  lap("B morton");
   // ---- stage C ----
   hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
   hipLaunchKernelGGL(k_zero_i32, grid1(ntiles + 2), dim3(256), 0, s, ntiles + 2, estart_);
   if (E > 0) {
-    hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, keys_a_, estart_, flags_);
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, E, 0,
-                                             std::min(64, kEdgeBits + kIdBits + bits_for(2 * (int64_t)ntiles)), s));
+    hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, vb, eb, keys_a_,
+                       estart_, flags_);
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_a_, keys_b_, E, 0,
+                                             std::min(64, eb + vb + bits_for(2 * (int64_t)ntiles)), s));
     hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, keys_b_, in.edges, in.alpha, in.beta, in.pos,
-                       A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_);
+                       A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V, eb);
   }
   hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, ntiles, estart_, estart_);
   {
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, counts_, A->grow, V + 1, s));
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->grow, V + 1, s));
   }
+  lap("C edges");
   // ---- stage D ----
   if (E > 0) {
-    hipLaunchKernelGGL(k_csr_keys, grid1(E), dim3(256), 0, s, E, A->eij, A->e_i2o, keys_a_, vals_a_);
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb, keys_a_, keys_b_, vals_a_,
-                                              reinterpret_cast<uint32_t*>(A->ginc), 2 * E, 0, kEdgeBits + kIdBits, s));
+    hipLaunchKernelGGL(k_csr_keys, grid1(E), dim3(256), 0, s, E, A->eij, A->e_i2o, eb, keys_a_, vals_a_);
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_,
+                                              reinterpret_cast<uint32_t*>(A->ginc), 2 * E, 0, eb + vb, s));
   }
+  lap("D csr");
   // ---- stage E ----
   if (T > 0 && in.tris) {
     hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
-    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, A->tris, keys_a_, counts_, flags_);
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, 3 * T, 0, kEdgeBits + kIdBits, s));
-    hipLaunchKernelGGL(k_low_bits, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, keys_b_, A->tinc);
-    tb = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, counts_, A->trow, V + 1, s));
+    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, tb, A->tris,
+                       keys_a_, counts_, flags_);
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_a_, keys_b_, 3 * T, 0, tb + vb, s));
+    hipLaunchKernelGGL(k_low_bits, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, keys_b_, tb, A->tinc);
+    tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->trow, V + 1, s));
   }
+  lap("E tris");
   // ---- stage F ----
   TileGraph G;
   G.V = V; G.depth = depth; G.grow = A->grow; G.ginc = A->ginc; G.eij = A->eij; G.e_i2o = A->e_i2o; G.e_o2i = A->e_o2i;
@@ -978,6 +1043,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
+  lap("F pass1+sync");
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
   if (hflags[0] & 5) return hipSuccess;  // a tile does not fit (or the partition is inconsistent): not ok
   if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)
@@ -990,6 +1056,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
+  lap("G pass2+sync");
   if (hflags[0] & 8) return hipSuccess;
   // weights for a following balanced pass come from these tiles
   hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A->v_i2o, tile_of_int_, A->tiles, w_int_);
