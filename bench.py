@@ -258,8 +258,9 @@ def main():
         if frame_ms:
             out["host_inclusive"] = {"ms_per_frame": frame_ms, "frames_per_s": 1e3 / frame_ms,
                                      "iterations_per_s": iters * 1e3 / frame_ms,
-                                     "note": "host arrays in -> plan build (CPU) + H2D + solve + D2H, "
-                                             "one handle re-uploaded per frame; informational, never `value`"}
+                                     "plan_on_device": bool(r.info("plan_on_device")),
+                                     "note": "host arrays in -> H2D + plan build (on the GPU when plan_on_device) + solve + "
+                                             "D2H, one handle re-uploaded per frame; informational, never `value`"}
         tr = profiled_traffic("batch%d" % args.batch if args.batch else args.workload,
                               "k_tile" if path == 2 else "k_primal")
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):

@@ -20,6 +20,7 @@ PATHS = {
     "tile_small": dict(path=2, tile_own=64, tile_depth=2),
     "tile_deep": dict(path=2, tile_own=256, tile_depth=6),
     "tile_nograph": dict(path=2, use_graph=0),
+    "tile_hostplan": dict(path=2, plan_device=0),
 }
 
 
