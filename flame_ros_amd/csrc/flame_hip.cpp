@@ -156,6 +156,11 @@ struct flame_hip_graph {
   float* in_wgt = nullptr;
   float* in_x0 = nullptr;
   int32_t* in_tris = nullptr;
+  float* in_mu = nullptr;    // graph sync on the device: measured idepths, variances, predictions
+  float* in_var = nullptr;
+  float* in_pred = nullptr;
+  bool sync_on_device = false;  // the derived edge list lives in in_edges (sync.edges is stale)
+  bool beta_is_alpha = false;   // staged graph sync: beta = alpha, one buffer
   int32_t* dflags = nullptr;
   bool host_perms = true;  // plan.v_i2o / v_o2i / e_i2o / e_o2i / tris are valid on the host
   // costs
@@ -350,6 +355,8 @@ int flame_hip_graph_upload_batch(flame_hip_graph* g, int32_t num_graphs, const i
   return rc;
 }
 
+static int finish_upload(flame_hip_graph* g);
+
 // ---- device plan path (row f3): inputs are staged in the caller's order, the plan is built by
 // plan_dev.hip, the initial state is permuted by a kernel.  Returns 1 = done, 0 = not eligible /
 // could not be built there (the caller falls back to the host builder), < 0 = error. ----
@@ -372,8 +379,10 @@ int alloc_tile_arrays(void* ctx, size_t ntiles, size_t nv, size_t ne, size_t ns)
 
 static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_t* edges,
                               const float* alpha, const float* beta, const float* z, const float* wgt,
-                              const float* x0, const int32_t* tris) {
-  const int32_t V = g->V, E = g->E, T = tris ? g->T : 0;
+                              const float* x0, const int32_t* tris, bool staged = false, bool have_x0 = false) {
+  // staged: the inputs are already in the in_* device buffers (graph sync on the device)
+  const int32_t V = g->V, E = g->E, T = (tris || (staged && g->T > 0)) ? g->T : 0;
+  if (!staged) have_x0 = x0 != nullptr;
   Plan& P = g->plan;
   const PlanSizing sz = plan_sizing(g->opt, V, E);
   if (!g->plan_device || g->opt.path == FLAME_HIP_PATH_GLOBAL ||
@@ -391,6 +400,14 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     tprev = now;
   };
   // ---- stage the caller's arrays ----
+  if (staged) {
+    if ((rc = dev_alloc(g->caps, &g->dflags, 8))) return rc;
+    HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
+    HIPCHK(launch_check_finite(s, V, g->in_z, g->dflags));
+    HIPCHK(launch_check_finite(s, V, g->in_wgt, g->dflags));
+    HIPCHK(launch_check_finite(s, E, g->in_alpha, g->dflags));
+    if (have_x0) HIPCHK(launch_check_finite(s, V, g->in_x0, g->dflags));
+  } else {
   if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_edges, (size_t)E)) ||
       (rc = dev_alloc(g->caps, &g->in_alpha, (size_t)E)) || (rc = dev_alloc(g->caps, &g->in_beta, (size_t)E)) ||
       (rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) ||
@@ -415,6 +432,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   HIPCHK(launch_check_finite(s, E, g->in_alpha, g->dflags));
   HIPCHK(launch_check_finite(s, E, g->in_beta, g->dflags));
   if (x0) HIPCHK(launch_check_finite(s, V, g->in_x0, g->dflags));
+  }
   lap("stage inputs");
   // ---- plan arrays ----
   if ((rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) || (rc = dev_alloc(g->caps, &g->v_o2i_dev, (size_t)V)) ||
@@ -425,7 +443,8 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       (rc = dev_alloc(g->caps, &g->tinc, 3 * (size_t)T)))
     return rc;
   DevPlanInputs in;
-  in.pos = g->in_pos; in.edges = g->in_edges; in.alpha = g->in_alpha; in.beta = g->in_beta;
+  in.pos = g->in_pos; in.edges = g->in_edges; in.alpha = g->in_alpha;
+  in.beta = (staged && g->beta_is_alpha) ? g->in_alpha : g->in_beta;
   in.tris = T > 0 ? g->in_tris : nullptr;
   DevPlanArrays A;
   A.v_o2i = g->v_o2i_dev; A.v_i2o = g->v_i2o_dev; A.e_o2i = g->e_o2i_dev; A.e_i2o = g->e_i2o_dev;
@@ -509,7 +528,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   }
   g->cur = 0;
   if ((rc = dev_alloc(g->caps, &g->pos, V))) return rc;
-  HIPCHK(launch_init_state(s, V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, x0 ? g->in_x0 : nullptr, g->A[0],
+  HIPCHK(launch_init_state(s, V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, have_x0 ? g->in_x0 : nullptr, g->A[0],
                            g->B[0], g->pos));
   if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)T)))
     return rc;
@@ -546,6 +565,8 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   if (!g) return FLAME_HIP_ERR_ARG;
   const int32_t V = g->V, E = g->E;
   if (edges != g->sync.edges.data()) g->synced = false;
+  g->sync_on_device = false;
+  g->beta_is_alpha = false;
   if ((V > 0 && (!pos || !z || !wgt)) || (E > 0 && (!edges || !alpha || !beta)))
     return FLAME_HIP_ERR_ARG;
   g->uploaded = false;
@@ -643,6 +664,14 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
         (rc = dev_alloc(g->caps, &g->e_o2i_dev, (size_t)E)) || (rc = h2d(g->stream, g->e_o2i_dev, P.e_o2i)))
       return rc;
   }
+  return finish_upload(g);
+}
+
+// buffers every uploaded graph needs, whichever builder made its plan
+static int finish_upload(flame_hip_graph* g) {
+  const int32_t V = g->V, E = g->E;
+  const Plan& P = g->plan;
+  int rc;
   if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
   if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V))) return rc;
   if ((rc = dev_alloc(g->caps, &g->dl_v, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->dl_q, 3 * (size_t)E))) return rc;
@@ -675,7 +704,58 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     if (std::isnan(idepth_var[v])) return FLAME_HIP_ERR_NAN;
     if (!(idepth_var[v] < sp->idepth_var_max_graph)) return FLAME_HIP_ERR_ARG;  // fails the gate
   }
-  int rc = graph_sync_host(*sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, &g->sync);
+  int rc;
+  g->sync_on_device = false;
+  if (g->device >= 0 && g->plan_device && V >= 2 && T > 0 && g->opt.path != FLAME_HIP_PATH_GLOBAL) {
+    // ---- on the device: edges of the triangulation, alpha, data terms; then the device plan ----
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(wait_last_solve(g));
+    hipStream_t s = g->stream;
+    HIPCHK(hipStreamSynchronize(s));
+    float sc = 1.0f;
+    if (sp->rescale_data) {  // mean in the oracle's order (sequential, float64)
+      double acc = 0.0;
+      for (int32_t v = 0; v < V; ++v) acc += (double)idepth_mu[v];
+      sc = (float)(acc / (double)V);
+      if (!(sc > 0.0f)) sc = 1.0f;
+    }
+    if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_tris, 3 * (size_t)T)) ||
+        (rc = dev_alloc(g->caps, &g->in_mu, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_var, (size_t)V)) ||
+        (rc = dev_alloc(g->caps, &g->in_pred, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) ||
+        (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)) ||
+        (rc = dev_alloc(g->caps, &g->in_edges, 3 * (size_t)T)) || (rc = dev_alloc(g->caps, &g->in_alpha, 3 * (size_t)T)))
+      return rc;
+    HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->in_mu, idepth_mu, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->in_var, idepth_var, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    if (prediction) HIPCHK(hipMemcpyAsync(g->in_pred, prediction, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    int32_t E = 0;
+    bool index_error = false;
+    HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error));
+    if (index_error) return FLAME_HIP_ERR_ARG;
+    const bool use_pred = sp->init_with_prediction && prediction;
+    HIPCHK(g->planner.sync_data(s, V, g->in_mu, g->in_var, use_pred ? g->in_pred : nullptr, sc,
+                                sp->adaptive_data_weights, sp->init_with_prediction, g->in_z, g->in_wgt, g->in_x0));
+    g->V = V; g->E = E; g->T = T;
+    g->uploaded = false;
+    g->n_send_v = g->n_send_e = g->n_recv_v = g->n_recv_e = 0;
+    g->drop_execs();
+    g->solves_since_upload = 0;
+    g->beta_is_alpha = true;
+    rc = upload_device_plan(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, true);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      if ((rc = finish_upload(g))) return rc;
+      g->synced = true;
+      g->sync_on_device = true;
+      g->sync.scale = sc;
+      if (scale) *scale = sc;
+      return 0;
+    }
+    // not eligible for the device plan (e.g. one isolated tile): fall through to the host builder
+  }
+  rc = graph_sync_host(*sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, &g->sync);
   if (rc) return rc;
   const int32_t E = (int32_t)(g->sync.edges.size() / 2);
   if ((rc = flame_hip_graph_resize(g, V, E, T))) return rc;
@@ -692,6 +772,12 @@ int flame_hip_graph_edges(const flame_hip_graph* g, int32_t* edges) {
   if (!g || !g->uploaded) return FLAME_HIP_ERR_STATE;
   if (!g->synced) return FLAME_HIP_ERR_STATE;  // the caller supplied the edge list itself
   if (g->E > 0 && !edges) return FLAME_HIP_ERR_ARG;
+  if (g->sync_on_device) {
+    if (hipSetDevice(g->device) != hipSuccess ||
+        memcpy_sync(g->stream, edges, g->in_edges, sizeof(int2) * (size_t)g->E, hipMemcpyDeviceToHost) != hipSuccess)
+      return FLAME_HIP_ERR_HIP;
+    return 0;
+  }
   std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)g->E);
   return 0;
 }

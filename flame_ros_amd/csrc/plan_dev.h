@@ -75,6 +75,14 @@ class DevPlanner {
                    int depth, const DevPlanInputs& in, DevPlanArrays* arrays, AllocTilesFn alloc_tiles,
                    void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error);
 
+  // Graph sync on the device (row a7): unique undirected edges (i < j, lexicographic) of a
+  // triangulation + alpha = 1 / |pos_i - pos_j|; edges / alpha need 3T entries.  Synchronises (E).
+  hipError_t edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
+                             int2* edges, float* alpha, int32_t* E_out, bool* index_error);
+  // z = mu / scale, wgt = 1 or 1 / var, x0 = prediction / scale where finite (else z)
+  hipError_t sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
+                       float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0);
+
   // weights for the next build: none / from the tiles of the last build / from the cost-density grid
   void set_weights_none() { weight_mode_ = 0; }
   void set_weights_from_tiles() { weight_mode_ = 1; }

@@ -821,6 +821,59 @@ __global__ void k_copy4(const float* src, float* dst) {
   if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------
+// Graph sync on the device (row a7 / f3): the unique undirected edges of a triangulation, i < j, in
+// lexicographic order, with alpha = 1 / |pos_i - pos_j| (statement: oracle nltgv2_graph_sync).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halfedge_keys(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
+                                                       int vb, uint64_t* keys, int32_t* flags) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n3) return;
+  const int32_t t = k / 3, c = k - 3 * t;
+  const int32_t a = tris[3 * t + c], b = tris[3 * t + (c == 2 ? 0 : c + 1)];
+  if (a < 0 || b < 0 || a >= V || b >= V || a == b) {
+    atomicOr(&flags[0], 2);
+    keys[k] = ~0ull;
+    return;
+  }
+  keys[k] = ((uint64_t)min(a, b) << vb) | (uint64_t)max(a, b);
+}
+
+__global__ __launch_bounds__(256) void k_unique_flag(int32_t n, const uint64_t* __restrict__ keys, int32_t* f) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t key = keys[k];
+  f[k] = (key != ~0ull && (k == 0 || key != keys[k - 1])) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_edge_compact(int32_t n, const uint64_t* __restrict__ keys,
+                                                      const int32_t* __restrict__ f, const int32_t* __restrict__ idx,
+                                                      const float2* __restrict__ pos, int vb, int2* edges,
+                                                      float* alpha, int32_t* total) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  if (k == n - 1) total[0] = idx[k] + f[k];
+  if (!f[k]) return;
+  const uint64_t key = keys[k];
+  const int32_t i = (int32_t)(key >> vb), j = (int32_t)(key & ((1ull << vb) - 1));
+  const float2 pi = pos[i], pj = pos[j];
+  const float dx = pi.x - pj.x, dy = pi.y - pj.y;
+  edges[idx[k]] = make_int2(i, j);
+  alpha[idx[k]] = 1.0f / sqrtf(dx * dx + dy * dy);  // -ffp-contract=off: two roundings, as the oracle
+}
+
+__global__ __launch_bounds__(256) void k_sync_data(int32_t V, const float* __restrict__ mu,
+                                                   const float* __restrict__ var, const float* __restrict__ pred,
+                                                   float scale, int adaptive, int init_pred, float* z, float* wgt,
+                                                   float* x0) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const float zi = mu[v] / scale;
+  z[v] = zi;
+  wgt[v] = adaptive ? 1.0f / var[v] : 1.0f;
+  x0[v] = (init_pred && pred && isfinite(pred[v])) ? pred[v] / scale : zi;
+}
+
 template <class T>
 hipError_t dalloc(T** p, size_t n) {
   if (*p) (void)hipFree(*p);
@@ -1061,6 +1114,40 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // weights for a following balanced pass come from these tiles
   hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A->v_i2o, tile_of_int_, A->tiles, w_int_);
   *ok = true;
+  return hipGetLastError();
+}
+
+hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
+                                       int2* edges, float* alpha, int32_t* E_out, bool* index_error) {
+  *E_out = 0;
+  *index_error = false;
+  if (T <= 0) return hipSuccess;
+  const int32_t n = 3 * T;
+  HIPRET(reserve(V, n, T, 1));  // E <= 3T
+  const int vb = bits_for(V);
+  int32_t* f = reinterpret_cast<int32_t*>(vals_a_);
+  int32_t* idx = reinterpret_cast<int32_t*>(vals_b_);
+  HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(k_halfedge_keys, grid1(n), dim3(256), 0, s, n, V, tris, vb, keys_a_, flags_);
+  size_t tb = cub_bytes_;
+  HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb, keys_a_, keys_b_, n, 0, std::min(64, 2 * vb), s));
+  hipLaunchKernelGGL(k_unique_flag, grid1(n), dim3(256), 0, s, n, keys_b_, f);
+  tb = cub_bytes_;
+  HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, f, idx, n, s));
+  hipLaunchKernelGGL(k_edge_compact, grid1(n), dim3(256), 0, s, n, keys_b_, f, idx, pos, vb, edges, alpha, flags_ + 4);
+  int32_t h[8];
+  HIPRET(hipMemcpyAsync(h, flags_, sizeof(h), hipMemcpyDeviceToHost, s));
+  HIPRET(hipStreamSynchronize(s));
+  HIPRET(hipGetLastError());
+  if (h[0] & 2) { *index_error = true; return hipSuccess; }
+  *E_out = h[4];
+  return hipSuccess;
+}
+
+hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
+                                 float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0) {
+  if (V <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_sync_data, grid1(V), dim3(256), 0, s, V, mu, var, pred, scale, adaptive, init_pred, z, wgt, x0);
   return hipGetLastError();
 }
 

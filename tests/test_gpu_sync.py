@@ -30,6 +30,8 @@ def test_sync_solve_unscale_triangles(gpu, adaptive, rescale, init_pred):
         o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
         scale = r.sync_features(g.pos, g.z, var, g.tris, sp, prediction=pred)
         assert np.float32(scale) == np.float32(s["scale"])
+        assert r.info("plan_on_device") == 1  # sync + plan both ran on the GPU
+        assert np.array_equal(r.edges(), s["edges"])
         o.solve(oracle_params(), 150)
         r.step(default_params(), 150)
         so, do = o.costs(oracle_params())
