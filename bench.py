@@ -222,6 +222,19 @@ def main():
         ts = ts[1:]
         frame_ms = sorted(ts)[1]
 
+    part_info = None
+    if partition:  # per-exchange cost, measured apart from the timed region: pack + P2P + unpack
+        torch.cuda.synchronize(); dist.barrier()
+        t0x = time.perf_counter()
+        for _ in range(20):
+            ps.exchange()
+        torch.cuda.synchronize(); dist.barrier()
+        ex_us = (time.perf_counter() - t0x) / 20 * 1e6
+        sb, rb = 4 * (6 * ps.n_send[0] + 3 * ps.n_send[1]), 4 * (6 * ps.n_recv[0] + 3 * ps.n_recv[1])
+        part_info = {"halo_depth": args.halo_depth, "exchanges_per_step": max(0, -(-iters // args.halo_depth) - 1),
+                     "send_bytes_rank0": sb, "recv_bytes_rank0": rb, "peers_rank0": len(ps.peers),
+                     "exchange_us": ex_us, "own_vertices_rank0": int(ps.sub.n_own),
+                     "halo_vertices_rank0": int(len(ps.sub.vid) - ps.sub.n_own)}
     if rank == 0:
         nfr = max(args.batch, 1)
         total_iters = (1 if partition else world) * args.steps * iters * nfr
@@ -255,6 +268,8 @@ def main():
                                  "tile path keeps state in LDS across iterations, so its real HBM "
                                  "traffic is below the per-iteration algorithmic bytes."},
         }
+        if part_info:
+            out["partition"] = part_info
         if frame_ms:
             out["host_inclusive"] = {"ms_per_frame": frame_ms, "frames_per_s": 1e3 / frame_ms,
                                      "iterations_per_s": iters * 1e3 / frame_ms,

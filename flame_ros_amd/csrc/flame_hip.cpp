@@ -901,8 +901,9 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   HIPCHK(hipEventRecord(g->ev0, s));
   int launches = 0, cur_out = g->cur;
   if (num_iters > 0 && g->V > 0) {
-    if (g->use_graph && s == g->stream && g->solves_since_upload > 0) {  // a frame stream that
-      // re-uploads before every solve never pays capture + instantiate
+    if (g->use_graph && g->solves_since_upload > 0) {  // a frame stream that re-uploads before
+      // every solve never pays capture + instantiate; the captured launches replay on any stream
+      // (the subdomain solver of the multi-GPU path passes its own)
       GraphExecEntry* hit = nullptr;
       for (auto& e : g->execs)
         if (e.iters == num_iters && e.cur == g->cur && std::memcmp(&e.p, &sp, sizeof(sp)) == 0) hit = &e;
@@ -1180,8 +1181,8 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
 
 int flame_hip_halo_bytes(const flame_hip_graph* g, int64_t* send_bytes, int64_t* recv_bytes) {
   if (!g) return FLAME_HIP_ERR_ARG;
-  if (send_bytes) *send_bytes = 16 * (2 * (int64_t)g->n_send_v + g->n_send_e);
-  if (recv_bytes) *recv_bytes = 16 * (2 * (int64_t)g->n_recv_v + g->n_recv_e);
+  if (send_bytes) *send_bytes = 4 * (6 * (int64_t)g->n_send_v + 3 * (int64_t)g->n_send_e);
+  if (recv_bytes) *recv_bytes = 4 * (6 * (int64_t)g->n_recv_v + 3 * (int64_t)g->n_recv_e);
   return 0;
 }
 
@@ -1192,7 +1193,7 @@ int flame_hip_halo_pack(flame_hip_graph* g, void* send_buf_dev, void* stream) {
   HIPCHK(hipSetDevice(g->device));
   hipStream_t s = stream ? (hipStream_t)stream : g->stream;
   HIPCHK(launch_halo_pack(s, g->n_send_v, g->n_send_e, g->halo_send_v, g->halo_send_e,
-                          g->A[g->cur], g->B[g->cur], g->q[g->cur], (float4*)send_buf_dev));
+                          g->A[g->cur], g->B[g->cur], g->q[g->cur], (float*)send_buf_dev));
   return 0;
 }
 
@@ -1203,7 +1204,7 @@ int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* st
   HIPCHK(hipSetDevice(g->device));
   hipStream_t s = stream ? (hipStream_t)stream : g->stream;
   HIPCHK(launch_halo_unpack(s, g->n_recv_v, g->n_recv_e, g->halo_recv_v, g->halo_recv_e,
-                            (const float4*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
+                            (const float*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
   return 0;
 }
 

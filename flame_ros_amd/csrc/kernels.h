@@ -46,9 +46,9 @@ hipError_t launch_costs(hipStream_t s, int32_t V, int32_t E, const int2* eij, co
 // ---- halo exchange pack / unpack (multi-GPU subdomains) ----
 hipError_t launch_halo_pack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
                             const int32_t* eidx, const float4* A, const float4* B, const float4* q,
-                            float4* out);
+                            float* out);
 hipError_t launch_halo_unpack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
-                              const int32_t* eidx, const float4* in, float4* A, float4* B, float4* q);
+                              const int32_t* eidx, const float* in, float4* A, float4* B, float4* q);
 
 // ---- per-triangle stage ----
 struct TriParamsDev {

@@ -680,9 +680,9 @@ __global__ __launch_bounds__(256) void k_raster_fill(int32_t width, int32_t heig
 }
 
 // ------------------------------------------------------------------------------------------
-// Halo exchange (multi-GPU subdomains): gather the full state of listed own
-// vertices / edges into a contiguous send buffer, scatter a received buffer into halo entries.
-// Layout: nv x {A, B} float4 pairs, then ne x q float4.
+// Halo exchange (multi-GPU subdomains): gather the state that CHANGES of the listed
+// own vertices / edges into a contiguous send buffer, scatter a received buffer into halo entries.
+// Layout: nv x {x, w1, w2, xb, w1b, w2b} (24 B), then ne x {q1, q2, q3} (12 B).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_halo_pack(int32_t nv, int32_t ne,
                                                    const int32_t* __restrict__ vidx,
@@ -690,30 +690,39 @@ __global__ __launch_bounds__(256) void k_halo_pack(int32_t nv, int32_t ne,
                                                    const float4* __restrict__ A,
                                                    const float4* __restrict__ B,
                                                    const float4* __restrict__ q,
-                                                   float4* __restrict__ out) {
+                                                   float* __restrict__ out) {
   const int32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < nv) {
     const int32_t v = vidx[t];
-    out[2 * t] = A[v];
-    out[2 * t + 1] = B[v];
+    const float4 a = A[v], b = B[v];
+    float2* o = reinterpret_cast<float2*>(out + 6 * (size_t)t);  // 24-byte records: 8-byte aligned
+    o[0] = make_float2(a.x, a.y);
+    o[1] = make_float2(a.z, b.x);
+    o[2] = make_float2(b.y, b.z);
   } else if (t < nv + ne) {
-    out[2 * nv + (t - nv)] = q[eidx[t - nv]];
+    const float4 qq = q[eidx[t - nv]];
+    float* o = out + 6 * (size_t)nv + 3 * (size_t)(t - nv);
+    o[0] = qq.x; o[1] = qq.y; o[2] = qq.z;
   }
 }
 
 __global__ __launch_bounds__(256) void k_halo_unpack(int32_t nv, int32_t ne,
                                                      const int32_t* __restrict__ vidx,
                                                      const int32_t* __restrict__ eidx,
-                                                     const float4* __restrict__ in,
+                                                     const float* __restrict__ in,
                                                      float4* __restrict__ A, float4* __restrict__ B,
                                                      float4* __restrict__ q) {
   const int32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < nv) {
     const int32_t v = vidx[t];
-    A[v] = in[2 * t];
-    B[v] = in[2 * t + 1];
+    const float2* r = reinterpret_cast<const float2*>(in + 6 * (size_t)t);
+    const float2 r0 = r[0], r1 = r[1], r2 = r[2];
+    // the data term z (A.w) and the data weight (B.w) are constants the receiver already holds
+    A[v].x = r0.x; A[v].y = r0.y; A[v].z = r1.x;
+    B[v].x = r1.y; B[v].y = r2.x; B[v].z = r2.y;
   } else if (t < nv + ne) {
-    q[eidx[t - nv]] = in[2 * nv + (t - nv)];
+    const float* r = in + 6 * (size_t)nv + 3 * (size_t)(t - nv);
+    q[eidx[t - nv]] = make_float4(r[0], r[1], r[2], 0.0f);
   }
 }
 
@@ -789,14 +798,14 @@ hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height
 
 hipError_t launch_halo_pack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
                             const int32_t* eidx, const float4* A, const float4* B, const float4* q,
-                            float4* out) {
+                            float* out) {
   if (nv + ne <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_halo_pack, dim3((nv + ne + 255) / 256), dim3(256), 0, s, nv, ne, vidx, eidx, A, B, q, out);
   return hipGetLastError();
 }
 
 hipError_t launch_halo_unpack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
-                              const int32_t* eidx, const float4* in, float4* A, float4* B, float4* q) {
+                              const int32_t* eidx, const float* in, float4* A, float4* B, float4* q) {
   if (nv + ne <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_halo_unpack, dim3((nv + ne + 255) / 256), dim3(256), 0, s, nv, ne, vidx, eidx, in, A, B, q);
   return hipGetLastError();

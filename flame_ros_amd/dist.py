@@ -23,6 +23,10 @@ from dataclasses import dataclass
 
 import numpy as np
 
+# halo records (float32 words): what changes per exchange -- {x, w1, w2, xb, w1b, w2b} per vertex,
+# {q1, q2, q3} per edge (include/flame_hip.h, flame_hip_halo_pack)
+VREC, EREC = 6, 3
+
 
 # ---------------------------------------------------------------- replicas mode
 def shard_frames(num_frames, rank, world):
@@ -67,16 +71,29 @@ class Subdomain:
 
 def build_subdomain(pos, edges, part, rank, depth):
     """Own vertices of `rank` + `depth` halo rings, the local edge set, and what to receive."""
-    import scipy.sparse as sp
-    from scipy.sparse.csgraph import dijkstra
     V, E = len(pos), len(edges)
     own = np.flatnonzero(part == rank)
-    A = sp.coo_matrix((np.ones(E), (edges[:, 0], edges[:, 1])), shape=(V, V))
-    A = (A + A.T).tocsr()
-    if len(own):
-        dist = dijkstra(A, unweighted=True, indices=own, min_only=True, limit=depth)
-    else:
-        dist = np.full(V, np.inf)
+    # level-synchronous breadth-first rings from the own set over a CSR of the undirected graph:
+    # only the `depth` rings around this rank's vertices are ever touched
+    ends = np.concatenate([edges[:, 0], edges[:, 1]]).astype(np.int64)
+    nbrs = np.concatenate([edges[:, 1], edges[:, 0]]).astype(np.int64)
+    order = np.argsort(ends, kind="stable")
+    indices = nbrs[order]
+    indptr = np.zeros(V + 1, np.int64)
+    np.cumsum(np.bincount(ends, minlength=V), out=indptr[1:])
+    dist = np.full(V, np.inf)
+    dist[own] = 0
+    frontier = own
+    for r in range(1, depth + 1):
+        if len(frontier) == 0:
+            break
+        starts, stops = indptr[frontier], indptr[frontier + 1]
+        cnt = stops - starts
+        # concatenated neighbour lists of the frontier
+        idx = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+        cand = np.unique(indices[idx])
+        frontier = cand[np.isinf(dist[cand])]
+        dist[frontier] = r
     halo = np.flatnonzero((dist > 0) & (dist <= depth))
     vid = np.concatenate([own, halo]).astype(np.int64)
     ring_g = np.full(V, depth + 1, np.int64)
@@ -145,15 +162,15 @@ class PartitionedSolver:
         i32 = lambda a: np.asarray(a, np.int32)  # noqa: E731
         self.solver.halo_register(i32(send_v), i32(send_e), i32(recv_v), i32(recv_e))
 
-    # packed buffer layout: all vertex records (8 floats each, peers in order) then all edge
-    # records (4 floats each, peers in order) -> per-peer messages are two slices each
+    # packed buffer layout: all vertex records (VREC floats each, peers in order) then all edge
+    # records (EREC floats each, peers in order) -> per-peer messages are two slices each
     def _slices(self, cnt, n):
-        out, ov, oe = {}, 0, 8 * n[0]
+        out, ov, oe = {}, 0, VREC * n[0]
         for r in self.peers:
             nv, ne = cnt[r]
-            out[r] = ((ov, ov + 8 * nv), (oe, oe + 4 * ne))
-            ov += 8 * nv
-            oe += 4 * ne
+            out[r] = ((ov, ov + VREC * nv), (oe, oe + EREC * ne))
+            ov += VREC * nv
+            oe += EREC * ne
         return out
 
     def exchange(self):
@@ -168,7 +185,7 @@ class PartitionedSolver:
     def _exchange(self):
         dist = self.dist
         sbuf = self.solver.halo_pack()
-        rbuf = sbuf.new_empty(8 * self.n_recv[0] + 4 * self.n_recv[1])
+        rbuf = sbuf.new_empty(VREC * self.n_recv[0] + EREC * self.n_recv[1])
         ops, ssl, rsl = [], self._slices(self.send_cnt, self.n_send), self._slices(self.recv_cnt, self.n_recv)
         for r in self.peers:
             for a, b in ssl[r]:
@@ -225,7 +242,7 @@ class HipSubdomainSolver:
         # pack/unpack, torch copies and the RCCL P2P ops issued under stream_context().  (A NULL
         # stream would mean "the handle's own stream" to the C ABI, unordered with torch.)
         self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
-        options.setdefault("use_graph", 0)  # solves run on the torch stream, not the handle's
+        # the D-iteration local solve is captured once into a hipGraph and replayed on this stream
         self.reg = GraphRegularizer(pos, edges, alpha, beta, z, wgt, x0=x0, device=device, **options)
         self.n_send = self.n_recv = (0, 0)
 
@@ -244,7 +261,7 @@ class HipSubdomainSolver:
 
     def halo_pack(self):
         with self.stream_context():
-            buf = self.torch.empty(8 * self.n_send[0] + 4 * self.n_send[1],
+            buf = self.torch.empty(VREC * self.n_send[0] + EREC * self.n_send[1],
                                    dtype=self.torch.float32, device=self.device)
         self._l.check(self.reg._lib.flame_hip_halo_pack(self.reg._h, self._C.c_void_p(buf.data_ptr()),
                                                         self._stream()), "flame_hip_halo_pack")

@@ -187,11 +187,12 @@ int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip
 int flame_hip_download(flame_hip_graph* g, float* x, float* w1, float* w2, float* q);
 int flame_hip_download_bar(flame_hip_graph* g, float* xb, float* w1b, float* w2b);
 
-/* ---- multi-GPU subdomains: halo exchange of the FULL solver state every D
+/* ---- multi-GPU subdomains: halo exchange of the solver state every D
  * iterations.  The handle holds one subdomain (own vertices + D halo rings); the caller registers
  * which of its vertices/edges (caller's ids) other ranks need (send) and which halo entries other
  * ranks own (recv).  pack/unpack move them between the solver state and a contiguous DEVICE buffer
- * (layout: n_v x {x,w1,w2,z | xb,w1b,w2b,wgt} then n_e x {q1,q2,q3,0}, float32) that the caller
+ * (layout: n_v x {x,w1,w2,xb,w1b,w2b} then n_e x {q1,q2,q3}, float32: only what changes -- the
+ * receiver holds the data terms and weights of its halo vertices since its upload) that the caller
  * hands to RCCL (ncclSend/ncclRecv, e.g. torch.distributed P2P ops).  stream: hipStream_t or NULL
  * (= the handle's stream). */
 int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t* send_v,

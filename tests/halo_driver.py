@@ -42,12 +42,12 @@ def run_subdomains_one_gpu(g, world, depth, iters):
 
     def slices(cnt_by_peer, peers):
         nv = sum(c[0] for c in cnt_by_peer.values())
-        out, ov, oe = {}, 0, 8 * nv
+        out, ov, oe = {}, 0, fdist.VREC * nv
         for o in peers:
             a, b = cnt_by_peer[o]
-            out[o] = ((ov, ov + 8 * a), (oe, oe + 4 * b))
-            ov += 8 * a
-            oe += 4 * b
+            out[o] = ((ov, ov + fdist.VREC * a), (oe, oe + fdist.EREC * b))
+            ov += fdist.VREC * a
+            oe += fdist.EREC * b
         return out
 
     p = default_params()
@@ -64,7 +64,7 @@ def run_subdomains_one_gpu(g, world, depth, iters):
           with torch.cuda.stream(shared):
               peers = [o for o in range(world) if o != r]
               recv_cnt = {o: offs[o][r] for o in peers}          # what o sends to r
-              rbuf = torch.empty(8 * sum(c[0] for c in recv_cnt.values()) + 4 * sum(c[1] for c in recv_cnt.values()),
+              rbuf = torch.empty(fdist.VREC * sum(c[0] for c in recv_cnt.values()) + fdist.EREC * sum(c[1] for c in recv_cnt.values()),
                                  dtype=torch.float32, device="cuda:0")
               rs = slices(recv_cnt, peers)
               for o in peers:

@@ -28,18 +28,17 @@ class OracleSubdomainSolver:
 
     def halo_pack(self):
         o = self.o
-        v = np.stack([o.x, o.w1, o.w2, o.z, o.xb, o.w1b, o.w2b, o.wgt], 1)[self.sv]
-        q = np.concatenate([o.q[self.se], np.zeros((len(self.se), 1), np.float32)], 1)
+        v = np.stack([o.x, o.w1, o.w2, o.xb, o.w1b, o.w2b], 1)[self.sv]  # fdist.VREC words
+        q = o.q[self.se]                                                  # fdist.EREC words
         return torch.from_numpy(np.concatenate([v.ravel(), q.ravel()]).astype(np.float32))
 
     def halo_unpack(self, buf):
         o, b = self.o, buf.numpy()
         nv = len(self.rv)
-        v = b[:8 * nv].reshape(nv, 8)
-        for k, a in enumerate((o.x, o.w1, o.w2, None, o.xb, o.w1b, o.w2b, None)):
-            if a is not None:
-                a[self.rv] = v[:, k]
-        o.q[self.re] = b[8 * nv:].reshape(-1, 4)[:, :3]
+        v = b[:fdist.VREC * nv].reshape(nv, fdist.VREC)
+        for k, a in enumerate((o.x, o.w1, o.w2, o.xb, o.w1b, o.w2b)):
+            a[self.rv] = v[:, k]
+        o.q[self.re] = b[fdist.VREC * nv:].reshape(-1, fdist.EREC)
 
     def step(self, params, n):
         self.o.solve(params, n)
@@ -78,9 +77,9 @@ def _worker(rank, world, port, V, depth, iters, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,depth,iters", [(2, 4, 19), (3, 2, 9), (2, 1, 5)])
-def test_partitioned_solve_matches_serial_oracle(tmp_path, world, depth, iters):
-    V = 1500
+@pytest.mark.parametrize("world,depth,iters,V", [(2, 4, 19, 1500), (3, 2, 9, 1500), (2, 1, 5, 1500),
+                                                  (2, 16, 50, 6000)])  # depth 16 = the bench's default halo
+def test_partitioned_solve_matches_serial_oracle(tmp_path, world, depth, iters, V):
     out = str(tmp_path / "res.npz")
     mp.spawn(_worker, args=(world, _free_port(), V, depth, iters, out), nprocs=world, join=True)
     g = graphgen.synthetic(V, seed=11)
