@@ -57,6 +57,25 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
   return x;
 }
 
+template <int NTB, class T>
+__device__ void bitonic_sort(T* a, int m) {  // m a power of two, ascending
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < m; i += NTB) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const T x = a[i], y = a[ixj];
+          const bool asc = (i & k) == 0;
+          if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
+
 // ------------------------------------------------------------------------------------------
 // Stage A: recursive coordinate bisection, one level per round of kernels.
 // seg tables (int32, kSegCap each): lo, hi, leaves, first; two tables ping-pong per level.
@@ -256,6 +275,164 @@ __global__ __launch_bounds__(256) void k_rcb_assign(int32_t V, int32_t* seg_pos,
   seg_pos[p] = child_base[s] + ((leaves[s] > 1 && p >= mid[s]) ? 1 : 0);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Stage A, deep levels: once a segment holds <= kSubCap vertices its whole remaining bisection
+// subtree is finished by ONE workgroup in LDS (sort by (segment, rank), integer weight prefix, the
+// same split rule), instead of ~12 dependent launches per level.
+// ------------------------------------------------------------------------------------------
+constexpr int kSubCap = 8192;    // vertices of a subtree
+constexpr int kSubLeaves = 256;  // tiles of a subtree
+constexpr int kSubThreads = 1024;
+
+__global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg_cur, SegTab cur, SegTab out,
+                                                             int32_t* nseg_out, int32_t ntiles, int32_t* perm,
+                                                             int32_t* seg_pos, const float2* __restrict__ pos,
+                                                             const uint32_t* __restrict__ rank_x,
+                                                             const uint32_t* __restrict__ rank_y,
+                                                             const int32_t* __restrict__ w_int, int weighted, int vb,
+                                                             int32_t* flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int sidx = blockIdx.x, tid = threadIdx.x;
+  if (sidx == 0 && tid == 0) nseg_out[0] = ntiles;
+  if (sidx >= nseg_cur[0]) return;
+  const int32_t glo = cur.lo[sidx], ghi = cur.hi[sidx], gleaves = cur.leaves[sidx], gfirst = cur.first[sidx];
+  const int n = ghi - glo;
+  if (n > kSubCap || gleaves > kSubLeaves) { if (tid == 0) atomicOr(&flags[0], 16); return; }
+  uint64_t* packed = reinterpret_cast<uint64_t*>(smem);                 // kSubCap
+  long long* wpre = reinterpret_cast<long long*>(packed + kSubCap);     // kSubCap
+  long long* part = wpre + kSubCap;                                     // kSubThreads partial sums
+  uint8_t* segof = reinterpret_cast<uint8_t*>(part + kSubThreads);      // kSubCap
+  int32_t* tb = reinterpret_cast<int32_t*>(segof + kSubCap);            // 2 tables x 4 x kSubLeaves
+  uint32_t* bb = reinterpret_cast<uint32_t*>(tb + 8 * kSubLeaves);      // 4 x kSubLeaves
+  int32_t* mid_raw = reinterpret_cast<int32_t*>(bb + 4 * kSubLeaves);   // kSubLeaves
+  int32_t* mid_fin = mid_raw + kSubLeaves;                              // kSubLeaves
+  int32_t* cbase = mid_fin + kSubLeaves;                                // kSubLeaves
+  __shared__ int s_nloc, s_more;
+  int32_t *lo = tb, *hi = tb + kSubLeaves, *lv = tb + 2 * kSubLeaves, *fi = tb + 3 * kSubLeaves;
+  int32_t *lo2 = tb + 4 * kSubLeaves, *hi2 = tb + 5 * kSubLeaves, *lv2 = tb + 6 * kSubLeaves, *fi2 = tb + 7 * kSubLeaves;
+  for (int p = tid; p < n; p += kSubThreads) { packed[p] = (uint64_t)(uint32_t)perm[glo + p]; segof[p] = 0; }
+  if (tid == 0) { lo[0] = 0; hi[0] = n; lv[0] = gleaves; fi[0] = gfirst; s_nloc = 1; s_more = gleaves > 1; }
+  __syncthreads();
+  const int m = next_pow2(max(n, 1));
+  while (s_more) {
+    const int nloc = s_nloc;
+    for (int k = tid; k < nloc; k += kSubThreads) {
+      bb[4 * k] = bb[4 * k + 1] = 0xffffffffu; bb[4 * k + 2] = bb[4 * k + 3] = 0u;
+      mid_raw[k] = hi[k];
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += kSubThreads) {
+      const int k = segof[p];
+      if (lv[k] > 1) {
+        const float2 q = pos[(uint32_t)packed[p]];
+        const uint32_t ux = ord_f(q.x), uy = ord_f(q.y);
+        atomicMin(&bb[4 * k], ux); atomicMin(&bb[4 * k + 1], uy);
+        atomicMax(&bb[4 * k + 2], ux); atomicMax(&bb[4 * k + 3], uy);
+      }
+    }
+    __syncthreads();
+    for (int p = tid; p < m; p += kSubThreads) {
+      if (p >= n) { packed[p] = ~0ull; continue; }
+      const uint32_t id = (uint32_t)packed[p];
+      const int k = segof[p];
+      uint32_t r = id;
+      if (lv[k] > 1) {
+        const float ex = unord_f(bb[4 * k + 2]) - unord_f(bb[4 * k]);
+        const float ey = unord_f(bb[4 * k + 3]) - unord_f(bb[4 * k + 1]);
+        r = ey > ex ? rank_y[id] : rank_x[id];
+      }
+      packed[p] = ((uint64_t)(((uint32_t)k << vb) | r) << 32) | id;
+    }
+    __syncthreads();
+    bitonic_sort<kSubThreads, uint64_t>(packed, m);
+    if (weighted) {  // inclusive prefix of the weights in the sorted order
+      const int C = (m + kSubThreads - 1) / kSubThreads;
+      long long acc = 0;
+      for (int c = 0; c < C; ++c) {
+        const int p = tid * C + c;
+        if (p < n) { acc += w_int[(uint32_t)packed[p]]; wpre[p] = acc; }
+      }
+      part[tid] = acc;
+      __syncthreads();
+      for (int off = 1; off < kSubThreads; off <<= 1) {
+        const long long u = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += u;
+        __syncthreads();
+      }
+      const long long base = tid > 0 ? part[tid - 1] : 0;
+      for (int c = 0; c < C; ++c) {
+        const int p = tid * C + c;
+        if (p < n) wpre[p] += base;
+      }
+      __syncthreads();
+      for (int p = tid; p < n; p += kSubThreads) {
+        const int k = segof[p];  // segments keep their position ranges through the sort
+        const int32_t L = lv[k];
+        if (L <= 1) continue;
+        const int32_t l1 = L / 2, slo = lo[k], shi = hi[k];
+        const long long sbase = slo > 0 ? wpre[slo - 1] : 0;
+        const long long rhs = 2 * (wpre[shi - 1] - sbase) * l1;
+        const long long w = w_int[(uint32_t)packed[p]];
+        const long long before = wpre[p] - w - sbase;
+        const bool c = (2 * before + w) * L >= rhs;
+        bool cprev = false;
+        if (p > slo) {
+          const long long wp = w_int[(uint32_t)packed[p - 1]];
+          cprev = (2 * (wpre[p - 1] - wp - sbase) + wp) * L >= rhs;
+        }
+        if (c && !cprev) mid_raw[k] = p;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {  // children of every local segment (<= kSubLeaves: serial)
+      int nn = 0, more = 0;
+      for (int k = 0; k < nloc; ++k) {
+        const int32_t L = lv[k], slo = lo[k], shi = hi[k];
+        cbase[k] = nn;
+        if (L > 1) {
+          const int32_t l1 = L / 2;
+          int32_t mid;
+          if (weighted) {
+            mid = mid_raw[k];
+            mid = max(slo + l1, min(mid, shi - (L - l1)));
+            mid = max(slo, min(mid, shi));
+          } else {
+            mid = slo + (int32_t)(((long long)(shi - slo) * l1) / L);
+          }
+          mid_fin[k] = mid;
+          lo2[nn] = slo; hi2[nn] = mid; lv2[nn] = l1; fi2[nn] = fi[k];
+          lo2[nn + 1] = mid; hi2[nn + 1] = shi; lv2[nn + 1] = L - l1; fi2[nn + 1] = fi[k] + l1;
+          more |= (l1 > 1) || (L - l1 > 1);
+          nn += 2;
+        } else {
+          mid_fin[k] = shi;
+          lo2[nn] = slo; hi2[nn] = shi; lv2[nn] = L; fi2[nn] = fi[k];
+          nn += 1;
+        }
+      }
+      s_nloc = nn; s_more = more;
+    }
+    __syncthreads();
+    for (int p = tid; p < n; p += kSubThreads) {
+      const int k = segof[p];
+      segof[p] = (uint8_t)(cbase[k] + ((lv[k] > 1 && p >= mid_fin[k]) ? 1 : 0));
+    }
+    __syncthreads();
+    { int32_t* t; t = lo; lo = lo2; lo2 = t; t = hi; hi = hi2; hi2 = t; t = lv; lv = lv2; lv2 = t; t = fi; fi = fi2; fi2 = t; }
+  }
+  // every local segment is one tile now
+  for (int p = tid; p < n; p += kSubThreads) {
+    perm[glo + p] = (int32_t)(uint32_t)packed[p];
+    seg_pos[glo + p] = fi[segof[p]];
+  }
+  for (int k = tid; k < s_nloc; k += kSubThreads) {
+    const int t = fi[k];
+    out.lo[t] = glo + lo[k]; out.hi[t] = glo + hi[k]; out.leaves[t] = lv[k]; out.first[t] = t;
+  }
+}
+
 // after the last level: every segment is one tile, in tile order
 __global__ __launch_bounds__(kSegCap) void k_rcb_check(const int32_t* nseg, SegTab t, int32_t ntiles, int32_t* flags) {
   const int s = threadIdx.x;
@@ -429,24 +606,6 @@ __device__ __forceinline__ int32_t hash_lookup(const TileLds& L, int32_t gid) {
   return -1;
 }
 
-template <int NTB, class T>
-__device__ void bitonic_sort(T* a, int m) {  // m a power of two, ascending
-  const int tid = threadIdx.x;
-  for (int k = 2; k <= m; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < m; i += NTB) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const T x = a[i], y = a[ixj];
-          const bool asc = (i & k) == 0;
-          if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
-        }
-      }
-      __syncthreads();
-    }
-}
-
-__device__ __forceinline__ int next_pow2(int n) { int m = 1; while (m < n) m <<= 1; return m; }
 
 // breadth-first halo rings; returns through s_n / s_ring_end (shared), sets *fail on overflow
 template <int NTB>
@@ -1017,8 +1176,14 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int levels = 0;
   while ((1 << levels) < ntiles) ++levels;
+  // deep levels in LDS: from the first level whose segments hold <= kSubCap vertices (1.5 x margin
+  // for uneven weighted splits) and <= kSubLeaves tiles
+  int sub_level = levels;
+  if (use_subtree_)
+    for (int L = 0; L < levels; ++L)
+      if (((int64_t)V >> L) * 3 / 2 + 2 <= kSubCap && ((ntiles >> L) + 1) * 2 <= kSubLeaves) { sub_level = L; break; }
   int cur = 0;
-  for (int lev = 0; lev < levels; ++lev, cur ^= 1) {
+  for (int lev = 0; lev < sub_level; ++lev, cur ^= 1) {
     hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
     if (lev == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, rank_x, rank_y, seg_pos_, tab[cur].leaves, bbox,
@@ -1035,6 +1200,20 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_rcb_split, dim3(1), dim3(kSegCap), 0, s, nseg + cur, nseg + (cur ^ 1), tab[cur], tab[cur ^ 1],
                        mid_raw[cur], mid_raw[cur ^ 1], weighted ? 1 : 0, child_base, mid_out, bbox);
     hipLaunchKernelGGL(k_rcb_assign, grid1(V), dim3(256), 0, s, V, seg_pos_, child_base, mid_out, tab[cur].leaves);
+  }
+  if (sub_level < levels) {
+    const size_t lds_sub = (size_t)kSubCap * 16 + kSubThreads * 8 + kSubCap + (8 + 4 + 3) * kSubLeaves * 4;
+    static bool sub_attr = false;
+    if (!sub_attr) {
+      HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rcb_subtree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds_sub));
+      sub_attr = true;
+    }
+    if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
+    if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
+    hipLaunchKernelGGL(k_rcb_subtree, dim3(1 << sub_level), dim3(kSubThreads), lds_sub, s, nseg + cur, tab[cur], tab[cur ^ 1],
+                       nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb, flags_);
+    cur ^= 1;
   }
   hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
   const SegTab leaf = tab[cur];  // lo = vstart, hi = vstart + n_own per tile
@@ -1098,6 +1277,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   HIPRET(hipGetLastError());
   lap("F pass1+sync");
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
+  if (hflags[0] & 16) {  // a subtree outgrew its workgroup: every level through the global kernels
+    use_subtree_ = false;
+    return build(s, opt, V, E, T, ntiles, depth, in, A, alloc_tiles, alloc_ctx, tiles_host, ok, index_error);
+  }
   if (hflags[0] & 5) return hipSuccess;  // a tile does not fit (or the partition is inconsistent): not ok
   if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)
     return hipErrorOutOfMemory;
