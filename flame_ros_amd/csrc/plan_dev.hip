@@ -138,18 +138,19 @@ __global__ void k_save_gbbox(const uint32_t* bbox, float* gbbox) {
 
 // Global ranks of the vertices along x and along y in the total order (coordinate, id): the order
 // of any subset along an axis is the order of these ranks, so the per-level sorts use short keys.
-__global__ __launch_bounds__(256) void k_rank_keys(int32_t V, const float2* __restrict__ pos, int axis, int vb,
-                                                   uint64_t* keys) {
+__global__ __launch_bounds__(256) void k_rank_keys(int32_t V, const float2* __restrict__ pos, int axis,
+                                                   uint32_t* keys, uint32_t* vals) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
   const float2 q = pos[v];
-  keys[v] = ((uint64_t)ord_f(axis ? q.y : q.x) << vb) | (uint64_t)v;
+  keys[v] = ord_f(axis ? q.y : q.x);  // the (stable) radix sort breaks ties by input order = id
+  vals[v] = (uint32_t)v;
 }
 
-__global__ __launch_bounds__(256) void k_rank_scatter(int32_t V, const uint64_t* __restrict__ keys, int vb,
+__global__ __launch_bounds__(256) void k_rank_scatter(int32_t V, const uint32_t* __restrict__ sorted_ids,
                                                       uint32_t* rank) {
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p < V) rank[(uint32_t)(keys[p] & ((1ull << vb) - 1))] = (uint32_t)p;
+  if (p < V) rank[sorted_ids[p]] = (uint32_t)p;
 }
 
 __global__ __launch_bounds__(256) void k_rcb_keys(int32_t V, const int32_t* __restrict__ perm,
@@ -291,9 +292,12 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
                                                              const uint32_t* __restrict__ rank_x,
                                                              const uint32_t* __restrict__ rank_y,
                                                              const int32_t* __restrict__ w_int, int weighted, int vb,
-                                                             int32_t* flags) {
+                                                             int direct, int32_t* flags) {
+  // direct != 0 (the subtree is the whole graph, no global ranks were made): sort on
+  // (segment, ordered coordinate, id) packed in 62 bits; else on (segment, global rank) | id
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int sidx = blockIdx.x, tid = threadIdx.x;
+  const uint64_t idmask = direct ? ((1ull << kIdBits) - 1) : 0xffffffffull;
   if (sidx == 0 && tid == 0) nseg_out[0] = ntiles;
   if (sidx >= nseg_cur[0]) return;
   const int32_t glo = cur.lo[sidx], ghi = cur.hi[sidx], gleaves = cur.leaves[sidx], gfirst = cur.first[sidx];
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
     for (int p = tid; p < n; p += kSubThreads) {
       const int k = segof[p];
       if (lv[k] > 1) {
-        const float2 q = pos[(uint32_t)packed[p]];
+        const float2 q = pos[(uint32_t)(packed[p] & idmask)];
         const uint32_t ux = ord_f(q.x), uy = ord_f(q.y);
         atomicMin(&bb[4 * k], ux); atomicMin(&bb[4 * k + 1], uy);
         atomicMax(&bb[4 * k + 2], ux); atomicMax(&bb[4 * k + 3], uy);
@@ -334,15 +338,17 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
     __syncthreads();
     for (int p = tid; p < m; p += kSubThreads) {
       if (p >= n) { packed[p] = ~0ull; continue; }
-      const uint32_t id = (uint32_t)packed[p];
+      const uint32_t id = (uint32_t)(packed[p] & idmask);
       const int k = segof[p];
-      uint32_t r = id;
+      uint32_t r = direct ? 0u : id;
       if (lv[k] > 1) {
         const float ex = unord_f(bb[4 * k + 2]) - unord_f(bb[4 * k]);
         const float ey = unord_f(bb[4 * k + 3]) - unord_f(bb[4 * k + 1]);
-        r = ey > ex ? rank_y[id] : rank_x[id];
+        if (direct) { const float2 q = pos[id]; r = ord_f(ey > ex ? q.y : q.x); }
+        else r = ey > ex ? rank_y[id] : rank_x[id];
       }
-      packed[p] = ((uint64_t)(((uint32_t)k << vb) | r) << 32) | id;
+      packed[p] = direct ? (((uint64_t)k << (32 + kIdBits)) | ((uint64_t)r << kIdBits) | id)
+                         : (((uint64_t)(((uint32_t)k << vb) | r) << 32) | id);
     }
     __syncthreads();
     bitonic_sort<kSubThreads, uint64_t>(packed, m);
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       long long acc = 0;
       for (int c = 0; c < C; ++c) {
         const int p = tid * C + c;
-        if (p < n) { acc += w_int[(uint32_t)packed[p]]; wpre[p] = acc; }
+        if (p < n) { acc += w_int[(uint32_t)(packed[p] & idmask)]; wpre[p] = acc; }
       }
       part[tid] = acc;
       __syncthreads();
@@ -374,12 +380,12 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
         const int32_t l1 = L / 2, slo = lo[k], shi = hi[k];
         const long long sbase = slo > 0 ? wpre[slo - 1] : 0;
         const long long rhs = 2 * (wpre[shi - 1] - sbase) * l1;
-        const long long w = w_int[(uint32_t)packed[p]];
+        const long long w = w_int[(uint32_t)(packed[p] & idmask)];
         const long long before = wpre[p] - w - sbase;
         const bool c = (2 * before + w) * L >= rhs;
         bool cprev = false;
         if (p > slo) {
-          const long long wp = w_int[(uint32_t)packed[p - 1]];
+          const long long wp = w_int[(uint32_t)(packed[p - 1] & idmask)];
           cprev = (2 * (wpre[p - 1] - wp - sbase) + wp) * L >= rhs;
         }
         if (c && !cprev) mid_raw[k] = p;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
   }
   // every local segment is one tile now
   for (int p = tid; p < n; p += kSubThreads) {
-    perm[glo + p] = (int32_t)(uint32_t)packed[p];
+    perm[glo + p] = (int32_t)(uint32_t)(packed[p] & idmask);
     seg_pos[glo + p] = fi[segof[p]];
   }
   for (int k = tid; k < s_nloc; k += kSubThreads) {
@@ -474,34 +480,36 @@ __global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t*
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const int2* __restrict__ edges,
                                                    const int32_t* __restrict__ v_o2i,
-                                                   const int32_t* __restrict__ tile_of_int, int vb, int eb,
-                                                   uint64_t* keys, int32_t* tile_ecnt, int32_t* flags) {
+                                                   const int32_t* __restrict__ tile_of_int, int vb,
+                                                   uint64_t* keys, uint32_t* vals, int32_t* tile_ecnt,
+                                                   int32_t* flags) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   const int2 ij = edges[e];
   if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {  // build_plan's index check
     atomicOr(&flags[0], 2);
-    keys[e] = (uint64_t)e;
+    keys[e] = 0;
+    vals[e] = (uint32_t)e;
     return;
   }
   const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
   const int32_t ti = tile_of_int[si], tj = tile_of_int[sj];
   const uint32_t bucket = 2u * (uint32_t)ti + (ti == tj ? 0u : 1u);
-  keys[e] = ((uint64_t)bucket << (vb + eb)) | ((uint64_t)si << eb) | (uint64_t)e;
+  keys[e] = ((uint64_t)bucket << vb) | (uint64_t)si;  // stable sort: equal keys stay in edge-id order
+  vals[e] = (uint32_t)e;
   atomicAdd(&tile_ecnt[ti], 1);
 }
 
-__global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint64_t* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* __restrict__ sorted_e,
                                                      const int2* __restrict__ edges,
                                                      const float* __restrict__ alpha,
                                                      const float* __restrict__ beta,
                                                      const float2* __restrict__ pos,
                                                      const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
-                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t* deg, int32_t V,
-                                                     int eb) {
+                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t* deg, int32_t V) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= E) return;
-  const int32_t e = (int32_t)(keys[k] & ((1ull << eb) - 1));
+  const int32_t e = (int32_t)sorted_e[k];
   const int2 ij = edges[e];
   if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {
     // flagged by k_edge_keys (the plan is rejected after the next sync); keep every index in range
@@ -542,34 +550,32 @@ __global__ __launch_bounds__(1024) void k_scan_small(int n, const int32_t* in, i
 // Stage D / E: incidence CSR (ascending ORIGINAL edge id per vertex), triangle CSR
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_csr_keys(int32_t E, const int2* __restrict__ eij,
-                                                  const int32_t* __restrict__ e_i2o, int eb, uint64_t* keys,
+                                                  const int32_t* __restrict__ e_o2i, uint64_t* keys,
                                                   uint32_t* vals) {
-  const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= E) return;
+  // entry order = ORIGINAL edge id: the stable sort by vertex leaves every vertex's incidences in
+  // ascending original edge id (the summation order of the arithmetic contract)
+  const int32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int32_t k = e_o2i[e];
   const int2 ij = eij[k];
-  const uint64_t eo = (uint64_t)e_i2o[k];
-  keys[2 * k] = ((uint64_t)ij.x << eb) | eo;
-  vals[2 * k] = (uint32_t)k;
-  keys[2 * k + 1] = ((uint64_t)ij.y << eb) | eo;
-  vals[2 * k + 1] = (uint32_t)k | 0x80000000u;
+  keys[2 * e] = (uint64_t)ij.x;
+  vals[2 * e] = (uint32_t)k;
+  keys[2 * e + 1] = (uint64_t)ij.y;
+  vals[2 * e + 1] = (uint32_t)k | 0x80000000u;
 }
 
 __global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
-                                                  const int32_t* __restrict__ v_o2i, int tb, int32_t* tris_int,
-                                                  uint64_t* keys, int32_t* cnt, int32_t* flags) {
+                                                  const int32_t* __restrict__ v_o2i, int32_t* tris_int,
+                                                  uint64_t* keys, uint32_t* vals, int32_t* cnt, int32_t* flags) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
   const int32_t vo = tris[k];
-  if (vo < 0 || vo >= V) { atomicOr(&flags[0], 2); tris_int[k] = 0; keys[k] = (uint64_t)(k / 3); return; }
+  vals[k] = (uint32_t)(k / 3);  // corners in triangle order: the stable sort keeps ascending triangle id
+  if (vo < 0 || vo >= V) { atomicOr(&flags[0], 2); tris_int[k] = 0; keys[k] = 0; return; }
   const int32_t v = v_o2i[vo];
   tris_int[k] = v;
-  keys[k] = ((uint64_t)v << tb) | (uint64_t)(k / 3);
+  keys[k] = (uint64_t)v;
   atomicAdd(&cnt[v], 1);
-}
-
-__global__ __launch_bounds__(256) void k_low_bits(int32_t n, const uint64_t* __restrict__ keys, int bits, int32_t* out) {
-  const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k < n) out[k] = (int32_t)(keys[k] & ((1ull << bits) - 1));
 }
 
 __global__ __launch_bounds__(256) void k_zero_i32(int32_t n, int32_t* p) {
@@ -1082,7 +1088,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
                   t = std::max<int64_t>(T + T / 4, capT_);
     const int64_t n = std::max<int64_t>(std::max<int64_t>(v, 2 * e), 3 * t);
     HIPRET(dalloc(&keys_a_, (size_t)n)); HIPRET(dalloc(&keys_b_, (size_t)n));
-    HIPRET(dalloc(&vals_a_, (size_t)std::max(2 * e, 2 * v))); HIPRET(dalloc(&vals_b_, (size_t)std::max(2 * e, 2 * v)));
+    HIPRET(dalloc(&vals_a_, (size_t)std::max(std::max(2 * e, 2 * v), 3 * t))); HIPRET(dalloc(&vals_b_, (size_t)std::max(std::max(2 * e, 2 * v), 3 * t)));
     HIPRET(dalloc(&seg_pos_, (size_t)v)); HIPRET(dalloc(&tile_of_int_, (size_t)v));
     HIPRET(dalloc(&w_int_, (size_t)v)); HIPRET(dalloc(&wsort_, (size_t)v)); HIPRET(dalloc(&wscan_, (size_t)v));
     HIPRET(dalloc(&counts_, (size_t)v + 2));
@@ -1090,7 +1096,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     // temp storage of the library sorts / scans at the largest sizes
     size_t need = 0, b = 0;
     HIPRET(hipcub::DeviceRadixSort::SortKeys(nullptr, b, keys_a_, keys_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)(2 * e), 0, 64, nullptr)); need = std::max(need, b);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, vals_a_, vals_b_, vals_a_, vals_b_, (int)v, 0, 32, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceScan::InclusiveSum(nullptr, b, wsort_, wscan_, (int)v, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, counts_, counts_, (int)v + 1, nullptr)); need = std::max(need, b);
@@ -1153,7 +1159,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   int32_t* nseg = st + 16 * kSegCap;  // [2]
   int32_t* perm = A->v_i2o;
   const bool weighted = weight_mode_ != 0;
-  const int vb = bits_for(V), eb = bits_for(std::max(E, 1)), tb = bits_for(std::max(T, 1));
+  const int vb = bits_for(V);
   uint32_t* rank_x = vals_a_;          // 2E >= V entries each (planar graphs: E >= V; reserve() sizes
   uint32_t* rank_y = vals_a_ + capV_;  //   vals_* for max(2E, 2V))
   uint32_t* key32_a = vals_b_;
@@ -1167,13 +1173,6 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // (weight_mode_ 1: w_int_ was filled by the previous build's tiles, see below)
 
   // ---- stage A ----
-  for (int axis = 0; axis < 2; ++axis) {  // global ranks along x and y
-    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, axis, vb, keys_b_);
-    size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_b_, keys_a_, V, 0, 32 + vb, s));
-    hipLaunchKernelGGL(k_rank_scatter, grid1(V), dim3(256), 0, s, V, keys_a_, vb, axis ? rank_y : rank_x);
-  }
-  hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int levels = 0;
   while ((1 << levels) < ntiles) ++levels;
   // deep levels in LDS: from the first level whose segments hold <= kSubCap vertices (1.5 x margin
@@ -1182,6 +1181,14 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (use_subtree_)
     for (int L = 0; L < levels; ++L)
       if (((int64_t)V >> L) * 3 / 2 + 2 <= kSubCap && ((ntiles >> L) + 1) * 2 <= kSubLeaves) { sub_level = L; break; }
+  const bool need_ranks = sub_level > 0;  // a lone subtree sorts on the coordinates themselves
+  for (int axis = 0; axis < 2 && need_ranks; ++axis) {  // global ranks along x and y
+    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, axis, key32_a, val32_a);
+    size_t tb2 = cub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, key32_a, key32_b, val32_a, val32_b, V, 0, 32, s));
+    hipLaunchKernelGGL(k_rank_scatter, grid1(V), dim3(256), 0, s, V, val32_b, axis ? rank_y : rank_x);
+  }
+  hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int cur = 0;
   for (int lev = 0; lev < sub_level; ++lev, cur ^= 1) {
     hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
@@ -1212,7 +1219,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
     if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_subtree, dim3(1 << sub_level), dim3(kSubThreads), lds_sub, s, nseg + cur, tab[cur], tab[cur ^ 1],
-                       nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb, flags_);
+                       nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb,
+                       need_ranks ? 0 : 1, flags_);
     cur ^= 1;
   }
   hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
@@ -1232,13 +1240,13 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
   hipLaunchKernelGGL(k_zero_i32, grid1(ntiles + 2), dim3(256), 0, s, ntiles + 2, estart_);
   if (E > 0) {
-    hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, vb, eb, keys_a_,
-                       estart_, flags_);
+    hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, vb, keys_a_,
+                       vals_a_, estart_, flags_);
     size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_a_, keys_b_, E, 0,
-                                             std::min(64, eb + vb + bits_for(2 * (int64_t)ntiles)), s));
-    hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, keys_b_, in.edges, in.alpha, in.beta, in.pos,
-                       A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V, eb);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_, vals_b_, E, 0,
+                                              std::min(64, vb + bits_for(2 * (int64_t)ntiles)), s));
+    hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, vals_b_, in.edges, in.alpha, in.beta, in.pos,
+                       A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V);
   }
   hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, ntiles, estart_, estart_);
   {
@@ -1248,20 +1256,20 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   lap("C edges");
   // ---- stage D ----
   if (E > 0) {
-    hipLaunchKernelGGL(k_csr_keys, grid1(E), dim3(256), 0, s, E, A->eij, A->e_i2o, eb, keys_a_, vals_a_);
+    hipLaunchKernelGGL(k_csr_keys, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, keys_a_, vals_a_);
     size_t tb2 = cub_bytes_;
     HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_,
-                                              reinterpret_cast<uint32_t*>(A->ginc), 2 * E, 0, eb + vb, s));
+                                              reinterpret_cast<uint32_t*>(A->ginc), 2 * E, 0, vb, s));
   }
   lap("D csr");
   // ---- stage E ----
   if (T > 0 && in.tris) {
     hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
-    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, tb, A->tris,
-                       keys_a_, counts_, flags_);
+    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, A->tris,
+                       keys_a_, vals_a_, counts_, flags_);
     size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_a_, keys_b_, 3 * T, 0, tb + vb, s));
-    hipLaunchKernelGGL(k_low_bits, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, keys_b_, tb, A->tinc);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_,
+                                              reinterpret_cast<uint32_t*>(A->tinc), 3 * T, 0, vb, s));
     tb2 = cub_bytes_;
     HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->trow, V + 1, s));
   }
