@@ -481,8 +481,7 @@ __global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t*
 __global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const int2* __restrict__ edges,
                                                    const int32_t* __restrict__ v_o2i,
                                                    const int32_t* __restrict__ tile_of_int, int vb,
-                                                   uint64_t* keys, uint32_t* vals, int32_t* tile_ecnt,
-                                                   int32_t* flags) {
+                                                   uint64_t* keys, uint32_t* vals, int32_t* flags) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   const int2 ij = edges[e];
@@ -497,11 +496,11 @@ __global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const i
   const uint32_t bucket = 2u * (uint32_t)ti + (ti == tj ? 0u : 1u);
   keys[e] = ((uint64_t)bucket << vb) | (uint64_t)si;  // stable sort: equal keys stay in edge-id order
   vals[e] = (uint32_t)e;
-  atomicAdd(&tile_ecnt[ti], 1);
 }
 
 __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* __restrict__ sorted_e,
-                                                     const int2* __restrict__ edges,
+                                                     const uint64_t* __restrict__ sorted_keys, int vb,
+                                                     int32_t* estart, const int2* __restrict__ edges,
                                                      const float* __restrict__ alpha,
                                                      const float* __restrict__ beta,
                                                      const float2* __restrict__ pos,
@@ -511,6 +510,10 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
   if (k >= E) return;
   const int32_t e = (int32_t)sorted_e[k];
   const int2 ij = edges[e];
+  {  // first edge of every owner tile (tiles without edges are filled in by k_estart_fill)
+    const int32_t t = (int32_t)((sorted_keys[k] >> vb) >> 1);
+    if (k == 0 || (int32_t)((sorted_keys[k - 1] >> vb) >> 1) != t) estart[t] = k;
+  }
   if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {
     // flagged by k_edge_keys (the plan is rejected after the next sync); keep every index in range
     e_i2o[k] = e; e_o2i[e] = k;
@@ -524,26 +527,15 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
   e_o2i[e] = k;
   eij[k] = make_int2(si, sj);
   ew[k] = make_float4(alpha[e], beta[e], pi.x - pj.x, pi.y - pj.y);
-  atomicAdd(&deg[si], 1);
-  atomicAdd(&deg[sj], 1);
+  (void)deg;
 }
 
-// exclusive scan of n <= 1024 + 1 ints in one block: out[i] = sum_{j<i} in[j], out[n] = total
-__global__ __launch_bounds__(1024) void k_scan_small(int n, const int32_t* in, int32_t* out) {
-  __shared__ int32_t sc[1024];
-  const int i = threadIdx.x;
-  const int32_t v = i < n ? in[i] : 0;
-  sc[i] = v;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    const int32_t u = i >= off ? sc[i - off] : 0;
-    __syncthreads();
-    sc[i] += u;
-    __syncthreads();
-  }
-  if (i < n) out[i] = sc[i] - v;
-  if (i == n - 1) out[n] = sc[i];
-  if (n == 0 && i == 0) out[0] = 0;
+// estart[t] = first internal edge owned by tile t; tiles that own no edge take the next tile's start
+__global__ void k_estart_fill(int ntiles, int32_t E, int32_t* estart) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  estart[ntiles] = E;
+  for (int t = ntiles - 1; t >= 0; --t)
+    if (estart[t] < 0) estart[t] = estart[t + 1];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -578,9 +570,16 @@ __global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const i
   atomicAdd(&cnt[v], 1);
 }
 
-__global__ __launch_bounds__(256) void k_zero_i32(int32_t n, int32_t* p) {
-  const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k < n) p[k] = 0;
+// CSR row offsets from the sorted row keys: row[u] = first entry whose key is >= u, row[V] = n
+__global__ __launch_bounds__(256) void k_row_offsets(int32_t n, const uint64_t* __restrict__ sorted_keys, int32_t V,
+                                                     int32_t* row) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = (int32_t)sorted_keys[i];
+  const int32_t prev = i > 0 ? (int32_t)sorted_keys[i - 1] : -1;
+  for (int32_t u = prev + 1; u <= v; ++u) row[u] = i;
+  if (i == n - 1)
+    for (int32_t u = v + 1; u <= V; ++u) row[u] = n;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1237,22 +1236,17 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
 
   lap("B morton");
   // ---- stage C ----
-  hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
-  hipLaunchKernelGGL(k_zero_i32, grid1(ntiles + 2), dim3(256), 0, s, ntiles + 2, estart_);
+  HIPRET(hipMemsetAsync(estart_, 0xff, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   if (E > 0) {
     hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, vb, keys_a_,
-                       vals_a_, estart_, flags_);
+                       vals_a_, flags_);
     size_t tb2 = cub_bytes_;
     HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_, vals_b_, E, 0,
                                               std::min(64, vb + bits_for(2 * (int64_t)ntiles)), s));
-    hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, vals_b_, in.edges, in.alpha, in.beta, in.pos,
-                       A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V);
+    hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, vals_b_, keys_b_, vb, estart_, in.edges, in.alpha,
+                       in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V);
   }
-  hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, ntiles, estart_, estart_);
-  {
-    size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->grow, V + 1, s));
-  }
+  hipLaunchKernelGGL(k_estart_fill, dim3(1), dim3(64), 0, s, ntiles, E, estart_);
   lap("C edges");
   // ---- stage D ----
   if (E > 0) {
@@ -1260,18 +1254,19 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     size_t tb2 = cub_bytes_;
     HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_,
                                               reinterpret_cast<uint32_t*>(A->ginc), 2 * E, 0, vb, s));
+    hipLaunchKernelGGL(k_row_offsets, grid1(2 * (int64_t)E), dim3(256), 0, s, 2 * E, keys_b_, V, A->grow);
+  } else {
+    HIPRET(hipMemsetAsync(A->grow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
   }
   lap("D csr");
   // ---- stage E ----
   if (T > 0 && in.tris) {
-    hipLaunchKernelGGL(k_zero_i32, grid1(V + 2), dim3(256), 0, s, V + 2, counts_);
     hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, A->tris,
                        keys_a_, vals_a_, counts_, flags_);
     size_t tb2 = cub_bytes_;
     HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_,
                                               reinterpret_cast<uint32_t*>(A->tinc), 3 * T, 0, vb, s));
-    tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->trow, V + 1, s));
+    hipLaunchKernelGGL(k_row_offsets, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, keys_b_, V, A->trow);
   }
   lap("E tris");
   // ---- stage F ----
