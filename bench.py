@@ -58,21 +58,40 @@ def parity_check(g, iters, device, opts):
             "oracle_smoothness_cost": so, "oracle_data_cost": do}
 
 
-def profiled_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/
-    collect.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH x2 gfx950 correction).  PMC counters
-    cannot be read inside an un-profiled run, so this is the figure of the last committed profile
-    of the same workload, or None."""
+def kernel_src_sha():
+    """Hash of the sources the committed PMC passes belong to (profiles/summarize.py writes the same):
+    counters of an older kernel are not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/common.h", "flame_ros_amd/csrc/plan.cpp",
+                "flame_ros_amd/csrc/plan_dev.hip", "flame_ros_amd/csrc/flame_hip.cpp"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_counters(workload, kernel):
+    """HBM bytes per launch of `kernel` (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950
+    correction) and its LDS counters per launch, from the newest committed rocprofv3 PMC summary of
+    the same workload (profiles/collect.sh).  PMC counters cannot be read inside an un-profiled run;
+    the summary is only used when it was taken from THESE sources (kernel_src_sha), else None."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_summary.json" % workload))):
         try:
             d = json.load(open(f))
-            for k, v in d.get("traffic_bytes_per_launch", {}).items():
-                if kernel in k:
-                    best = {"bytes_per_launch": v, "source": os.path.relpath(f, ROOT)}
         except Exception:
-            pass
+            continue
+        rec = {"source": os.path.relpath(f, ROOT), "kernel_src_sha": d.get("kernel_src_sha"), "bytes_per_launch": None,
+               "lds": None}
+        for k, v in d.get("traffic_bytes_per_launch", {}).items():
+            if kernel in k:
+                rec["bytes_per_launch"] = v
+        for k, v in d.get("lds_per_launch", {}).items():
+            if kernel in k:
+                rec["lds"] = v
+        best = rec
+    if best and best["kernel_src_sha"] != kernel_src_sha():
+        return {"source": best["source"], "stale": True, "bytes_per_launch": None, "lds": None}
     return best
 
 
@@ -264,9 +283,11 @@ def main():
                          "launch_us": launch_us, "iters_per_launch": iters_per_launch,
                          "alg_bytes_per_iter": alg_bytes_iter,
                          "note": "achieved = (84E+60V) x iterations per launch / mean launch "
-                                 "duration (HIP events on the solve stream, incl. launch gaps). The "
-                                 "tile path keeps state in LDS across iterations, so its real HBM "
-                                 "traffic is below the per-iteration algorithmic bytes."},
+                                 "duration (HIP events on the solve stream, incl. launch gaps): the "
+                                 "contract's figure. The tile path keeps state in LDS across iterations, "
+                                 "so it is NOT HBM-bound: see measured_hbm_gbps (PMC traffic / launch "
+                                 "time), blocked_floor_bytes_per_launch and the lds block for what "
+                                 "limits it."},
         }
         if part_info:
             out["partition"] = part_info
@@ -276,11 +297,39 @@ def main():
                                      "plan_on_device": bool(r.info("plan_on_device")),
                                      "note": "host arrays in -> H2D + plan build (on the GPU when plan_on_device) + solve + "
                                              "D2H, one handle re-uploaded per frame; informational, never `value`"}
-        tr = profiled_traffic("batch%d" % args.batch if args.batch else args.workload,
-                              "k_tile" if path == 2 else "k_primal")
+        rl = out["roofline"]
+        if path == 2 and not args.batch:
+            # what a temporally blocked launch has to move at least: every tile reads its local
+            # state + constants once and writes what it owns (per-iteration algorithmic bytes do
+            # not apply to a kernel that keeps d iterations on chip)
+            nv, ne = r.info("tile_ext_vertices"), r.info("tile_loc_edges")
+            floor = nv * (32 + 8) + ne * (16 + 28) + g.V * 32 + g.E * 16
+            rl["blocked_floor_bytes_per_launch"] = floor
+            rl["halo_redundancy"] = {"vertices": nv / g.V, "edges": ne / max(g.E, 1)}
+        tr = profiled_counters("batch%d" % args.batch if args.batch else args.workload,
+                               "k_tile" if path == 2 else "k_primal")
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
-            out["roofline"]["traffic"] = tr["bytes_per_launch"]
-            out["roofline"]["traffic_source"] = tr["source"]
+            rl["traffic_source"] = tr["source"] + (" (stale: other kernel sources, not quoted)" if tr.get("stale") else "")
+            if tr.get("bytes_per_launch"):
+                rl["traffic"] = tr["bytes_per_launch"]
+                rl["measured_hbm_gbps"] = tr["bytes_per_launch"] / (launch_us * 1e-6) / 1e9
+                rl["measured_hbm_frac"] = rl["measured_hbm_gbps"] / HBM_PEAK_GBPS
+                if rl.get("blocked_floor_bytes_per_launch"):
+                    rl["traffic_over_blocked_floor"] = tr["bytes_per_launch"] / rl["blocked_floor_bytes_per_launch"]
+            if tr.get("lds"):
+                L = tr["lds"]
+                ntl = max(r.info("num_tiles"), 1)
+                cus = 256.0
+                act = L.get("SQ_LDS_IDX_ACTIVE", 0.0) / min(ntl, cus)        # LDS-array cycles per busy CU
+                # issue floor from the guide's LDS table (cycles per wave-instruction): the kernel's
+                # LDS instructions are ds_read_b128 (4) and ds_write_b96 (array 8); take 4 as the floor
+                rl["lds"] = {"idx_active_cycles_per_cu_launch": act,
+                             "bank_conflict_cycles_per_cu_launch": L.get("SQ_LDS_BANK_CONFLICT", 0.0) / min(ntl, cus),
+                             "bank_conflict_share": L.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(L.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
+                             "insts_lds_per_cu_launch": L.get("SQ_INSTS_LDS", 0.0) / min(ntl, cus),
+                             "issue_floor_cycles_per_cu_launch": 4.0 * L.get("SQ_INSTS_LDS", 0.0) / min(ntl, cus),
+                             "note": "SQ_* from a separate rocprofv3 --pmc pass; floor = 4 LDS-array cycles per "
+                                     "wave-instruction (ds_read_b128, conflict-free; MI355X guide LDS table)"}
         if args.batch:
             out["metric"] = "primal-dual iterations/sec over a batch of %d independent %d-vertex graphs" % (
                 args.batch, frames[0].V)

@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lroctx64"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

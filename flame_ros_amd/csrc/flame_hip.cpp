@@ -9,6 +9,7 @@
 #include "../../include/flame_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <roctracer/roctx.h>
 
 #include <chrono>
 #include <cmath>
@@ -34,6 +35,12 @@ using namespace flamehip;
   } while (0)
 
 namespace {
+
+// roctx range over one ABI call (visible in rocprofv3 --marker-trace; SURVEY.md 5 "tracing")
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { roctxRangePush(name); }
+  ~RoctxRange() { roctxRangePop(); }
+};
 
 struct GraphExecEntry {
   int32_t iters;
@@ -562,6 +569,7 @@ static int ensure_host_perms(flame_hip_graph* g) {
 int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* edges,
                            const float* alpha, const float* beta, const float* z,
                            const float* wgt, const float* x0, const int32_t* tris) {
+  RoctxRange roctx_("flame_hip_graph_upload");
   if (!g) return FLAME_HIP_ERR_ARG;
   const int32_t V = g->V, E = g->E;
   if (edges != g->sync.edges.data()) g->synced = false;
@@ -697,6 +705,7 @@ int32_t flame_hip_feature_gate(int32_t n, const float* idepth_var, float var_max
 int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, int32_t V, int32_t T,
                          const float* pos, const float* idepth_mu, const float* idepth_var,
                          const int32_t* tris, const float* prediction, float* scale) {
+  RoctxRange roctx_("flame_hip_graph_sync");
   if (!g || !sp || V < 0 || T < 0) return FLAME_HIP_ERR_ARG;
   if ((V > 0 && (!pos || !idepth_mu || !idepth_var)) || (T > 0 && !tris)) return FLAME_HIP_ERR_ARG;
   if (!all_finite(pos, 2 * (size_t)V) || !all_finite(idepth_mu, V)) return FLAME_HIP_ERR_NAN;
@@ -886,6 +895,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
 
 int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_iters,
                     void* stream) {
+  RoctxRange roctx_("flame_hip_solve");
   int rc = require_device(g);
   if (rc) return rc;
   if (!p || num_iters < 0) return FLAME_HIP_ERR_ARG;
@@ -965,6 +975,7 @@ int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches) {
 }
 
 int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smooth, double* data) {
+  RoctxRange roctx_("flame_hip_costs");
   int rc = require_device(g);
   if (rc) return rc;
   if (!p) return FLAME_HIP_ERR_ARG;
@@ -986,6 +997,7 @@ static void fill_tri_params(const float Kinv[9], const flame_hip_tri_params* tp,
 
 int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
                         float* vtx_normals, uint8_t* tri_valid, float* tri_normals) {
+  RoctxRange roctx_("flame_hip_triangles");
   int rc = require_device(g);
   if (rc) return rc;
   if (!Kinv || !tp) return FLAME_HIP_ERR_ARG;
@@ -1117,6 +1129,7 @@ int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip
 }
 
 static int download_impl(flame_hip_graph* g, bool bar, float* a0, float* a1, float* a2, float* q) {
+  RoctxRange roctx_("flame_hip_download");
   int rc = require_device(g);
   if (rc) return rc;
   if ((rc = flame_hip_sync(g))) return rc;

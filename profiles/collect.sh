@@ -1,15 +1,17 @@
 #!/bin/bash
 # profiles/collect.sh <round-tag> [bench args...] -- run on the GPU box (gpurun).  Produces under
-# gpurun_out/<tag>/: the rocprofv3 kernel-trace stats of `python bench.py` and two SEPARATE PMC
-# passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md "HBM" prescribes, then a summary
-# (summary.md + kernel_stats.csv) that is copied by hand into profiles/.
+# gpurun_out/<tag>/: the rocprofv3 kernel-trace stats of `python bench.py`, two SEPARATE PMC passes
+# for the HBM traffic (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md "HBM" prescribes, one PMC pass
+# for the LDS counters, then a summary (summary.md / summary.json / kernel_stats.csv) that is copied
+# by hand into profiles/.  Every rocprofv3 run uses --kernel-trace only (no sys/hip/hsa trace).
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-tag=${1:-r01}; shift
+tag=${1:-r02}; shift
 out=gpurun_out/$tag; mkdir -p $out
 BENCH="python bench.py --no-cpu --steps 10 --warmup 2 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- $BENCH > $out/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- $BENCH > $out/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- $BENCH > $out/bench_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_lds -o p -- $BENCH > $out/bench_lds.log 2>&1
 python bench.py --steps 10 --warmup 2 $* > $out/bench.json 2> $out/bench.err
 python profiles/summarize.py $out

@@ -55,6 +55,36 @@ for k, t in traffic.items():
     total = (2 * fe + wr) * 1024
     summary[k] = total
     lines.append("| `%s` | %.1f | %.0f | %.1f | %.3f |" % (k[:70], fe, 2 * fe * 1024, wr, total / 1e6))
+# LDS counters of the dominant kernel (one separate PMC pass), per launch and per CU
+lds = {}
+f = find("pmc_lds", "*counter_collection.csv")
+if f:
+    acc, disp = defaultdict(lambda: defaultdict(float)), defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[r["Kernel_Name"]].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
+    lines.append("\n## LDS counters (separate --pmc pass), per launch, summed over the chip\n")
+    lines.append("| kernel | launches | SQ_LDS_IDX_ACTIVE | SQ_LDS_BANK_CONFLICT | conflict share | SQ_INSTS_LDS | SQ_WAIT_INST_LDS | SQ_ACTIVE_INST_LDS | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES |\n|---|---|---|---|---|---|---|---|---|---|")
+    for k, c in acc.items():
+        n = max(len(disp[k]), 1)
+        if c.get("SQ_INSTS_LDS", 0) <= 0:
+            continue
+        per = {name: v / n for name, v in c.items()}
+        lds[k] = dict(per, launches=n)
+        act = per.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        lines.append("| `%s` | %d | %.4g | %.4g | %.2f | %.4g | %.4g | %.4g | %.4g | %.4g |" % (
+            k[:60], n, act, per.get("SQ_LDS_BANK_CONFLICT", 0), per.get("SQ_LDS_BANK_CONFLICT", 0) / max(act, 1),
+            per.get("SQ_INSTS_LDS", 0), per.get("SQ_WAIT_INST_LDS", 0), per.get("SQ_ACTIVE_INST_LDS", 0),
+            per.get("SQ_WAVE_CYCLES", 0), per.get("SQ_BUSY_CYCLES", 0)))
+
+# hash of the sources the counters belong to: bench.py only quotes them while it still matches
+import hashlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/common.h", "flame_ros_amd/csrc/plan.cpp",
+            "flame_ros_amd/csrc/plan_dev.hip", "flame_ros_amd/csrc/flame_hip.cpp"):
+    h.update(open(os.path.join(root, rel), "rb").read())
+src_sha = h.hexdigest()[:16]
 bj = os.path.join(d, "bench.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     try:
@@ -62,7 +92,7 @@ if os.path.exists(bj) and os.path.getsize(bj):
         lines.append("\n## bench.py line (un-profiled run)\n\n```json\n%s\n```" % json.dumps(b, indent=1))
     except Exception as e:  # noqa
         lines.append("\n(bench.json unreadable: %s)" % e)
-json.dump({"traffic_bytes_per_launch": summary, "kernels": [dict(zip(
+json.dump({"kernel_src_sha": src_sha, "lds_per_launch": lds, "traffic_bytes_per_launch": summary, "kernels": [dict(zip(
     ("kernel", "calls", "avg_us", "min_us", "median_us", "max_us", "total_ms"), r)) for r in rows]},
     open(os.path.join(d, "summary.json"), "w"), indent=1)
 open(os.path.join(d, "summary.md"), "w").write("\n".join(lines) + "\n")

@@ -272,3 +272,19 @@ def test_triangle_stage_known_answers():
     x4 = x.copy(); x4[1] = np.nan
     tn4, tv4, vn4 = triangles(tp, Kinv, pos, x4, tris)
     assert tv4.tolist() == [0, 0, 0] and np.all(tn4 == 0) and np.all(np.isfinite(vn4))
+
+
+def test_oracle_is_clean_under_asan_ubsan(tmp_path):
+    """The oracle compiled with -fsanitize=address,undefined runs every entry point on a small
+    graph without a report (sanitizer build of the CPU checker)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-ffp-contract=off", "-fopenmp", os.path.join(root, "tests", "cpp", "oracle_sanitize.c"),
+                           os.path.join(root, "oracle", "nltgv2_oracle.c"), "-lm", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", OMP_NUM_THREADS="2")
+    p = subprocess.run([exe], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr[-3000:])
+    assert p.stdout.startswith("E=")
