@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-balance", action="store_true")
     ap.add_argument("--order-mode", type=int, default=-1)
+    ap.add_argument("--host-plan", action="store_true", help="build the plan with the host builder")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "partition"],
@@ -155,6 +156,7 @@ def main():
     if args.tile_threads: opts["tile_threads"] = args.tile_threads
     if args.no_graph: opts["use_graph"] = 0
     if args.no_balance: opts["balance"] = 0
+    if args.host_plan: opts["plan_device"] = 0
     if args.order_mode >= 0: opts["order_mode"] = args.order_mode
     p = default_params()
     if partition:

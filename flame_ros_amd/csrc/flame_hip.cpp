@@ -462,10 +462,11 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   int tile_own = sz.tile_own;
   const int depth = sz.depth;
   bool balanced = false, built = false;
+  int refine_left = 0;
   int ntiles = 0, cfg_nt = 0, cfg_ept = 0, cfg_vpt = 0;
   int64_t lds_max = 0;
   std::vector<TileDesc>& tiles = P.tiles;
-  for (int attempt = 0; attempt < 7 && !built; ++attempt) {
+  for (int attempt = 0; attempt < 7 + kBalanceRefinePasses && !built; ++attempt) {
     ntiles = (V + tile_own - 1) / tile_own;
     if (ntiles < 2) return 0;
     if (!balanced) {
@@ -499,13 +500,22 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     }
     if (ok && g->opt.balance && !balanced && ntiles >= 16) {
       balanced = true;
-      g->planner.set_weights_from_tiles();  // second, cost-weighted pass with the same tile count
+      refine_left = kBalanceRefinePasses;
+      HIPCHK(g->planner.weights_from_tiles(s, V, A));  // second, cost-weighted pass, same tile count
+      continue;
+    }
+    if (ok && balanced && refine_left > 0 && ntiles >= 16) {  // refinement passes (plan.cpp)
+      --refine_left;
+      long long total = 0;
+      for (const TileDesc& D : tiles) total += (long long)D.e_loc + 2 * (long long)D.n_ext;
+      HIPCHK(g->planner.weights_scale_by_tiles(s, V, ntiles, total, A));
       continue;
     }
     if (ok) { built = true; break; }
     // did not fit: smaller tiles, plain bisection again
     g->planner.drop_grid();
     balanced = false;
+    refine_left = 0;
     tile_own = std::max(16, tile_own / 2);
   }
   if (!built) return 0;

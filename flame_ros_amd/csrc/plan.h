@@ -84,6 +84,9 @@ struct Plan {
   int32_t wgrid_tiles = 0;   // tile count the field was built for
 };
 
+// cost-balance refinement passes after the first weighted bisection (first upload of a handle only)
+constexpr int kBalanceRefinePasses = 2;
+
 // Tile sizing shared by the host and the device builder (measured on MI355X).
 struct PlanSizing {
   int auto_own = 0, auto_depth = 0;  // what "auto" resolves to

@@ -85,8 +85,12 @@ class DevPlanner {
 
   // weights for the next build: none / from the tiles of the last build / from the cost-density grid
   void set_weights_none() { weight_mode_ = 0; }
-  void set_weights_from_tiles() { weight_mode_ = 1; }
   void set_weights_from_grid() { weight_mode_ = 2; }
+  // weights of the next build from the tiles of the last one: their cost density (second pass),
+  // or the current weights scaled by tile cost / mean tile cost (refinement passes)
+  hipError_t weights_from_tiles(hipStream_t s, int32_t V, const DevPlanArrays& arrays);
+  hipError_t weights_scale_by_tiles(hipStream_t s, int32_t V, int ntiles, long long total_cost,
+                                    const DevPlanArrays& arrays);
   // records the cost-density grid of the last build (device side, integer); grid_tiles() then
   // returns the tile count it was made for
   hipError_t update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in, const DevPlanArrays& arrays);

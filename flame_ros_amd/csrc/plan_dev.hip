@@ -938,6 +938,20 @@ __global__ __launch_bounds__(256) void k_weights_from_tiles(int32_t V, const int
   if (k < V) w_int[v_i2o[k]] = tile_weight_dev(tiles[tile_of_int[k]]);
 }
 
+// refinement pass: w_v <- w_v * cost(tile of v) * ntiles / total cost (plan.cpp, "refine weights")
+__global__ __launch_bounds__(256) void k_weights_scale(int32_t V, const int32_t* __restrict__ v_i2o,
+                                                       const int32_t* __restrict__ tile_of_int,
+                                                       const TileDesc* __restrict__ tiles, int32_t ntiles,
+                                                       long long total, int32_t* w_int) {
+  const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= V) return;
+  const TileDesc& D = tiles[tile_of_int[k]];
+  const long long cost = (long long)D.e_loc + 2 * (long long)D.n_ext;
+  const int32_t v = v_i2o[k];
+  const long long w = (long long)w_int[v] * cost * ntiles / max(total, 1ll);
+  w_int[v] = (int32_t)min(1ll << 28, max(1ll, w));
+}
+
 __device__ __forceinline__ int grid_cell_dev(const float* b, float2 q) {
   const float fx = (q.x - b[0]) / fmaxf(b[2] - b[0], 1e-20f);
   const float fy = (q.y - b[1]) / fmaxf(b[3] - b[1], 1e-20f);
@@ -1167,9 +1181,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   uint32_t* val32_b = reinterpret_cast<uint32_t*>(keys_a_) + capV_;
 
   HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
-  if (weight_mode_ == 2)
+  if (weight_mode_ == 2)  // (mode 1: w_int_ already holds the weights, see weights_from_tiles / _scale_)
     hipLaunchKernelGGL(k_weights_from_grid, grid1(V), dim3(256), 0, s, V, in.pos, grid_bounds_, grid_w_, w_int_);
-  // (weight_mode_ 1: w_int_ was filled by the previous build's tiles, see below)
 
   // ---- stage A ----
   int levels = 0;
@@ -1297,9 +1310,21 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   HIPRET(hipGetLastError());
   lap("G pass2+sync");
   if (hflags[0] & 8) return hipSuccess;
-  // weights for a following balanced pass come from these tiles
-  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A->v_i2o, tile_of_int_, A->tiles, w_int_);
   *ok = true;
+  return hipGetLastError();
+}
+
+hipError_t DevPlanner::weights_from_tiles(hipStream_t s, int32_t V, const DevPlanArrays& A) {
+  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, w_int_);
+  weight_mode_ = 1;
+  return hipGetLastError();
+}
+
+hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntiles, long long total_cost,
+                                              const DevPlanArrays& A) {
+  hipLaunchKernelGGL(k_weights_scale, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, ntiles, total_cost,
+                     w_int_);
+  weight_mode_ = 1;
   return hipGetLastError();
 }
 
