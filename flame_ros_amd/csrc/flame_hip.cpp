@@ -478,14 +478,10 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       }
     }
     bool ok = false, index_error = false;
+    int32_t nan_flag = 0;  // the finite-check word rides on the builder's first sync
     HIPCHK(g->planner.build(s, g->opt, V, E, T, ntiles, depth, in, &A, alloc_tile_arrays, &ctx, &tiles, &ok,
-                            &index_error));
-    if (attempt == 0) {  // the finite-check flag was complete at the builder's first sync
-      int32_t f = 0;
-      HIPCHK(hipMemcpyAsync(&f, g->dflags, sizeof(f), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      if (f & 1) return FLAME_HIP_ERR_NAN;
-    }
+                            &index_error, g->dflags, &nan_flag));
+    if (nan_flag & 1) return FLAME_HIP_ERR_NAN;
     if (index_error) return FLAME_HIP_ERR_ARG;
     if (ok) {
       int e_max = 0, upd_max = 0;

@@ -1137,7 +1137,8 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
 
 hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int ntiles,
                              int depth, const DevPlanInputs& in, DevPlanArrays* A, AllocTilesFn alloc_tiles,
-                             void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error) {
+                             void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error,
+                             const int32_t* user_flags_dev, int32_t* user_flags_host) {
   (void)opt;
   *ok = false;
   *index_error = false;
@@ -1289,13 +1290,17 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_);
   int32_t hflags[8];
   HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
+  if (user_flags_dev && user_flags_host)  // the caller's own check word rides on the same sync
+    HIPRET(hipMemcpyAsync(user_flags_host, user_flags_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
   lap("F pass1+sync");
+  if (user_flags_dev && user_flags_host && *user_flags_host) return hipSuccess;
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
   if (hflags[0] & 16) {  // a subtree outgrew its workgroup: every level through the global kernels
     use_subtree_ = false;
-    return build(s, opt, V, E, T, ntiles, depth, in, A, alloc_tiles, alloc_ctx, tiles_host, ok, index_error);
+    return build(s, opt, V, E, T, ntiles, depth, in, A, alloc_tiles, alloc_ctx, tiles_host, ok, index_error,
+                 user_flags_dev, user_flags_host);
   }
   if (hflags[0] & 5) return hipSuccess;  // a tile does not fit (or the partition is inconsistent): not ok
   if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)

@@ -69,7 +69,9 @@ int main(int argc, char** argv) {
     }
     for (int t = 0; t < T; ++t) tris[t] = flame::Triangle(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]);
     bool ok = sensor->updateGraph(0.033 * a, a, vtx, idepth, var, tris);
-    std::printf("update=%d hip_error=%d\n", ok ? 1 : 0, static_cast<int>(sensor->stats().stats("hip_error")));
+    std::printf("update=%d hip_error=%d update_ms=%.3f sync_graph_ms=%.3f nltgv2_ms=%.3f\n", ok ? 1 : 0,
+                static_cast<int>(sensor->stats().stats("hip_error")), sensor->stats().timings("update"),
+                sensor->stats().timings("sync_graph"), sensor->stats().timings("nltgv2"));
     if (!ok) return 3;
   }
 
