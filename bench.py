@@ -63,8 +63,8 @@ def kernel_src_sha():
     counters of an older kernel are not quoted."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/common.h", "flame_ros_amd/csrc/plan.cpp",
-                "flame_ros_amd/csrc/plan_dev.hip", "flame_ros_amd/csrc/flame_hip.cpp"):
+    for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/kernels.h", "flame_ros_amd/csrc/common.h",
+                "flame_ros_amd/csrc/plan.cpp"):
         h.update(open(os.path.join(ROOT, rel), "rb").read())
     return h.hexdigest()[:16]
 

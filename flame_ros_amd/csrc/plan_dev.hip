@@ -62,13 +62,12 @@ __device__ void bitonic_sort(T* a, int m) {  // m a power of two, ascending
   const int tid = threadIdx.x;
   for (int k = 2; k <= m; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < m; i += NTB) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const T x = a[i], y = a[ixj];
-          const bool asc = (i & k) == 0;
-          if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
-        }
+      for (int p = tid; p < (m >> 1); p += NTB) {  // pair p: i = lower index of the pair
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+        const int ixj = i | j;
+        const T x = a[i], y = a[ixj];
+        const bool asc = (i & k) == 0;
+        if ((x > y) == asc) { a[i] = y; a[ixj] = x; }
       }
       __syncthreads();
     }
@@ -94,12 +93,13 @@ __global__ void k_rcb_init(int32_t V, int32_t ntiles, int32_t* perm, int32_t* se
   }
 }
 
-__global__ __launch_bounds__(256) void k_rcb_bbox(int32_t V, const int32_t* __restrict__ perm,
-                                                  const float2* __restrict__ pos,
-                                                  const int32_t* __restrict__ seg_pos,
-                                                  const int32_t* __restrict__ leaves, uint32_t* bbox) {
+__global__ __launch_bounds__(1024) void k_rcb_bbox(int32_t V, const int32_t* __restrict__ perm,
+                                                   const float2* __restrict__ pos,
+                                                   const int32_t* __restrict__ seg_pos,
+                                                   const int32_t* __restrict__ leaves, uint32_t* bbox) {
   __shared__ int s_first, s_same;
-  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  __shared__ uint32_t s_red[4][16];
+  const int32_t p = blockIdx.x * 1024 + threadIdx.x;
   int32_t s = -1;
   uint32_t ux = 0, uy = 0;
   if (p < V) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_rcb_bbox(int32_t V, const int32_t* __re
   __syncthreads();
   if (p < V && s != s_first) s_same = 0;
   __syncthreads();
-  if (s_same) {  // the whole block lies in one segment: one set of atomics per wave
+  if (s_same) {  // the whole block lies in one segment: same-address atomics serialise, so ONE set per block
     if (s_first < 0 || leaves[s_first] <= 1) return;
     uint32_t mnx = p < V ? ux : 0xffffffffu, mny = p < V ? uy : 0xffffffffu;
     uint32_t mxx = p < V ? ux : 0u, mxy = p < V ? uy : 0u;
@@ -122,9 +122,14 @@ __global__ __launch_bounds__(256) void k_rcb_bbox(int32_t V, const int32_t* __re
       mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
       mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(&bbox[4 * s_first], mnx); atomicMin(&bbox[4 * s_first + 1], mny);
-      atomicMax(&bbox[4 * s_first + 2], mxx); atomicMax(&bbox[4 * s_first + 3], mxy);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[0][w] = mnx; s_red[1][w] = mny; s_red[2][w] = mxx; s_red[3][w] = mxy; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const int c = threadIdx.x;
+      uint32_t v = s_red[c][0];
+      for (int k = 1; k < 16; ++k) v = c < 2 ? min(v, s_red[c][k]) : max(v, s_red[c][k]);
+      if (c < 2) atomicMin(&bbox[4 * s_first + c], v); else atomicMax(&bbox[4 * s_first + c], v);
     }
   } else if (p < V && leaves[s] > 1) {
     atomicMin(&bbox[4 * s], ux); atomicMin(&bbox[4 * s + 1], uy);
@@ -531,11 +536,17 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
 }
 
 // estart[t] = first internal edge owned by tile t; tiles that own no edge take the next tile's start
-__global__ void k_estart_fill(int ntiles, int32_t E, int32_t* estart) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  estart[ntiles] = E;
-  for (int t = ntiles - 1; t >= 0; --t)
-    if (estart[t] < 0) estart[t] = estart[t + 1];
+__global__ __launch_bounds__(kSegCap) void k_estart_fill(int ntiles, int32_t E, int32_t* estart) {
+  const int t = threadIdx.x;
+  int32_t v = E;
+  if (t < ntiles) {
+    int u = t;
+    while (u < ntiles && estart[u] < 0) ++u;
+    v = u < ntiles ? estart[u] : E;
+  }
+  __syncthreads();
+  if (t < ntiles) estart[t] = v;
+  if (t == 0) estart[ntiles] = E;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1204,7 +1215,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int cur = 0;
   for (int lev = 0; lev < sub_level; ++lev, cur ^= 1) {
-    hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
+    hipLaunchKernelGGL(k_rcb_bbox, dim3((unsigned)((V + 1023) / 1024)), dim3(1024), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
     if (lev == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, rank_x, rank_y, seg_pos_, tab[cur].leaves, bbox,
                        vb, key32_a, val32_a);
@@ -1229,7 +1240,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                                  (int)lds_sub));
       sub_attr = true;
     }
-    if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
+    if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, dim3((unsigned)((V + 1023) / 1024)), dim3(1024), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
     if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_subtree, dim3(1 << sub_level), dim3(kSubThreads), lds_sub, s, nseg + cur, tab[cur], tab[cur ^ 1],
                        nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb,
@@ -1260,7 +1271,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, vals_b_, keys_b_, vb, estart_, in.edges, in.alpha,
                        in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V);
   }
-  hipLaunchKernelGGL(k_estart_fill, dim3(1), dim3(64), 0, s, ntiles, E, estart_);
+  hipLaunchKernelGGL(k_estart_fill, dim3(1), dim3(kSegCap), 0, s, ntiles, E, estart_);
   lap("C edges");
   // ---- stage D ----
   if (E > 0) {

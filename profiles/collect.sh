@@ -15,3 +15,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $out/pmc_lds -o p -- $BENCH > $out/bench_lds.log 2>&1
 python bench.py --steps 10 --warmup 2 $* > $out/bench.json 2> $out/bench.err
 python profiles/summarize.py $out
+# the raw traces are large (gpurun copies back <= 64 MiB): keep the summaries only
+rm -rf $out/trace $out/pmc_fetch $out/pmc_write $out/pmc_lds

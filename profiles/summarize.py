@@ -81,8 +81,8 @@ if f:
 import hashlib
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
-for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/common.h", "flame_ros_amd/csrc/plan.cpp",
-            "flame_ros_amd/csrc/plan_dev.hip", "flame_ros_amd/csrc/flame_hip.cpp"):
+for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/kernels.h", "flame_ros_amd/csrc/common.h",
+            "flame_ros_amd/csrc/plan.cpp"):
     h.update(open(os.path.join(root, rel), "rb").read())
 src_sha = h.hexdigest()[:16]
 bj = os.path.join(d, "bench.json")
