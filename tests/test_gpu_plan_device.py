@@ -57,6 +57,43 @@ def test_device_plan_equals_host_plan(gpu, name, opts):
     host.close(); dev.close()
 
 
+def _irregular(kind):
+    g = graphgen.synthetic(3000, seed=77)
+    rng = np.random.default_rng(5)
+    edges, alpha, beta = g.edges, g.alpha, g.beta
+    if kind == "isolated":      # 30 % of the vertices lose every edge (and their triangles)
+        dead = rng.random(g.V) < 0.3
+        keep = ~(dead[edges[:, 0]] | dead[edges[:, 1]])
+        edges, alpha, beta = edges[keep], alpha[keep], beta[keep]
+        tris = g.tris[~dead[g.tris].any(1)]
+    elif kind == "multi":       # 5 % of the edges twice, the copy with flipped orientation
+        dup = rng.random(len(edges)) < 0.05
+        edges = np.concatenate([edges, edges[dup][:, ::-1]])
+        alpha = np.concatenate([alpha, alpha[dup]]); beta = np.concatenate([beta, beta[dup]])
+        tris = g.tris
+    else:                       # no edges at all
+        edges, alpha, beta = edges[:0], alpha[:0], beta[:0]
+        tris = None
+    return g, np.ascontiguousarray(edges), alpha, beta, tris
+
+
+@pytest.mark.parametrize("kind", ["isolated", "multi", "noedges"])
+def test_device_plan_irregular_graphs(gpu, kind):
+    g, edges, alpha, beta, tris = _irregular(kind)
+    opts = dict(tile_own=64, tile_depth=3)
+    host = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=-1, **opts)
+    dev = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=0, **opts)
+    compare_plans(host, dev, kind)
+    from oracle import COracle
+    o = COracle(g.pos, edges, alpha, beta, g.z, g.wgt)
+    o.solve(oracle_params(), 25)
+    dev.step(default_params(), 25)
+    x, w1, w2, q = dev.download()
+    assert_bit_equal(x, o.x, kind + " x")
+    assert_bit_equal(q, o.q, kind + " q")
+    host.close(); dev.close()
+
+
 def test_device_plan_frame_stream(gpu):
     """Consecutive frames of different size on ONE handle each: from the second frame on both
     builders balance in one pass from their cost-density grid; every frame's plan is identical and
