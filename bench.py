@@ -131,8 +131,14 @@ def main():
     if local_rank >= torch.cuda.device_count():  # launcher restricted visibility to one GPU per rank
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # FLAME_BENCH_BACKEND=gloo: several ranks on ONE GPU (development check of the N>1 code paths;
+    # timing tensors then live on the host); the product backend is nccl (= RCCL over xGMI)
+    backend = os.environ.get("FLAME_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from flame_ros_amd import graphgen
     from flame_ros_amd.regularizer import GraphRegularizer, default_params
@@ -206,7 +212,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

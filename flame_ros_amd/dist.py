@@ -185,6 +185,12 @@ class PartitionedSolver:
     def _exchange(self):
         dist = self.dist
         sbuf = self.solver.halo_pack()
+        # gloo has no device-to-device path: stage through the host (tests with several ranks on ONE
+        # GPU; the product backend is nccl = RCCL, device buffers straight into ncclSend/ncclRecv)
+        staged = sbuf.is_cuda and dist.get_backend() == "gloo"
+        dev = sbuf.device
+        if staged:
+            sbuf = sbuf.cpu()
         rbuf = sbuf.new_empty(VREC * self.n_recv[0] + EREC * self.n_recv[1])
         ops, ssl, rsl = [], self._slices(self.send_cnt, self.n_send), self._slices(self.recv_cnt, self.n_recv)
         for r in self.peers:
@@ -197,6 +203,8 @@ class PartitionedSolver:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if staged:
+            rbuf = rbuf.to(dev)
         self.solver.halo_unpack(rbuf)
 
     def step(self, params, num_iters):

@@ -1,0 +1,81 @@
+"""-m gpu: the N>1 paths run by REAL processes on the one GPU of the test box (gloo between the
+ranks, halo buffers staged through the host): `PartitionedSolver` + `HipSubdomainSolver` (product
+classes) for 2 and 3 ranks, bit-identical to the oracle, and `bench.py` itself under
+`torch.distributed.run` in both N>1 modes (replicas, partition).  On a multi-GPU node the same code
+runs over nccl = RCCL with device buffers."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from oracle import COracle
+from oracle.cbind import default_params as oracle_params
+from tests.util import graphgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, V, depth, iters, out):
+    import torch
+    import torch.distributed as dist
+    from flame_ros_amd import dist as fdist
+    from flame_ros_amd.regularizer import default_params
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        g = graphgen.synthetic(V, seed=31)
+        ps = fdist.PartitionedSolver(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, fdist.make_hip_solver(0),
+                                     depth=depth)
+        ps.step(default_params(), iters)
+        x, w1, w2, q = ps.gather_solution()
+        if rank == 0:
+            np.savez(out, x=x, w1=w1, w2=w2, q=q)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,depth,iters", [(2, 16, 70), (3, 8, 30)])
+def test_partitioned_hip_solver_processes(gpu, tmp_path, world, depth, iters):
+    V = 9000
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), V, depth, iters, out), nprocs=world, join=True)
+    g = graphgen.synthetic(V, seed=31)
+    o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    o.solve(oracle_params(), iters)
+    r = np.load(out)
+    for k, want in (("x", o.x), ("w1", o.w1), ("w2", o.w2), ("q", o.q)):
+        assert np.array_equal(r[k].view(np.uint32), want.view(np.uint32)), k
+
+
+@pytest.mark.parametrize("mode", ["replicas", "partition"])
+def test_bench_runs_with_two_ranks(gpu, mode):
+    env = dict(os.environ, FLAME_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
+           "3", "--warmup", "1", "--workload", "5k", "--mode", mode, "--halo-depth", "8"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3
+    assert d["scaling"] == ("strong" if mode == "partition" else "weak")
+    if mode == "partition":
+        assert d["partition"]["send_bytes_rank0"] > 0 and d["partition"]["exchange_us"] > 0
+        assert d["config"]["parallelism"].startswith("partition2")
+    else:
+        assert d["config"]["parallelism"] == "replicas2"
