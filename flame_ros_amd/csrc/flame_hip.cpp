@@ -88,6 +88,16 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
   return 0;
 }
 
+// Asynchronous variant for the upload path: the source vectors outlive the call (plan members or
+// locals of a function that synchronises the stream before it returns), so a whole upload pays one
+// stream synchronisation instead of one per array.
+template <class T>
+int h2d_async(hipStream_t s, T* dst, const std::vector<T>& src) {
+  if (src.empty()) return 0;
+  HIPCHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return 0;
+}
+
 bool all_finite(const float* p, size_t n) {
   for (size_t k = 0; k < n; ++k)
     if (!std::isfinite(p[k])) return false;
@@ -312,6 +322,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "host_threads") {
     if (value < 0) return FLAME_HIP_ERR_ARG;
     g->opt.host_threads = value;
+  } else if (k == "tile_single_max") {
+    if (value < 0 || value > 2048) return FLAME_HIP_ERR_ARG;
+    g->opt.single_max = value;
   } else if (k == "plan_device") {
     g->plan_device = value != 0;
   } else if (k == "profile") {
@@ -638,45 +651,46 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
       HIPCHK(hipMemsetAsync(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
     }
     g->cur = 0;
-    if ((rc = h2d(g->stream, g->A[0], hA)) || (rc = h2d(g->stream, g->B[0], hB))) return rc;
-    if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d(g->stream, g->pos, hpos))) return rc;
+    if ((rc = h2d_async(g->stream, g->A[0], hA)) || (rc = h2d_async(g->stream, g->B[0], hB))) return rc;
+    if ((rc = dev_alloc(g->caps, &g->pos, V)) || (rc = h2d_async(g->stream, g->pos, hpos))) return rc;
     if ((rc = dev_alloc(g->caps, &g->eij, E)) || (rc = dev_alloc(g->caps, &g->ew, E)) ||
         (rc = dev_alloc(g->caps, &g->grow, (size_t)V + 1)) || (rc = dev_alloc(g->caps, &g->ginc, 2 * (size_t)E)))
       return rc;
     static_assert(sizeof(Int2) == sizeof(int2) && sizeof(Float4) == sizeof(float4) &&
                       sizeof(UInt2) == sizeof(uint2), "layout");
     if (E > 0) {
-      HIPCHK(memcpy_sync(g->stream, g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice));
-      HIPCHK(memcpy_sync(g->stream, g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice));
-      HIPCHK(memcpy_sync(g->stream, g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpyAsync(g->eij, P.eij.data(), sizeof(int2) * (size_t)E, hipMemcpyHostToDevice, g->stream));
+      HIPCHK(hipMemcpyAsync(g->ew, P.ew.data(), sizeof(float4) * (size_t)E, hipMemcpyHostToDevice, g->stream));
+      HIPCHK(hipMemcpyAsync(g->ginc, P.ginc.data(), sizeof(int32_t) * 2 * (size_t)E, hipMemcpyHostToDevice, g->stream));
     }
-    HIPCHK(memcpy_sync(g->stream, g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(g->grow, P.grow.data(), sizeof(int32_t) * ((size_t)V + 1), hipMemcpyHostToDevice, g->stream));
     if (P.has_tiles) {
-      if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d(g->stream, g->tiles, P.tiles)) ||
-          (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d(g->stream, g->t_vmap, P.t_vmap)) ||
-          (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d(g->stream, g->t_emap, P.t_emap)) ||
-          (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d(g->stream, g->t_srow, P.t_srow)) ||
+      if ((rc = dev_alloc(g->caps, &g->tiles, P.tiles.size())) || (rc = h2d_async(g->stream, g->tiles, P.tiles)) ||
+          (rc = dev_alloc(g->caps, &g->t_vmap, P.t_vmap.size())) || (rc = h2d_async(g->stream, g->t_vmap, P.t_vmap)) ||
+          (rc = dev_alloc(g->caps, &g->t_emap, P.t_emap.size())) || (rc = h2d_async(g->stream, g->t_emap, P.t_emap)) ||
+          (rc = dev_alloc(g->caps, &g->t_srow, P.t_srow.size())) || (rc = h2d_async(g->stream, g->t_srow, P.t_srow)) ||
           (rc = dev_alloc(g->caps, &g->t_eij, P.t_eij.size())) || (rc = dev_alloc(g->caps, &g->t_ew, P.t_ew.size())))
         return rc;
       if (!P.t_eij.empty()) {
-        HIPCHK(memcpy_sync(g->stream, g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice));
-        HIPCHK(memcpy_sync(g->stream, g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(g->t_eij, P.t_eij.data(), sizeof(uint2) * P.t_eij.size(), hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->t_ew, P.t_ew.data(), sizeof(float4) * P.t_ew.size(), hipMemcpyHostToDevice, g->stream));
       }
     }
     // the triangle arrays always exist: with T == 0 the vertex -> triangle CSR is all-empty rows, so
     // the triangle stage, mesh and dense maps run (degenerate normals, nothing covered)
-    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d(g->stream, g->tris, P.tris)) ||
+    if ((rc = dev_alloc(g->caps, &g->tris, P.tris.size())) || (rc = h2d_async(g->stream, g->tris, P.tris)) ||
         (rc = dev_alloc(g->caps, &g->trow, (size_t)V + 1)) ||
-        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d(g->stream, g->tinc, P.tinc)) ||
+        (rc = dev_alloc(g->caps, &g->tinc, P.tinc.size())) || (rc = h2d_async(g->stream, g->tinc, P.tinc)) ||
         (rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
       return rc;
-    if (P.T > 0) { if ((rc = h2d(g->stream, g->trow, P.trow))) return rc; }
+    if (P.T > 0) { if ((rc = h2d_async(g->stream, g->trow, P.trow))) return rc; }
     else HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), g->stream));
     // permutations for the device-side result paths
-    if ((rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) || (rc = h2d(g->stream, g->v_i2o_dev, P.v_i2o)) ||
-        (rc = dev_alloc(g->caps, &g->v_o2i_dev, (size_t)V)) || (rc = h2d(g->stream, g->v_o2i_dev, P.v_o2i)) ||
-        (rc = dev_alloc(g->caps, &g->e_o2i_dev, (size_t)E)) || (rc = h2d(g->stream, g->e_o2i_dev, P.e_o2i)))
+    if ((rc = dev_alloc(g->caps, &g->v_i2o_dev, (size_t)V)) || (rc = h2d_async(g->stream, g->v_i2o_dev, P.v_i2o)) ||
+        (rc = dev_alloc(g->caps, &g->v_o2i_dev, (size_t)V)) || (rc = h2d_async(g->stream, g->v_o2i_dev, P.v_o2i)) ||
+        (rc = dev_alloc(g->caps, &g->e_o2i_dev, (size_t)E)) || (rc = h2d_async(g->stream, g->e_o2i_dev, P.e_o2i)))
       return rc;
+      HIPCHK(hipStreamSynchronize(g->stream));  // the staged host arrays (hA, hB, hpos) end here
   }
   return finish_upload(g);
 }

@@ -168,11 +168,13 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   const int auto_depth = !one_round ? 3 : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
   int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
   int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
-  // Auto: a lone graph is one isolated tile only when it is small (<= 512 vertices): above that a
-  // few dozen depth-4 tiles on as many CUs finish sooner than one CU iterating alone (TUM-sized
-  // 1.2 k vertices: 0.33 ms vs 0.43 ms per 200 iterations).  tile_own >= V forces the single tile;
-  // batch frames are always single tiles (throughput, one CU per frame).
-  bool single = single_fits && (opt.tile_own >= V || (opt.tile_own <= 0 && V <= 512));
+  // Auto: a lone graph is one isolated tile only when it is small (<= single_max = 512 vertices):
+  // above that a few dozen depth-4 tiles on as many CUs finish sooner than one CU iterating alone
+  // (TUM-sized 1.2 k vertices: 0.32 ms vs 0.44 ms per 200 iterations).  A frame STREAM of such graphs
+  // is better off with the single tile all the same (its plan is trivial: 0.88 ms vs 1.00 ms per
+  // frame at 1.2 k vertices): option "tile_single_max" up to 2048.  tile_own >= V forces the single
+  // tile; batch frames are always single tiles (throughput, one CU per frame).
+  bool single = single_fits && (opt.tile_own >= V || (opt.tile_own <= 0 && V <= opt.single_max));
   if (single) { tile_own = std::max(V, 1); depth = 0; }
   PlanSizing sz;
   sz.auto_own = auto_own; sz.auto_depth = auto_depth;

@@ -22,6 +22,7 @@ struct PlanOptions {
   int host_threads = 0;  // plan-build threads (0 = up to 8)
   int balance = 1;       // second, cost-weighted bisection pass (equalises tile cost)
   int order_mode = 1;    // vertex order inside tiles / rings: 0 by degree, 1 spatial (gather locality)
+  int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   // batch of independent graphs (frames axis): nb + 1 vertex offsets; graph b = one isolated tile
   std::vector<int32_t> batch_voff;
 };

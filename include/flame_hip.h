@@ -80,7 +80,10 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
 
 /* Options are set BEFORE upload.  Keys: "path" (enum above), "tile_own" (target own vertices
  * per tile), "tile_depth" (halo depth = iterations per launch), "tile_threads", "use_graph"
- * (replay launches from a hipGraph).  Unknown key -> FLAME_HIP_ERR_ARG. */
+ * (replay launches from a hipGraph), "plan_device" (1 = build halo-tile plans on the GPU, default),
+ * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
+ * 512, up to 2048), "balance", "order_mode", "host_threads", "lds_bytes", "profile".
+ * Unknown key -> FLAME_HIP_ERR_ARG. */
 int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value);
 int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value);
 

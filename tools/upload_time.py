@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flame_ros_amd import graphgen
 from flame_ros_amd.regularizer import GraphRegularizer, default_params
 name = sys.argv[1] if len(sys.argv) > 1 else "50k"
-opts = dict(plan_device=int(sys.argv[2])) if len(sys.argv) > 2 else {}
+opts = dict((a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[2:])  # e.g. plan_device=0 tile_own=1200
 g, iters = graphgen.named(name)
 r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, **opts)
 p = default_params()
