@@ -331,7 +331,7 @@ def main():
             rl["blocked_floor_bytes_per_launch"] = floor
             rl["halo_redundancy"] = {"vertices": nv / g.V, "edges": ne / max(g.E, 1)}
         tr = profiled_counters("batch%d" % args.batch if args.batch else args.workload,
-                               "k_tile" if path == 2 else "k_primal")
+                               "k_tile<" if path == 2 else "k_primal")
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
             rl["traffic_source"] = tr["source"] + (" (stale: other kernel sources, not quoted)" if tr.get("stale") else "")
             if tr.get("bytes_per_launch"):

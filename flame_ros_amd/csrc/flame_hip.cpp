@@ -12,6 +12,7 @@
 #include <roctracer/roctx.h>
 
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -735,7 +736,10 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
   }
   int rc;
   g->sync_on_device = false;
-  if (g->device >= 0 && g->plan_device && V >= 2 && T > 0 && g->opt.path != FLAME_HIP_PATH_GLOBAL) {
+  // graphs that become one isolated tile (host plan) are synced on the host as well (E <= 3V bounds
+  // the edge count of a triangulation before it is known)
+  const bool lone_tile = plan_sizing(g->opt, V, (int32_t)std::min<int64_t>(3ll * V, INT32_MAX)).single;
+  if (g->device >= 0 && g->plan_device && V >= 2 && T > 0 && !lone_tile && g->opt.path != FLAME_HIP_PATH_GLOBAL) {
     // ---- on the device: edges of the triangulation, alpha, data terms; then the device plan ----
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(wait_last_solve(g));
