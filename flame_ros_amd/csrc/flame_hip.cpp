@@ -435,24 +435,12 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_tris, 3 * (size_t)T)) ||
       (rc = dev_alloc(g->caps, &g->dflags, 8)))
     return rc;
-  HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
-  if (E > 0) {
-    HIPCHK(hipMemcpyAsync(g->in_edges, edges, sizeof(int2) * (size_t)E, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(g->in_alpha, alpha, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(g->in_beta, beta, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
-  }
-  HIPCHK(hipMemcpyAsync(g->in_z, z, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-  if (x0) HIPCHK(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-  if (T > 0) HIPCHK(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
-  // non-finite inputs are found on the device (the flag is read with the builder's first sync)
+  // Only the positions are needed by the partition stages: they go first; the other arrays are
+  // staged by `stage_rest` once those stages are enqueued (plan_dev.hip "after_partition"), so the
+  // host-side staging copies overlap the bisection kernels.
   HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
+  HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
   HIPCHK(launch_check_finite(s, 2 * (int64_t)V, reinterpret_cast<const float*>(g->in_pos), g->dflags));
-  HIPCHK(launch_check_finite(s, V, g->in_z, g->dflags));
-  HIPCHK(launch_check_finite(s, V, g->in_wgt, g->dflags));
-  HIPCHK(launch_check_finite(s, E, g->in_alpha, g->dflags));
-  HIPCHK(launch_check_finite(s, E, g->in_beta, g->dflags));
-  if (x0) HIPCHK(launch_check_finite(s, V, g->in_x0, g->dflags));
   }
   lap("stage inputs");
   // ---- plan arrays ----
@@ -473,6 +461,30 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   A.tris = g->tris; A.trow = g->trow; A.tinc = g->tinc;
   TileAllocCtx ctx{g, &A};
 
+  bool rest_staged = staged;
+  auto stage_rest = [&]() -> hipError_t {
+    if (rest_staged) return hipSuccess;
+    rest_staged = true;
+    hipError_t e;
+#define STG(expr) do { e = (expr); if (e != hipSuccess) return e; } while (0)
+    if (E > 0) {
+      STG(hipMemcpyAsync(g->in_edges, edges, sizeof(int2) * (size_t)E, hipMemcpyHostToDevice, s));
+      STG(hipMemcpyAsync(g->in_alpha, alpha, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
+      STG(hipMemcpyAsync(g->in_beta, beta, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
+    }
+    STG(hipMemcpyAsync(g->in_z, z, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    STG(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    if (x0) STG(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    if (T > 0) STG(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
+    // non-finite inputs are found on the device (the flag is read with the builder's first sync)
+    STG(launch_check_finite(s, V, g->in_z, g->dflags));
+    STG(launch_check_finite(s, V, g->in_wgt, g->dflags));
+    STG(launch_check_finite(s, E, g->in_alpha, g->dflags));
+    STG(launch_check_finite(s, E, g->in_beta, g->dflags));
+    if (x0) STG(launch_check_finite(s, V, g->in_x0, g->dflags));
+#undef STG
+    return hipSuccess;
+  };
   int tile_own = sz.tile_own;
   const int depth = sz.depth;
   bool balanced = false, built = false;
@@ -494,7 +506,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     bool ok = false, index_error = false;
     int32_t nan_flag = 0;  // the finite-check word rides on the builder's first sync
     HIPCHK(g->planner.build(s, g->opt, V, E, T, ntiles, depth, in, &A, alloc_tile_arrays, &ctx, &tiles, &ok,
-                            &index_error, g->dflags, &nan_flag));
+                            &index_error, g->dflags, &nan_flag, stage_rest));
     if (nan_flag & 1) return FLAME_HIP_ERR_NAN;
     if (index_error) return FLAME_HIP_ERR_ARG;
     if (ok) {

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -71,12 +72,15 @@ class DevPlanner {
   // descriptors and *ok tells whether every tile could be built (false = the caller retries with
   // smaller tiles or falls back to the host builder).  user_flags_dev (optional): one device word of
   // the caller (e.g. a non-finite-input flag) copied to *user_flags_host with the builder's first
-  // sync; a non-zero word ends the build early (ok = false).  Returns a hipError_t.
+  // sync; a non-zero word ends the build early (ok = false).  after_partition (optional) is called
+  // once stages A and B -- which read only `in.pos` -- are enqueued: the caller stages its other
+  // arrays there, so the host-side copies overlap the partition kernels.  Returns a hipError_t.
   typedef int (*AllocTilesFn)(void* ctx, size_t ntiles, size_t nv, size_t ne, size_t ns);
   hipError_t build(hipStream_t s, const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int ntiles,
                    int depth, const DevPlanInputs& in, DevPlanArrays* arrays, AllocTilesFn alloc_tiles,
                    void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error,
-                   const int32_t* user_flags_dev = nullptr, int32_t* user_flags_host = nullptr);
+                   const int32_t* user_flags_dev = nullptr, int32_t* user_flags_host = nullptr,
+                   const std::function<hipError_t()>& after_partition = nullptr);
 
   // Graph sync on the device (row a7): unique undirected edges (i < j, lexicographic) of a
   // triangulation + alpha = 1 / |pos_i - pos_j|; edges / alpha need 3T entries.  Synchronises (E).

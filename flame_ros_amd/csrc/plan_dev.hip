@@ -1149,7 +1149,8 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
 hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, int32_t E, int32_t T, int ntiles,
                              int depth, const DevPlanInputs& in, DevPlanArrays* A, AllocTilesFn alloc_tiles,
                              void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error,
-                             const int32_t* user_flags_dev, int32_t* user_flags_host) {
+                             const int32_t* user_flags_dev, int32_t* user_flags_host,
+                             const std::function<hipError_t()>& after_partition) {
   (void)opt;
   *ok = false;
   *index_error = false;
@@ -1260,6 +1261,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_vertex_order, grid1(V), dim3(256), 0, s, V, keys_b_, vb, A->v_i2o, A->v_o2i, tile_of_int_);
 
   lap("B morton");
+  if (after_partition) HIPRET(after_partition());  // the caller's edge / data arrays arrive now
   // ---- stage C ----
   HIPRET(hipMemsetAsync(estart_, 0xff, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   if (E > 0) {
@@ -1311,7 +1313,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (hflags[0] & 16) {  // a subtree outgrew its workgroup: every level through the global kernels
     use_subtree_ = false;
     return build(s, opt, V, E, T, ntiles, depth, in, A, alloc_tiles, alloc_ctx, tiles_host, ok, index_error,
-                 user_flags_dev, user_flags_host);
+                 user_flags_dev, user_flags_host, nullptr);  // (the caller's arrays are staged by now)
   }
   if (hflags[0] & 5) return hipSuccess;  // a tile does not fit (or the partition is inconsistent): not ok
   if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)
