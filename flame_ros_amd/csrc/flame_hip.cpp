@@ -119,7 +119,8 @@ struct flame_hip_graph {
   int path = 0;  // resolved path after upload
 
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t stream_in = nullptr;  // input staging (H2D of a frame overlaps the partition kernels)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
   bool timed = false;
   int last_launches = 0;
 
@@ -255,7 +256,9 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
     }
     g->opt.lds_bytes = (int64_t)prop.sharedMemPerBlock > 0 ? (int64_t)prop.sharedMemPerBlock : 64 * 1024;
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) {
+        hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess) {
       delete g;
       return FLAME_HIP_ERR_NODEVICE;
     }
@@ -272,6 +275,8 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
     g->free_device();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    if (g->stream_in) { (void)hipStreamSynchronize(g->stream_in); (void)hipStreamDestroy(g->stream_in); }
     if (g->stream) (void)hipStreamDestroy(g->stream);
   }
   delete g;
@@ -467,15 +472,19 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     rest_staged = true;
     hipError_t e;
 #define STG(expr) do { e = (expr); if (e != hipSuccess) return e; } while (0)
+    // on the staging stream: the (host-synchronous) pageable copies do not wait for the partition
+    // kernels queued on the solve stream; that stream waits for the event instead
     if (E > 0) {
-      STG(hipMemcpyAsync(g->in_edges, edges, sizeof(int2) * (size_t)E, hipMemcpyHostToDevice, s));
-      STG(hipMemcpyAsync(g->in_alpha, alpha, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
-      STG(hipMemcpyAsync(g->in_beta, beta, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, s));
+      STG(hipMemcpyAsync(g->in_edges, edges, sizeof(int2) * (size_t)E, hipMemcpyHostToDevice, g->stream_in));
+      STG(hipMemcpyAsync(g->in_alpha, alpha, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, g->stream_in));
+      STG(hipMemcpyAsync(g->in_beta, beta, sizeof(float) * (size_t)E, hipMemcpyHostToDevice, g->stream_in));
     }
-    STG(hipMemcpyAsync(g->in_z, z, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-    STG(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-    if (x0) STG(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-    if (T > 0) STG(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
+    STG(hipMemcpyAsync(g->in_z, z, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream_in));
+    STG(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream_in));
+    if (x0) STG(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream_in));
+    if (T > 0) STG(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, g->stream_in));
+    STG(hipEventRecord(g->ev_in, g->stream_in));
+    STG(hipStreamWaitEvent(s, g->ev_in, 0));
     // non-finite inputs are found on the device (the flag is read with the builder's first sync)
     STG(launch_check_finite(s, V, g->in_z, g->dflags));
     STG(launch_check_finite(s, V, g->in_wgt, g->dflags));
@@ -615,6 +624,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(wait_last_solve(g));
     HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream_in));
     g->drop_execs();  // captured launches hold the old grid / pointers
     g->solves_since_upload = 0;
     rc = upload_device_plan(g, pos, edges, alpha, beta, z, wgt, x0, tris);

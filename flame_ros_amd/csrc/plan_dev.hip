@@ -1157,9 +1157,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // FLAME_HIP_PLAN_TIMING=1: synchronise after every stage and print its wall time (dev aid)
   static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
   auto tprev = std::chrono::steady_clock::now();
+  static const bool timing_nosync = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '2';  // host enqueue time only
   auto lap = [&](const char* what) {
     if (!timing) return;
-    (void)hipStreamSynchronize(s);
+    if (!timing_nosync) (void)hipStreamSynchronize(s);
     const auto now = std::chrono::steady_clock::now();
     std::fprintf(stderr, "[plan_dev] %-14s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tprev).count());
     tprev = now;
