@@ -93,47 +93,36 @@ __global__ void k_rcb_init(int32_t V, int32_t ntiles, int32_t* perm, int32_t* se
   }
 }
 
-__global__ __launch_bounds__(1024) void k_rcb_bbox(int32_t V, const int32_t* __restrict__ perm,
-                                                   const float2* __restrict__ pos,
-                                                   const int32_t* __restrict__ seg_pos,
-                                                   const int32_t* __restrict__ leaves, uint32_t* bbox) {
-  __shared__ int s_first, s_same;
+// bounding box of every unfinished segment: one workgroup per segment walks its (contiguous) range
+// -- no atomics (same-address atomics serialise: the atomic version took ~100 us per level)
+__global__ __launch_bounds__(1024) void k_rcb_bbox(const int32_t* __restrict__ nseg, SegTab t,
+                                                   const int32_t* __restrict__ perm,
+                                                   const float2* __restrict__ pos, uint32_t* bbox) {
   __shared__ uint32_t s_red[4][16];
-  const int32_t p = blockIdx.x * 1024 + threadIdx.x;
-  int32_t s = -1;
-  uint32_t ux = 0, uy = 0;
-  if (p < V) {
-    s = seg_pos[p];
+  const int s = blockIdx.x;
+  if (s >= nseg[0] || t.leaves[s] <= 1) return;
+  const int32_t lo = t.lo[s], hi = t.hi[s];
+  uint32_t mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0u, mxy = 0u;
+  for (int32_t p = lo + threadIdx.x; p < hi; p += 1024) {
     const float2 q = pos[perm[p]];
-    ux = ord_f(q.x); uy = ord_f(q.y);
+    const uint32_t ux = ord_f(q.x), uy = ord_f(q.y);
+    mnx = min(mnx, ux); mny = min(mny, uy); mxx = max(mxx, ux); mxy = max(mxy, uy);
   }
-  if (threadIdx.x == 0) { s_first = s; s_same = 1; }
-  __syncthreads();
-  if (p < V && s != s_first) s_same = 0;
-  __syncthreads();
-  if (s_same) {  // the whole block lies in one segment: same-address atomics serialise, so ONE set per block
-    if (s_first < 0 || leaves[s_first] <= 1) return;
-    uint32_t mnx = p < V ? ux : 0xffffffffu, mny = p < V ? uy : 0xffffffffu;
-    uint32_t mxx = p < V ? ux : 0u, mxy = p < V ? uy : 0u;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, off, 64));
-      mny = min(mny, (uint32_t)__shfl_xor((int)mny, off, 64));
-      mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
-      mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_red[0][w] = mnx; s_red[1][w] = mny; s_red[2][w] = mxx; s_red[3][w] = mxy; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-      const int c = threadIdx.x;
-      uint32_t v = s_red[c][0];
-      for (int k = 1; k < 16; ++k) v = c < 2 ? min(v, s_red[c][k]) : max(v, s_red[c][k]);
-      if (c < 2) atomicMin(&bbox[4 * s_first + c], v); else atomicMax(&bbox[4 * s_first + c], v);
-    }
-  } else if (p < V && leaves[s] > 1) {
-    atomicMin(&bbox[4 * s], ux); atomicMin(&bbox[4 * s + 1], uy);
-    atomicMax(&bbox[4 * s + 2], ux); atomicMax(&bbox[4 * s + 3], uy);
+  for (int off = 32; off > 0; off >>= 1) {
+    mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, off, 64));
+    mny = min(mny, (uint32_t)__shfl_xor((int)mny, off, 64));
+    mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
+    mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_red[0][w] = mnx; s_red[1][w] = mny; s_red[2][w] = mxx; s_red[3][w] = mxy; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int c = threadIdx.x;
+    uint32_t v = s_red[c][0];
+    for (int k = 1; k < 16; ++k) v = c < 2 ? min(v, s_red[c][k]) : max(v, s_red[c][k]);
+    bbox[4 * s + c] = v;
   }
 }
 
@@ -1217,7 +1206,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int cur = 0;
   for (int lev = 0; lev < sub_level; ++lev, cur ^= 1) {
-    hipLaunchKernelGGL(k_rcb_bbox, dim3((unsigned)((V + 1023) / 1024)), dim3(1024), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
+    hipLaunchKernelGGL(k_rcb_bbox, dim3(1u << lev), dim3(1024), 0, s, nseg + cur, tab[cur], perm, in.pos, bbox);
     if (lev == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, rank_x, rank_y, seg_pos_, tab[cur].leaves, bbox,
                        vb, key32_a, val32_a);
@@ -1242,7 +1231,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                                  (int)lds_sub));
       sub_attr = true;
     }
-    if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, dim3((unsigned)((V + 1023) / 1024)), dim3(1024), 0, s, V, perm, in.pos, seg_pos_, tab[cur].leaves, bbox);
+    if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, dim3(1), dim3(1024), 0, s, nseg + cur, tab[cur], perm, in.pos, bbox);
     if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_subtree, dim3(1 << sub_level), dim3(kSubThreads), lds_sub, s, nseg + cur, tab[cur], tab[cur ^ 1],
                        nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb,
