@@ -320,14 +320,24 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       mid_raw[k] = hi[k];
     }
     __syncthreads();
-    for (int p = tid; p < n; p += kSubThreads) {
-      const int k = segof[p];
-      if (lv[k] > 1) {
+    // bounding boxes: one WAVE per local segment walks its range and shuffle-reduces (LDS atomics
+    // on a handful of addresses serialise)
+    for (int k = tid >> 6; k < nloc; k += kSubThreads / 64) {
+      if (lv[k] <= 1) continue;
+      uint32_t mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0u, mxy = 0u;
+      for (int p = lo[k] + (tid & 63); p < hi[k]; p += 64) {
         const float2 q = pos[(uint32_t)(packed[p] & idmask)];
         const uint32_t ux = ord_f(q.x), uy = ord_f(q.y);
-        atomicMin(&bb[4 * k], ux); atomicMin(&bb[4 * k + 1], uy);
-        atomicMax(&bb[4 * k + 2], ux); atomicMax(&bb[4 * k + 3], uy);
+        mnx = min(mnx, ux); mny = min(mny, uy); mxx = max(mxx, ux); mxy = max(mxy, uy);
       }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, off, 64));
+        mny = min(mny, (uint32_t)__shfl_xor((int)mny, off, 64));
+        mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
+        mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
+      }
+      if ((tid & 63) == 0) { bb[4 * k] = mnx; bb[4 * k + 1] = mny; bb[4 * k + 2] = mxx; bb[4 * k + 3] = mxy; }
     }
     __syncthreads();
     for (int p = tid; p < m; p += kSubThreads) {
@@ -345,7 +355,30 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
                          : (((uint64_t)(((uint32_t)k << vb) | r) << 32) | id);
     }
     __syncthreads();
-    bitonic_sort<kSubThreads, uint64_t>(packed, m);
+    if (m <= 2048) {  // small windows: the bitonic network beats a fixed-size 8192-key radix sort
+      bitonic_sort<kSubThreads, uint64_t>(packed, m);
+    } else {  // block radix sort of the whole window on the significant key bits (the weight-prefix
+       // area is free at this point and serves as the sort's exchange storage)
+      typedef hipcub::BlockRadixSort<uint64_t, kSubThreads, kSubCap / kSubThreads> BlockSort;
+      static_assert(sizeof(typename BlockSort::TempStorage) <= sizeof(long long) * (kSubCap + kSubThreads), "sort storage");
+      typename BlockSort::TempStorage& tmp = *reinterpret_cast<typename BlockSort::TempStorage*>(wpre);
+      uint64_t keys[kSubCap / kSubThreads];
+#pragma unroll
+      for (int i = 0; i < kSubCap / kSubThreads; ++i) {
+        const int p = tid * (kSubCap / kSubThreads) + i;
+        keys[i] = p < m ? packed[p] : ~0ull;
+      }
+      __syncthreads();
+      // stable: the padding (p >= n, all ones) stays behind any real key
+      BlockSort(tmp).Sort(keys, direct ? 0 : 32, direct ? 32 + kIdBits + 8 : 32 + vb + 8);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kSubCap / kSubThreads; ++i) {
+        const int p = tid * (kSubCap / kSubThreads) + i;
+        if (p < m) packed[p] = keys[i];
+      }
+      __syncthreads();
+    }
     if (weighted) {  // inclusive prefix of the weights in the sorted order
       const int C = (m + kSubThreads - 1) / kSubThreads;
       long long acc = 0;
