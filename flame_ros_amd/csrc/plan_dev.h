@@ -110,7 +110,8 @@ class DevPlanner {
 
   int weight_mode_ = 0;
   int grid_tiles_ = 0;
-  bool use_subtree_ = true;  // deep bisection levels in one LDS kernel (off after an overflow)
+  bool use_subtree_ = true;  // deep bisection levels in one LDS kernel
+  int sub_extra_levels_ = 0; // hand-over level pushed down after a subtree overflow
   // capacities
   int64_t capV_ = 0, capE_ = 0, capT_ = 0, capTiles_ = 0;
   size_t cub_bytes_ = 0;

@@ -1228,7 +1228,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   int sub_level = levels;
   if (use_subtree_)
     for (int L = 0; L < levels; ++L)
-      if (((int64_t)V >> L) * 3 / 2 + 2 <= kSubCap && ((ntiles >> L) + 1) * 2 <= kSubLeaves) { sub_level = L; break; }
+      if (((int64_t)V >> L) * 5 / 4 + 2 <= kSubCap && ((ntiles >> L) + 1) * 2 <= kSubLeaves) {
+        sub_level = std::min(levels, L + sub_extra_levels_);  // (+1 per overflow seen on this handle)
+        break;
+      }
   const bool need_ranks = sub_level > 0;  // a lone subtree sorts on the coordinates themselves
   for (int axis = 0; axis < 2 && need_ranks; ++axis) {  // global ranks along x and y
     hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, axis, key32_a, val32_a);
@@ -1333,8 +1336,9 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   lap("F pass1+sync");
   if (user_flags_dev && user_flags_host && *user_flags_host) return hipSuccess;
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
-  if (hflags[0] & 16) {  // a subtree outgrew its workgroup: every level through the global kernels
-    use_subtree_ = false;
+  if (hflags[0] & 16) {  // a subtree outgrew its workgroup (uneven weighted splits): hand over one
+    // level later from now on; after three such steps every level goes through the global kernels
+    if (++sub_extra_levels_ > 3) use_subtree_ = false;
     return build(s, opt, V, E, T, ntiles, depth, in, A, alloc_tiles, alloc_ctx, tiles_host, ok, index_error,
                  user_flags_dev, user_flags_host, nullptr);  // (the caller's arrays are staged by now)
   }
