@@ -32,12 +32,13 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
+    extra = os.environ.get("FLAME_EXTRA_HIPCC_FLAGS", "").split()  # dev aid (A/B of kernel variants)
+    if not force and not needs_build() and not extra:
         return LIB
     objs = []
     for s in SOURCES:
         o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -112,6 +112,7 @@ class DevPlanner {
   int grid_tiles_ = 0;
   bool use_subtree_ = true;  // deep bisection levels in one LDS kernel
   int sub_extra_levels_ = 0; // hand-over level pushed down after a subtree overflow
+  bool attr_set_ = false, sub_attr_set_ = false;  // dynamic-LDS opt-in done on this handle's device
   // capacities
   int64_t capV_ = 0, capE_ = 0, capT_ = 0, capTiles_ = 0;
   size_t cub_bytes_ = 0;

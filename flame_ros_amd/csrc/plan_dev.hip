@@ -1189,13 +1189,12 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   };
   HIPRET(reserve(V, E, T, ntiles));
   lap("reserve");
-  static bool attr_set = false;
   const size_t lds1 = ((size_t)(V + 31) / 32) * 4 + kCapExt * 4 + kHash * 8;
   const size_t lds2 = lds1 + (size_t)kSortPad * 8;
-  if (!attr_set) {
+  if (!attr_set_) {  // per planner (= per handle = per device), not per process
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    attr_set = true;
+    attr_set_ = true;
   }
   // segment tables
   int32_t* st = seg_tab_;
@@ -1261,11 +1260,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   }
   if (sub_level < levels) {
     const size_t lds_sub = (size_t)kSubCap * 16 + kSubThreads * 8 + kSubCap + (8 + 4 + 3) * kSubLeaves * 4;
-    static bool sub_attr = false;
-    if (!sub_attr) {
+    if (!sub_attr_set_) {
       HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rcb_subtree), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds_sub));
-      sub_attr = true;
+      sub_attr_set_ = true;
     }
     if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, dim3(1), dim3(1024), 0, s, nseg + cur, tab[cur], perm, in.pos, bbox);
     if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
