@@ -331,6 +331,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "tile_single_max") {
     if (value < 0 || value > 2048) return FLAME_HIP_ERR_ARG;
     g->opt.single_max = value;
+  } else if (k == "debug_sub_cap") {
+    g->opt.debug_sub_cap = value;
   } else if (k == "plan_device") {
     g->plan_device = value != 0;
   } else if (k == "profile") {

@@ -23,6 +23,8 @@ struct PlanOptions {
   int balance = 1;       // second, cost-weighted bisection pass (equalises tile cost)
   int order_mode = 1;    // vertex order inside tiles / rings: 0 by degree, 1 spatial (gather locality)
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
+  int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
+                         // this many vertices on its first try (exercises the recovery path)
   // batch of independent graphs (frames axis): nb + 1 vertex offsets; graph b = one isolated tile
   std::vector<int32_t> batch_voff;
 };

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
                                                              const uint32_t* __restrict__ rank_x,
                                                              const uint32_t* __restrict__ rank_y,
                                                              const int32_t* __restrict__ w_int, int weighted, int vb,
-                                                             int direct, int32_t* flags) {
+                                                             int direct, int cap, int32_t* flags) {
   // direct != 0 (the subtree is the whole graph, no global ranks were made): sort on
   // (segment, ordered coordinate, id) packed in 62 bits; else on (segment, global rank) | id
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
   if (sidx >= nseg_cur[0]) return;
   const int32_t glo = cur.lo[sidx], ghi = cur.hi[sidx], gleaves = cur.leaves[sidx], gfirst = cur.first[sidx];
   const int n = ghi - glo;
-  if (n > kSubCap || gleaves > kSubLeaves) { if (tid == 0) atomicOr(&flags[0], 16); return; }
+  if (n > cap || gleaves > kSubLeaves) { if (tid == 0) atomicOr(&flags[0], 16); return; }
   uint64_t* packed = reinterpret_cast<uint64_t*>(smem);                 // kSubCap
   long long* wpre = reinterpret_cast<long long*>(packed + kSubCap);     // kSubCap
   long long* part = wpre + kSubCap;                                     // kSubThreads partial sums
@@ -1173,7 +1173,6 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                              void* alloc_ctx, std::vector<TileDesc>* tiles_host, bool* ok, bool* index_error,
                              const int32_t* user_flags_dev, int32_t* user_flags_host,
                              const std::function<hipError_t()>& after_partition) {
-  (void)opt;
   *ok = false;
   *index_error = false;
   // FLAME_HIP_PLAN_TIMING=1: synchronise after every stage and print its wall time (dev aid)
@@ -1269,7 +1268,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_subtree, dim3(1 << sub_level), dim3(kSubThreads), lds_sub, s, nseg + cur, tab[cur], tab[cur ^ 1],
                        nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb,
-                       need_ranks ? 0 : 1, flags_);
+                       need_ranks ? 0 : 1, (opt.debug_sub_cap > 0 && sub_extra_levels_ == 0) ? std::min(opt.debug_sub_cap, kSubCap) : kSubCap,
+                       flags_);
     cur ^= 1;
   }
   hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);

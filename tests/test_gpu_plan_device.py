@@ -117,6 +117,20 @@ def test_device_plan_frame_stream(gpu):
     host.close(); dev.close()
 
 
+def test_device_plan_subtree_overflow_recovery(gpu):
+    """The LDS subtree kernel of the bisection reports an overflow (forced here through the
+    debug_sub_cap test hook; in production: very uneven weighted splits): the builder hands over
+    one level later and the plan still equals the host builder's."""
+    g, _ = graphgen.named("50k")
+    host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
+    dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, debug_sub_cap=2000)
+    compare_plans(host, dev, "overflow recovery")
+    host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+    dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+    compare_plans(host, dev, "after recovery")
+    host.close(); dev.close()
+
+
 def test_device_plan_error_conventions(gpu):
     """Bad indices and non-finite inputs are found by the device builder's own checks."""
     g = graphgen.synthetic(4000, seed=9)
