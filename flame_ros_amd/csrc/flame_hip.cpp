@@ -164,6 +164,7 @@ struct flame_hip_graph {
   int32_t* e_o2i_dev = nullptr;
   float* dl_v = nullptr;  // download staging: 3V floats
   float* dl_q = nullptr;  // 3E floats
+  float* dl_n = nullptr;  // 3V floats (vertex normals of flame_hip_frame_results)
   // device plan builder (row f3) and the staged inputs it reads (caller's order)
   int plan_device = 1;
   DevPlanner planner;
@@ -727,7 +728,9 @@ static int finish_upload(flame_hip_graph* g) {
   int rc;
   if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
   if ((rc = dev_alloc(g->caps, &g->mesh_pts, 3 * (size_t)V))) return rc;
-  if ((rc = dev_alloc(g->caps, &g->dl_v, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->dl_q, 3 * (size_t)E))) return rc;
+  if ((rc = dev_alloc(g->caps, &g->dl_v, 3 * (size_t)V)) || (rc = dev_alloc(g->caps, &g->dl_q, 3 * (size_t)E)) ||
+      (rc = dev_alloc(g->caps, &g->dl_n, 3 * (size_t)V)))
+    return rc;
   if ((rc = dev_alloc(g->caps, &g->partials, 2 * (size_t)costs_num_blocks(V, E)))) return rc;
   if (g->profile && P.has_tiles) {
     if ((rc = dev_alloc(g->caps, &g->prof, P.tiles.size() * kProfWords))) return rc;
@@ -1084,6 +1087,56 @@ static void fill_tri_params(const float Kinv[9], const flame_hip_tri_params* tp,
   d->max_len2 = max_len * max_len;
   d->min_idepth = tp->min_triangle_idepth;
   for (int k = 0; k < 9; ++k) d->Kinv[k] = Kinv[k];
+}
+
+// Everything flame::Flame::update() reads back after the solve, in ONE call with ONE stream
+// synchronisation (each of costs / download / triangles / graph_edges alone pays its own).
+int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float scale_back,
+                            const float Kinv[9], const flame_hip_tri_params* tp, double* smooth, double* data,
+                            float* x, float* vtx_normals, uint8_t* tri_valid, int32_t* edges) {
+  RoctxRange roctx_("flame_hip_frame_results");
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (((smooth || data) && !p) || ((vtx_normals || tri_valid) && (!Kinv || !tp)) || !std::isfinite(scale_back))
+    return FLAME_HIP_ERR_ARG;
+  if (g->plan.T <= 0 && g->T > 0 && (vtx_normals || tri_valid)) return FLAME_HIP_ERR_STATE;
+  if (edges && !g->synced) return FLAME_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = g->stream;
+  if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));  // a solve on a caller's stream
+  const int32_t V = g->V, E = g->E, T = g->plan.T;
+  const int nb = costs_num_blocks(V, E);
+  std::vector<double> h(2 * (size_t)nb);
+  if (smooth || data) {  // costs are taken BEFORE the state goes back to the caller's units
+    HIPCHK(launch_costs(s, V, E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], p->data_factor, g->partials));
+    HIPCHK(hipMemcpyAsync(h.data(), g->partials, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+  }
+  if (scale_back != 1.0f) HIPCHK(launch_scale_state(s, V, g->A[g->cur], g->B[g->cur], scale_back));
+  if (x && V > 0) {
+    HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], g->dl_v));
+    HIPCHK(hipMemcpyAsync(x, g->dl_v, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
+  }
+  if (vtx_normals || tri_valid) {
+    TriParamsDev d;
+    fill_tri_params(Kinv, tp, &d);
+    HIPCHK(launch_triangles(s, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d, g->tri_normals,
+                            g->tri_valid, g->vtx_normals));
+    if (vtx_normals && V > 0) {
+      HIPCHK(launch_download_rows3(s, V, g->v_o2i_dev, g->vtx_normals, g->dl_n));
+      HIPCHK(hipMemcpyAsync(vtx_normals, g->dl_n, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToHost, s));
+    }
+    if (tri_valid && T > 0) HIPCHK(hipMemcpyAsync(tri_valid, g->tri_valid, (size_t)T, hipMemcpyDeviceToHost, s));
+  }
+  if (edges && E > 0) {
+    if (g->sync_on_device) HIPCHK(hipMemcpyAsync(edges, g->in_edges, sizeof(int2) * (size_t)E, hipMemcpyDeviceToHost, s));
+    else std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)E);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  double sm = 0.0, da = 0.0;
+  for (int b = 0; b < nb; ++b) { sm += h[2 * b]; da += h[2 * b + 1]; }
+  if (smooth) *smooth = sm;
+  if (data) *data = da;
+  return 0;
 }
 
 int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,

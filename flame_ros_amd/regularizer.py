@@ -250,6 +250,20 @@ class GraphRegularizer:
                                                _ptr(tv), _ptr(tn)), "flame_hip_triangles")
         return tn, tv, vn
 
+    def frame_results(self, params, Kinv, tri_params, scale_back=1.0, with_edges=False):
+        """What flame::Flame::update() reads back after the solve, with one synchronisation:
+        (smooth, data, x[V], vtx_normals[V,3], tri_valid[T], edges[E,2] or None)."""
+        Kinv = _f32(Kinv).reshape(9)
+        x = np.empty(self.V, np.float32)
+        vn = np.empty((self.V, 3), np.float32)
+        tv = np.empty(self.T, np.uint8)
+        e = np.empty((self.E, 2), np.int32) if with_edges else None
+        s, d = C.c_double(), C.c_double()
+        _l.check(self._lib.flame_hip_frame_results(self._h, C.byref(params), float(scale_back), _ptr(Kinv),
+                                                   C.byref(tri_params), C.byref(s), C.byref(d), _ptr(x), _ptr(vn),
+                                                   _ptr(tv), _ptr(e)), "flame_hip_frame_results")
+        return s.value, d.value, x, vn, tv, e
+
     def mesh(self, Kinv, tri_params):
         """Row f1: (points[V,12] PointNormalUV layout, faces[F,3] reversed winding)."""
         Kinv = _f32(Kinv).reshape(9)

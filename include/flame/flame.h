@@ -292,34 +292,29 @@ class Flame {
                          tidx.data(), prediction ? prediction->data() : nullptr, &scale);
     if (rc) return fail(rc);
     const int32_t E = graph_.numEdges();
-    std::vector<int32_t> eidx(2 * static_cast<size_t>(E));
-    if ((rc = flame_hip_graph_edges(graph_.handle(), eidx.data()))) return fail(rc);
     stats_.tock("sync_graph");
 
     // ---- regulariser (rows a2-a6) ----
     stats_.tick("nltgv2");
     if (params_.do_nltgv2) {
-      rc = reg::step(params_.rparams, &graph_, params_.nltgv2_iterations);
+      rc = reg::step(params_.rparams, &graph_, params_.nltgv2_iterations, /*wait=*/false);
       if (rc) return fail(rc);
     }
-    stats_.tock("nltgv2");
+    // ---- costs (a6), idepths back in the caller's units, per-triangle stage (a8), edge list: one
+    // library call, one synchronisation.  Everything downstream (triangle filters, mesh, maps) works
+    // on un-scaled inverse depths with the un-scaled thresholds. ----
     const flame_hip_params cp = reg::toC(params_.rparams);
     double smooth = 0.0, data = 0.0;
-    if ((rc = flame_hip_costs(graph_.handle(), &cp, &smooth, &data))) return fail(rc);
-    // back to the caller's units: everything downstream (idepths, triangle filters, mesh, maps)
-    // works on un-scaled inverse depths with the un-scaled thresholds
-    if (scale != 1.0f && (rc = flame_hip_scale_state(graph_.handle(), scale))) return fail(rc);
+    std::vector<int32_t> eidx(2 * static_cast<size_t>(E));
     std::vector<float> idepths(V, 0.0f);
-    if ((rc = flame_hip_download(graph_.handle(), idepths.data(), nullptr, nullptr, nullptr))) return fail(rc);
-
-    // ---- per-triangle stage (row a8) ----
-    stats_.tick("interpolate");
     std::vector<float> normals(3 * static_cast<size_t>(V), 0.0f);
     std::vector<uint8_t> tri_valid(T, 0);
     const flame_hip_tri_params tp = triParams();
-    if ((rc = flame_hip_triangles(graph_.handle(), Kinv_, &tp, normals.data(), tri_valid.data(), nullptr)))
-      return fail(rc);
-    stats_.tock("interpolate");
+    rc = flame_hip_frame_results(graph_.handle(), &cp, scale, Kinv_, &tp, &smooth, &data, idepths.data(),
+                                 normals.data(), tri_valid.data(), eidx.data());
+    if (rc) return fail(rc);
+    stats_.tock("nltgv2");
+    stats_.setTiming("interpolate", 0.0);  // folded into the call above (device time: see nltgv2_device)
 
     // ---- commit: every cached output changes together ----
     vtx_ = vtx;

@@ -97,11 +97,13 @@ class Graph {
 };
 
 // num_iters x (dualStep; primalStep; extraGradientStep).  Returns 0 or a flame_hip error code.
-inline int step(const Params& params, Graph* graph, int num_iters = 1) {
+// wait = false leaves the iterations running on the handle's stream (the next library call orders
+// itself behind them).
+inline int step(const Params& params, Graph* graph, int num_iters = 1, bool wait = true) {
   if (!graph || !graph->valid()) return FLAME_HIP_ERR_STATE;
   const flame_hip_params p = toC(params);
   int rc = flame_hip_solve(graph->handle(), &p, num_iters, nullptr);
-  return rc ? rc : flame_hip_sync(graph->handle());
+  return (rc || !wait) ? rc : flame_hip_sync(graph->handle());
 }
 
 inline float smoothnessCost(const Params& params, const Graph& graph) {

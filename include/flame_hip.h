@@ -165,6 +165,16 @@ int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smoot
 int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp,
                         float* vtx_normals, uint8_t* tri_valid, float* tri_normals);
 
+/* Everything flame::Flame::update() reads back after flame_hip_solve, in one call with ONE stream
+ * synchronisation: the two costs (in the solver's units, i.e. before scale_back is applied), then
+ * the state times scale_back (1 = leave it; rescale_data: the scale flame_hip_graph_sync returned),
+ * the idepths x (V), the per-triangle stage (vtx_normals 3V, tri_valid T) and the edge list derived
+ * by flame_hip_graph_sync (2E).  Any output pointer may be NULL.  Synchronises. */
+int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float scale_back,
+                            const float Kinv[9], const flame_hip_tri_params* tp, double* smooth,
+                            double* data, float* x, float* vtx_normals, uint8_t* tri_valid,
+                            int32_t* edges);
+
 /* "Next" row f1: the mesh as flame_ros publishes it on /flame/mesh.  Replaces the
  * vertex loop and face loop of publishDepthMesh (reference src/utils.cc:184-230): points = V x 12
  * floats in flame_ros::PointNormalUV layout {x,y,z,0 | nx,ny,nz,0 | u/(W-1), v/(H-1), 0, 0}

@@ -53,3 +53,31 @@ def test_sync_solve_unscale_triangles(gpu, adaptive, rescale, init_pred):
         assert np.array_equal(tv, tv_o)
         assert_bit_equal(vn, vn_o, "vertex normals")
     r.close()
+
+
+@pytest.mark.parametrize("rescale", [0, 1])
+def test_frame_results_one_call(gpu, rescale):
+    """flame_hip_frame_results (what flame::Flame::update reads back, one synchronisation) against
+    the oracle: costs in the solver's units, then idepths / normals / validity in the caller's."""
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    tp = default_tri_params(640, 480)
+    otp = OTri(*[getattr(tp, f[0]) for f in tp._fields_])
+    for V in (5000, 900):  # device-built plan / one isolated tile (host sync + host plan)
+        g, var, pred = features(V, 50 + V)
+        sp = default_sync_params(0, rescale, 1, 0.01)
+        s = oracle_sync(OSync(0, rescale, 1, 0.01), g.pos, g.z, var, g.tris, pred)
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+        o.solve(oracle_params(), 80)
+        so, do = o.costs(oracle_params())
+        o.scale_state(s["scale"])
+        tn_o, tv_o, vn_o = oracle_triangles(otp, Kinv, g.pos, o.x, g.tris)
+        r = GraphRegularizer.empty(device=0, tile_single_max=2048)
+        scale = r.sync_features(g.pos, g.z, var, g.tris, sp, prediction=pred)
+        r.step(default_params(), 80, sync=False)  # frame_results orders itself behind the solve
+        sg, dg, x, vn, tv, e = r.frame_results(default_params(), Kinv, tp, scale_back=scale, with_edges=True)
+        assert abs(sg - so) <= 1e-9 * so and abs(dg - do) <= 1e-9 * max(do, 1e-30)
+        assert_bit_equal(x, o.x, "x")
+        assert_bit_equal(vn, vn_o, "vertex normals")
+        assert np.array_equal(tv, tv_o) and np.array_equal(e, s["edges"])
+        r.close()

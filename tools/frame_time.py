@@ -24,3 +24,12 @@ for k in range(6):
     t4 = time.perf_counter()
     print("sync %.3f  solve %.3f  costs+x+edges %.3f  triangles %.3f  total %.3f ms" % (
         (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3), file=sys.stderr)
+for k in range(6):  # same frame, results through the one-synchronisation call the façade uses
+    t0 = time.perf_counter()
+    scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
+    t1 = time.perf_counter()
+    r.step(p, iters, sync=False)
+    out = r.frame_results(p, Kinv, tp, scale_back=scale, with_edges=True)
+    t2 = time.perf_counter()
+    print("sync %.3f  solve+frame_results %.3f  total %.3f ms" % (
+        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t2 - t0) * 1e3), file=sys.stderr)
