@@ -132,13 +132,20 @@ __device__ __forceinline__ int wave_max(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 
+// Packed fp32: the (w1, w2) halves of every update are the same operation on two floats, which
+// CDNA3+ issues as ONE v_pk_{add,mul,fma}_f32 (IEEE, the same rounding as the scalar op).  The
+// iteration phases are VALU-issue bound (4 cycles per wave64 instruction, 4 waves per SIMD), so
+// bar[] and the incidence slots keep the pair first: bar = {w1b, w2b, xb, -}, slot = {c1, c2, cx, -}.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Phase D on the first K of this thread's edges: every gather is issued before the first use.
+// ew = {alpha, beta, dx, dy}; es/ed = LDS addresses of the source / target incidence slot.
 template <int K, int EPT>
-__device__ __forceinline__ void tile_phase_d(const float4* bar, float4* cs,
-                                             const uint32_t (&eij)[EPT], const uint32_t (&ess)[EPT],
-                                             const uint32_t (&esd)[EPT], const float4 (&ew)[EPT],
-                                             float (&q1)[EPT], float (&q2)[EPT], float (&q3)[EPT],
-                                             float sigma) {
+__device__ __forceinline__ void tile_phase_d(const float4* bar, const uint32_t (&eij)[EPT],
+                                             float4* const (&es)[EPT], float4* const (&ed)[EPT],
+                                             const float4 (&ew)[EPT], float (&q1)[EPT],
+                                             f2v (&q23)[EPT], float sigma) {
   float4 bi[K], bj[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -147,37 +154,82 @@ __device__ __forceinline__ void tile_phase_d(const float4* bar, float4* cs,
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) { keep_w(bi[k]); keep_w(bj[k]); }
+  const f2v sg = {sigma, sigma};
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    dual_edge(bi[k], bj[k], ew[k], sigma, q1[k], q2[k], q3[k]);
-    const float aq = ew[k].x * q1[k], b2 = ew[k].y * q2[k], b3 = ew[k].y * q3[k];
-    // one 16-byte store per endpoint (ds_write_b128) instead of three scattered dwords
-    lds_store3(&cs[ess[k]], aq, fmaf(-ew[k].z, aq, b2), fmaf(-ew[k].w, aq, b3));
-    lds_store3(&cs[esd[k]], -aq, -b2, -b3);
+    // same expressions as dual_edge(), the (w1, w2) pair packed
+    const f2v wi = {bi[k].x, bi[k].y}, wj = {bj[k].x, bj[k].y};
+    const f2v be = {ew[k].y, ew[k].y}, nd = {-ew[k].z, -ew[k].w};
+    float t = bi[k].z - bj[k].z;
+    t = fmaf(-bi[k].x, ew[k].z, t);
+    t = fmaf(-bi[k].y, ew[k].w, t);
+    const float K1 = ew[k].x * t;
+    const f2v K23 = be * (wi - wj);
+    q1[k] = proj_unit(fmaf(sigma, K1, q1[k]));
+    f2v u = pk_fma(sg, K23, q23[k]);
+    u.x = proj_unit(u.x);
+    u.y = proj_unit(u.y);
+    q23[k] = u;
+    const float aq = ew[k].x * q1[k];
+    const f2v aq2 = {aq, aq};
+    const f2v b23 = be * u;
+    const f2v s23 = pk_fma(nd, aq2, b23);  // {fmaf(-dx, aq, b2), fmaf(-dy, aq, b3)}
+    // one 12-byte store per endpoint; -(a*b) == (-a)*b bit-for-bit, so the target side is two
+    // multiplies with a negated operand instead of three sign flips
+    lds_store3(es[k], s23.x, s23.y, aq);
+    const f2v n23 = (-be) * u;
+    lds_store3(ed[k], n23.x, n23.y, -ew[k].x * q1[k]);
   }
 }
 
 // nk (number of active edge blocks) is wave-uniform: dispatch to the matching unrolled body
 template <int K, int EPT>
 struct PhaseD {
-  static __device__ __forceinline__ void run(int nk, const float4* bar, float4* cs,
-                                             const uint32_t (&eij)[EPT],
-                                             const uint32_t (&ess)[EPT], const uint32_t (&esd)[EPT],
+  static __device__ __forceinline__ void run(int nk, const float4* bar, const uint32_t (&eij)[EPT],
+                                             float4* const (&es)[EPT], float4* const (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
-                                             float (&q2)[EPT], float (&q3)[EPT], float sigma) {
-    if (nk == K) tile_phase_d<K, EPT>(bar, cs, eij, ess, esd, ew, q1, q2, q3, sigma);
-    else PhaseD<K - 1, EPT>::run(nk, bar, cs, eij, ess, esd, ew, q1, q2, q3, sigma);
+                                             f2v (&q23)[EPT], float sigma) {
+    if (nk == K) tile_phase_d<K, EPT>(bar, eij, es, ed, ew, q1, q23, sigma);
+    else PhaseD<K - 1, EPT>::run(nk, bar, eij, es, ed, ew, q1, q23, sigma);
   }
 };
 template <int EPT>
 struct PhaseD<0, EPT> {
-  static __device__ __forceinline__ void run(int, const float4*, float4*,
-                                             const uint32_t (&)[EPT], const uint32_t (&)[EPT],
-                                             const uint32_t (&)[EPT], const float4 (&)[EPT],
-                                             float (&)[EPT], float (&)[EPT], float (&)[EPT], float) {}
+  static __device__ __forceinline__ void run(int, const float4*, const uint32_t (&)[EPT],
+                                             float4* const (&)[EPT], float4* const (&)[EPT],
+                                             const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],
+                                             float) {}
 };
 
 constexpr int kPRound = kSlotRound;  // incidence slots read per round of phase P
+
+// Phase P: K consecutive incidence slots of this lane's row, all reads issued before the first use
+// (constant offsets: no address arithmetic), then the dependent fma chain in slot order.
+template <int K>
+__device__ __forceinline__ void sum_slots(const float4* row, f2v nt2, float ntau, f2v& w, float& x) {
+  float4 t[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) t[u] = row[u];
+#pragma unroll
+  for (int u = 0; u < K; ++u) keep_w(t[u]);
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    const f2v c = {t[u].x, t[u].y};
+    w = pk_fma(nt2, c, w);
+    x = fmaf(ntau, t[u].z, x);
+  }
+}
+template <int K>
+struct SlotTail {  // n (wave-uniform, < kPRound) remaining slots
+  static __device__ __forceinline__ void run(int n, const float4* row, f2v nt2, float ntau, f2v& w, float& x) {
+    if (n == K) sum_slots<K>(row, nt2, ntau, w, x);
+    else SlotTail<K - 1>::run(n, row, nt2, ntau, w, x);
+  }
+};
+template <>
+struct SlotTail<0> {
+  static __device__ __forceinline__ void run(int, const float4*, f2v, float, f2v&, float&) {}
+};
 
 template <int NT, int EPT, int VPT>
 __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
@@ -202,9 +254,6 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   // active-set cutoffs live in lanes: lane l < 32 holds ring_end[l], lane 32+l holds level_end[l]
   int cut = 0;
   if ((lane & 31) <= kMaxDepth) cut = (lane < 32) ? D.ring_end[lane & 31] : D.level_end[lane & 31];
-
-  const int zslot = D.nslots + kDummySlots;  // the always-zero slot
-  if (tid == 0) cs[zslot] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // ---- global loads: index lists first, then every dependent gather, nothing waited between ----
   int gi[VPT];
@@ -241,27 +290,40 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     q1[k] = qq.x; q2[k] = qq.y; q3[k] = qq.z;
   }
 
-  float vx[VPT], vw1[VPT], vw2[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT], vw1b[VPT], vw2b[VPT];
+  // Every incidence slot starts at +0 and the padding of a row (slots past the vertex's degree, up
+  // to the group's pitch) is never written: phase P sums a wave-uniform number of slots per row
+  // without a per-lane bound, because fmaf(-tau, +0, x) == x bit-for-bit.  The stores go out while
+  // the global loads above are in flight.
+  for (int i = tid; i < D.nslots; i += NT) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float vx[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT];
+  f2v vw[VPT], vwb[VPT];
   int wdeg[VPT];
+  const float4* vrow[VPT];
   const float tl = a.p.tl;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
-    vx[k] = vA[k].x; vw1[k] = vA[k].y; vw2[k] = vA[k].z; vz[k] = vA[k].w;
-    vxb[k] = vB[k].x; vw1b[k] = vB[k].y; vw2b[k] = vB[k].z; vwgt[k] = vB[k].w;
+    vx[k] = vA[k].x; vw[k].x = vA[k].y; vw[k].y = vA[k].z; vz[k] = vA[k].w;
+    vxb[k] = vB[k].x; vwb[k].x = vB[k].y; vwb[k].y = vB[k].z; vwgt[k] = vB[k].w;
     vt[k] = tl * vwgt[k];
-    if (lv >= n_upd) vs[k] = 0;  // outermost ring / padding lanes: no incidence slots
-    if (lv < n_ext) bar[lv] = vB[k];
+    if (lv >= n_upd) vs[k] = 0;  // outermost ring / padding lanes: no row of their own (they sum
+                                 // somebody else's slots into a value that is never published)
+    if (lv < n_ext) bar[lv] = make_float4(vB[k].y, vB[k].z, vB[k].x, 0.f);
     wdeg[k] = wave_max((int)(vs[k] >> 16));
+    vrow[k] = cs + (vs[k] & 0xffffu);
   }
-  uint32_t eij[EPT], ess[EPT], esd[EPT];
+  uint32_t eij[EPT];
+  float4 *es[EPT], *ed[EPT];
+  f2v q23[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const bool real = (k * NT + tid) < e_loc;
     eij[k] = real ? er[k].x : 0u;  // padding edges gather local vertex 0 and write trash slots
     const uint32_t ss = er[k].y & 0xffffu, sd = er[k].y >> 16;
-    ess[k] = (real && ss != 0xffffu) ? ss : dummy;
-    esd[k] = (real && sd != 0xffffu) ? sd : dummy;
+    es[k] = cs + ((real && ss != 0xffffu) ? ss : dummy);
+    ed[k] = cs + ((real && sd != 0xffffu) ? sd : dummy);
+    q23[k].x = q2[k]; q23[k].y = q3[k];
   }
   __syncthreads();
   // optional in-kernel timeline (debug): [tile][0]=start, [1]=loaded, [2it]=after phase D of
@@ -270,6 +332,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   if (prof && tid == 0) { prof[0] = t_start; prof[1] = __builtin_readcyclecounter(); }
 
   const float sigma = a.p.sigma, ntau = -a.p.tau, theta = a.p.theta;
+  const f2v nt2 = {ntau, ntau}, th2 = {theta, theta};
   const float x_min = a.p.x_min, x_max = a.p.x_max;
   const int iters = a.iters;
   for (int it = 1; it <= iters; ++it) {
@@ -282,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     // wave-uniform: this wave's k-th edge block covers local edges [k NT + wbase, +64)
     const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
     // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
-    PhaseD<EPT, EPT>::run(nk, bar, cs, eij, ess, esd, ew, q1, q2, q3, sigma);
+    PhaseD<EPT, EPT>::run(nk, bar, eij, es, ed, ew, q1, q23, sigma);
     __syncthreads();
     if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it] = __builtin_readcyclecounter();
     // ---- phase P: primal descent (slot order = ascending original edge id), prox, extra-grad ----
@@ -290,32 +353,21 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     for (int k = 0; k < VPT; ++k) {
       if (k * NT + wbase < v_act) {  // wave-uniform
         const int lv = k * NT + tid;
-        const int sb = (int)(vs[k] & 0xffffu), deg = (int)(vs[k] >> 16);
-        const float xp = vx[k], w1p = vw1[k], w2p = vw2[k];
-        float x = xp, w1 = w1p, w2 = w2p;
-        // incidence j of this lane is at sb + j (rows have an odd pitch: a column read is
-        // conflict-free across lanes).  Past the vertex's degree the lane reads the shared +0
-        // slot instead: fmaf(-tau, +0, x) == x bit-for-bit, so the dependent fma chain carries
-        // no select (the select is on the address, ahead of the load).
-        for (int j = 0; j < wdeg[k]; j += kPRound) {  // wave-uniform trip count
-          float4 t[kPRound];
-#pragma unroll
-          for (int u = 0; u < kPRound; ++u) t[u] = cs[(j + u < deg) ? (sb + j + u) : zslot];
-#pragma unroll
-          for (int u = 0; u < kPRound; ++u) keep_w(t[u]);
-#pragma unroll
-          for (int u = 0; u < kPRound; ++u) {
-            x = fmaf(ntau, t[u].x, x);
-            w1 = fmaf(ntau, t[u].y, w1);
-            w2 = fmaf(ntau, t[u].z, w2);
-          }
-        }
+        const float xp = vx[k];
+        const f2v wp = vw[k];
+        float x = xp;
+        f2v w = wp;
+        // incidence j of this lane is at row[j] (rows have an odd pitch: a column read is
+        // conflict-free across lanes); the wave sums the longest row's length from every row
+        const float4* row = vrow[k];
+        int j = wdeg[k];  // wave-uniform
+        for (; j >= kPRound; j -= kPRound, row += kPRound) sum_slots<kPRound>(row, nt2, ntau, w, x);
+        SlotTail<kPRound - 1>::run(j, row, nt2, ntau, w, x);
         x = prox_l1(x, vz[k], vt[k], x_min, x_max);
         vxb[k] = fmaf(theta, x - xp, x);
-        vw1b[k] = fmaf(theta, w1 - w1p, w1);
-        vw2b[k] = fmaf(theta, w2 - w2p, w2);
-        vx[k] = x; vw1[k] = w1; vw2[k] = w2;
-        if (lv < n_upd) lds_store3(&bar[lv], vxb[k], vw1b[k], vw2b[k]);
+        vwb[k] = pk_fma(th2, w - wp, w);
+        vx[k] = x; vw[k] = w;
+        if (lv < n_upd) lds_store3(&bar[lv], vwb[k].x, vwb[k].y, vxb[k]);
       }
     }
     __syncthreads();
@@ -327,14 +379,14 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
-      a.A_dst[D.vstart + lv] = make_float4(vx[k], vw1[k], vw2[k], vz[k]);
-      a.B_dst[D.vstart + lv] = make_float4(vxb[k], vw1b[k], vw2b[k], vwgt[k]);
+      a.A_dst[D.vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, vz[k]);
+      a.B_dst[D.vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
     }
   }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int le = k * NT + tid;
-    if (le < e_own) a.q_dst[D.estart + le] = make_float4(q1[k], q2[k], q3[k], 0.0f);
+    if (le < e_own) a.q_dst[D.estart + le] = make_float4(q1[k], q23[k].x, q23[k].y, 0.0f);
   }
   if (prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
