@@ -241,15 +241,20 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
   const TileDesc& D = a.tiles[tile_id];
   const int tid = threadIdx.x;
-  const unsigned long long t_start = __builtin_readcyclecounter();
+  // the whole descriptor header up front, before anything with side effects: the compiler then
+  // fetches it with scalar loads in one go (a uniform *vector* load per use, each followed by a
+  // wait, was three serial round trips in front of the index loads)
   const int n_own = D.n_own, n_ext = D.n_ext, n_upd = D.n_upd;
   const int e_own = D.e_own, e_loc = D.e_loc, depth = D.depth;
+  const int vstart = D.vstart, estart = D.estart, nslots = D.nslots;
+  const int vmap_off = D.vmap_off, emap_off = D.emap_off, erec_off = D.erec_off, srow_off = D.srow_off;
   if (n_ext == 0) return;  // empty tile (more tiles than vertices)
+  const unsigned long long t_start = a.prof ? __builtin_readcyclecounter() : 0ull;
   float4* bar = reinterpret_cast<float4*>(smem);
-  float4* cs = bar + n_ext;  // D.nslots + kDummySlots incidence slots
+  float4* cs = bar + n_ext;  // nslots + kDummySlots incidence slots
   const int lane = tid & 63;
   const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
-  const uint32_t dummy = (uint32_t)(D.nslots + lane);  // per-lane trash slot: inert writes/reads
+  const uint32_t dummy = (uint32_t)(nslots + lane);  // per-lane trash slot: inert writes/reads
 
   // active-set cutoffs live in lanes: lane l < 32 holds ring_end[l], lane 32+l holds level_end[l]
   int cut = 0;
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
-    gi[k] = a.t_vmap[D.vmap_off + min(lv, n_ext - 1)];
-    vs[k] = a.t_srow[D.srow_off + min(lv, n_upd - 1)];
+    gi[k] = a.t_vmap[vmap_off + min(lv, n_ext - 1)];
+    vs[k] = a.t_srow[srow_off + min(lv, n_upd - 1)];
   }
   uint2 er[EPT];
   float4 ew[EPT];
@@ -270,17 +275,19 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int lec = min(k * NT + tid, max(e_loc - 1, 0));  // arrays carry one pad element
-    er[k] = a.t_eij[D.erec_off + lec];
-    ew[k] = a.t_ew[D.erec_off + lec];
-    qi[k] = a.t_emap[D.emap_off + lec];
+    er[k] = a.t_eij[erec_off + lec];
+    ew[k] = a.t_ew[erec_off + lec];
+    qi[k] = a.t_emap[emap_off + lec];
   }
   float4 vA[VPT], vB[VPT];
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
-    // the outermost ring is read-only: it needs x_bar (B) but not the primal state (A); fewer
-    // active lanes = fewer cache lines for the vector-memory unit to walk
-    vA[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k * NT + tid < n_upd) vA[k] = a.A_src[gi[k]];
+    // the outermost ring is read-only: it needs x_bar (B) but not the primal state (A).  Its lanes
+    // all read the tile's first own vertex instead (one cache line for the vector-memory unit to
+    // walk, the value is never used); a select on the address, NOT a branch around the load -- a
+    // predicated load makes the compiler wait for it inside the branch, which put a third
+    // dependent round trip (indices -> A -> B, q) into the load phase.
+    vA[k] = a.A_src[(k * NT + tid < n_upd) ? gi[k] : vstart];
     vB[k] = a.B_src[gi[k]];
   }
   float q1[EPT], q2[EPT], q3[EPT];
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   // to the group's pitch) is never written: phase P sums a wave-uniform number of slots per row
   // without a per-lane bound, because fmaf(-tau, +0, x) == x bit-for-bit.  The stores go out while
   // the global loads above are in flight.
-  for (int i = tid; i < D.nslots; i += NT) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < nslots; i += NT) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   float vx[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT];
   f2v vw[VPT], vwb[VPT];
@@ -379,14 +386,14 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
-      a.A_dst[D.vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, vz[k]);
-      a.B_dst[D.vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
+      a.A_dst[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, vz[k]);
+      a.B_dst[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
     }
   }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int le = k * NT + tid;
-    if (le < e_own) a.q_dst[D.estart + le] = make_float4(q1[k], q23[k].x, q23[k].y, 0.0f);
+    if (le < e_own) a.q_dst[estart + le] = make_float4(q1[k], q23[k].x, q23[k].y, 0.0f);
   }
   if (prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
