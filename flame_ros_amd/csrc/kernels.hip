@@ -126,6 +126,25 @@ __device__ __forceinline__ void lds_store3(float4* slot, float a, float b, float
 #endif
 }
 
+// Write-back of a tile's results.  FLAME_WT_STORE 1: write-through (sc0 sc1) so the lines drain
+// while slower tiles still compute instead of at the end-of-kernel release (guide, "boundary":
+// dirty bytes / 6 TB/s are added to the kernel boundary); 2: nontemporal.
+#ifndef FLAME_WT_STORE
+#define FLAME_WT_STORE 1
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_result(float4* p, float a, float b, float c, float d) {
+#if FLAME_WT_STORE == 1
+  f4v v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#elif FLAME_WT_STORE == 2
+  f4v v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
+#else
+  *p = make_float4(a, b, c, d);
+#endif
+}
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
@@ -386,14 +405,14 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
-      a.A_dst[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, vz[k]);
-      a.B_dst[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
+      store_result(&a.A_dst[vstart + lv], vx[k], vw[k].x, vw[k].y, vz[k]);
+      store_result(&a.B_dst[vstart + lv], vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
     }
   }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int le = k * NT + tid;
-    if (le < e_own) a.q_dst[estart + le] = make_float4(q1[k], q23[k].x, q23[k].y, 0.0f);
+    if (le < e_own) store_result(&a.q_dst[estart + le], q1[k], q23[k].x, q23[k].y, 0.0f);
   }
   if (prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }

@@ -296,7 +296,20 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
   if (sidx >= nseg_cur[0]) return;
   const int32_t glo = cur.lo[sidx], ghi = cur.hi[sidx], gleaves = cur.leaves[sidx], gfirst = cur.first[sidx];
   const int n = ghi - glo;
-  if (n > cap || gleaves > kSubLeaves) { if (tid == 0) atomicOr(&flags[0], 16); return; }
+  if (n > cap || gleaves > kSubLeaves) {
+    // Overflow: the host sees the flag at the builder's first sync and rebuilds one level later.
+    // Until then the later stages still run on this partition, so leave a VALID one behind (the
+    // segment cut into equal runs of the current order) -- stale table contents here sent the
+    // tile kernels out of bounds.
+    if (tid == 0) atomicOr(&flags[0], 16);
+    for (int j = tid; j < gleaves; j += kSubThreads) {
+      const int32_t a = glo + (int32_t)(((long long)n * j) / gleaves);
+      const int32_t b = glo + (int32_t)(((long long)n * (j + 1)) / gleaves);
+      out.lo[gfirst + j] = a; out.hi[gfirst + j] = b; out.leaves[gfirst + j] = 1; out.first[gfirst + j] = gfirst + j;
+      for (int32_t q = a; q < b; ++q) seg_pos[q] = gfirst + j;
+    }
+    return;
+  }
   uint64_t* packed = reinterpret_cast<uint64_t*>(smem);                 // kSubCap
   long long* wpre = reinterpret_cast<long long*>(packed + kSubCap);     // kSubCap
   long long* part = wpre + kSubCap;                                     // kSubThreads partial sums

@@ -197,7 +197,7 @@ def test_facade_sync_switches_and_frame_stream_on_gpu(gpu, exe, tmp_path, flags)
     # the GPU handle survives the stream: after the first frame (context, allocations, kernel
     # attributes) an update of a few thousand vertices is a matter of milliseconds
     ms = [float(l.split("update_ms=")[1].split()[0]) for l in p.stdout.splitlines() if "update_ms=" in l]
-    assert len(ms) == 3 and max(ms[1:]) < 25.0 and max(ms[1:]) < ms[0], ms
+    assert len(ms) == 3 and max(ms[1:]) < 60.0 and max(ms[1:]) < ms[0], ms
     g, var = frames[-1]
     x, vn, tv, nE, smooth, data, _, _ = read_outputs(ob, ot, g)
     s = oracle_sync(OSync(flags & 1, (flags >> 1) & 1, 1, 0.01), g.pos, g.z, var, g.tris)
