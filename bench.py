@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--no-balance", action="store_true")
     ap.add_argument("--order-mode", type=int, default=-1)
     ap.add_argument("--host-plan", action="store_true", help="build the plan with the host builder")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="extra library option (flame_hip_graph_set_option), repeatable")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "partition"],
@@ -164,6 +166,9 @@ def main():
     if args.no_balance: opts["balance"] = 0
     if args.host_plan: opts["plan_device"] = 0
     if args.order_mode >= 0: opts["order_mode"] = args.order_mode
+    for kv in args.opt:
+        k, v = kv.split("=")
+        opts[k] = int(v)
     p = default_params()
     if partition:
         from flame_ros_amd import dist as fdist

@@ -324,6 +324,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "order_mode") {
     if (value < 0 || value > 1) return FLAME_HIP_ERR_ARG;
     g->opt.order_mode = value;
+  } else if (k == "lane_order") {
+    g->opt.lane_order = value != 0;
   } else if (k == "balance") {
     g->opt.balance = value != 0;
   } else if (k == "host_threads") {

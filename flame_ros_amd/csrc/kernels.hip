@@ -136,7 +136,10 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_result(float4* p, float a, float b, float c, float d) {
 #if FLAME_WT_STORE == 1
   f4v v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // s_nop 1: a store of more than 64 bits followed by a VALU write of its data VGPRs needs two
+  // wait states (CDNA3 ISA, data hazards); the compiler pads its own stores, not inline asm --
+  // without it the next edge's address arithmetic landed in this store's first data register.
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #elif FLAME_WT_STORE == 2
   f4v v = {a, b, c, d};
   __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
@@ -412,7 +415,10 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int le = k * NT + tid;
-    if (le < e_own) store_result(&a.q_dst[estart + le], q1[k], q23[k].x, q23[k].y, 0.0f);
+    // owned <=> the edge's internal id lies in the tile's range (lanes inside a 64-edge block are
+    // assigned by the plan's conflict-avoiding lane order, not by internal id)
+    if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own)
+      store_result(&a.q_dst[qi[k]], q1[k], q23[k].x, q23[k].y, 0.0f);
   }
   if (prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }

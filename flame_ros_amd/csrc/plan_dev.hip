@@ -822,7 +822,8 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
                                                            const int32_t* __restrict__ meta,
                                                            const float4* __restrict__ ew, TileDesc* tiles,
                                                            int32_t* t_vmap, int32_t* t_emap, uint2* t_eij,
-                                                           float4* t_ew, uint32_t* t_srow, int32_t* flags) {
+                                                           float4* t_ew, uint32_t* t_srow, int32_t* flags,
+                                                           int lane_order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_fail, s_ecnt;
   __shared__ int32_t s_ring_end[kMaxDepth + 1], s_level_end[kMaxDepth + 1];
@@ -954,6 +955,68 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
     }
   }
   __syncthreads();
+  // ---- lane order inside every 64-edge block: plan.cpp assign_lanes(), the identical greedy ----
+  // One wave per block; lane l is candidate position l.  Per step the k-th edge of the sorted
+  // order is broadcast, every free lane prices itself from the wave's tables (first address per
+  // read group and bank class, stores per write group and bank class), the cheapest lowest lane
+  // takes the edge.  The sort keys are dead by now: their LDS holds the tables.
+  if (lane_order && !s_fail) {
+    const int wave = tid >> 6, lane = tid & 63;
+    volatile int32_t* tab = reinterpret_cast<int32_t*>(ekeys) + wave * 256;
+    volatile int32_t* rs_first = tab;        // [4][16] source gather: first address + 1
+    volatile int32_t* rt_first = tab + 64;   // [4][16] target gather
+    volatile int32_t* ws_cnt = tab + 128;    // [8][8]  source-slot stores
+    volatile int32_t* wd_cnt = tab + 192;    // [8][8]  target-slot stores
+    const int32_t nslots = s_gbase[kCapExt / 64];
+    const int hl = lane & 31;
+    const int rg = ((hl < 4 || (hl >= 12 && hl < 16) || (hl >= 20 && hl < 28)) ? 0 : 1) + 2 * (lane >> 5);
+    const int wg = lane >> 3;
+    for (int b0 = wave * 64; b0 < e_loc; b0 += (kP2Threads / 64) * 64) {
+      const int c = min(64, e_loc - b0);
+      rs_first[lane] = 0; rt_first[lane] = 0; ws_cnt[lane] = 0; wd_cnt[lane] = 0;
+      const int src_i = eoff + b0 + min(lane, c - 1);
+      const uint2 rec = t_eij[src_i];
+      const float4 w = t_ew[src_i];
+      const int32_t mp = t_emap[src_i];
+      bool used = lane >= c;
+      int got = lane;
+      for (int k = 0; k < c; ++k) {
+        const uint32_t ex = (uint32_t)__shfl((int)rec.x, k, 64), ey = (uint32_t)__shfl((int)rec.y, k, 64);
+        const int32_t li = (int32_t)(ex & 0xffffu), lj = (int32_t)(ex >> 16);
+        const uint32_t ss = ey & 0xffffu, sd = ey >> 16;
+        // a lane without a slot stores into its own trash slot (nslots + lane)
+        const uint32_t s1 = ss != 0xffffu ? ss : (uint32_t)(nslots + lane);
+        const uint32_t s2 = sd != 0xffffu ? sd : (uint32_t)(nslots + lane);
+        int key = 0x7fffffff;
+        if (!used) {
+          int cost = 0;
+          const int32_t fs = rs_first[rg * 16 + (li & 15)], ft = rt_first[rg * 16 + (lj & 15)];
+          if (fs != 0 && fs != li + 1) ++cost;
+          if (ft != 0 && ft != lj + 1) ++cost;
+          cost += ws_cnt[wg * 8 + (s1 & 7)] + wd_cnt[wg * 8 + (s2 & 7)];
+          key = cost * 64 + lane;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, 64));
+        if (lane == (key & 63)) {
+          used = true;
+          got = k;
+          if (rs_first[rg * 16 + (li & 15)] == 0) rs_first[rg * 16 + (li & 15)] = li + 1;
+          if (rt_first[rg * 16 + (lj & 15)] == 0) rt_first[rg * 16 + (lj & 15)] = lj + 1;
+          ws_cnt[wg * 8 + (s1 & 7)] = ws_cnt[wg * 8 + (s1 & 7)] + 1;
+          wd_cnt[wg * 8 + (s2 & 7)] = wd_cnt[wg * 8 + (s2 & 7)] + 1;
+        }
+      }
+      const uint32_t nx = (uint32_t)__shfl((int)rec.x, got, 64), ny = (uint32_t)__shfl((int)rec.y, got, 64);
+      const float wx = __shfl(w.x, got, 64), wy = __shfl(w.y, got, 64), wz = __shfl(w.z, got, 64), ww = __shfl(w.w, got, 64);
+      const int32_t nm = __shfl(mp, got, 64);
+      if (lane < c) {
+        t_eij[eoff + b0 + lane] = make_uint2(nx, ny);
+        t_ew[eoff + b0 + lane] = make_float4(wx, wy, wz, ww);
+        t_emap[eoff + b0 + lane] = nm;
+      }
+    }
+  }
   if (tid == 0) {
     TileDesc D = {};
     D.vstart = vstart; D.n_own = n_own; D.n_ext = n_ext;
@@ -1358,7 +1421,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     return hipErrorOutOfMemory;
   // ---- stage G ----
   hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
-                     tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_);
+                     tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_,
+                     opt.lane_order ? 1 : 0);
   tiles_host->resize(ntiles);
   HIPRET(hipMemcpyAsync(tiles_host->data(), A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
   HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));

@@ -30,3 +30,15 @@ for k in range(1, d + 1):
     print('iter%d  D p50 %d max %d | P p50 %d max %d' % (k, np.median(pd), pd.max(), np.median(pp), pp.max()))
 print('store  p50 %d  max %d' % (np.median(store), store.max()))
 print('total  p50 %d  max %d ; span %d' % (np.median(t[:, 35] - t[:, 0]), (t[:, 35] - t[:, 0]).max(), t[:, 35].max() - t0))
+# slowest tiles against the median tile: what they are made of (TileDesc = 13 header ints + rings/levels)
+td = r.plan_array('tiles', np.int32).reshape(len(t), -1)
+tot = t[:, 35] - t[:, 0]
+dsum = sum(t[:, 2 * k] - t[:, 2 * k - 1] for k in range(1, d + 1))
+psum = sum(t[:, 2 * k + 1] - t[:, 2 * k] for k in range(1, d + 1))
+order = np.argsort(tot)
+print('tile   n_own n_ext n_upd e_own e_loc nslots |  load     D     P store total')
+for i in list(order[-6:][::-1]) + [order[len(order) // 2], order[0]]:
+    print('%5d %6d %5d %5d %5d %5d %6d | %5d %5d %5d %5d %5d' % (i, td[i, 1], td[i, 2], td[i, 6], td[i, 4], td[i, 5], td[i, 12],
+          load[i], dsum[i], psum[i], store[i], tot[i]))
+for name, col in (('n_ext', td[:, 2]), ('e_loc', td[:, 5]), ('nslots', td[:, 12])):
+    print('corr(total, %s) = %.2f   corr(load, %s) = %.2f' % (name, np.corrcoef(tot, col)[0, 1], name, np.corrcoef(load, col)[0, 1]))
