@@ -292,31 +292,39 @@ __global__ __launch_bounds__(NT) void k_tile(const TileArgs a) {
     vs[k] = a.t_srow[srow_off + min(lv, n_upd - 1)];
   }
   uint2 er[EPT];
-  float4 ew[EPT];
   int qi[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int lec = min(k * NT + tid, max(e_loc - 1, 0));  // arrays carry one pad element
     er[k] = a.t_eij[erec_off + lec];
-    ew[k] = a.t_ew[erec_off + lec];
     qi[k] = a.t_emap[emap_off + lec];
   }
+  // Loads return in issue order, so they are issued in the order of first need: x_bar (B) of every
+  // local vertex fills bar[] and is all the first workgroup barrier waits for; the edge constants,
+  // q and the primal state (A) are still in flight across that barrier and are waited for by the
+  // wave that needs them (phase D: ew, q; phase P: A).
   float4 vA[VPT], vB[VPT];
 #pragma unroll
-  for (int k = 0; k < VPT; ++k) {
-    // the outermost ring is read-only: it needs x_bar (B) but not the primal state (A).  Its lanes
-    // all read the tile's first own vertex instead (one cache line for the vector-memory unit to
-    // walk, the value is never used); a select on the address, NOT a branch around the load -- a
-    // predicated load makes the compiler wait for it inside the branch, which put a third
-    // dependent round trip (indices -> A -> B, q) into the load phase.
-    vA[k] = a.A_src[(k * NT + tid < n_upd) ? gi[k] : vstart];
-    vB[k] = a.B_src[gi[k]];
+  for (int k = 0; k < VPT; ++k) vB[k] = a.B_src[gi[k]];
+  float4 ew[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int lec = min(k * NT + tid, max(e_loc - 1, 0));
+    ew[k] = a.t_ew[erec_off + lec];
   }
   float q1[EPT], q2[EPT], q3[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const float4 qq = a.q_src[e_loc > 0 ? qi[k] : 0];
     q1[k] = qq.x; q2[k] = qq.y; q3[k] = qq.z;
+  }
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    // the outermost ring is read-only: it needs x_bar (B) but not the primal state (A).  Its lanes
+    // all read the tile's first own vertex instead (one cache line for the vector-memory unit to
+    // walk, the value is never used); a select on the address, NOT a branch around the load -- a
+    // predicated load makes the compiler wait for it inside the branch.
+    vA[k] = a.A_src[(k * NT + tid < n_upd) ? gi[k] : vstart];
   }
 
   // Every incidence slot starts at +0 and the padding of a row (slots past the vertex's degree, up

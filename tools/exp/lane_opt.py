@@ -54,7 +54,7 @@ def swaps(assign, E, passes=2):
     return assign
 
 rng = np.random.default_rng(0)
-res = {"sorted": [], "greedy_exact": [], "greedy+swap": []}
+res = {"sorted": [], "greedy_exact": [], "greedy_rev": [], "greedy_hard_first": [], "greedy_rand": []}
 tiles = rng.choice(len(td), 6, replace=False)
 for t in tiles:
     D = td[t]; e_loc, off = D[5], D[10]
@@ -64,5 +64,10 @@ for t in tiles:
         c = len(E)
         res["sorted"].append(cost_of(list(range(c)), E))
         a = greedy(E, range(c)); res["greedy_exact"].append(cost_of(a, E))
-        a = swaps(a, E); res["greedy+swap"].append(cost_of(a, E))
+        a = greedy(E, range(c - 1, -1, -1)); res["greedy_rev"].append(cost_of(a, E))
+        from collections import Counter
+        cs = Counter(e[2] % 8 for e in E if e[2] != 0xffff); cd = Counter(e[3] % 8 for e in E if e[3] != 0xffff); ct = Counter(e[1] % 16 for e in E)
+        hard = sorted(range(c), key=lambda i: -(cs.get(E[i][2] % 8, 0) + cd.get(E[i][3] % 8, 0) + ct[E[i][1] % 16]))
+        a = greedy(E, hard); res["greedy_hard_first"].append(cost_of(a, E))
+        a = greedy(E, list(rng.permutation(c))); res["greedy_rand"].append(cost_of(a, E))
 for k, v in res.items(): print(k, "mean extra cycles/block %.2f" % np.mean(v), "n", len(v))
