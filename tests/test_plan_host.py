@@ -88,7 +88,9 @@ PLANS = [(2000, dict(tile_own=64, tile_depth=3)), (3000, dict(tile_own=200, tile
 @pytest.mark.parametrize("V,opts", PLANS)
 def test_plan_invariants(V, opts):
     g = graphgen.synthetic(V, seed=V)
-    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **opts)
+    # the sorted local edge order (lane_order = 0); the conflict-avoiding lane order is checked
+    # against it in test_lane_order_permutes_inside_blocks
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, lane_order=0, **opts)
     assert r.info("path") == lib.PATH_TILE
     v_o2i, v_i2o = r.plan_array("v_o2i", np.int32), r.plan_array("v_i2o", np.int32)
     e_o2i, e_i2o = r.plan_array("e_o2i", np.int32), r.plan_array("e_i2o", np.int32)
@@ -169,6 +171,60 @@ def test_plan_invariants(V, opts):
     assert r.info("tile_lds_bytes") <= r.info("lds_bytes")
     assert r.info("tile_threads") * r.info("tile_ept") >= max(t.e_loc for t in tiles)
     assert r.info("tile_threads") * r.info("tile_vpt") >= max(t.n_ext for t in tiles)
+
+
+def _read_groups():
+    g = []
+    for lane in range(64):
+        h = lane & 31
+        g.append((0 if (h < 4 or 12 <= h < 16 or 20 <= h < 28) else 1) + 2 * (lane >> 5))
+    return np.array(g)
+
+
+def _phase_d_conflicts(rec, nslots):
+    """Modelled extra LDS cycles of one 64-edge block (MI355X guide, LDS): ds_read_b128 in 4 groups
+    of 16 lanes with 16 bank classes, ds_write_b96 in 8 groups of 8 lanes with 8 classes; equal
+    addresses broadcast; a group costs its busiest class."""
+    c = len(rec)
+    lanes = np.arange(c)
+    li, lj = rec[:, 0] & 0xffff, rec[:, 0] >> 16
+    ss, sd = rec[:, 1] & 0xffff, rec[:, 1] >> 16
+    ss = np.where(ss == 0xffff, nslots + lanes, ss)
+    sd = np.where(sd == 0xffff, nslots + lanes, sd)
+    rg = _read_groups()[:c]
+    extra = 0
+    for idx, grp, mod in ((li, rg, 16), (lj, rg, 16), (ss, lanes >> 3, 8), (sd, lanes >> 3, 8)):
+        for q in np.unique(grp):
+            a = np.unique(idx[grp == q])
+            extra += int(np.bincount(a % mod, minlength=mod).max()) - 1
+    return extra
+
+
+@pytest.mark.parametrize("V,opts", PLANS[:3])
+def test_lane_order_permutes_inside_blocks(V, opts):
+    """lane_order = 1 (default): inside every block of 64 local edges (one wave's share of phase D)
+    the edges are re-assigned to lanes against LDS bank conflicts; which edges a block holds, and
+    every other plan array, is unchanged, and the modelled conflict cycles go down."""
+    g = graphgen.synthetic(V, seed=V)
+    r0 = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, lane_order=0, **opts)
+    r1 = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **opts)
+    for name, dt in (("v_o2i", np.int32), ("e_o2i", np.int32), ("grow", np.int32), ("ginc", np.int32),
+                     ("tiles", np.int32), ("t_vmap", np.int32), ("t_srow", np.uint32)):
+        assert np.array_equal(r0.plan_array(name, dt), r1.plan_array(name, dt)), name
+    e0, e1 = r0.plan_array("t_emap", np.int32), r1.plan_array("t_emap", np.int32)
+    c0 = np.concatenate([r0.plan_array("t_eij", np.uint32).reshape(-1, 2), r0.plan_array("t_ew", np.uint32).reshape(-1, 4)], axis=1)
+    c1 = np.concatenate([r1.plan_array("t_eij", np.uint32).reshape(-1, 2), r1.plan_array("t_ew", np.uint32).reshape(-1, 4)], axis=1)
+    before = after = 0
+    for T in tiles_of(r0):
+        for b0 in range(0, T.e_loc, 64):
+            s = slice(T.emap_off + b0, T.emap_off + min(b0 + 64, T.e_loc))
+            p = np.argsort(e1[s], kind="stable")
+            q = np.argsort(e0[s], kind="stable")
+            assert np.array_equal(e1[s][p], e0[s][q])            # the same edges ...
+            assert np.array_equal(c1[s][p], c0[s][q])            # ... with their records
+            before += _phase_d_conflicts(c0[s, :2], T.nslots)
+            after += _phase_d_conflicts(c1[s, :2], T.nslots)
+    assert after < 0.8 * before, (before, after)
 
 
 def test_tile_schedule_reproduces_global_iteration():
