@@ -198,6 +198,7 @@ struct flame_hip_graph {
   std::vector<GraphExecEntry> execs;
   CapMap caps;
   int solves_since_upload = 0;
+  bool lanes_applied = false;  // lane_order = 1: the conflict-avoiding lane order is in the device arrays
 
   void drop_execs() {
     for (auto& e : execs) (void)hipGraphExecDestroy(e.exec);
@@ -325,7 +326,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     if (value < 0 || value > 1) return FLAME_HIP_ERR_ARG;
     g->opt.order_mode = value;
   } else if (k == "lane_order") {
-    g->opt.lane_order = value != 0;
+    if (value < 0 || value > 2) return FLAME_HIP_ERR_ARG;
+    g->opt.lane_order = value;
   } else if (k == "balance") {
     g->opt.balance = value != 0;
   } else if (k == "host_threads") {
@@ -632,6 +634,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     HIPCHK(hipStreamSynchronize(g->stream_in));
     g->drop_execs();  // captured launches hold the old grid / pointers
     g->solves_since_upload = 0;
+    g->lanes_applied = false;
     rc = upload_device_plan(g, pos, edges, alpha, beta, z, wgt, x0, tris);
     if (rc < 0) return rc;
   } else {
@@ -804,6 +807,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     g->n_send_v = g->n_send_e = g->n_recv_v = g->n_recv_e = 0;
     g->drop_execs();
     g->solves_since_upload = 0;
+    g->lanes_applied = false;
     g->beta_is_alpha = true;
     rc = upload_device_plan(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, true);
     if (rc < 0) return rc;
@@ -961,6 +965,16 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   sp.lambda = p->data_factor; sp.tau = p->step_x; sp.sigma = p->step_q; sp.theta = p->theta;
   sp.x_min = p->x_min; sp.x_max = p->x_max;
   sp.tl = p->step_x * p->data_factor;
+  // The plan is being solved a second time, i.e. it is reused (a resident graph, the subdomain
+  // solver, a bench): only now the lanes of every 64-edge block are re-assigned against LDS bank
+  // conflicts (plan.h lane_order = 1) -- a frame stream that solves each graph once never pays.
+  if (g->path == FLAME_HIP_PATH_TILE && g->opt.lane_order == 1 && !g->lanes_applied &&
+      g->solves_since_upload > 0 && num_iters > 0 && g->V > 0) {
+    int e_max = 0;
+    for (const TileDesc& D : g->plan.tiles) e_max = std::max(e_max, D.e_loc);
+    HIPCHK(launch_assign_lanes(s, (int32_t)g->plan.tiles.size(), e_max, g->tiles, g->t_eij, g->t_ew, g->t_emap));
+    g->lanes_applied = true;
+  }
   HIPCHK(hipEventRecord(g->ev0, s));
   int launches = 0, cur_out = g->cur;
   if (num_iters > 0 && g->V > 0) {
@@ -1356,6 +1370,18 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
     else if (k == "t_ew") { dev = g->t_ew; n = ne; esz = 16; }
     else if (k == "t_srow") { dev = g->t_srow; n = ns; }
     else return FLAME_HIP_ERR_ARG;
+    if (buf && cap_bytes > 0 && n > 0) {
+      if (hipSetDevice(g->device) != hipSuccess ||
+          memcpy_sync(g->stream, buf, dev, (size_t)std::min<int64_t>(cap_bytes, n * esz), hipMemcpyDeviceToHost) != hipSuccess)
+        return FLAME_HIP_ERR_HIP;
+    }
+    return n;
+  }
+  if (g->lanes_applied && g->device >= 0 && (k == "t_emap" || k == "t_eij" || k == "t_ew")) {
+    // host-built plan whose lane order was applied on the device afterwards: the device holds it
+    const void* dev = k == "t_emap" ? (const void*)g->t_emap : k == "t_eij" ? (const void*)g->t_eij : (const void*)g->t_ew;
+    n = (int64_t)P.t_emap.size();
+    esz = k == "t_emap" ? 4 : k == "t_eij" ? 8 : 16;
     if (buf && cap_bytes > 0 && n > 0) {
       if (hipSetDevice(g->device) != hipSuccess ||
           memcpy_sync(g->stream, buf, dev, (size_t)std::min<int64_t>(cap_bytes, n * esz), hipMemcpyDeviceToHost) != hipSuccess)

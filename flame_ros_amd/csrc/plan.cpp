@@ -580,7 +580,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
           O.eij[le] = {li | (lj << 16), (uint32_t)slot_src[le] | ((uint32_t)slot_dst[le] << 16)};
           O.ew[le] = P.ew[k];
         }
-        if (opt.lane_order) assign_lanes(D.e_loc, D.nslots, O.eij, O.ew, O.emap);
+        if (opt.lane_order == 2) assign_lanes(D.e_loc, D.nslots, O.eij, O.ew, O.emap);
       }
     };
     lap("tiles setup");

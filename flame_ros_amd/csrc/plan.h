@@ -22,7 +22,10 @@ struct PlanOptions {
   int host_threads = 0;  // plan-build threads (0 = up to 8)
   int balance = 1;       // second, cost-weighted bisection pass (equalises tile cost)
   int order_mode = 1;    // vertex order inside tiles / rings: 0 by degree, 1 spatial (gather locality)
-  int lane_order = 1;    // lanes inside every 64-edge block assigned to avoid LDS bank conflicts
+  // lanes inside every 64-edge block assigned against LDS bank conflicts (+2 % iterations/s, but
+  // 60 us of GPU time at 50 k vertices, more on the host): 0 never; 1 when a plan is solved a
+  // SECOND time (a frame stream that solves every graph once never pays for it); 2 at build time
+  int lane_order = 1;
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
                          // this many vertices on its first try (exercises the recovery path)

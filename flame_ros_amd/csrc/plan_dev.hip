@@ -815,6 +815,74 @@ __global__ __launch_bounds__(kSegCap) void k_tile_offsets(int ntiles, int32_t* m
   if (t == kSegCap - 1) { flags[1] = sc[0][t]; flags[2] = sc[1][t]; flags[3] = sc[2][t]; }
 }
 
+// Lane order inside one block of 64 local edges (plan.cpp assign_lanes(), the identical greedy),
+// run by ONE wave; lane l is candidate position l.  Per step the k-th edge of the sorted order is
+// broadcast, every free lane prices itself from the wave's tables, the cheapest lowest lane takes
+// the edge.  The tables live in registers, one entry per lane: lane g*16+c holds the first address
+// (+1) gathered in read group g from bank class c (source and target tables), lane w*8+c the
+// number of stores of write group w into class c (source- and target-slot tables); lookups are
+// lane reads, the winner is found with ballots -- no LDS, no barriers.
+__device__ __forceinline__ void assign_lanes_block(int lane, int b0, int e_loc, int32_t eoff, int32_t nslots,
+                                                   uint2* t_eij, float4* t_ew, int32_t* t_emap) {
+  const int hl = lane & 31;
+  const int rg = ((hl < 4 || (hl >= 12 && hl < 16) || (hl >= 20 && hl < 28)) ? 0 : 1) + 2 * (lane >> 5);
+  const int wg = lane >> 3;
+  const int c = min(64, e_loc - b0);
+  const int src_i = eoff + b0 + min(lane, c - 1);
+  const uint2 rec = t_eij[src_i];
+  const float4 w = t_ew[src_i];
+  const int32_t mp = t_emap[src_i];
+  int32_t T_rs = 0, T_rt = 0, T_ws = 0, T_wd = 0;
+  bool used = lane >= c;
+  int got = lane;
+  for (int k = 0; k < c; ++k) {
+    const uint32_t ex = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, k);
+    const uint32_t ey = (uint32_t)__builtin_amdgcn_readlane((int)rec.y, k);
+    const int32_t li = (int32_t)(ex & 0xffffu), lj = (int32_t)(ex >> 16);
+    const uint32_t ss = ey & 0xffffu, sd = ey >> 16;
+    // a lane without a slot stores into its own trash slot (nslots + lane)
+    const uint32_t s1 = ss != 0xffffu ? ss : (uint32_t)(nslots + lane);
+    const uint32_t s2 = sd != 0xffffu ? sd : (uint32_t)(nslots + lane);
+    const int32_t fs = __shfl(T_rs, rg * 16 + (li & 15), 64), ft = __shfl(T_rt, rg * 16 + (lj & 15), 64);
+    int cost = __shfl(T_ws, wg * 8 + (int)(s1 & 7), 64) + __shfl(T_wd, wg * 8 + (int)(s2 & 7), 64);
+    if (fs != 0 && fs != li + 1) ++cost;
+    if (ft != 0 && ft != lj + 1) ++cost;
+    int best = -1;
+    for (int cc = 0; best < 0; ++cc) {  // the cheapest free lane, lowest first (costs are small)
+      const unsigned long long m = __ballot(!used && cost == cc);
+      if (m) best = (int)__builtin_ctzll(m);
+    }
+    const int hb = best & 31;
+    const int rgb = ((hb < 4 || (hb >= 12 && hb < 16) || (hb >= 20 && hb < 28)) ? 0 : 1) + 2 * (best >> 5);
+    const int wgb = best >> 3;
+    const uint32_t s1b = ss != 0xffffu ? ss : (uint32_t)(nslots + best);
+    const uint32_t s2b = sd != 0xffffu ? sd : (uint32_t)(nslots + best);
+    if (lane == best) { used = true; got = k; }
+    if (lane == rgb * 16 + (li & 15) && T_rs == 0) T_rs = li + 1;
+    if (lane == rgb * 16 + (lj & 15) && T_rt == 0) T_rt = lj + 1;
+    if (lane == wgb * 8 + (int)(s1b & 7)) ++T_ws;
+    if (lane == wgb * 8 + (int)(s2b & 7)) ++T_wd;
+  }
+  const uint32_t nx = (uint32_t)__shfl((int)rec.x, got, 64), ny = (uint32_t)__shfl((int)rec.y, got, 64);
+  const float wx = __shfl(w.x, got, 64), wy = __shfl(w.y, got, 64), wz = __shfl(w.z, got, 64), ww = __shfl(w.w, got, 64);
+  const int32_t nm = __shfl(mp, got, 64);
+  if (lane < c) {
+    t_eij[eoff + b0 + lane] = make_uint2(nx, ny);
+    t_ew[eoff + b0 + lane] = make_float4(wx, wy, wz, ww);
+    t_emap[eoff + b0 + lane] = nm;
+  }
+}
+
+// The same on a finished plan (lane_order = 1: when a plan is solved a second time, see
+// flame_hip.cpp): grid (tiles, blocks of 4 edge blocks), one wave per 64-edge block.
+__global__ __launch_bounds__(256) void k_assign_lanes(const TileDesc* __restrict__ tiles, uint2* t_eij, float4* t_ew,
+                                                      int32_t* t_emap) {
+  const TileDesc D = tiles[blockIdx.x];
+  const int b0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64;
+  if (D.n_ext <= 0 || b0 >= D.e_loc) return;
+  assign_lanes_block(threadIdx.x & 63, b0, D.e_loc, D.erec_off, D.nslots, t_eij, t_ew, t_emap);
+}
+
 __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const int32_t* __restrict__ vstart_tab,
                                                            const int32_t* __restrict__ vend_tab,
                                                            const int32_t* __restrict__ estart,
@@ -955,67 +1023,11 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
     }
   }
   __syncthreads();
-  // ---- lane order inside every 64-edge block: plan.cpp assign_lanes(), the identical greedy ----
-  // One wave per block; lane l is candidate position l.  Per step the k-th edge of the sorted
-  // order is broadcast, every free lane prices itself from the wave's tables (first address per
-  // read group and bank class, stores per write group and bank class), the cheapest lowest lane
-  // takes the edge.  The sort keys are dead by now: their LDS holds the tables.
+  // ---- lane order at build time (lane_order = 2): plan.cpp assign_lanes(), the identical greedy ----
   if (lane_order && !s_fail) {
-    const int wave = tid >> 6, lane = tid & 63;
-    volatile int32_t* tab = reinterpret_cast<int32_t*>(ekeys) + wave * 256;
-    volatile int32_t* rs_first = tab;        // [4][16] source gather: first address + 1
-    volatile int32_t* rt_first = tab + 64;   // [4][16] target gather
-    volatile int32_t* ws_cnt = tab + 128;    // [8][8]  source-slot stores
-    volatile int32_t* wd_cnt = tab + 192;    // [8][8]  target-slot stores
     const int32_t nslots = s_gbase[kCapExt / 64];
-    const int hl = lane & 31;
-    const int rg = ((hl < 4 || (hl >= 12 && hl < 16) || (hl >= 20 && hl < 28)) ? 0 : 1) + 2 * (lane >> 5);
-    const int wg = lane >> 3;
-    for (int b0 = wave * 64; b0 < e_loc; b0 += (kP2Threads / 64) * 64) {
-      const int c = min(64, e_loc - b0);
-      rs_first[lane] = 0; rt_first[lane] = 0; ws_cnt[lane] = 0; wd_cnt[lane] = 0;
-      const int src_i = eoff + b0 + min(lane, c - 1);
-      const uint2 rec = t_eij[src_i];
-      const float4 w = t_ew[src_i];
-      const int32_t mp = t_emap[src_i];
-      bool used = lane >= c;
-      int got = lane;
-      for (int k = 0; k < c; ++k) {
-        const uint32_t ex = (uint32_t)__shfl((int)rec.x, k, 64), ey = (uint32_t)__shfl((int)rec.y, k, 64);
-        const int32_t li = (int32_t)(ex & 0xffffu), lj = (int32_t)(ex >> 16);
-        const uint32_t ss = ey & 0xffffu, sd = ey >> 16;
-        // a lane without a slot stores into its own trash slot (nslots + lane)
-        const uint32_t s1 = ss != 0xffffu ? ss : (uint32_t)(nslots + lane);
-        const uint32_t s2 = sd != 0xffffu ? sd : (uint32_t)(nslots + lane);
-        int key = 0x7fffffff;
-        if (!used) {
-          int cost = 0;
-          const int32_t fs = rs_first[rg * 16 + (li & 15)], ft = rt_first[rg * 16 + (lj & 15)];
-          if (fs != 0 && fs != li + 1) ++cost;
-          if (ft != 0 && ft != lj + 1) ++cost;
-          cost += ws_cnt[wg * 8 + (s1 & 7)] + wd_cnt[wg * 8 + (s2 & 7)];
-          key = cost * 64 + lane;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, 64));
-        if (lane == (key & 63)) {
-          used = true;
-          got = k;
-          if (rs_first[rg * 16 + (li & 15)] == 0) rs_first[rg * 16 + (li & 15)] = li + 1;
-          if (rt_first[rg * 16 + (lj & 15)] == 0) rt_first[rg * 16 + (lj & 15)] = lj + 1;
-          ws_cnt[wg * 8 + (s1 & 7)] = ws_cnt[wg * 8 + (s1 & 7)] + 1;
-          wd_cnt[wg * 8 + (s2 & 7)] = wd_cnt[wg * 8 + (s2 & 7)] + 1;
-        }
-      }
-      const uint32_t nx = (uint32_t)__shfl((int)rec.x, got, 64), ny = (uint32_t)__shfl((int)rec.y, got, 64);
-      const float wx = __shfl(w.x, got, 64), wy = __shfl(w.y, got, 64), wz = __shfl(w.z, got, 64), ww = __shfl(w.w, got, 64);
-      const int32_t nm = __shfl(mp, got, 64);
-      if (lane < c) {
-        t_eij[eoff + b0 + lane] = make_uint2(nx, ny);
-        t_ew[eoff + b0 + lane] = make_float4(wx, wy, wz, ww);
-        t_emap[eoff + b0 + lane] = nm;
-      }
-    }
+    for (int b0 = (tid >> 6) * 64; b0 < e_loc; b0 += (kP2Threads / 64) * 64)
+      assign_lanes_block(tid & 63, b0, e_loc, eoff, nslots, t_eij, t_ew, t_emap);
   }
   if (tid == 0) {
     TileDesc D = {};
@@ -1422,7 +1434,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // ---- stage G ----
   hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
                      tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_,
-                     opt.lane_order ? 1 : 0);
+                     opt.lane_order == 2 ? 1 : 0);
   tiles_host->resize(ntiles);
   HIPRET(hipMemcpyAsync(tiles_host->data(), A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
   HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
@@ -1493,6 +1505,14 @@ hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const D
   hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, s, V, reinterpret_cast<unsigned long long*>(grid_sum_),
                      grid_cnt_, grid_w_);
   grid_tiles_ = ntiles;
+  return hipGetLastError();
+}
+
+hipError_t launch_assign_lanes(hipStream_t s, int32_t ntiles, int32_t e_max, const TileDesc* tiles, uint2* t_eij,
+                               float4* t_ew, int32_t* t_emap) {
+  if (ntiles <= 0 || e_max <= 0) return hipSuccess;
+  const unsigned by = (unsigned)((e_max + 255) / 256);
+  hipLaunchKernelGGL(k_assign_lanes, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
   return hipGetLastError();
 }
 

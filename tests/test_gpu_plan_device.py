@@ -37,6 +37,8 @@ def compare_plans(host, dev, what):
 
 CASES = [
     ("5k", dict()),
+    ("5k", dict(lane_order=2)),
+    ("50k", dict(lane_order=2)),
     ("5k", dict(balance=0)),
     ("5k", dict(tile_own=64, tile_depth=2)),
     ("5k", dict(tile_own=300, tile_depth=6)),
@@ -55,6 +57,38 @@ def test_device_plan_equals_host_plan(gpu, name, opts):
     dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, **opts)
     compare_plans(host, dev, "%s %s" % (name, opts))
     host.close(); dev.close()
+
+
+@pytest.mark.parametrize("name,plan_device", [("5k", 1), ("5k", 0), ("tum", 0), ("50k", 1)])
+def test_lane_order_on_second_solve_equals_build_time(gpu, name, plan_device):
+    """lane_order = 1 (default): the plan keeps the sorted lane order until it is solved a SECOND
+    time (a frame stream never pays for it); what the device then writes is exactly what
+    lane_order = 2 builds (host builder and device builder), and the results stay bit-exact."""
+    g, _ = graphgen.named(name)
+    kw = dict(plan_device=plan_device)
+    if name == "tum": kw["tile_single_max"] = 2048  # one isolated tile
+    built = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, lane_order=2, **kw)
+    lazy = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, **kw)
+    sorted_ = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, lane_order=0, **kw)
+    lists = [("t_emap", np.int32), ("t_eij", np.uint32), ("t_ew", np.uint32)]
+    for n, dt in lists:
+        assert np.array_equal(lazy.plan_array(n, dt), sorted_.plan_array(n, dt)), n
+    o = make_oracle(g)
+    for k in range(3):
+        o.solve(oracle_params(), 21)
+        for r in (built, lazy, sorted_):
+            r.step(default_params(), 21)
+        if k == 0:  # one solve: still the sorted order
+            assert np.array_equal(lazy.plan_array("t_emap", np.int32), sorted_.plan_array("t_emap", np.int32))
+    differs = False
+    for n, dt in lists:
+        assert np.array_equal(lazy.plan_array(n, dt), built.plan_array(n, dt)), n
+        differs |= not np.array_equal(lazy.plan_array(n, dt), sorted_.plan_array(n, dt))
+    assert differs
+    for r in (built, lazy, sorted_):
+        x, w1, w2, q = r.download()
+        assert_bit_equal(x, o.x, "x"); assert_bit_equal(q, o.q, "q")
+        r.close()
 
 
 def _irregular(kind):
