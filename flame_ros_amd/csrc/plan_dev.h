@@ -138,6 +138,16 @@ class DevPlanner {
   int32_t* grid_w_ = nullptr;      // kGrid^2
   float* grid_bounds_ = nullptr;   // mn.x mn.y mx.x mx.y of the frame the grid was made from
   float* gbbox_ = nullptr;         // global bbox of the current frame (4 floats)
+  // stage E (vertex -> triangle CSR) runs beside the edge stages on a stream of its own, with its
+  // own sort scratch
+  hipStream_t s2_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  int64_t capT2_ = 0;
+  size_t tcub_bytes_ = 0;
+  void* tcub_tmp_ = nullptr;
+  uint64_t* tkeys_a_ = nullptr;  // 3T
+  uint64_t* tkeys_b_ = nullptr;
+  uint32_t* tvals_a_ = nullptr;
 };
 
 // Conflict-avoiding lane order applied to a finished plan on the device (plan.h PlanOptions::

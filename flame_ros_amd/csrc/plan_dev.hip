@@ -273,12 +273,44 @@ __global__ __launch_bounds__(256) void k_rcb_assign(int32_t V, int32_t* seg_pos,
 
 // ------------------------------------------------------------------------------------------
 // Stage A, deep levels: once a segment holds <= kSubCap vertices its whole remaining bisection
-// subtree is finished by ONE workgroup in LDS (sort by (segment, rank), integer weight prefix, the
-// same split rule), instead of ~12 dependent launches per level.
+// subtree is finished by ONE workgroup in LDS, instead of ~12 dependent launches per level.
+// The subtree's vertices are sorted ONCE along x and once along y (global ranks = the total order
+// (coordinate, id); a lone subtree that is the whole graph sorts the coordinates themselves, stably
+// from id order).  Every level then only PARTITIONS the two lists stably (one block scan of the
+// side flags per list): both stay sorted inside every segment, so the bounding box of a segment is
+// the two ends of its lists and the order along the chosen axis is simply that axis' list.  The
+// split rule (integer weight prefix along the chosen axis) is the host builder's.
 // ------------------------------------------------------------------------------------------
 constexpr int kSubCap = 8192;    // vertices of a subtree
 constexpr int kSubLeaves = 256;  // tiles of a subtree
 constexpr int kSubThreads = 1024;
+constexpr int kSubItems = kSubCap / kSubThreads;
+typedef hipcub::BlockRadixSort<uint32_t, kSubThreads, kSubItems, uint32_t> SubPairSort;
+constexpr size_t kSubSortBytes =
+    sizeof(SubPairSort::TempStorage) > 2048 * 8 ? sizeof(SubPairSort::TempStorage) : 2048 * 8;
+// lists (2 x u16), global ids (u32), side + segment of position (u8), thread partials (i64),
+// 2 segment tables x 4 + 5 per-segment words + 2 per-segment i64 prefixes, sort scratch
+constexpr size_t kSubLdsBytes = (size_t)kSubCap * (2 + 2 + 4 + 1 + 1) + (size_t)kSubThreads * 8 +
+                                (size_t)kSubLeaves * (8 + 5) * 4 + (size_t)kSubLeaves * 2 * 8 + kSubSortBytes + 64;
+
+static_assert(kSubLdsBytes <= 160 * 1024 - 256, "subtree kernel LDS");
+
+// exclusive prefix of one value per thread over the workgroup (v in, prefix out; a[] = scratch)
+template <class T>
+__device__ __forceinline__ T block_exclusive(T v, T* a) {
+  const int tid = threadIdx.x;
+  a[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < kSubThreads; off <<= 1) {
+    const T u = tid >= off ? a[tid - off] : (T)0;
+    __syncthreads();
+    a[tid] += u;
+    __syncthreads();
+  }
+  const T r = a[tid] - v;
+  __syncthreads();
+  return r;
+}
 
 __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg_cur, SegTab cur, SegTab out,
                                                              int32_t* nseg_out, int32_t ntiles, int32_t* perm,
@@ -287,11 +319,8 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
                                                              const uint32_t* __restrict__ rank_y,
                                                              const int32_t* __restrict__ w_int, int weighted, int vb,
                                                              int direct, int cap, int32_t* flags) {
-  // direct != 0 (the subtree is the whole graph, no global ranks were made): sort on
-  // (segment, ordered coordinate, id) packed in 62 bits; else on (segment, global rank) | id
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int sidx = blockIdx.x, tid = threadIdx.x;
-  const uint64_t idmask = direct ? ((1ull << kIdBits) - 1) : 0xffffffffull;
   if (sidx == 0 && tid == 0) nseg_out[0] = ntiles;
   if (sidx >= nseg_cur[0]) return;
   const int32_t glo = cur.lo[sidx], ghi = cur.hi[sidx], gleaves = cur.leaves[sidx], gfirst = cur.first[sidx];
@@ -310,123 +339,129 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
     }
     return;
   }
-  uint64_t* packed = reinterpret_cast<uint64_t*>(smem);                 // kSubCap
-  long long* wpre = reinterpret_cast<long long*>(packed + kSubCap);     // kSubCap
-  long long* part = wpre + kSubCap;                                     // kSubThreads partial sums
-  uint8_t* segof = reinterpret_cast<uint8_t*>(part + kSubThreads);      // kSubCap
-  int32_t* tb = reinterpret_cast<int32_t*>(segof + kSubCap);            // 2 tables x 4 x kSubLeaves
-  uint32_t* bb = reinterpret_cast<uint32_t*>(tb + 8 * kSubLeaves);      // 4 x kSubLeaves
-  int32_t* mid_raw = reinterpret_cast<int32_t*>(bb + 4 * kSubLeaves);   // kSubLeaves
-  int32_t* mid_fin = mid_raw + kSubLeaves;                              // kSubLeaves
-  int32_t* cbase = mid_fin + kSubLeaves;                                // kSubLeaves
+  uint16_t* lx = reinterpret_cast<uint16_t*>(smem);                      // local index at x-order position p
+  uint16_t* ly = lx + kSubCap;                                           // ... at y-order position p
+  uint32_t* gid = reinterpret_cast<uint32_t*>(ly + kSubCap);             // vertex id of local index l
+  uint8_t* side = reinterpret_cast<uint8_t*>(gid + kSubCap);             // by local index: 1 = right child
+  uint8_t* segof = side + kSubCap;                                       // by position: local segment
+  long long* part = reinterpret_cast<long long*>(segof + kSubCap);       // kSubThreads
+  int32_t* tb = reinterpret_cast<int32_t*>(part + kSubThreads);          // 2 tables x 4 x kSubLeaves
+  int32_t* mid_raw = tb + 8 * kSubLeaves;
+  int32_t* mid_fin = mid_raw + kSubLeaves;
+  int32_t* cbase = mid_fin + kSubLeaves;
+  int32_t* axis = cbase + kSubLeaves;                                    // 1: split along y
+  int32_t* rlo = axis + kSubLeaves;                                      // right-flags before the segment
+  long long* pre_lo = reinterpret_cast<long long*>(rlo + kSubLeaves);    // weight prefix before the segment
+  long long* pre_hi = pre_lo + kSubLeaves;                               // ... through its last position
+  char* sort_tmp = reinterpret_cast<char*>(((uintptr_t)(pre_hi + kSubLeaves) + 15) & ~(uintptr_t)15);
   __shared__ int s_nloc, s_more;
   int32_t *lo = tb, *hi = tb + kSubLeaves, *lv = tb + 2 * kSubLeaves, *fi = tb + 3 * kSubLeaves;
   int32_t *lo2 = tb + 4 * kSubLeaves, *hi2 = tb + 5 * kSubLeaves, *lv2 = tb + 6 * kSubLeaves, *fi2 = tb + 7 * kSubLeaves;
-  for (int p = tid; p < n; p += kSubThreads) { packed[p] = (uint64_t)(uint32_t)perm[glo + p]; segof[p] = 0; }
+  for (int p = tid; p < n; p += kSubThreads) { gid[p] = (uint32_t)perm[glo + p]; segof[p] = 0; }
   if (tid == 0) { lo[0] = 0; hi[0] = n; lv[0] = gleaves; fi[0] = gfirst; s_nloc = 1; s_more = gleaves > 1; }
   __syncthreads();
+  // ---- the two sorted lists ----
   const int m = next_pow2(max(n, 1));
+  for (int ax = 0; ax < 2; ++ax) {
+    uint16_t* list = ax ? ly : lx;
+    const uint32_t* rank = ax ? rank_y : rank_x;
+    if (m <= 2048) {  // small windows: the bitonic network beats the fixed-size radix sort
+      uint64_t* packed = reinterpret_cast<uint64_t*>(sort_tmp);
+      for (int p = tid; p < m; p += kSubThreads) {
+        if (p >= n) { packed[p] = ~0ull; continue; }
+        const uint32_t id = gid[p];
+        uint32_t key;
+        if (direct) { const float2 q = pos[id]; key = ord_f(ax ? q.y : q.x); } else key = rank[id];
+        // ranks are unique; a lone subtree enters in id order, so (coordinate, local index) is the
+        // (coordinate, id) order
+        packed[p] = ((uint64_t)key << 32) | (uint32_t)p;
+      }
+      __syncthreads();
+      bitonic_sort<kSubThreads, uint64_t>(packed, m);
+      for (int p = tid; p < n; p += kSubThreads) list[p] = (uint16_t)(packed[p] & 0x1fffu);
+      __syncthreads();
+    } else {
+      SubPairSort::TempStorage& tmp = *reinterpret_cast<SubPairSort::TempStorage*>(sort_tmp);
+      uint32_t keys[kSubItems], vals[kSubItems];
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        vals[i] = (uint32_t)p;
+        keys[i] = 0xffffffffu;  // padding stays behind every real key (stable)
+        if (p < n) {
+          const uint32_t id = gid[p];
+          if (direct) { const float2 q = pos[id]; keys[i] = ord_f(ax ? q.y : q.x); } else keys[i] = rank[id];
+        }
+      }
+      // ranks are unique; a lone subtree enters in id order, so the stable sort on the coordinate
+      // alone yields the (coordinate, id) order
+      SubPairSort(tmp).Sort(keys, vals, 0, direct ? 32 : vb);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        if (p < n) list[p] = (uint16_t)vals[i];
+      }
+      __syncthreads();
+    }
+  }
+  // ---- levels ----
   while (s_more) {
     const int nloc = s_nloc;
     for (int k = tid; k < nloc; k += kSubThreads) {
-      bb[4 * k] = bb[4 * k + 1] = 0xffffffffu; bb[4 * k + 2] = bb[4 * k + 3] = 0u;
       mid_raw[k] = hi[k];
+      axis[k] = 0;
+      if (lv[k] > 1 && hi[k] > lo[k]) {  // the lists are sorted inside the segment: its box is their two ends
+        const float ex = pos[gid[lx[hi[k] - 1]]].x - pos[gid[lx[lo[k]]]].x;
+        const float ey = pos[gid[ly[hi[k] - 1]]].y - pos[gid[ly[lo[k]]]].y;
+        axis[k] = ey > ex ? 1 : 0;
+      }
     }
     __syncthreads();
-    // bounding boxes: one WAVE per local segment walks its range and shuffle-reduces (LDS atomics
-    // on a handful of addresses serialise)
-    for (int k = tid >> 6; k < nloc; k += kSubThreads / 64) {
-      if (lv[k] <= 1) continue;
-      uint32_t mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0u, mxy = 0u;
-      for (int p = lo[k] + (tid & 63); p < hi[k]; p += 64) {
-        const float2 q = pos[(uint32_t)(packed[p] & idmask)];
-        const uint32_t ux = ord_f(q.x), uy = ord_f(q.y);
-        mnx = min(mnx, ux); mny = min(mny, uy); mxx = max(mxx, ux); mxy = max(mxy, uy);
-      }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, off, 64));
-        mny = min(mny, (uint32_t)__shfl_xor((int)mny, off, 64));
-        mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
-        mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
-      }
-      if ((tid & 63) == 0) { bb[4 * k] = mnx; bb[4 * k + 1] = mny; bb[4 * k + 2] = mxx; bb[4 * k + 3] = mxy; }
-    }
-    __syncthreads();
-    for (int p = tid; p < m; p += kSubThreads) {
-      if (p >= n) { packed[p] = ~0ull; continue; }
-      const uint32_t id = (uint32_t)(packed[p] & idmask);
-      const int k = segof[p];
-      uint32_t r = direct ? 0u : id;
-      if (lv[k] > 1) {
-        const float ex = unord_f(bb[4 * k + 2]) - unord_f(bb[4 * k]);
-        const float ey = unord_f(bb[4 * k + 3]) - unord_f(bb[4 * k + 1]);
-        if (direct) { const float2 q = pos[id]; r = ord_f(ey > ex ? q.y : q.x); }
-        else r = ey > ex ? rank_y[id] : rank_x[id];
-      }
-      packed[p] = direct ? (((uint64_t)k << (32 + kIdBits)) | ((uint64_t)r << kIdBits) | id)
-                         : (((uint64_t)(((uint32_t)k << vb) | r) << 32) | id);
-    }
-    __syncthreads();
-    if (m <= 2048) {  // small windows: the bitonic network beats a fixed-size 8192-key radix sort
-      bitonic_sort<kSubThreads, uint64_t>(packed, m);
-    } else {  // block radix sort of the whole window on the significant key bits (the weight-prefix
-       // area is free at this point and serves as the sort's exchange storage)
-      typedef hipcub::BlockRadixSort<uint64_t, kSubThreads, kSubCap / kSubThreads> BlockSort;
-      static_assert(sizeof(typename BlockSort::TempStorage) <= sizeof(long long) * (kSubCap + kSubThreads), "sort storage");
-      typename BlockSort::TempStorage& tmp = *reinterpret_cast<typename BlockSort::TempStorage*>(wpre);
-      uint64_t keys[kSubCap / kSubThreads];
-#pragma unroll
-      for (int i = 0; i < kSubCap / kSubThreads; ++i) {
-        const int p = tid * (kSubCap / kSubThreads) + i;
-        keys[i] = p < m ? packed[p] : ~0ull;
-      }
-      __syncthreads();
-      // stable: the padding (p >= n, all ones) stays behind any real key
-      BlockSort(tmp).Sort(keys, direct ? 0 : 32, direct ? 32 + kIdBits + 8 : 32 + vb + 8);
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < kSubCap / kSubThreads; ++i) {
-        const int p = tid * (kSubCap / kSubThreads) + i;
-        if (p < m) packed[p] = keys[i];
-      }
-      __syncthreads();
-    }
-    if (weighted) {  // inclusive prefix of the weights in the sorted order
-      const int C = (m + kSubThreads - 1) / kSubThreads;
+    if (weighted) {  // integer weight prefix along every segment's chosen axis, split rule per position
+      long long pref[kSubItems];
+      int32_t wv[kSubItems];
       long long acc = 0;
-      for (int c = 0; c < C; ++c) {
-        const int p = tid * C + c;
-        if (p < n) { acc += w_int[(uint32_t)(packed[p] & idmask)]; wpre[p] = acc; }
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        wv[i] = 0;
+        if (p < n) {
+          const int k = segof[p];
+          wv[i] = w_int[gid[axis[k] ? ly[p] : lx[p]]];
+          acc += wv[i];
+        }
+        pref[i] = acc;
       }
-      part[tid] = acc;
+      const long long base = block_exclusive<long long>(acc, part);
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        if (p >= n) continue;
+        pref[i] += base;
+        const int k = segof[p];
+        if (p == lo[k]) pre_lo[k] = pref[i] - wv[i];
+        if (p == hi[k] - 1) pre_hi[k] = pref[i];
+      }
       __syncthreads();
-      for (int off = 1; off < kSubThreads; off <<= 1) {
-        const long long u = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += u;
-        __syncthreads();
-      }
-      const long long base = tid > 0 ? part[tid - 1] : 0;
-      for (int c = 0; c < C; ++c) {
-        const int p = tid * C + c;
-        if (p < n) wpre[p] += base;
-      }
-      __syncthreads();
-      for (int p = tid; p < n; p += kSubThreads) {
-        const int k = segof[p];  // segments keep their position ranges through the sort
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        if (p >= n) continue;
+        const int k = segof[p];
         const int32_t L = lv[k];
         if (L <= 1) continue;
-        const int32_t l1 = L / 2, slo = lo[k], shi = hi[k];
-        const long long sbase = slo > 0 ? wpre[slo - 1] : 0;
-        const long long rhs = 2 * (wpre[shi - 1] - sbase) * l1;
-        const long long w = w_int[(uint32_t)(packed[p] & idmask)];
-        const long long before = wpre[p] - w - sbase;
-        const bool c = (2 * before + w) * L >= rhs;
+        const int32_t l1 = L / 2, slo = lo[k];
+        const long long sbase = pre_lo[k];
+        const long long rhs = 2 * (pre_hi[k] - sbase) * l1;
+        const long long w = wv[i];
+        const bool c = (2 * (pref[i] - w - sbase) + w) * L >= rhs;
         bool cprev = false;
         if (p > slo) {
-          const long long wp = w_int[(uint32_t)(packed[p - 1] & idmask)];
-          cprev = (2 * (wpre[p - 1] - wp - sbase) + wp) * L >= rhs;
+          long long wp, pp;
+          if (i > 0) { wp = wv[i - 1]; pp = pref[i - 1]; }
+          else { wp = w_int[gid[axis[k] ? ly[p - 1] : lx[p - 1]]]; pp = base; }
+          cprev = (2 * (pp - wp - sbase) + wp) * L >= rhs;
         }
         if (c && !cprev) mid_raw[k] = p;
       }
@@ -461,6 +496,43 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       s_nloc = nn; s_more = more;
     }
     __syncthreads();
+    // side of every vertex = its position along the chosen axis against the split
+    for (int p = tid; p < n; p += kSubThreads) {
+      const int k = segof[p];
+      side[axis[k] ? ly[p] : lx[p]] = (lv[k] > 1 && p >= mid_fin[k]) ? 1 : 0;
+    }
+    __syncthreads();
+    // stable partition of both lists: left children keep their order in front, right behind
+    for (int ax = 0; ax < 2; ++ax) {
+      uint16_t* list = ax ? ly : lx;
+      uint16_t it[kSubItems];
+      int32_t ex[kSubItems];
+      int32_t cnt = 0;
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        it[i] = 0; ex[i] = cnt;
+        if (p < n) { it[i] = list[p]; cnt += side[it[i]]; }
+      }
+      const int32_t base = block_exclusive<int32_t>(cnt, reinterpret_cast<int32_t*>(part));
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        if (p >= n) continue;
+        ex[i] += base;
+        if (p == lo[segof[p]]) rlo[segof[p]] = ex[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        const int p = tid * kSubItems + i;
+        if (p >= n) continue;
+        const int k = segof[p];
+        const int32_t r = ex[i] - rlo[k];  // right-flags before p inside the segment
+        list[side[it[i]] ? mid_fin[k] + r : p - r] = it[i];
+      }
+      __syncthreads();
+    }
     for (int p = tid; p < n; p += kSubThreads) {
       const int k = segof[p];
       segof[p] = (uint8_t)(cbase[k] + ((lv[k] > 1 && p >= mid_fin[k]) ? 1 : 0));
@@ -470,7 +542,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
   }
   // every local segment is one tile now
   for (int p = tid; p < n; p += kSubThreads) {
-    perm[glo + p] = (int32_t)(uint32_t)(packed[p] & idmask);
+    perm[glo + p] = (int32_t)gid[lx[p]];
     seg_pos[glo + p] = fi[segof[p]];
   }
   for (int k = tid; k < s_nloc; k += kSubThreads) {
@@ -604,7 +676,7 @@ __global__ __launch_bounds__(256) void k_csr_keys(int32_t E, const int2* __restr
 
 __global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
                                                   const int32_t* __restrict__ v_o2i, int32_t* tris_int,
-                                                  uint64_t* keys, uint32_t* vals, int32_t* cnt, int32_t* flags) {
+                                                  uint64_t* keys, uint32_t* vals, int32_t* flags) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
   const int32_t vo = tris[k];
@@ -613,7 +685,6 @@ __global__ __launch_bounds__(256) void k_tri_keys(int32_t n3, int32_t V, const i
   const int32_t v = v_o2i[vo];
   tris_int[k] = v;
   keys[k] = (uint64_t)v;
-  atomicAdd(&cnt[v], 1);
 }
 
 // CSR row offsets from the sorted row keys: row[u] = first entry whose key is >= u, row[V] = n
@@ -1193,9 +1264,15 @@ DevPlanner::~DevPlanner() { release(); }
 void DevPlanner::release() {
   void* ptrs[] = {cub_tmp_, keys_a_, keys_b_, vals_a_, vals_b_, seg_pos_, tile_of_int_, w_int_, wsort_, wscan_,
                   counts_, seg_tab_, estart_, tile_ext_, tile_meta_, flags_, grid_sum_, grid_cnt_, grid_w_,
-                  grid_bounds_, gbbox_};
+                  grid_bounds_, gbbox_, tcub_tmp_, tkeys_a_, tkeys_b_, tvals_a_};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (s2_) (void)hipStreamDestroy(s2_);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
+  s2_ = nullptr; ev_fork_ = ev_join_ = nullptr;
+  tcub_tmp_ = nullptr; tkeys_a_ = tkeys_b_ = nullptr; tvals_a_ = nullptr;
+  capT2_ = 0; tcub_bytes_ = 0;
   cub_tmp_ = nullptr; keys_a_ = keys_b_ = nullptr; vals_a_ = vals_b_ = nullptr;
   seg_pos_ = tile_of_int_ = w_int_ = counts_ = seg_tab_ = estart_ = tile_ext_ = tile_meta_ = flags_ = nullptr;
   wsort_ = wscan_ = nullptr; grid_sum_ = nullptr; grid_cnt_ = grid_w_ = nullptr;
@@ -1237,6 +1314,19 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     if (need > cub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&cub_tmp_), need)); cub_bytes_ = need; }
   }
   (void)nk;
+  if (T > capT2_) {
+    const int64_t t3 = 3 * std::max<int64_t>(T + T / 4, 16);
+    HIPRET(dalloc(&tkeys_a_, (size_t)t3)); HIPRET(dalloc(&tkeys_b_, (size_t)t3)); HIPRET(dalloc(&tvals_a_, (size_t)t3));
+    size_t b = 0;
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, tkeys_a_, tkeys_b_, tvals_a_, tvals_a_, (int)t3, 0, 64, nullptr));
+    if (b > tcub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&tcub_tmp_), b)); tcub_bytes_ = b; }
+    capT2_ = t3 / 3;
+  }
+  if (!s2_) {
+    HIPRET(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+    HIPRET(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    HIPRET(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  }
   if (!seg_tab_) {
     // 2 tables x 4 arrays, bbox (4), mid_raw x 2, child_base, mid_out, nseg x 2
     HIPRET(dalloc(&seg_tab_, (size_t)kSegCap * 16 + 16));
@@ -1346,7 +1436,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_rcb_assign, grid1(V), dim3(256), 0, s, V, seg_pos_, child_base, mid_out, tab[cur].leaves);
   }
   if (sub_level < levels) {
-    const size_t lds_sub = (size_t)kSubCap * 16 + kSubThreads * 8 + kSubCap + (8 + 4 + 3) * kSubLeaves * 4;
+    const size_t lds_sub = kSubLdsBytes;
     if (!sub_attr_set_) {
       HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rcb_subtree), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds_sub));
@@ -1374,6 +1464,20 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
 
   lap("B morton");
   if (after_partition) HIPRET(after_partition());  // the caller's edge / data arrays arrive now
+  // ---- stage E: vertex -> triangle CSR; needs only the vertex order, so it runs beside the edge
+  // stages (C, D, tile pass 1) on a second stream and joins before the flags are read ----
+  const bool tri_stage = T > 0 && in.tris;
+  if (tri_stage) {
+    HIPRET(hipEventRecord(ev_fork_, s));
+    HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
+    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->v_o2i, A->tris,
+                       tkeys_a_, tvals_a_, flags_);
+    size_t tb2 = tcub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(tcub_tmp_, tb2, tkeys_a_, tkeys_b_, tvals_a_,
+                                              reinterpret_cast<uint32_t*>(A->tinc), 3 * T, 0, vb, s2_));
+    hipLaunchKernelGGL(k_row_offsets, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, tkeys_b_, V, A->trow);
+    HIPRET(hipEventRecord(ev_join_, s2_));
+  }
   // ---- stage C ----
   HIPRET(hipMemsetAsync(estart_, 0xff, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   if (E > 0) {
@@ -1398,21 +1502,13 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     HIPRET(hipMemsetAsync(A->grow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
   }
   lap("D csr");
-  // ---- stage E ----
-  if (T > 0 && in.tris) {
-    hipLaunchKernelGGL(k_tri_keys, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, V, in.tris, A->v_o2i, A->tris,
-                       keys_a_, vals_a_, counts_, flags_);
-    size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_,
-                                              reinterpret_cast<uint32_t*>(A->tinc), 3 * T, 0, vb, s));
-    hipLaunchKernelGGL(k_row_offsets, grid1(3 * (int64_t)T), dim3(256), 0, s, 3 * T, keys_b_, V, A->trow);
-  }
-  lap("E tris");
   // ---- stage F ----
   TileGraph G;
   G.V = V; G.depth = depth; G.grow = A->grow; G.ginc = A->ginc; G.eij = A->eij; G.e_i2o = A->e_i2o; G.e_o2i = A->e_o2i;
   hipLaunchKernelGGL(k_tile_pass1, dim3(ntiles), dim3(kP1Threads), lds1, s, G, leaf.lo, leaf.hi, tile_ext_, tile_meta_);
   hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_);
+  if (tri_stage) HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
+  lap("E tris (joined)");
   int32_t hflags[8];
   HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
   if (user_flags_dev && user_flags_host)  // the caller's own check word rides on the same sync
