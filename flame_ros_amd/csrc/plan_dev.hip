@@ -295,21 +295,23 @@ constexpr size_t kSubLdsBytes = (size_t)kSubCap * (2 + 2 + 4 + 1 + 1) + (size_t)
 
 static_assert(kSubLdsBytes <= 160 * 1024 - 256, "subtree kernel LDS");
 
-// exclusive prefix of one value per thread over the workgroup (v in, prefix out; a[] = scratch)
+// exclusive prefix of one value per thread over the workgroup (a[] = scratch of >= 16 entries):
+// shuffle scan inside the wave, the 16 wave totals through LDS -- two barriers
 template <class T>
 __device__ __forceinline__ T block_exclusive(T v, T* a) {
-  const int tid = threadIdx.x;
-  a[tid] = v;
-  __syncthreads();
-  for (int off = 1; off < kSubThreads; off <<= 1) {
-    const T u = tid >= off ? a[tid - off] : (T)0;
-    __syncthreads();
-    a[tid] += u;
-    __syncthreads();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const T u = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += u;
   }
-  const T r = a[tid] - v;
+  if (lane == 63) a[wave] = inc;
   __syncthreads();
-  return r;
+  T base = 0;
+  for (int w = 0; w < wave; ++w) base += a[w];
+  __syncthreads();
+  return base + inc - v;
 }
 
 __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg_cur, SegTab cur, SegTab out,
@@ -422,15 +424,20 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       long long pref[kSubItems];
       int32_t wv[kSubItems];
       long long acc = 0;
+      uint32_t g[kSubItems];
+      // (index reads, then every gather, then the sums: branch-free so that the eight dependent
+      // LDS -> LDS -> global chains of a thread overlap)
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
-        const int p = tid * kSubItems + i;
-        wv[i] = 0;
-        if (p < n) {
-          const int k = segof[p];
-          wv[i] = w_int[gid[axis[k] ? ly[p] : lx[p]]];
-          acc += wv[i];
-        }
+        const int pc = min(tid * kSubItems + i, n - 1);
+        g[i] = gid[axis[segof[pc]] ? ly[pc] : lx[pc]];
+      }
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) wv[i] = w_int[g[i]];
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) {
+        if (tid * kSubItems + i >= n) wv[i] = 0;
+        acc += wv[i];
         pref[i] = acc;
       }
       const long long base = block_exclusive<long long>(acc, part);
@@ -508,11 +515,15 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       uint16_t it[kSubItems];
       int32_t ex[kSubItems];
       int32_t cnt = 0;
+      int32_t fl[kSubItems];
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) it[i] = list[min(tid * kSubItems + i, n - 1)];
+#pragma unroll
+      for (int i = 0; i < kSubItems; ++i) fl[i] = side[it[i]];
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
-        const int p = tid * kSubItems + i;
-        it[i] = 0; ex[i] = cnt;
-        if (p < n) { it[i] = list[p]; cnt += side[it[i]]; }
+        ex[i] = cnt;
+        if (tid * kSubItems + i < n) cnt += fl[i];
       }
       const int32_t base = block_exclusive<int32_t>(cnt, reinterpret_cast<int32_t*>(part));
 #pragma unroll
@@ -529,7 +540,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
         if (p >= n) continue;
         const int k = segof[p];
         const int32_t r = ex[i] - rlo[k];  // right-flags before p inside the segment
-        list[side[it[i]] ? mid_fin[k] + r : p - r] = it[i];
+        list[fl[i] ? mid_fin[k] + r : p - r] = it[i];
       }
       __syncthreads();
     }
