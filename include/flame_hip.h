@@ -82,7 +82,9 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * per tile), "tile_depth" (halo depth = iterations per launch), "tile_threads", "use_graph"
  * (replay launches from a hipGraph), "plan_device" (1 = build halo-tile plans on the GPU, default),
  * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
- * 512, up to 2048), "balance", "order_mode", "host_threads", "lds_bytes", "profile".
+ * 512, up to 2048), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
+ * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
+ * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile".
  * Unknown key -> FLAME_HIP_ERR_ARG. */
 int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value);
 int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value);
