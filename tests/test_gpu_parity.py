@@ -168,6 +168,18 @@ def test_batch_of_frames(gpu):
         assert_bit_equal(x[sl], o.x, "frame %d x" % b)
         assert_bit_equal(w1[sl], o.w1, "frame %d w1" % b)
         assert_bit_equal(q[eoff[b]:eoff[b + 1]], o.q, "frame %d q" % b)
+    # the batch solved again (the lane order of the plan is re-assigned on the device before the
+    # second solve, option lane_order = 1) and a third time from the captured launch
+    emap0 = r.plan_array("t_emap", np.int32)
+    for _ in range(2):
+        r.step(default_params(), 50)
+    assert not np.array_equal(emap0, r.plan_array("t_emap", np.int32))
+    x, w1, w2, q = r.download()
+    for b, g in enumerate(gs):
+        o = make_oracle(g)
+        o.solve(oracle_params(), 250)
+        assert_bit_equal(x[r.voff[b]:r.voff[b + 1]], o.x, "frame %d x, resolved" % b)
+        assert_bit_equal(q[eoff[b]:eoff[b + 1]], o.q, "frame %d q, resolved" % b)
 
 
 def test_mesh_points_and_faces(gpu):
