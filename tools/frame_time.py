@@ -7,7 +7,8 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_
 name = sys.argv[1] if len(sys.argv) > 1 else "50k"
 g, iters = graphgen.named(name)
 var = np.full(g.V, 1e-4, np.float32)
-r = GraphRegularizer.empty(device=0)
+opts = {k: int(v) for k, v in (a.split("=") for a in sys.argv[2:])}  # e.g. tile_single_max=2048 (the facade's setting)
+r = GraphRegularizer.empty(device=0, **opts)
 p, sp, tp = default_params(), default_sync_params(), default_tri_params(g.width, g.height)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
 for k in range(6):
