@@ -142,12 +142,10 @@ class DevPlanner {
   // own sort scratch
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-  int64_t capT2_ = 0;
+  int64_t capV2_ = 0;
   size_t tcub_bytes_ = 0;
-  void* tcub_tmp_ = nullptr;
-  uint64_t* tkeys_a_ = nullptr;  // 3T
-  uint64_t* tkeys_b_ = nullptr;
-  uint32_t* tvals_a_ = nullptr;
+  void* tcub_tmp_ = nullptr;     // scan scratch of the triangle stage
+  int32_t* tcnt_ = nullptr;      // V + 1 counts, then V cursors
 };
 
 // Conflict-avoiding lane order applied to a finished plan on the device (plan.h PlanOptions::

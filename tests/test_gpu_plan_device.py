@@ -105,19 +105,37 @@ def _irregular(kind):
         edges = np.concatenate([edges, edges[dup][:, ::-1]])
         alpha = np.concatenate([alpha, alpha[dup]]); beta = np.concatenate([beta, beta[dup]])
         tris = g.tris
+    elif kind == "hubs":        # a few vertices of degree ~45: rows long enough for the heap sort of
+        hubs = rng.choice(g.V, 6, replace=False)  # the counting CSR; their triangles fan out likewise
+        extra, etris = [], []
+        for h in hubs:
+            d2 = ((g.pos - g.pos[h]) ** 2).sum(1)
+            near = np.argsort(d2)[1:60]
+            have = set(edges[edges[:, 0] == h, 1].tolist()) | set(edges[edges[:, 1] == h, 0].tolist())
+            new = [int(v) for v in near if int(v) not in have][:38]
+            extra += [(int(h), v) if k % 2 else (v, int(h)) for k, v in enumerate(new)]
+            etris += [(int(h), new[k], new[k + 1]) for k in range(len(new) - 1)]
+        extra = np.array(extra, np.int32)
+        d = g.pos[extra[:, 0]] - g.pos[extra[:, 1]]
+        a = (np.float32(1.0) / np.sqrt((d.astype(np.float32) ** 2).sum(1, dtype=np.float32))).astype(np.float32)
+        edges = np.concatenate([edges, extra]); alpha = np.concatenate([alpha, a]); beta = np.concatenate([beta, a])
+        tris = np.concatenate([g.tris, np.array(etris, np.int32)])
     else:                       # no edges at all
         edges, alpha, beta = edges[:0], alpha[:0], beta[:0]
         tris = None
     return g, np.ascontiguousarray(edges), alpha, beta, tris
 
 
-@pytest.mark.parametrize("kind", ["isolated", "multi", "noedges"])
+@pytest.mark.parametrize("kind", ["isolated", "multi", "hubs", "noedges"])
 def test_device_plan_irregular_graphs(gpu, kind):
     g, edges, alpha, beta, tris = _irregular(kind)
     opts = dict(tile_own=64, tile_depth=3)
     host = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=-1, **opts)
     dev = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=0, **opts)
     compare_plans(host, dev, kind)
+    if kind == "hubs":
+        grow = host.plan_array("grow", np.int32)
+        assert np.diff(grow).max() > 24  # long rows are there
     from oracle import COracle
     o = COracle(g.pos, edges, alpha, beta, g.z, g.wgt)
     o.solve(oracle_params(), 25)
