@@ -1272,11 +1272,21 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
                                                     const TileDesc* __restrict__ tiles,
                                                     const float* __restrict__ bounds,
                                                     unsigned long long* sum, int32_t* cnt) {
+  // vertices that are neighbours in internal order (same tile, Morton order) fall into the same
+  // cell: accumulate per workgroup in LDS, flush the touched cells once (integer sums: any order)
+  __shared__ unsigned long long s_sum[Plan::kGrid * Plan::kGrid];
+  __shared__ int32_t s_cnt[Plan::kGrid * Plan::kGrid];
+  for (int c = threadIdx.x; c < Plan::kGrid * Plan::kGrid; c += 256) { s_sum[c] = 0ull; s_cnt[c] = 0; }
+  __syncthreads();
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= V) return;
-  const int c = grid_cell_dev(bounds, pos[v_i2o[k]]);
-  atomicAdd(&sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]]));
-  atomicAdd(&cnt[c], 1);
+  if (k < V) {
+    const int c = grid_cell_dev(bounds, pos[v_i2o[k]]);
+    atomicAdd(&s_sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]]));
+    atomicAdd(&s_cnt[c], 1);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Plan::kGrid * Plan::kGrid; c += 256)
+    if (s_cnt[c]) { atomicAdd(&sum[c], s_sum[c]); atomicAdd(&cnt[c], s_cnt[c]); }
 }
 
 __global__ __launch_bounds__(1024) void k_grid_final(int32_t V, const unsigned long long* sum,
