@@ -93,8 +93,8 @@ __global__ void k_rcb_init(int32_t V, int32_t ntiles, int32_t* perm, int32_t* se
   }
 }
 
-// bounding box of every unfinished segment: one workgroup per segment walks its (contiguous) range
-// -- no atomics (same-address atomics serialise: the atomic version took ~100 us per level)
+// bounding box of the whole graph for a lone subtree (one workgroup walks the range; same-address
+// atomics serialise: an atomic version of the per-level boxes once took ~100 us per level)
 __global__ __launch_bounds__(1024) void k_rcb_bbox(const int32_t* __restrict__ nseg, SegTab t,
                                                    const int32_t* __restrict__ perm,
                                                    const float2* __restrict__ pos, uint32_t* bbox) {
@@ -126,58 +126,13 @@ __global__ __launch_bounds__(1024) void k_rcb_bbox(const int32_t* __restrict__ n
   }
 }
 
-// The same over the whole position range in chunks of 1024 (segments are contiguous position
-// ranges): a chunk that lies inside one segment is reduced by its workgroup and contributes four
-// atomics, one that straddles a boundary does so once per segment it touches.  (bbox is
-// reset per segment by k_rcb_init / k_rcb_split.)  One workgroup per segment took 16-25 us per level
-// at 50 k vertices -- a single CU walking 25-50 k positions.
-__global__ __launch_bounds__(256) void k_rcb_bbox_chunks(int32_t V, const int32_t* __restrict__ seg_pos,
-                                                         const int32_t* __restrict__ leaves,
-                                                         const int32_t* __restrict__ perm,
-                                                         const float2* __restrict__ pos, uint32_t* bbox) {
-  __shared__ uint32_t s_red[4][4];
-  const int32_t c0 = blockIdx.x * 1024, c1 = min(c0 + 1024, V);
-  const int32_t sa = seg_pos[c0], sb = seg_pos[c1 - 1];
-  uint32_t ux[4], uy[4];
-  int32_t sg[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int32_t p = c0 + j * 256 + threadIdx.x;
-    sg[j] = -1; ux[j] = uy[j] = 0u;
-    if (p < c1) { const float2 q = pos[perm[p]]; ux[j] = ord_f(q.x); uy[j] = ord_f(q.y); sg[j] = sa == sb ? sa : seg_pos[p]; }
-  }
-  for (int32_t cs = sa; cs <= sb; ++cs) {  // (a chunk holds one segment, at a boundary two or three)
-    if (leaves[cs] <= 1) continue;         // workgroup-uniform
-    uint32_t mnx = 0xffffffffu, mny = 0xffffffffu, mxx = 0u, mxy = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (sg[j] == cs) { mnx = min(mnx, ux[j]); mny = min(mny, uy[j]); mxx = max(mxx, ux[j]); mxy = max(mxy, uy[j]); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      mnx = min(mnx, (uint32_t)__shfl_xor((int)mnx, off, 64));
-      mny = min(mny, (uint32_t)__shfl_xor((int)mny, off, 64));
-      mxx = max(mxx, (uint32_t)__shfl_xor((int)mxx, off, 64));
-      mxy = max(mxy, (uint32_t)__shfl_xor((int)mxy, off, 64));
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_red[0][w] = mnx; s_red[1][w] = mny; s_red[2][w] = mxx; s_red[3][w] = mxy; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-      const int c = threadIdx.x;
-      uint32_t v = s_red[c][0];
-      for (int k = 1; k < 4; ++k) v = c < 2 ? min(v, s_red[c][k]) : max(v, s_red[c][k]);
-      if (c < 2) atomicMin(&bbox[4 * cs + c], v); else atomicMax(&bbox[4 * cs + c], v);
-    }
-    __syncthreads();
-  }
-}
 
 __global__ void k_save_gbbox(const uint32_t* bbox, float* gbbox) {
   if (threadIdx.x < 4) gbbox[threadIdx.x] = unord_f(bbox[threadIdx.x]);
 }
 
-// Global ranks of the vertices along x and along y in the total order (coordinate, id): the order
-// of any subset along an axis is the order of these ranks, so the per-level sorts use short keys.
+// Sort keys of the two entry sorts: the vertex ids sorted along x and along y in the total order
+// (coordinate, id) are the two lists every bisection level partitions.
 __global__ __launch_bounds__(256) void k_rank_keys(int32_t V, const float2* __restrict__ pos, int axis,
                                                    uint32_t* keys, uint32_t* vals) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -187,43 +142,8 @@ __global__ __launch_bounds__(256) void k_rank_keys(int32_t V, const float2* __re
   vals[v] = (uint32_t)v;
 }
 
-__global__ __launch_bounds__(256) void k_rank_scatter(int32_t V, const uint32_t* __restrict__ sorted_ids,
-                                                      uint32_t* rank) {
-  const int32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p < V) rank[sorted_ids[p]] = (uint32_t)p;
-}
 
-__global__ __launch_bounds__(256) void k_rcb_keys(int32_t V, const int32_t* __restrict__ perm,
-                                                  const uint32_t* __restrict__ rank_x,
-                                                  const uint32_t* __restrict__ rank_y,
-                                                  const int32_t* __restrict__ seg_pos,
-                                                  const int32_t* __restrict__ leaves,
-                                                  const uint32_t* __restrict__ bbox, int vb, uint32_t* keys,
-                                                  uint32_t* vals) {
-  const int32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= V) return;
-  const int32_t s = seg_pos[p], v = perm[p];
-  uint32_t r = 0;
-  if (leaves[s] > 1) {
-    const float ex = unord_f(bbox[4 * s + 2]) - unord_f(bbox[4 * s]);
-    const float ey = unord_f(bbox[4 * s + 3]) - unord_f(bbox[4 * s + 1]);
-    r = ey > ex ? rank_y[v] : rank_x[v];
-  } else {
-    r = (uint32_t)v;  // a finished segment: any fixed order
-  }
-  keys[p] = ((uint32_t)s << vb) | r;
-  vals[p] = (uint32_t)v;
-}
 
-__global__ __launch_bounds__(256) void k_rcb_post(int32_t V, const uint32_t* __restrict__ vals,
-                                                  int32_t* perm, const int32_t* __restrict__ w_int,
-                                                  long long* wsort) {
-  const int32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= V) return;
-  const int32_t v = (int32_t)vals[p];
-  perm[p] = v;
-  if (wsort) wsort[p] = w_int[v];
-}
 
 // first position m of the segment with (2 acc(m) + w_m) leaves >= 2 total l1 (plan.cpp split_range)
 __global__ __launch_bounds__(256) void k_rcb_mid(int32_t V, const int32_t* __restrict__ seg_pos, SegTab t,
@@ -306,16 +226,88 @@ __global__ __launch_bounds__(kSegCap) void k_rcb_split(const int32_t* nseg_cur, 
   bbox[4 * s + 2] = bbox[4 * s + 3] = 0u;
 }
 
-__global__ __launch_bounds__(256) void k_rcb_assign(int32_t V, int32_t* seg_pos,
-                                                    const int32_t* __restrict__ child_base,
-                                                    const int32_t* __restrict__ mid,
-                                                    const int32_t* __restrict__ leaves) {
+
+
+// ---- global bisection levels on two presorted lists ----
+// lx / ly = the vertex ids sorted along x / along y in the total order (coordinate, id), both grouped
+// by segment (a segment is the same position range [lo, hi) in both).  A level never sorts: the box
+// of a segment is the two ends of its lists, the order along the chosen axis is that axis' list, and
+// both lists are PARTITIONED stably into the children (one scan of the side flags, x flags in the
+// low and y flags in the high half of a 64-bit counter).
+__global__ __launch_bounds__(256) void k_lvl_axis(const int32_t* __restrict__ nseg, SegTab t,
+                                                  const uint32_t* __restrict__ lx, const uint32_t* __restrict__ ly,
+                                                  const float2* __restrict__ pos, int32_t* axis, float* gbbox) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nseg[0]) return;
+  const int32_t lo = t.lo[s], hi = t.hi[s];
+  int a = 0;
+  if (hi > lo) {
+    const float x0 = pos[lx[lo]].x, x1 = pos[lx[hi - 1]].x, y0 = pos[ly[lo]].y, y1 = pos[ly[hi - 1]].y;
+    if (t.leaves[s] > 1) a = (y1 - y0) > (x1 - x0) ? 1 : 0;
+    if (gbbox && s == 0) { gbbox[0] = x0; gbbox[1] = y0; gbbox[2] = x1; gbbox[3] = y1; }  // level 0: the whole frame
+  }
+  axis[s] = a;
+}
+
+__global__ __launch_bounds__(256) void k_lvl_wgather(int32_t V, const int32_t* __restrict__ seg_pos,
+                                                     const int32_t* __restrict__ axis,
+                                                     const uint32_t* __restrict__ lx, const uint32_t* __restrict__ ly,
+                                                     const int32_t* __restrict__ w_int, long long* wsort) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  wsort[p] = w_int[axis[seg_pos[p]] ? ly[p] : lx[p]];
+}
+
+// side of every vertex (1 = right child) = its position along its segment's axis against the split
+__global__ __launch_bounds__(256) void k_lvl_side(int32_t V, const int32_t* __restrict__ seg_pos,
+                                                  const int32_t* __restrict__ axis,
+                                                  const int32_t* __restrict__ leaves,
+                                                  const int32_t* __restrict__ mid,
+                                                  const uint32_t* __restrict__ lx, const uint32_t* __restrict__ ly,
+                                                  int32_t* side) {
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= V) return;
   const int32_t s = seg_pos[p];
-  seg_pos[p] = child_base[s] + ((leaves[s] > 1 && p >= mid[s]) ? 1 : 0);
+  side[axis[s] ? ly[p] : lx[p]] = (leaves[s] > 1 && p >= mid[s]) ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void k_lvl_flags(int32_t V, const uint32_t* __restrict__ lx,
+                                                   const uint32_t* __restrict__ ly, const int32_t* __restrict__ side,
+                                                   long long* flags) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  flags[p] = (long long)side[lx[p]] | ((long long)side[ly[p]] << 32);
+}
+
+// stable partition of both lists + the segment of every position on the next level
+__global__ __launch_bounds__(256) void k_lvl_scatter(int32_t V, int32_t* seg_pos, SegTab t,
+                                                     const int32_t* __restrict__ mid,
+                                                     const int32_t* __restrict__ child_base,
+                                                     const long long* __restrict__ flags,
+                                                     const long long* __restrict__ scan,  // inclusive
+                                                     const uint32_t* __restrict__ lx, const uint32_t* __restrict__ ly,
+                                                     uint32_t* lx2, uint32_t* ly2) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  const int32_t s = seg_pos[p];
+  const int32_t lo = t.lo[s], m = mid[s];
+  const bool split = t.leaves[s] > 1;
+  const long long f = flags[p], ex = scan[p] - f, base = lo > 0 ? scan[lo - 1] : 0;
+  const int32_t fx = (int32_t)(f & 1), fy = (int32_t)((f >> 32) & 1);
+  const int32_t rx = (int32_t)((ex & 0xffffffffll) - (base & 0xffffffffll));  // right-flags before p in the segment
+  const int32_t ry = (int32_t)((ex >> 32) - (base >> 32));
+  lx2[fx ? m + rx : p - rx] = lx[p];
+  ly2[fy ? m + ry : p - ry] = ly[p];
+  seg_pos[p] = child_base[s] + ((split && p >= m) ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_lvl_posx(int32_t V, const uint32_t* __restrict__ lx, uint32_t* posx,
+                                                  int32_t* perm) {
+  const int32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= V) return;
+  posx[lx[p]] = (uint32_t)p;
+  perm[p] = (int32_t)lx[p];
+}
 
 // ------------------------------------------------------------------------------------------
 // Stage A, deep levels: once a segment holds <= kSubCap vertices its whole remaining bisection
@@ -363,10 +355,14 @@ __device__ __forceinline__ T block_exclusive(T v, T* a) {
 __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg_cur, SegTab cur, SegTab out,
                                                              int32_t* nseg_out, int32_t ntiles, int32_t* perm,
                                                              int32_t* seg_pos, const float2* __restrict__ pos,
-                                                             const uint32_t* __restrict__ rank_x,
-                                                             const uint32_t* __restrict__ rank_y,
+                                                             const uint32_t* __restrict__ glx,
+                                                             const uint32_t* __restrict__ gly,
+                                                             const uint32_t* __restrict__ posx,
                                                              const int32_t* __restrict__ w_int, int weighted, int vb,
                                                              int direct, int cap, int32_t* flags) {
+  // direct != 0: the subtree is the whole graph in id order (perm = identity) and sorts itself along
+  // both axes; else its two sorted lists are the ranges [glo, ghi) of the global lists glx / gly
+  // (posx = position of a vertex in glx), and perm is written only at the end
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int sidx = blockIdx.x, tid = threadIdx.x;
   if (sidx == 0 && tid == 0) nseg_out[0] = ntiles;
@@ -383,7 +379,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       const int32_t a = glo + (int32_t)(((long long)n * j) / gleaves);
       const int32_t b = glo + (int32_t)(((long long)n * (j + 1)) / gleaves);
       out.lo[gfirst + j] = a; out.hi[gfirst + j] = b; out.leaves[gfirst + j] = 1; out.first[gfirst + j] = gfirst + j;
-      for (int32_t q = a; q < b; ++q) seg_pos[q] = gfirst + j;
+      for (int32_t q = a; q < b; ++q) { seg_pos[q] = gfirst + j; if (!direct) perm[q] = (int32_t)glx[q]; }
     }
     return;
   }
@@ -405,24 +401,24 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
   __shared__ int s_nloc, s_more;
   int32_t *lo = tb, *hi = tb + kSubLeaves, *lv = tb + 2 * kSubLeaves, *fi = tb + 3 * kSubLeaves;
   int32_t *lo2 = tb + 4 * kSubLeaves, *hi2 = tb + 5 * kSubLeaves, *lv2 = tb + 6 * kSubLeaves, *fi2 = tb + 7 * kSubLeaves;
-  for (int p = tid; p < n; p += kSubThreads) { gid[p] = (uint32_t)perm[glo + p]; segof[p] = 0; }
+  for (int p = tid; p < n; p += kSubThreads) {
+    gid[p] = direct ? (uint32_t)perm[glo + p] : glx[glo + p];
+    segof[p] = 0;
+    if (!direct) { lx[p] = (uint16_t)p; ly[p] = (uint16_t)(posx[gly[glo + p]] - (uint32_t)glo); }
+  }
   if (tid == 0) { lo[0] = 0; hi[0] = n; lv[0] = gleaves; fi[0] = gfirst; s_nloc = 1; s_more = gleaves > 1; }
   __syncthreads();
-  // ---- the two sorted lists ----
+  // ---- a lone subtree sorts itself: stable from id order, so the coordinate alone gives the
+  // (coordinate, id) order ----
   const int m = next_pow2(max(n, 1));
-  for (int ax = 0; ax < 2; ++ax) {
+  for (int ax = 0; ax < 2 && direct; ++ax) {
     uint16_t* list = ax ? ly : lx;
-    const uint32_t* rank = ax ? rank_y : rank_x;
     if (m <= 2048) {  // small windows: the bitonic network beats the fixed-size radix sort
       uint64_t* packed = reinterpret_cast<uint64_t*>(sort_tmp);
       for (int p = tid; p < m; p += kSubThreads) {
         if (p >= n) { packed[p] = ~0ull; continue; }
-        const uint32_t id = gid[p];
-        uint32_t key;
-        if (direct) { const float2 q = pos[id]; key = ord_f(ax ? q.y : q.x); } else key = rank[id];
-        // ranks are unique; a lone subtree enters in id order, so (coordinate, local index) is the
-        // (coordinate, id) order
-        packed[p] = ((uint64_t)key << 32) | (uint32_t)p;
+        const float2 q = pos[gid[p]];
+        packed[p] = ((uint64_t)ord_f(ax ? q.y : q.x) << 32) | (uint32_t)p;
       }
       __syncthreads();
       bitonic_sort<kSubThreads, uint64_t>(packed, m);
@@ -436,14 +432,9 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
         const int p = tid * kSubItems + i;
         vals[i] = (uint32_t)p;
         keys[i] = 0xffffffffu;  // padding stays behind every real key (stable)
-        if (p < n) {
-          const uint32_t id = gid[p];
-          if (direct) { const float2 q = pos[id]; keys[i] = ord_f(ax ? q.y : q.x); } else keys[i] = rank[id];
-        }
+        if (p < n) { const float2 q = pos[gid[p]]; keys[i] = ord_f(ax ? q.y : q.x); }
       }
-      // ranks are unique; a lone subtree enters in id order, so the stable sort on the coordinate
-      // alone yields the (coordinate, id) order
-      SubPairSort(tmp).Sort(keys, vals, 0, direct ? 32 : vb);
+      SubPairSort(tmp).Sort(keys, vals, 0, 32);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
@@ -1445,8 +1436,8 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
   }
   if (!seg_tab_) {
-    // 2 tables x 4 arrays, bbox (4), mid_raw x 2, child_base, mid_out, nseg x 2
-    HIPRET(dalloc(&seg_tab_, (size_t)kSegCap * 16 + 16));
+    // 2 tables x 4 arrays, bbox (4), mid_raw x 2, child_base, mid_out, nseg x 2 (+ pad), axis
+    HIPRET(dalloc(&seg_tab_, (size_t)kSegCap * 17 + 32));
     HIPRET(dalloc(&flags_, 8));
     HIPRET(dalloc(&grid_sum_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_cnt_, (size_t)Plan::kGrid * Plan::kGrid));
@@ -1502,13 +1493,6 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   int32_t* perm = A->v_i2o;
   const bool weighted = weight_mode_ != 0;
   const int vb = bits_for(V);
-  uint32_t* rank_x = vals_a_;          // 2E >= V entries each (planar graphs: E >= V; reserve() sizes
-  uint32_t* rank_y = vals_a_ + capV_;  //   vals_* for max(2E, 2V))
-  uint32_t* key32_a = vals_b_;
-  uint32_t* key32_b = vals_b_ + capV_;
-  uint32_t* val32_a = reinterpret_cast<uint32_t*>(keys_a_);
-  uint32_t* val32_b = reinterpret_cast<uint32_t*>(keys_a_) + capV_;
-
   HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
   if (weight_mode_ == 2)  // (mode 1: w_int_ already holds the weights, see weights_from_tiles / _scale_)
     hipLaunchKernelGGL(k_weights_from_grid, grid1(V), dim3(256), 0, s, V, in.pos, grid_bounds_, grid_w_, w_int_);
@@ -1525,34 +1509,43 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
         sub_level = std::min(levels, L + sub_extra_levels_);  // (+1 per overflow seen on this handle)
         break;
       }
-  const bool need_ranks = sub_level > 0;  // a lone subtree sorts on the coordinates themselves
-  for (int axis = 0; axis < 2 && need_ranks; ++axis) {  // global ranks along x and y
-    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, axis, key32_a, val32_a);
+  const bool lists = sub_level > 0;  // (a lone subtree sorts itself, on the coordinates)
+  // the two sorted lists, double-buffered; scratch of the two entry sorts
+  uint32_t* LX[2] = {vals_a_, vals_a_ + capV_};
+  uint32_t* LY[2] = {vals_b_, vals_b_ + capV_};
+  uint32_t* key_in = reinterpret_cast<uint32_t*>(keys_a_);
+  uint32_t* key_out = reinterpret_cast<uint32_t*>(keys_a_) + capV_;
+  uint32_t* val_in = reinterpret_cast<uint32_t*>(keys_b_);
+  uint32_t* posx = reinterpret_cast<uint32_t*>(keys_b_) + capV_;
+  int32_t* side = counts_;
+  int32_t* axis = st + 16 * kSegCap + 16;
+  for (int ax = 0; ax < 2 && lists; ++ax) {  // ids sorted along x and along y: (coordinate, id)
+    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, ax, key_in, val_in);
     size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, key32_a, key32_b, val32_a, val32_b, V, 0, 32, s));
-    hipLaunchKernelGGL(k_rank_scatter, grid1(V), dim3(256), 0, s, V, val32_b, axis ? rank_y : rank_x);
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, key_in, key_out, val_in, ax ? LY[0] : LX[0], V, 0, 32, s));
   }
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
-  int cur = 0;
-  for (int lev = 0; lev < sub_level; ++lev, cur ^= 1) {
-    hipLaunchKernelGGL(k_rcb_bbox_chunks, dim3((unsigned)((V + 1023) / 1024)), dim3(256), 0, s, V, seg_pos_, tab[cur].leaves, perm,
-                       in.pos, bbox);
-    if (lev == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
-    hipLaunchKernelGGL(k_rcb_keys, grid1(V), dim3(256), 0, s, V, perm, rank_x, rank_y, seg_pos_, tab[cur].leaves, bbox,
-                       vb, key32_a, val32_a);
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb, key32_a, key32_b, val32_a, val32_b, V, 0,
-                                              std::min(32, vb + lev + 1), s));
-    hipLaunchKernelGGL(k_rcb_post, grid1(V), dim3(256), 0, s, V, val32_b, perm, w_int_, weighted ? wsort_ : nullptr);
+  int cur = 0, lb = 0;
+  for (int lev = 0; lev < sub_level; ++lev, cur ^= 1, lb ^= 1) {
+    hipLaunchKernelGGL(k_lvl_axis, dim3((unsigned)(((1 << lev) + 255) / 256)), dim3(256), 0, s, nseg + cur, tab[cur], LX[lb], LY[lb],
+                       in.pos, axis, lev == 0 ? gbbox_ : nullptr);
     if (weighted) {
-      tb = cub_bytes_;
+      hipLaunchKernelGGL(k_lvl_wgather, grid1(V), dim3(256), 0, s, V, seg_pos_, axis, LX[lb], LY[lb], w_int_, wsort_);
+      size_t tb = cub_bytes_;
       HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
       hipLaunchKernelGGL(k_rcb_mid, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], wsort_, wscan_, mid_raw[cur]);
     }
     hipLaunchKernelGGL(k_rcb_split, dim3(1), dim3(kSegCap), 0, s, nseg + cur, nseg + (cur ^ 1), tab[cur], tab[cur ^ 1],
                        mid_raw[cur], mid_raw[cur ^ 1], weighted ? 1 : 0, child_base, mid_out, bbox);
-    hipLaunchKernelGGL(k_rcb_assign, grid1(V), dim3(256), 0, s, V, seg_pos_, child_base, mid_out, tab[cur].leaves);
+    hipLaunchKernelGGL(k_lvl_side, grid1(V), dim3(256), 0, s, V, seg_pos_, axis, tab[cur].leaves, mid_out, LX[lb], LY[lb], side);
+    hipLaunchKernelGGL(k_lvl_flags, grid1(V), dim3(256), 0, s, V, LX[lb], LY[lb], side, wsort_);
+    size_t tb = cub_bytes_;
+    HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+    hipLaunchKernelGGL(k_lvl_scatter, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], mid_out, child_base, wsort_, wscan_,
+                       LX[lb], LY[lb], LX[lb ^ 1], LY[lb ^ 1]);
   }
+  // perm = the x list (any order inside a segment serves the later stages); posx for the subtrees
+  if (lists) hipLaunchKernelGGL(k_lvl_posx, grid1(V), dim3(256), 0, s, V, LX[lb], posx, perm);
   if (sub_level < levels) {
     const size_t lds_sub = kSubLdsBytes;
     if (!sub_attr_set_) {
@@ -1563,8 +1556,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     if (sub_level == 0) hipLaunchKernelGGL(k_rcb_bbox, dim3(1), dim3(1024), 0, s, nseg + cur, tab[cur], perm, in.pos, bbox);
     if (sub_level == 0) hipLaunchKernelGGL(k_save_gbbox, dim3(1), dim3(64), 0, s, bbox, gbbox_);
     hipLaunchKernelGGL(k_rcb_subtree, dim3(1 << sub_level), dim3(kSubThreads), lds_sub, s, nseg + cur, tab[cur], tab[cur ^ 1],
-                       nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, rank_x, rank_y, w_int_, weighted ? 1 : 0, vb,
-                       need_ranks ? 0 : 1, (opt.debug_sub_cap > 0 && sub_extra_levels_ == 0) ? std::min(opt.debug_sub_cap, kSubCap) : kSubCap,
+                       nseg + (cur ^ 1), ntiles, perm, seg_pos_, in.pos, LX[lb], LY[lb], posx, w_int_, weighted ? 1 : 0, vb,
+                       lists ? 0 : 1, (opt.debug_sub_cap > 0 && sub_extra_levels_ == 0) ? std::min(opt.debug_sub_cap, kSubCap) : kSubCap,
                        flags_);
     cur ^= 1;
   }
