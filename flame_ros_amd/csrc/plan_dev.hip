@@ -609,30 +609,44 @@ __global__ __launch_bounds__(kSegCap) void k_rcb_check(const int32_t* nseg, SegT
 // ------------------------------------------------------------------------------------------
 // Stage B: order inside tiles = Morton code of the pixel position (plan.cpp, order_mode 1)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_keys(int32_t V, const int32_t* __restrict__ perm,
-                                                   const float2* __restrict__ pos,
-                                                   const int32_t* __restrict__ seg_pos,
-                                                   const float* __restrict__ gb, int vb, uint64_t* keys) {
-  const int32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= V) return;
-  const int32_t v = perm[p];
-  const float2 q = pos[v];
+// One workgroup per tile sorts the tile's own vertices by (Morton code, id) in LDS (a tile holds a
+// few hundred vertices; a library sort of all V 64-bit keys was seven launches).
+constexpr int kOrderCap = 2048;
+__global__ __launch_bounds__(256) void k_tile_order(int32_t V, int32_t ntiles, const int32_t* __restrict__ tlo,
+                                                    const int32_t* __restrict__ thi,
+                                                    const float2* __restrict__ pos, const float* __restrict__ gb,
+                                                    int32_t* v_i2o, int32_t* v_o2i, int32_t* tile_of_int,
+                                                    int32_t* flags) {
+  __shared__ uint64_t keys[kOrderCap];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int32_t lo = max(0, min(tlo[t], V)), hi = max(lo, min(thi[t], V));  // (tables of a rejected
+  const int n = hi - lo;                                                    //  partition stay in range)
+  if (n > kOrderCap) {  // cannot be a tile of any kernel configuration: keep the order, flag the plan
+    if (tid == 0) atomicOr(&flags[0], 4);
+    for (int p = tid; p < n; p += 256) { const int32_t v = v_i2o[lo + p]; v_o2i[v] = lo + p; tile_of_int[lo + p] = t; }
+    return;
+  }
   const float mnx = gb[0], mny = gb[1], mxx = gb[2], mxy = gb[3];
-  const uint32_t qx = (uint32_t)(65535.0f * (q.x - mnx) / fmaxf(mxx - mnx, 1e-20f));
-  const uint32_t qy = (uint32_t)(65535.0f * (q.y - mny) / fmaxf(mxy - mny, 1e-20f));
-  const uint32_t code = spread16(qx) | (spread16(qy) << 1);
-  keys[p] = ((uint64_t)seg_pos[p] << (32 + vb)) | ((uint64_t)code << vb) | (uint64_t)v;
-}
-
-__global__ __launch_bounds__(256) void k_vertex_order(int32_t V, const uint64_t* __restrict__ keys, int vb,
-                                                      int32_t* v_i2o, int32_t* v_o2i, int32_t* tile_of_int) {
-  const int32_t p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= V) return;
-  const uint64_t k = keys[p];
-  const int32_t v = (int32_t)(k & ((1ull << vb) - 1));
-  v_i2o[p] = v;
-  v_o2i[v] = p;
-  tile_of_int[p] = (int32_t)(k >> (32 + vb));
+  const int m = next_pow2(max(n, 1));
+  for (int p = tid; p < m; p += 256) {
+    uint64_t k = ~0ull;
+    if (p < n) {
+      const int32_t v = v_i2o[lo + p];
+      const float2 q = pos[v];
+      const uint32_t qx = (uint32_t)(65535.0f * (q.x - mnx) / fmaxf(mxx - mnx, 1e-20f));
+      const uint32_t qy = (uint32_t)(65535.0f * (q.y - mny) / fmaxf(mxy - mny, 1e-20f));
+      k = ((uint64_t)(spread16(qx) | (spread16(qy) << 1)) << 32) | (uint32_t)v;
+    }
+    keys[p] = k;
+  }
+  __syncthreads();
+  bitonic_sort<256, uint64_t>(keys, m);
+  for (int p = tid; p < n; p += 256) {
+    const int32_t v = (int32_t)(uint32_t)keys[p];
+    v_i2o[lo + p] = v;
+    v_o2i[v] = lo + p;
+    tile_of_int[lo + p] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1427,6 +1441,11 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(dalloc(&tcnt_, 2 * (size_t)v + 2));
     size_t b = 0;
     HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, tcnt_, tcnt_, (int)v + 1, nullptr));
+    size_t b2 = 0;  // the second stream also sorts the y list (stage A)
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, reinterpret_cast<uint32_t*>(tcnt_), reinterpret_cast<uint32_t*>(tcnt_),
+                                              reinterpret_cast<uint32_t*>(tcnt_), reinterpret_cast<uint32_t*>(tcnt_), (int)v, 0, 32,
+                                              nullptr));
+    b = std::max(b, b2);
     if (b > tcub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&tcub_tmp_), b)); tcub_bytes_ = b; }
     capV2_ = v;
   }
@@ -1519,10 +1538,20 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   uint32_t* posx = reinterpret_cast<uint32_t*>(keys_b_) + capV_;
   int32_t* side = counts_;
   int32_t* axis = st + 16 * kSegCap + 16;
-  for (int ax = 0; ax < 2 && lists; ++ax) {  // ids sorted along x and along y: (coordinate, id)
-    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, ax, key_in, val_in);
+  if (lists) {  // ids sorted along x (this stream) and along y (second stream): (coordinate, id)
+    HIPRET(hipEventRecord(ev_fork_, s));
+    HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
+    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, 0, key_in, val_in);
     size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, key_in, key_out, val_in, ax ? LY[0] : LX[0], V, 0, 32, s));
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, key_in, key_out, val_in, LX[0], V, 0, 32, s));
+    uint32_t* key_in2 = reinterpret_cast<uint32_t*>(wsort_);  // (the weight scratch is not in use yet)
+    uint32_t* key_out2 = reinterpret_cast<uint32_t*>(wsort_) + capV_;
+    uint32_t* val_in2 = reinterpret_cast<uint32_t*>(wscan_);
+    hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s2_, V, in.pos, 1, key_in2, val_in2);
+    size_t tb3 = tcub_bytes_;
+    HIPRET(hipcub::DeviceRadixSort::SortPairs(tcub_tmp_, tb3, key_in2, key_out2, val_in2, LY[0], V, 0, 32, s2_));
+    HIPRET(hipEventRecord(ev_join_, s2_));
+    HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
   }
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
   int cur = 0, lb = 0;
@@ -1566,12 +1595,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   lap("A rcb");
 
   // ---- stage B ----
-  hipLaunchKernelGGL(k_tile_keys, grid1(V), dim3(256), 0, s, V, perm, in.pos, seg_pos_, gbbox_, vb, keys_a_);
-  {
-    size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(cub_tmp_, tb2, keys_a_, keys_b_, V, 0, std::min(64, 32 + vb + bits_for(ntiles)), s));
-  }
-  hipLaunchKernelGGL(k_vertex_order, grid1(V), dim3(256), 0, s, V, keys_b_, vb, A->v_i2o, A->v_o2i, tile_of_int_);
+  HIPRET(hipMemsetAsync(A->v_o2i, 0, sizeof(int32_t) * (size_t)V, s));  // (every entry is an index for the later
+  HIPRET(hipMemsetAsync(tile_of_int_, 0, sizeof(int32_t) * (size_t)V, s));  //  stages, whatever the partition)
+  hipLaunchKernelGGL(k_tile_order, dim3((unsigned)ntiles), dim3(256), 0, s, V, ntiles, leaf.lo, leaf.hi, in.pos, gbbox_, perm,
+                     A->v_o2i, tile_of_int_, flags_);
 
   lap("B morton");
   if (after_partition) HIPRET(after_partition());  // the caller's edge / data arrays arrive now
