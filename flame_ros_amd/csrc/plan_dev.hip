@@ -652,42 +652,63 @@ __global__ __launch_bounds__(256) void k_tile_order(int32_t V, int32_t ntiles, c
 // ------------------------------------------------------------------------------------------
 // Stage C: edge order (owner tile of the source, level 0 before level 1, source, original id)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_edge_keys(int32_t E, int32_t V, const int2* __restrict__ edges,
-                                                   const int32_t* __restrict__ v_o2i,
-                                                   const int32_t* __restrict__ tile_of_int, int vb,
-                                                   uint64_t* keys, uint32_t* vals, int32_t* flags) {
-  const int32_t e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
-  const int2 ij = edges[e];
+// Edge order by counting: bucket (source vertex u, cross-tile flag) in the order of the edge array --
+// per tile first the buckets (u, 0) of its vertices in internal order, then the buckets (u, 1) --
+// i.e. index 2 lo_t + (cross ? n_t : 0) + (u - lo_t).  Count, exclusive scan, fill through a cursor,
+// every bucket sorted by original edge id (k_csr_rows): the order the stable sort on
+// (tile, cross, source) gave, in 7 short launches instead of a 9-launch merge sort of E keys.
+__device__ __forceinline__ int32_t edge_bucket(const int2 ij, int32_t V, const int32_t* __restrict__ v_o2i,
+                                               const int32_t* __restrict__ tile_of_int,
+                                               const int32_t* __restrict__ tlo, const int32_t* __restrict__ thi,
+                                               int32_t* flags) {
   if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {  // build_plan's index check
-    atomicOr(&flags[0], 2);
-    keys[e] = 0;
-    vals[e] = (uint32_t)e;
-    return;
+    if (flags) atomicOr(&flags[0], 2);
+    return 0;
   }
   const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
   const int32_t ti = tile_of_int[si], tj = tile_of_int[sj];
-  const uint32_t bucket = 2u * (uint32_t)ti + (ti == tj ? 0u : 1u);
-  keys[e] = ((uint64_t)bucket << vb) | (uint64_t)si;  // stable sort: equal keys stay in edge-id order
-  vals[e] = (uint32_t)e;
+  const int32_t lo = tlo[ti], n = thi[ti] - lo;
+  return 2 * lo + (ti == tj ? 0 : n) + (si - lo);
 }
 
+__global__ __launch_bounds__(256) void k_edge_count(int32_t E, int32_t V, const int2* __restrict__ edges,
+                                                    const int32_t* __restrict__ v_o2i,
+                                                    const int32_t* __restrict__ tile_of_int,
+                                                    const int32_t* __restrict__ tlo, const int32_t* __restrict__ thi,
+                                                    int32_t* cnt, int32_t* flags) {
+  const int32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  atomicAdd(&cnt[edge_bucket(edges[e], V, v_o2i, tile_of_int, tlo, thi, flags)], 1);
+}
+
+__global__ __launch_bounds__(256) void k_edge_fill(int32_t E, int32_t V, const int2* __restrict__ edges,
+                                                   const int32_t* __restrict__ v_o2i,
+                                                   const int32_t* __restrict__ tile_of_int,
+                                                   const int32_t* __restrict__ tlo, const int32_t* __restrict__ thi,
+                                                   const int32_t* __restrict__ off, int32_t* cursor, uint32_t* out) {
+  const int32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int32_t b = edge_bucket(edges[e], V, v_o2i, tile_of_int, tlo, thi, nullptr);
+  out[off[b] + atomicAdd(&cursor[b], 1)] = (uint32_t)e;
+}
+
+
 __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* __restrict__ sorted_e,
-                                                     const uint64_t* __restrict__ sorted_keys, int vb,
-                                                     int32_t* estart, const int2* __restrict__ edges,
+                                                     const int2* __restrict__ edges,
                                                      const float* __restrict__ alpha,
                                                      const float* __restrict__ beta,
                                                      const float2* __restrict__ pos,
                                                      const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
-                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t* deg, int32_t V) {
+                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t V, int32_t ntiles,
+                                                     const int32_t* __restrict__ tlo,
+                                                     const int32_t* __restrict__ off, int32_t* estart) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  // estart[t] = first internal edge owned by tile t = where its first bucket starts
+  if (k < ntiles) estart[k] = off[2 * max(0, min(tlo[k], V))];
+  if (k == ntiles) estart[k] = E;
   if (k >= E) return;
   const int32_t e = (int32_t)sorted_e[k];
   const int2 ij = edges[e];
-  {  // first edge of every owner tile (tiles without edges are filled in by k_estart_fill)
-    const int32_t t = (int32_t)((sorted_keys[k] >> vb) >> 1);
-    if (k == 0 || (int32_t)((sorted_keys[k - 1] >> vb) >> 1) != t) estart[t] = k;
-  }
   if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {
     // flagged by k_edge_keys (the plan is rejected after the next sync); keep every index in range
     e_i2o[k] = e; e_o2i[e] = k;
@@ -701,22 +722,8 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
   e_o2i[e] = k;
   eij[k] = make_int2(si, sj);
   ew[k] = make_float4(alpha[e], beta[e], pi.x - pj.x, pi.y - pj.y);
-  (void)deg;
 }
 
-// estart[t] = first internal edge owned by tile t; tiles that own no edge take the next tile's start
-__global__ __launch_bounds__(kSegCap) void k_estart_fill(int ntiles, int32_t E, int32_t* estart) {
-  const int t = threadIdx.x;
-  int32_t v = E;
-  if (t < ntiles) {
-    int u = t;
-    while (u < ntiles && estart[u] < 0) ++u;
-    v = u < ntiles ? estart[u] : E;
-  }
-  __syncthreads();
-  if (t < ntiles) estart[t] = v;
-  if (t == 0) estart[ntiles] = E;
-}
 
 // ------------------------------------------------------------------------------------------
 // Stage D / E: incidence CSR (ascending ORIGINAL edge id per vertex), triangle CSR
@@ -1419,7 +1426,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
   if (V > capV_ || E > capE_ || T > capT_) {
     const int64_t v = std::max<int64_t>(V + V / 4, capV_), e = std::max<int64_t>(E + E / 4, capE_),
                   t = std::max<int64_t>(T + T / 4, capT_);
-    const int64_t n = std::max<int64_t>(std::max<int64_t>(v, 2 * e), 3 * t);
+    const int64_t n = std::max<int64_t>(std::max<int64_t>(2 * v + 1, 2 * e), 3 * t);  // (stage C: 4V + 1 ints in keys_b_)
     HIPRET(dalloc(&keys_a_, (size_t)n)); HIPRET(dalloc(&keys_b_, (size_t)n));
     HIPRET(dalloc(&vals_a_, (size_t)std::max(std::max(2 * e, 2 * v), 3 * t))); HIPRET(dalloc(&vals_b_, (size_t)std::max(std::max(2 * e, 2 * v), 3 * t)));
     HIPRET(dalloc(&seg_pos_, (size_t)v)); HIPRET(dalloc(&tile_of_int_, (size_t)v));
@@ -1432,7 +1439,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, vals_a_, vals_b_, vals_a_, vals_b_, (int)v, 0, 32, nullptr)); need = std::max(need, b);
     HIPRET(hipcub::DeviceScan::InclusiveSum(nullptr, b, wsort_, wscan_, (int)v, nullptr)); need = std::max(need, b);
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, counts_, counts_, (int)v + 1, nullptr)); need = std::max(need, b);
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, counts_, counts_, 2 * (int)v + 2, nullptr)); need = std::max(need, b);  // (edge buckets: 2V + 1)
     if (need > cub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&cub_tmp_), need)); cub_bytes_ = need; }
   }
   (void)nk;
@@ -1621,17 +1628,24 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     HIPRET(hipEventRecord(ev_join_, s2_));
   }
   // ---- stage C ----
-  HIPRET(hipMemsetAsync(estart_, 0xff, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   if (E > 0) {
-    hipLaunchKernelGGL(k_edge_keys, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, vb, keys_a_,
-                       vals_a_, flags_);
+    int32_t* ecnt = reinterpret_cast<int32_t*>(keys_b_);     // 2V + 1 bucket counts, then 2V cursors (8-byte keys:
+    int32_t* ecur = ecnt + 2 * (size_t)V + 1;                //   room for 2 n >= 4 V + 1 ints)
+    int32_t* eoff = reinterpret_cast<int32_t*>(vals_b_);     // (the lists of stage A are dead)
+    uint32_t* esorted = reinterpret_cast<uint32_t*>(keys_a_);
+    HIPRET(hipMemsetAsync(ecnt, 0, sizeof(int32_t) * (4 * (size_t)V + 1), s));
+    hipLaunchKernelGGL(k_edge_count, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, ecnt,
+                       flags_);
     size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, keys_a_, keys_b_, vals_a_, vals_b_, E, 0,
-                                              std::min(64, vb + bits_for(2 * (int64_t)ntiles)), s));
-    hipLaunchKernelGGL(k_edge_gather, grid1(E), dim3(256), 0, s, E, vals_b_, keys_b_, vb, estart_, in.edges, in.alpha,
-                       in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, counts_, V);
+    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, ecnt, eoff, 2 * V + 1, s));
+    hipLaunchKernelGGL(k_edge_fill, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, eoff,
+                       ecur, esorted);
+    hipLaunchKernelGGL(k_csr_rows<false>, grid1(2 * (int64_t)V), dim3(256), 0, s, 2 * V, eoff, nullptr, esorted);
+    hipLaunchKernelGGL(k_edge_gather, grid1(std::max<int64_t>(E, ntiles + 1)), dim3(256), 0, s, E, esorted, in.edges, in.alpha,
+                       in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, V, ntiles, leaf.lo, eoff, estart_);
+  } else {
+    HIPRET(hipMemsetAsync(estart_, 0, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   }
-  hipLaunchKernelGGL(k_estart_fill, dim3(1), dim3(kSegCap), 0, s, ntiles, E, estart_);
   lap("C edges");
   // ---- stage D ----
   if (E > 0) {
