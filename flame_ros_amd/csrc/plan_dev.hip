@@ -848,6 +848,8 @@ __device__ __forceinline__ int32_t hash_lookup(const TileLds& L, int32_t gid) {
 }
 
 
+constexpr int kRowLanes = 4;  // threads per incidence row in the tile passes
+
 // breadth-first halo rings; returns through s_n / s_ring_end (shared), sets *fail on overflow
 template <int NTB>
 __device__ void tile_rings(const TileGraph& G, const TileLds& L, int32_t vstart, int32_t n_own, int* s_n,
@@ -867,9 +869,11 @@ __device__ void tile_rings(const TileGraph& G, const TileLds& L, int32_t vstart,
   int prev_lo = 0, prev_hi = n_own;
   for (int r = 1; r <= kMaxDepth; ++r) {
     if (r <= G.depth) {
-      for (int f = prev_lo + tid; f < prev_hi; f += NTB) {
-        const int32_t v = L.ext[f];
-        for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s) {
+      // (kRowLanes threads share a vertex's incidence row: the dependent loads row -> entry -> edge of a
+      // thread that walks a whole row alone are the latency of these passes)
+      for (int it = tid; it < (prev_hi - prev_lo) * kRowLanes; it += NTB) {
+        const int32_t v = L.ext[prev_lo + it / kRowLanes];
+        for (int32_t s = G.grow[v] + it % kRowLanes; s < G.grow[v + 1]; s += kRowLanes) {
           const int32_t ent = G.ginc[s];
           const int2 ij = G.eij[ent & 0x7fffffff];
           const int32_t u = ent < 0 ? ij.x : ij.y;
@@ -956,16 +960,17 @@ __global__ __launch_bounds__(kP1Threads) void k_tile_pass1(TileGraph G, const in
   const int n_ext = s_n;
   tile_hash_build<kP1Threads>(L, n_ext);
   int cnt = 0;
-  for (int lv = tid; lv < n_ext; lv += kP1Threads) {
+  for (int it = tid; it < n_ext * kRowLanes; it += kP1Threads) {
+    const int lv = it / kRowLanes, sub = it % kRowLanes;
     const int32_t v = L.ext[lv];
     const int rv = ring_of(s_ring_end, lv);
-    for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s) {
+    for (int32_t s = G.grow[v] + sub; s < G.grow[v + 1]; s += kRowLanes) {
       const int32_t ent = G.ginc[s];
       if (ent < 0) continue;  // v is the target; the source adds the edge
       uint64_t key;
       if (local_edge_key(G, L, s_ring_end, ent, lv, rv, G.eij[ent].y, &key)) ++cnt;
     }
-    tile_ext[(size_t)t * kCapExt + lv] = v;
+    if (sub == 0) tile_ext[(size_t)t * kCapExt + lv] = v;
   }
   if (cnt) atomicAdd(&s_ecnt, cnt);
   __syncthreads();
@@ -1117,10 +1122,11 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
   __syncthreads();
   tile_hash_build<kP2Threads>(L, n_ext);
   // ---- local edges: every local vertex contributes its outgoing incidences ----
-  for (int lv = tid; lv < n_ext; lv += kP2Threads) {
+  for (int it = tid; it < n_ext * kRowLanes; it += kP2Threads) {
+    const int lv = it / kRowLanes;
     const int32_t v = L.ext[lv];
     const int rv = ring_of(s_ring_end, lv);
-    for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s) {
+    for (int32_t s = G.grow[v] + it % kRowLanes; s < G.grow[v + 1]; s += kRowLanes) {
       const int32_t ent = G.ginc[s];
       if (ent < 0) continue;
       uint64_t key;
@@ -1170,15 +1176,16 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
     s_gbase[kCapExt / 64] = base;
   }
   __syncthreads();
-  for (int lv = tid; lv < n_upd; lv += kP2Threads) {
+  for (int it = tid; it < n_upd * kRowLanes; it += kP2Threads) {
+    const int lv = it / kRowLanes, sub = it % kRowLanes;
     const int32_t v = L.ext[lv];
     const int32_t deg = G.grow[v + 1] - G.grow[v];
     const int g = lv >> 6;
     const int32_t s0 = s_gbase[g] + (lv - (g << 6)) * s_gw[g];
-    t_srow[soff + lv] = (uint32_t)s0 | ((uint32_t)deg << 16);
+    if (sub == 0) t_srow[soff + lv] = (uint32_t)s0 | ((uint32_t)deg << 16);
     const int rv = ring_of(s_ring_end, lv);
-    int j = 0;
-    for (int32_t s = G.grow[v]; s < G.grow[v + 1]; ++s, ++j) {
+    int j = sub;
+    for (int32_t s = G.grow[v] + sub; s < G.grow[v + 1]; s += kRowLanes, j += kRowLanes) {
       const int32_t ent = G.ginc[s];
       const int32_t k = ent & 0x7fffffff;
       const int role = ent < 0 ? 1 : 0;  // 1: v is the target
