@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
   long long* pre_lo = reinterpret_cast<long long*>(rlo + kSubLeaves);    // weight prefix before the segment
   long long* pre_hi = pre_lo + kSubLeaves;                               // ... through its last position
   char* sort_tmp = reinterpret_cast<char*>(((uintptr_t)(pre_hi + kSubLeaves) + 15) & ~(uintptr_t)15);
-  __shared__ int s_nloc, s_more;
+  __shared__ int s_nloc, s_more, s_more_next;
   int32_t *lo = tb, *hi = tb + kSubLeaves, *lv = tb + 2 * kSubLeaves, *fi = tb + 3 * kSubLeaves;
   int32_t *lo2 = tb + 4 * kSubLeaves, *hi2 = tb + 5 * kSubLeaves, *lv2 = tb + 6 * kSubLeaves, *fi2 = tb + 7 * kSubLeaves;
   for (int p = tid; p < n; p += kSubThreads) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
     segof[p] = 0;
     if (!direct) { lx[p] = (uint16_t)p; ly[p] = (uint16_t)(posx[gly[glo + p]] - (uint32_t)glo); }
   }
-  if (tid == 0) { lo[0] = 0; hi[0] = n; lv[0] = gleaves; fi[0] = gfirst; s_nloc = 1; s_more = gleaves > 1; }
+  if (tid == 0) { lo[0] = 0; hi[0] = n; lv[0] = gleaves; fi[0] = gfirst; s_nloc = 1; s_more = gleaves > 1; s_more_next = 0; }
   __syncthreads();
   // ---- a lone subtree sorts itself: stable from id order, so the coordinate alone gives the
   // (coordinate, id) order ----
@@ -511,34 +511,42 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       }
       __syncthreads();
     }
-    if (tid == 0) {  // children of every local segment (<= kSubLeaves: serial)
-      int nn = 0, more = 0;
-      for (int k = 0; k < nloc; ++k) {
-        const int32_t L = lv[k], slo = lo[k], shi = hi[k];
-        cbase[k] = nn;
+    {  // children of every local segment: one thread per segment, child slots by a block scan
+      int32_t L = 0, slo = 0, shi = 0, mid = 0, nch = 0;
+      if (tid < nloc) {
+        L = lv[tid]; slo = lo[tid]; shi = hi[tid];
         if (L > 1) {
           const int32_t l1 = L / 2;
-          int32_t mid;
           if (weighted) {
-            mid = mid_raw[k];
+            mid = mid_raw[tid];
             mid = max(slo + l1, min(mid, shi - (L - l1)));
             mid = max(slo, min(mid, shi));
           } else {
             mid = slo + (int32_t)(((long long)(shi - slo) * l1) / L);
           }
-          mid_fin[k] = mid;
-          lo2[nn] = slo; hi2[nn] = mid; lv2[nn] = l1; fi2[nn] = fi[k];
-          lo2[nn + 1] = mid; hi2[nn + 1] = shi; lv2[nn + 1] = L - l1; fi2[nn + 1] = fi[k] + l1;
-          more |= (l1 > 1) || (L - l1 > 1);
-          nn += 2;
+          nch = 2;
         } else {
-          mid_fin[k] = shi;
-          lo2[nn] = slo; hi2[nn] = shi; lv2[nn] = L; fi2[nn] = fi[k];
-          nn += 1;
+          mid = shi;
+          nch = 1;
         }
       }
-      s_nloc = nn; s_more = more;
+      const int32_t nn = block_exclusive<int32_t>(nch, reinterpret_cast<int32_t*>(part));
+      if (tid < nloc) {
+        cbase[tid] = nn;
+        mid_fin[tid] = mid;
+        if (nch == 2) {
+          const int32_t l1 = L / 2;
+          lo2[nn] = slo; hi2[nn] = mid; lv2[nn] = l1; fi2[nn] = fi[tid];
+          lo2[nn + 1] = mid; hi2[nn + 1] = shi; lv2[nn + 1] = L - l1; fi2[nn + 1] = fi[tid] + l1;
+          if (l1 > 1 || L - l1 > 1) s_more_next = 1;
+        } else {
+          lo2[nn] = slo; hi2[nn] = shi; lv2[nn] = L; fi2[nn] = fi[tid];
+        }
+        if (tid == nloc - 1) s_nloc = nn + nch;
+      }
     }
+    __syncthreads();
+    if (tid == 0) { s_more = s_more_next; s_more_next = 0; }
     __syncthreads();
     // side of every vertex = its position along the chosen axis against the split
     for (int p = tid; p < n; p += kSubThreads) {
