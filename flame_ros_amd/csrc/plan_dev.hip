@@ -324,8 +324,9 @@ constexpr int kSubLeaves = 256;  // tiles of a subtree
 constexpr int kSubThreads = 1024;
 constexpr int kSubItems = kSubCap / kSubThreads;
 typedef hipcub::BlockRadixSort<uint32_t, kSubThreads, kSubItems, uint32_t> SubPairSort;
+// (after the entry sorts the same LDS holds the subtree's weights by local index)
 constexpr size_t kSubSortBytes =
-    sizeof(SubPairSort::TempStorage) > 2048 * 8 ? sizeof(SubPairSort::TempStorage) : 2048 * 8;
+    sizeof(SubPairSort::TempStorage) > (size_t)kSubCap * 4 ? sizeof(SubPairSort::TempStorage) : (size_t)kSubCap * 4;
 // lists (2 x u16), global ids (u32), side + segment of position (u8), thread partials (i64),
 // 2 segment tables x 4 + 5 per-segment words + 2 per-segment i64 prefixes, sort scratch
 constexpr size_t kSubLdsBytes = (size_t)kSubCap * (2 + 2 + 4 + 1 + 1) + (size_t)kSubThreads * 8 +
@@ -444,6 +445,10 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       __syncthreads();
     }
   }
+  int32_t* wl = reinterpret_cast<int32_t*>(sort_tmp);  // weights by local index (the sort scratch is free now)
+  if (weighted)
+    for (int p = tid; p < n; p += kSubThreads) wl[p] = w_int[gid[p]];
+  __syncthreads();
   // ---- levels ----
   while (s_more) {
     const int nloc = s_nloc;
@@ -461,16 +466,12 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       long long pref[kSubItems];
       int32_t wv[kSubItems];
       long long acc = 0;
-      uint32_t g[kSubItems];
-      // (index reads, then every gather, then the sums: branch-free so that the eight dependent
-      // LDS -> LDS -> global chains of a thread overlap)
+      // (branch-free, so that the eight dependent LDS chains of a thread overlap)
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
         const int pc = min(tid * kSubItems + i, n - 1);
-        g[i] = gid[axis[segof[pc]] ? ly[pc] : lx[pc]];
+        wv[i] = wl[axis[segof[pc]] ? ly[pc] : lx[pc]];
       }
-#pragma unroll
-      for (int i = 0; i < kSubItems; ++i) wv[i] = w_int[g[i]];
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
         if (tid * kSubItems + i >= n) wv[i] = 0;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
         if (p > slo) {
           long long wp, pp;
           if (i > 0) { wp = wv[i - 1]; pp = pref[i - 1]; }
-          else { wp = w_int[gid[axis[k] ? ly[p - 1] : lx[p - 1]]]; pp = base; }
+          else { wp = wl[axis[k] ? ly[p - 1] : lx[p - 1]]; pp = base; }
           cprev = (2 * (pp - wp - sbase) + wp) * L >= rhs;
         }
         if (c && !cprev) mid_raw[k] = p;
