@@ -228,6 +228,20 @@ __global__ __launch_bounds__(kSegCap) void k_rcb_split(const int32_t* nseg_cur, 
 
 
 
+// several scratch arrays zeroed by ONE launch (a build had a dozen separate memsets)
+struct ZeroJob { int32_t* p[4]; int64_t n[4]; };
+__global__ __launch_bounds__(256) void k_zero4(ZeroJob j) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int a = 0; a < 4; ++a)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.n[a]; i += stride) j.p[a][i] = 0;
+}
+inline void zero4(hipStream_t s, int32_t* a, int64_t na, int32_t* b = nullptr, int64_t nb = 0, int32_t* c = nullptr,
+                  int64_t nc = 0, int32_t* d = nullptr, int64_t nd = 0) {
+  ZeroJob j = {{a, b, c, d}, {a ? na : 0, b ? nb : 0, c ? nc : 0, d ? nd : 0}};
+  const int64_t m = std::max(std::max(j.n[0], j.n[1]), std::max(j.n[2], j.n[3]));
+  hipLaunchKernelGGL(k_zero4, dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (m + 255) / 256))), dim3(256), 0, s, j);
+}
+
 // ---- global bisection levels on two presorted lists ----
 // lx / ly = the vertex ids sorted along x / along y in the total order (coordinate, id), both grouped
 // by segment (a segment is the same position range [lo, hi) in both).  A level never sorts: the box
@@ -1553,7 +1567,9 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   int32_t* perm = A->v_i2o;
   const bool weighted = weight_mode_ != 0;
   const int vb = bits_for(V);
-  HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
+  // flags; the vertex order outputs (every entry is an index for the later stages, whatever the
+  // partition); the triangle stage's counts and cursors
+  zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, (T > 0 && in.tris) ? tcnt_ : nullptr, 2 * (int64_t)V + 2);
   if (weight_mode_ == 2)  // (mode 1: w_int_ already holds the weights, see weights_from_tiles / _scale_)
     hipLaunchKernelGGL(k_weights_from_grid, grid1(V), dim3(256), 0, s, V, in.pos, grid_bounds_, grid_w_, w_int_);
 
@@ -1636,8 +1652,6 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   lap("A rcb");
 
   // ---- stage B ----
-  HIPRET(hipMemsetAsync(A->v_o2i, 0, sizeof(int32_t) * (size_t)V, s));  // (every entry is an index for the later
-  HIPRET(hipMemsetAsync(tile_of_int_, 0, sizeof(int32_t) * (size_t)V, s));  //  stages, whatever the partition)
   hipLaunchKernelGGL(k_tile_order, dim3((unsigned)ntiles), dim3(256), 0, s, V, ntiles, leaf.lo, leaf.hi, in.pos, gbbox_, perm,
                      A->v_o2i, tile_of_int_, flags_);
 
@@ -1649,7 +1663,6 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (tri_stage) {
     HIPRET(hipEventRecord(ev_fork_, s));
     HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
-    HIPRET(hipMemsetAsync(tcnt_, 0, sizeof(int32_t) * (2 * (size_t)V + 2), s2_));  // counts, then cursors
     int32_t* tcursor = tcnt_ + V + 1;
     hipLaunchKernelGGL(k_tri_count, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->v_o2i, A->tris, tcnt_,
                        flags_);
@@ -1667,7 +1680,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     int32_t* ecur = ecnt + 2 * (size_t)V + 1;                //   room for 2 n >= 4 V + 1 ints)
     int32_t* eoff = reinterpret_cast<int32_t*>(vals_b_);     // (the lists of stage A are dead)
     uint32_t* esorted = reinterpret_cast<uint32_t*>(keys_a_);
-    HIPRET(hipMemsetAsync(ecnt, 0, sizeof(int32_t) * (4 * (size_t)V + 1), s));
+    // stage C's bucket counts + cursors, stage D's counts and cursors
+    zero4(s, ecnt, 4 * (int64_t)V + 1, counts_, (int64_t)V + 1, reinterpret_cast<int32_t*>(wsort_), V);
     hipLaunchKernelGGL(k_edge_count, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, ecnt,
                        flags_);
     size_t tb2 = cub_bytes_;
@@ -1684,8 +1698,6 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // ---- stage D ----
   if (E > 0) {
     int32_t* cursor = reinterpret_cast<int32_t*>(wsort_);  // (the weight scratch of stage A is free)
-    HIPRET(hipMemsetAsync(counts_, 0, sizeof(int32_t) * ((size_t)V + 1), s));
-    HIPRET(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)V, s));
     hipLaunchKernelGGL(k_csr_count, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, counts_);
     size_t tb2 = cub_bytes_;
     HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->grow, V + 1, s));
