@@ -133,6 +133,33 @@ int h2d_pinned(hipStream_t s, PinnedArena& ar, T* dst, const std::vector<T>& src
   return h2d_pinned(s, ar, dst, src.data(), src.size());
 }
 
+// Results leave the same way: device -> page-locked arena (asynchronous DMAs), ONE synchronisation,
+// then plain memcpys into the caller's (pageable) buffers.
+struct D2HBatch {
+  PinnedArena& ar;
+  hipStream_t s;
+  struct Item { void* dst; const void* tmp; size_t bytes; };
+  std::vector<Item> items;
+  D2HBatch(PinnedArena& a, hipStream_t st) : ar(a), s(st) {}
+  hipError_t add(void* dst, const void* dev, size_t bytes) {
+    if (!bytes || !dst) return hipSuccess;
+    ar.used = (ar.used + 63) & ~(size_t)63;
+    if (ar.used + bytes > ar.cap)  // (reserve() was sized for every piece: not expected)
+      return hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, s);
+    void* tmp = ar.base + ar.used;
+    ar.used += bytes;
+    items.push_back({dst, tmp, bytes});
+    return hipMemcpyAsync(tmp, dev, bytes, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t finish() {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    for (const Item& it : items) std::memcpy(it.dst, it.tmp, it.bytes);
+    items.clear();
+    return hipSuccess;
+  }
+};
+
 template <class T>
 int h2d_async(hipStream_t s, T* dst, const std::vector<T>& src) {
   if (src.empty()) return 0;
@@ -240,6 +267,7 @@ struct flame_hip_graph {
   CapMap caps;
   int solves_since_upload = 0;
   PinnedArena pin;             // page-locked staging of the host arrays of an upload
+  PinnedArena pout;            // page-locked landing area of the results (frame_results, download)
   char* harena = nullptr;      // device arena the host-built plan of the current upload lives in
   bool lanes_applied = false;  // lane_order = 1: the conflict-avoiding lane order is in the device arrays
 
@@ -260,6 +288,7 @@ struct flame_hip_graph {
     }
     caps.clear();
     pin.release();
+    pout.release();
     map_pixels = 0;
     n_send_v = n_send_e = n_recv_v = n_recv_e = 0;
   }
@@ -1177,14 +1206,17 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
   const int32_t V = g->V, E = g->E, T = g->plan.T;
   const int nb = costs_num_blocks(V, E);
   std::vector<double> h(2 * (size_t)nb);
+  HIPCHK(g->pout.reserve(sizeof(double) * h.size() + sizeof(float) * 4 * (size_t)V + (size_t)std::max(T, 0) +
+                         sizeof(int2) * (size_t)E + 64 * 8));
+  D2HBatch out(g->pout, s);
   if (smooth || data) {  // costs are taken BEFORE the state goes back to the caller's units
     HIPCHK(launch_costs(s, V, E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], p->data_factor, g->partials));
-    HIPCHK(hipMemcpyAsync(h.data(), g->partials, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(out.add(h.data(), g->partials, sizeof(double) * h.size()));
   }
   if (scale_back != 1.0f) HIPCHK(launch_scale_state(s, V, g->A[g->cur], g->B[g->cur], scale_back));
   if (x && V > 0) {
     HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], g->dl_v));
-    HIPCHK(hipMemcpyAsync(x, g->dl_v, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
+    HIPCHK(out.add(x, g->dl_v, sizeof(float) * (size_t)V));
   }
   if (vtx_normals || tri_valid) {
     TriParamsDev d;
@@ -1193,15 +1225,15 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
                             g->tri_valid, g->vtx_normals));
     if (vtx_normals && V > 0) {
       HIPCHK(launch_download_rows3(s, V, g->v_o2i_dev, g->vtx_normals, g->dl_n));
-      HIPCHK(hipMemcpyAsync(vtx_normals, g->dl_n, sizeof(float) * 3 * (size_t)V, hipMemcpyDeviceToHost, s));
+      HIPCHK(out.add(vtx_normals, g->dl_n, sizeof(float) * 3 * (size_t)V));
     }
-    if (tri_valid && T > 0) HIPCHK(hipMemcpyAsync(tri_valid, g->tri_valid, (size_t)T, hipMemcpyDeviceToHost, s));
+    if (tri_valid && T > 0) HIPCHK(out.add(tri_valid, g->tri_valid, (size_t)T));
   }
   if (edges && E > 0) {
-    if (g->sync_on_device) HIPCHK(hipMemcpyAsync(edges, g->in_edges, sizeof(int2) * (size_t)E, hipMemcpyDeviceToHost, s));
+    if (g->sync_on_device) HIPCHK(out.add(edges, g->in_edges, sizeof(int2) * (size_t)E));
     else std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)E);
   }
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(out.finish());
   double sm = 0.0, da = 0.0;
   for (int b = 0; b < nb; ++b) { sm += h[2 * b]; da += h[2 * b + 1]; }
   if (smooth) *smooth = sm;
@@ -1307,17 +1339,19 @@ static int download_impl(flame_hip_graph* g, bool bar, float* a0, float* a1, flo
   const int32_t V = g->V, E = g->E;
   hipStream_t s = g->stream;
   // results leave in the caller's order: permuted by a kernel into a staging buffer, then copied
+  HIPCHK(g->pout.reserve(sizeof(float) * 3 * ((size_t)V + (size_t)E) + 64 * 6));
+  D2HBatch out(g->pout, s);
   if ((a0 || a1 || a2) && V > 0) {
     HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, bar ? g->B[g->cur] : g->A[g->cur], g->dl_v));
-    if (a0) HIPCHK(hipMemcpyAsync(a0, g->dl_v, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
-    if (a1) HIPCHK(hipMemcpyAsync(a1, g->dl_v + V, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
-    if (a2) HIPCHK(hipMemcpyAsync(a2, g->dl_v + 2 * (size_t)V, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s));
+    HIPCHK(out.add(a0, g->dl_v, sizeof(float) * (size_t)V));
+    HIPCHK(out.add(a1, g->dl_v + V, sizeof(float) * (size_t)V));
+    HIPCHK(out.add(a2, g->dl_v + 2 * (size_t)V, sizeof(float) * (size_t)V));
   }
   if (q && E > 0) {
     HIPCHK(launch_download_rows3(s, E, g->e_o2i_dev, g->q[g->cur], g->dl_q));
-    HIPCHK(hipMemcpyAsync(q, g->dl_q, sizeof(float) * 3 * (size_t)E, hipMemcpyDeviceToHost, s));
+    HIPCHK(out.add(q, g->dl_q, sizeof(float) * 3 * (size_t)E));
   }
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(out.finish());
   return 0;
 }
 

@@ -140,6 +140,8 @@ class DevPlanner {
   float* gbbox_ = nullptr;         // global bbox of the current frame (4 floats)
   // stage E (vertex -> triangle CSR) runs beside the edge stages on a stream of its own, with its
   // own sort scratch
+  char* hpin_ = nullptr;         // page-locked landing area of the builder's D2H copies (flags, descriptors)
+  size_t hpin_bytes_ = 0;
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   int64_t capV2_ = 0;

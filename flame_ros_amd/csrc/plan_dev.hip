@@ -1444,6 +1444,8 @@ void DevPlanner::release() {
                   grid_bounds_, gbbox_, tcub_tmp_, tcnt_};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (hpin_) (void)hipHostFree(hpin_);
+  hpin_ = nullptr; hpin_bytes_ = 0;
   if (s2_) (void)hipStreamDestroy(s2_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
@@ -1517,6 +1519,15 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(dalloc(&grid_cnt_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_w_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_bounds_, 4)); HIPRET(dalloc(&gbbox_, 4));
+  }
+  {  // D2H copies land in page-locked memory (a copy into pageable memory is staged and waited for)
+    const size_t need = 256 + sizeof(TileDesc) * (size_t)std::max<int64_t>(ntiles + ntiles / 4, 64);
+    if (need > hpin_bytes_) {
+      if (hpin_) (void)hipHostFree(hpin_);
+      hpin_ = nullptr; hpin_bytes_ = 0;
+      HIPRET(hipHostMalloc(reinterpret_cast<void**>(&hpin_), need, hipHostMallocDefault));
+      hpin_bytes_ = need;
+    }
   }
   if (ntiles > capTiles_) {
     const int64_t n = std::max<int64_t>(ntiles + ntiles / 4, 64);
@@ -1716,12 +1727,15 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_);
   if (tri_stage) HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
   lap("E tris (joined)");
-  int32_t hflags[8];
-  HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
+  int32_t* hflags = reinterpret_cast<int32_t*>(hpin_);
+  int32_t* huser = reinterpret_cast<int32_t*>(hpin_ + 64);
+  TileDesc* htiles = reinterpret_cast<TileDesc*>(hpin_ + 256);
+  HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (user_flags_dev && user_flags_host)  // the caller's own check word rides on the same sync
-    HIPRET(hipMemcpyAsync(user_flags_host, user_flags_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPRET(hipMemcpyAsync(huser, user_flags_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
+  if (user_flags_dev && user_flags_host) *user_flags_host = *huser;
   lap("F pass1+sync");
   if (user_flags_dev && user_flags_host && *user_flags_host) return hipSuccess;
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
@@ -1738,11 +1752,11 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
                      tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_,
                      opt.lane_order == 2 ? 1 : 0);
-  tiles_host->resize(ntiles);
-  HIPRET(hipMemcpyAsync(tiles_host->data(), A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
-  HIPRET(hipMemcpyAsync(hflags, flags_, sizeof(hflags), hipMemcpyDeviceToHost, s));
+  HIPRET(hipMemcpyAsync(htiles, A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
+  HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
+  tiles_host->assign(htiles, htiles + ntiles);
   lap("G pass2+sync");
   if (hflags[0] & 8) return hipSuccess;
   *ok = true;
@@ -1787,8 +1801,8 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   tb = cub_bytes_;
   HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, f, idx, n, s));
   hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, flags_ + 4);
-  int32_t h[8];
-  HIPRET(hipMemcpyAsync(h, flags_, sizeof(h), hipMemcpyDeviceToHost, s));
+  int32_t* h = reinterpret_cast<int32_t*>(hpin_);  // (page-locked, see reserve())
+  HIPRET(hipMemcpyAsync(h, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
   if (h[0] & 2) { *index_error = true; return hipSuccess; }
