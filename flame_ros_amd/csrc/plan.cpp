@@ -517,7 +517,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
                            (uint64_t)(uint32_t)P.e_i2o[k]);
           }
         }
-        std::sort(keys.begin(), keys.end());
+        if (!std::is_sorted(keys.begin(), keys.end())) std::sort(keys.begin(), keys.end());  // (an isolated tile emits them in order)
         D.e_loc = (int32_t)keys.size();
         D.estart = estart[t];
         D.e_own = estart[t + 1] - estart[t];
