@@ -652,12 +652,11 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     if ((rc = dev_alloc(g->caps, &g->A[b], V)) || (rc = dev_alloc(g->caps, &g->B[b], V)) ||
         (rc = dev_alloc(g->caps, &g->q[b], E)))
       return rc;
-    HIPCHK(hipMemsetAsync(g->q[b], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), s));
   }
   g->cur = 0;
   if ((rc = dev_alloc(g->caps, &g->pos, V))) return rc;
   HIPCHK(launch_init_state(s, V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, have_x0 ? g->in_x0 : nullptr, g->A[0],
-                           g->B[0], g->pos));
+                           g->B[0], g->pos, E > 0 ? E : 1, g->q[0], g->q[1]));
   if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)T)))
     return rc;
   if (T == 0) HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
@@ -949,8 +948,7 @@ int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float*
   HIPCHK(hipMemcpyAsync(g->in_wgt, wgt, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream));
   if (x0) HIPCHK(hipMemcpyAsync(g->in_x0, x0, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, g->stream));
   HIPCHK(launch_init_state(g->stream, V, g->v_i2o_dev, nullptr, g->in_z, g->in_wgt, x0 ? g->in_x0 : nullptr,
-                           g->A[g->cur], g->B[g->cur], nullptr));
-  HIPCHK(hipMemsetAsync(g->q[g->cur], 0, sizeof(float4) * (size_t)(E > 0 ? E : 1), g->stream));
+                           g->A[g->cur], g->B[g->cur], nullptr, E > 0 ? E : 1, g->q[g->cur], nullptr));
   HIPCHK(hipStreamSynchronize(g->stream));
   return 0;
 }

@@ -67,7 +67,8 @@ hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int
 
 // ---- host boundary with a device-resident plan: state init / results out in the caller's order ----
 hipError_t launch_init_state(hipStream_t s, int32_t V, const int32_t* v_i2o, const float2* pos_o, const float* z,
-                             const float* wgt, const float* x0, float4* A, float4* B, float2* pos_i);
+                             const float* wgt, const float* x0, float4* A, float4* B, float2* pos_i, int32_t nq,
+                             float4* q0, float4* q1);
 // out = 3 planes of V floats {x | w1 | w2} in the caller's vertex order
 hipError_t launch_download_vertex(hipStream_t s, int32_t V, const int32_t* v_o2i, const float4* S, float* out);
 // out[3 o .. 3 o + 2] = S[o2i[o]].xyz (edge duals, vertex normals)

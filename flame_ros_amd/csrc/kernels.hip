@@ -9,6 +9,8 @@
 // (this file is compiled with -ffp-contract=off), per-vertex accumulation of -tau K^T q in
 // ascending ORIGINAL edge id.  The projection v / max(1,|v|) equals clamp(v,-1,1) bit-for-bit
 // for every non-NaN v (v/1 = v; v/|v| = +-1), so it is one v_med3_f32.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace flamehip {
@@ -656,8 +658,14 @@ __global__ __launch_bounds__(256) void k_init_state(int32_t V, const int32_t* __
                                                     const float2* __restrict__ pos_o,
                                                     const float* __restrict__ z, const float* __restrict__ wgt,
                                                     const float* __restrict__ x0, float4* __restrict__ A,
-                                                    float4* __restrict__ B, float2* __restrict__ pos_i) {
+                                                    float4* __restrict__ B, float2* __restrict__ pos_i,
+                                                    int32_t nq, float4* __restrict__ q0, float4* __restrict__ q1) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
+  // q = 0 in the buffers given (the dual state of a fresh upload), by the same launch
+  for (int32_t e = k; e < nq; e += gridDim.x * 256) {
+    if (q0) q0[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q1) q1[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (k >= V) return;
   const int32_t o = v_i2o[k];
   const float zi = z[o];
@@ -872,9 +880,11 @@ hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int
 }
 
 hipError_t launch_init_state(hipStream_t s, int32_t V, const int32_t* v_i2o, const float2* pos_o, const float* z,
-                             const float* wgt, const float* x0, float4* A, float4* B, float2* pos_i) {
-  if (V <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_init_state, dim3((V + 255) / 256), dim3(256), 0, s, V, v_i2o, pos_o, z, wgt, x0, A, B, pos_i);
+                             const float* wgt, const float* x0, float4* A, float4* B, float2* pos_i, int32_t nq,
+                             float4* q0, float4* q1) {
+  if (V <= 0 && nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_init_state, dim3((std::max(V, 1) + 255) / 256), dim3(256), 0, s, V, v_i2o, pos_o, z, wgt, x0, A, B,
+                     pos_i, nq, q0, q1);
   return hipGetLastError();
 }
 

@@ -1332,7 +1332,9 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
 }
 
 __global__ __launch_bounds__(1024) void k_grid_final(int32_t V, const unsigned long long* sum,
-                                                     const int32_t* cnt, int32_t* grid_w) {
+                                                     const int32_t* cnt, int32_t* grid_w, const float* gbbox,
+                                                     float* bounds) {
+  if (threadIdx.x < 4) bounds[threadIdx.x] = gbbox[threadIdx.x];  // the frame the grid was made from
   __shared__ unsigned long long s_tot[1024];
   const int c = threadIdx.x;  // kGrid * kGrid == 1024
   s_tot[c] = sum[c];
@@ -1346,9 +1348,6 @@ __global__ __launch_bounds__(1024) void k_grid_final(int32_t V, const unsigned l
   grid_w[c] = cnt[c] > 0 ? (int32_t)((long long)sum[c] / cnt[c]) : mean;
 }
 
-__global__ void k_copy4(const float* src, float* dst) {
-  if (threadIdx.x < 4) dst[threadIdx.x] = src[threadIdx.x];
-}
 
 // ------------------------------------------------------------------------------------------
 // Graph sync on the device (row a7 / f3): the unique undirected edges of a triangulation, i < j, in
@@ -1820,13 +1819,11 @@ hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, cons
 hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in,
                                    const DevPlanArrays& A) {
   const int n = Plan::kGrid * Plan::kGrid;
-  HIPRET(hipMemsetAsync(grid_sum_, 0, sizeof(long long) * n, s));
-  HIPRET(hipMemsetAsync(grid_cnt_, 0, sizeof(int32_t) * n, s));
-  hipLaunchKernelGGL(k_copy4, dim3(1), dim3(64), 0, s, gbbox_, grid_bounds_);
-  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, s, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, grid_bounds_,
+  zero4(s, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n);
+  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, s, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, gbbox_,
                      reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_);
   hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, s, V, reinterpret_cast<unsigned long long*>(grid_sum_),
-                     grid_cnt_, grid_w_);
+                     grid_cnt_, grid_w_, gbbox_, grid_bounds_);
   grid_tiles_ = ntiles;
   return hipGetLastError();
 }
