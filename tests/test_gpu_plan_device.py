@@ -146,6 +146,29 @@ def test_device_plan_irregular_graphs(gpu, kind):
     host.close(); dev.close()
 
 
+def test_star_graph_falls_back_to_global_path(gpu):
+    """One hub of degree V-1: no tile plan can hold it (its incidence row alone exceeds the LDS).  Both
+    builders give up on tiles -- the device builder's counting CSR sorts the 6 k-entry row by heap
+    sort, it does not hang -- and the global path matches the oracle."""
+    g = graphgen.synthetic(6000, seed=3)
+    hub = 17
+    others = np.array([v for v in range(g.V) if v != hub], np.int32)
+    edges = np.stack([np.full(len(others), hub, np.int32), others], 1)
+    edges[::2] = edges[::2, ::-1]
+    edges = np.ascontiguousarray(edges)
+    d = g.pos[edges[:, 0]] - g.pos[edges[:, 1]]
+    a = (np.float32(1) / np.sqrt((d ** 2).sum(1, dtype=np.float32))).astype(np.float32)
+    from oracle import COracle
+    o = COracle(g.pos, edges, a, a, g.z, g.wgt)
+    o.solve(oracle_params(), 40)
+    for plan_device in (1, 0):
+        r = GraphRegularizer(g.pos, edges, a, a, g.z, g.wgt, tris=None, plan_device=plan_device)
+        assert r.info("path") == _l.PATH_GLOBAL
+        r.step(default_params(), 40)
+        assert_bit_equal(r.download()[0], o.x, "star x")
+        r.close()
+
+
 def test_device_plan_frame_stream(gpu):
     """Consecutive frames of different size on ONE handle each: from the second frame on both
     builders balance in one pass from their cost-density grid; every frame's plan is identical and
