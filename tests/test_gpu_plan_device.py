@@ -192,6 +192,26 @@ def test_device_plan_frame_stream(gpu):
     host.close(); dev.close()
 
 
+def test_device_plan_growing_frames(gpu):
+    """Frames that grow threefold each on ONE handle: every scratch buffer of the builder (lists,
+    counters, page-locked landing areas, tile arrays) is re-reserved on the way."""
+    host = dev = None
+    for k, V in enumerate((3000, 9000, 27000, 2500)):
+        g = graphgen.synthetic(V, seed=60 + k)
+        if host is None:
+            host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
+            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+        else:
+            host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+            dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+        compare_plans(host, dev, "growing frame %d (V=%d)" % (k, V))
+        o = make_oracle(g)
+        o.solve(oracle_params(), 17)
+        dev.step(default_params(), 17)
+        assert_bit_equal(dev.download()[0], o.x, "growing frame %d x" % k)
+    host.close(); dev.close()
+
+
 def test_device_plan_subtree_overflow_recovery(gpu):
     """The LDS subtree kernel of the bisection reports an overflow (forced here through the
     debug_sub_cap test hook; in production: very uneven weighted splits): the builder hands over
