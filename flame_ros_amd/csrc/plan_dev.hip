@@ -800,15 +800,9 @@ __global__ __launch_bounds__(256) void k_tri_fill(int32_t n3, int32_t V, const i
 }
 
 // one thread per row: ascending order (insertion sort; heap sort for long rows, so that a vertex of
-// huge degree costs d log d, not d^2); CONVERT: entries (original edge id << 1 | role) become
+// huge degree costs d log d, not d^2), the rows of a block staged in LDS when they fit; CONVERT: entries (original edge id << 1 | role) become
 // (internal edge id | role << 31)
-template <bool CONVERT>
-__global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __restrict__ row,
-                                                  const int32_t* __restrict__ e_o2i, uint32_t* out) {
-  const int32_t v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= V) return;
-  uint32_t* a = out + row[v];
-  const int d = row[v + 1] - row[v];
+__device__ __forceinline__ void sort_row(uint32_t* a, int d) {
   if (d <= 24) {
     for (int i = 1; i < d; ++i) {
       const uint32_t x = a[i];
@@ -833,11 +827,39 @@ __global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __re
       sift(0, end);
     }
   }
-  if (CONVERT)
+}
+
+constexpr int kRowsLds = 6144;  // entries of 256 consecutive rows staged in LDS (else sorted in place)
+template <bool CONVERT>
+__global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __restrict__ row,
+                                                  const int32_t* __restrict__ e_o2i, uint32_t* out) {
+  __shared__ uint32_t s_a[kRowsLds];
+  const int32_t v0 = blockIdx.x * 256, v1 = min(v0 + 256, V);
+  const int32_t r0 = row[v0], r1 = row[v1];
+  const int32_t v = v0 + threadIdx.x;
+  const bool lds = r1 - r0 <= kRowsLds;  // the block's rows are one contiguous range of the array
+  if (lds) {
+    for (int32_t i = threadIdx.x; i < r1 - r0; i += 256) s_a[i] = out[r0 + i];
+    __syncthreads();
+  }
+  if (v < V) {
+    const int d = row[v + 1] - row[v];
+    sort_row(lds ? s_a + (row[v] - r0) : out + row[v], d);
+  }
+  if (lds) {
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < r1 - r0; i += 256) {
+      const uint32_t x = s_a[i];
+      out[r0 + i] = CONVERT ? ((uint32_t)e_o2i[x >> 1] | ((x & 1u) << 31)) : x;
+    }
+  } else if (CONVERT && v < V) {
+    uint32_t* a = out + row[v];
+    const int d = row[v + 1] - row[v];
     for (int i = 0; i < d; ++i) {
       const uint32_t x = a[i];
       a[i] = (uint32_t)e_o2i[x >> 1] | ((x & 1u) << 31);
     }
+  }
 }
 
 
