@@ -1,19 +1,24 @@
 // flame_ros_amd/csrc/plan_dev.hip -- see plan_dev.h.  The graph plan built by HIP kernels
 // (SURVEY.md 8f row f3).  Stage by stage the same rules as plan.cpp, so the arrays are identical:
 //
-//   A  partition     level-synchronous recursive coordinate bisection: per level one radix sort of
-//                    (segment, ordered coordinate along the segment's longer axis, vertex id), an
-//                    int64 prefix sum of the integer cost weights, and the split rule of
-//                    plan.cpp split_range() evaluated at every position in parallel
-//   B  vertex order  radix sort of (tile, Morton code of the pixel position, vertex id)
-//   C  edge order    radix sort of (owner tile of the source x cross-tile flag, source, edge id)
-//   D  incidence CSR radix sort of (vertex, original edge id) over the 2E incidences
-//   E  triangle CSR  radix sort of (vertex, triangle id) over the 3T corners
+//   A  partition     recursive coordinate bisection on two PRESORTED lists (the vertex ids along x and
+//                    along y, total order (coordinate, id)): per level the box of a segment is the two
+//                    ends of its lists, an int64 prefix sum of the integer cost weights along the
+//                    chosen axis' list and the split rule of plan.cpp split_range() evaluated at every
+//                    position, then a stable partition of both lists (one 64-bit flag scan); deep
+//                    levels: one workgroup per subtree, the same in LDS (k_rcb_subtree)
+//   B  vertex order  one workgroup per tile: (Morton code of the pixel position, vertex id) sorted in LDS
+//   C  edge order    by counting: buckets (source, cross-tile flag) in tile order, scan, cursor fill,
+//                    every bucket sorted by original edge id by its own thread
+//   D  incidence CSR by counting: per-vertex rows, every row sorted by original edge id
+//   E  triangle CSR  the same over the 3T corners, on a second stream
 //   F  tiles, pass 1 one workgroup per tile: breadth-first halo rings over the CSR with an LDS bitmap
 //                    of the vertices, rings sorted by internal id, local edge count
 //   G  tiles, pass 2 local edge keys (level, owned, source, edge id) sorted in LDS, gather lists,
 //                    incidence slots (odd pitch per 64-vertex group), local edge records
-// Only hipcub's device-wide radix sort / scan are library code; everything else is written here.
+// Library code: hipcub's device sort (the two entry sorts), device scan, block radix sort.  rocprim
+// sorts fewer than ~1 M keys by block sort + log2 merge passes (7 launches for 50 k keys, 19 for
+// 300 k), which is why every sort that could be a counting pass is one.
 #include "plan_dev.h"
 
 #include <hipcub/hipcub.hpp>
