@@ -1,0 +1,34 @@
+"""dev helper (gpurun): a long frame stream of random sizes on ONE handle through the facade-style calls
+(graph sync -> solve -> frame_results), single-tile and halo plans mixed; every 25th frame is checked
+against the oracle, device memory in use is printed at the start and at the end (leak check)."""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flame_ros_amd import graphgen
+from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_sync_params, default_tri_params
+from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
+from oracle import COracle
+from tests.util import oracle_params, bits
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(11)
+r = GraphRegularizer.empty(device=0, tile_single_max=2048)
+Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
+p, sp = default_params(), default_sync_params()
+free0 = torch.cuda.mem_get_info()[0]
+t0 = time.perf_counter(); bad = 0
+for k in range(n):
+    V = int(rng.choice([300, 900, 1500, 2600, 5000, 12000, 30000], p=[.15, .25, .2, .15, .1, .1, .05]))
+    g = graphgen.synthetic(V, seed=1000 + k)
+    var = np.full(g.V, 1e-4, np.float32)
+    scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
+    r.step(p, 60, sync=False)
+    out = r.frame_results(p, Kinv, default_tri_params(g.width, g.height), scale_back=scale, with_edges=True)
+    if k % 25 == 0:
+        s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"]); o.solve(oracle_params(), 60)
+        nb = int((bits(out[2]) != bits(o.x)).sum()); bad += nb
+        print("frame %4d V %6d  plan_on_device %d  bad words %d" % (k, V, r.info("plan_on_device"), nb), flush=True)
+dt = time.perf_counter() - t0
+free1 = torch.cuda.mem_get_info()[0]
+print("frames %d in %.1f s (incl. graph generation); device memory in use changed by %.1f MiB; bad words %d" % (n, dt, (free0 - free1) / 2**20, bad))
+r.close()
