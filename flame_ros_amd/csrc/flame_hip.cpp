@@ -1053,6 +1053,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
       g->solves_since_upload > 0 && num_iters > 0 && g->V > 0) {
     int e_max = 0;
     for (const TileDesc& D : g->plan.tiles) e_max = std::max(e_max, D.e_loc);
+    if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));  // (the first solve may have run on another stream)
     HIPCHK(launch_assign_lanes(s, (int32_t)g->plan.tiles.size(), e_max, g->tiles, g->t_eij, g->t_ew, g->t_emap));
     g->lanes_applied = true;
   }
