@@ -189,6 +189,9 @@ struct flame_hip_graph {
   hipStream_t stream = nullptr;
   hipStream_t stream_in = nullptr;  // input staging (H2D of a frame overlaps the partition kernels)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
+  hipEvent_t ev_state = nullptr;  // last state-writing work on `stream` (upload, scale, filter, results)
+  bool state_pending = false;     // ev_state was recorded since the last full synchronisation
+  float state_scale = 1.0f;       // factor applied to the resident state since its upload (rescale_data epilogue)
   bool timed = false;
   int last_launches = 0;
 
@@ -333,7 +336,8 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
-        hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_state, hipEventDisableTiming) != hipSuccess) {
       delete g;
       return FLAME_HIP_ERR_NODEVICE;
     }
@@ -351,6 +355,7 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    if (g->ev_state) (void)hipEventDestroy(g->ev_state);
     if (g->stream_in) { (void)hipStreamSynchronize(g->stream_in); (void)hipStreamDestroy(g->stream_in); }
     if (g->stream) (void)hipStreamDestroy(g->stream);
   }
@@ -363,6 +368,18 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
 static hipError_t wait_last_solve(flame_hip_graph* g) {
   if (g->device < 0 || !g->timed) return hipSuccess;
   return hipEventSynchronize(g->ev1);
+}
+
+// State-writing work enqueued on the handle's own stream (upload, un-scaling, filters) is marked
+// with an event; a solve / halo pack / unpack on a CALLER's stream orders itself behind it
+// (the device-plan upload returns with k_init_state still in flight).
+static hipError_t mark_state(flame_hip_graph* g) {
+  g->state_pending = true;
+  return hipEventRecord(g->ev_state, g->stream);
+}
+static hipError_t order_after_state(flame_hip_graph* g, hipStream_t s) {
+  if (s == g->stream || !g->state_pending) return hipSuccess;
+  return hipStreamWaitEvent(s, g->ev_state, 0);
 }
 
 int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T) {
@@ -584,6 +601,9 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   for (int attempt = 0; attempt < 7 + kBalanceRefinePasses && !built; ++attempt) {
     ntiles = (V + tile_own - 1) / tile_own;
     if (ntiles < 2) return 0;
+    // every retry halves tile_own: the tile count may have outgrown the builder's segment tables
+    // (kSegCap) -- the host builder shrinks safely in that case
+    if (attempt > 0 && !DevPlanner::eligible(g->opt, V, E, T, tile_own, depth, false, g->opt.lds_bytes)) return 0;
     if (!balanced) {
       if (g->opt.balance && ntiles >= 16 && g->planner.grid_tiles() == ntiles) {
         g->planner.set_weights_from_grid();  // a frame stream balances in ONE pass
@@ -708,6 +728,10 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     g->solves_since_upload = 0;
     g->lanes_applied = false;
     rc = upload_device_plan(g, pos, edges, alpha, beta, z, wgt, x0, tris);
+    if (rc <= 0) {  // not built there: copies from the caller's arrays may still be in flight
+      (void)hipStreamSynchronize(g->stream);
+      (void)hipStreamSynchronize(g->stream_in);
+    }
     if (rc < 0) return rc;
   } else {
     rc = 0;
@@ -825,6 +849,8 @@ static int finish_upload(flame_hip_graph* g) {
   }
   g->uploaded = true;
   g->timed = false;
+  g->state_scale = 1.0f;
+  HIPCHK(mark_state(g));
   return 0;
 }
 
@@ -892,6 +918,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     g->lanes_applied = false;
     g->beta_is_alpha = true;
     rc = upload_device_plan(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, true);
+    if (rc <= 0) (void)hipStreamSynchronize(s);  // the H2D copies of the caller's arrays end here
     if (rc < 0) return rc;
     if (rc == 1) {
       if ((rc = finish_upload(g))) return rc;
@@ -950,6 +977,7 @@ int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float*
   HIPCHK(launch_init_state(g->stream, V, g->v_i2o_dev, nullptr, g->in_z, g->in_wgt, x0 ? g->in_x0 : nullptr,
                            g->A[g->cur], g->B[g->cur], nullptr, E > 0 ? E : 1, g->q[g->cur], nullptr));
   HIPCHK(hipStreamSynchronize(g->stream));
+  g->state_scale = 1.0f;
   return 0;
 }
 
@@ -1049,6 +1077,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   // The plan is being solved a second time, i.e. it is reused (a resident graph, the subdomain
   // solver, a bench): only now the lanes of every 64-edge block are re-assigned against LDS bank
   // conflicts (plan.h lane_order = 1) -- a frame stream that solves each graph once never pays.
+  HIPCHK(order_after_state(g, s));
   if (g->path == FLAME_HIP_PATH_TILE && g->opt.lane_order == 1 && !g->lanes_applied &&
       g->solves_since_upload > 0 && num_iters > 0 && g->V > 0) {
     int e_max = 0;
@@ -1199,6 +1228,13 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     return FLAME_HIP_ERR_ARG;
   if (g->plan.T <= 0 && g->T > 0 && (vtx_normals || tri_valid)) return FLAME_HIP_ERR_STATE;
   if (edges && !g->synced) return FLAME_HIP_ERR_STATE;
+  // The un-scaling is applied to the resident state in place, ONCE per upload: a second call on the
+  // same frame does not scale again, and cannot report costs any more (they are defined in the
+  // solver's units).
+  if (g->state_scale != 1.0f) {
+    if (smooth || data) return FLAME_HIP_ERR_STATE;
+    scale_back = 1.0f;
+  }
   HIPCHK(hipSetDevice(g->device));
   hipStream_t s = g->stream;
   if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));  // a solve on a caller's stream
@@ -1212,7 +1248,11 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     HIPCHK(launch_costs(s, V, E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], p->data_factor, g->partials));
     HIPCHK(out.add(h.data(), g->partials, sizeof(double) * h.size()));
   }
-  if (scale_back != 1.0f) HIPCHK(launch_scale_state(s, V, g->A[g->cur], g->B[g->cur], scale_back));
+  if (scale_back != 1.0f) {
+    HIPCHK(launch_scale_state(s, V, g->A[g->cur], g->B[g->cur], scale_back));
+    g->state_scale *= scale_back;
+    HIPCHK(mark_state(g));
+  }
   if (x && V > 0) {
     HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], g->dl_v));
     HIPCHK(out.add(x, g->dl_v, sizeof(float) * (size_t)V));
@@ -1287,6 +1327,7 @@ int flame_hip_graph_filter(flame_hip_graph* g, int32_t kind, int32_t passes) {
   for (int32_t k = 0; k < passes; ++k)
     HIPCHK(launch_graph_filter(g->stream, g->V, kind, g->grow, g->ginc, g->eij, g->A[g->cur],
                                g->B[g->cur], g->filter_tmp));
+  if (passes > 0) HIPCHK(mark_state(g));
   return 0;
 }
 
@@ -1297,6 +1338,8 @@ int flame_hip_scale_state(flame_hip_graph* g, float s) {
   HIPCHK(hipSetDevice(g->device));
   if (g->timed) HIPCHK(hipStreamWaitEvent(g->stream, g->ev1, 0));
   HIPCHK(launch_scale_state(g->stream, g->V, g->A[g->cur], g->B[g->cur], s));
+  g->state_scale *= s;
+  HIPCHK(mark_state(g));
   return 0;
 }
 
@@ -1409,6 +1452,7 @@ int flame_hip_halo_pack(flame_hip_graph* g, void* send_buf_dev, void* stream) {
   if (!send_buf_dev && (g->n_send_v + g->n_send_e) > 0) return FLAME_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(g->device));
   hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  HIPCHK(order_after_state(g, s));
   HIPCHK(launch_halo_pack(s, g->n_send_v, g->n_send_e, g->halo_send_v, g->halo_send_e,
                           g->A[g->cur], g->B[g->cur], g->q[g->cur], (float*)send_buf_dev));
   return 0;
@@ -1420,6 +1464,7 @@ int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* st
   if (!recv_buf_dev && (g->n_recv_v + g->n_recv_e) > 0) return FLAME_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(g->device));
   hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  HIPCHK(order_after_state(g, s));
   HIPCHK(launch_halo_unpack(s, g->n_recv_v, g->n_recv_e, g->halo_recv_v, g->halo_recv_e,
                             (const float*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
   return 0;

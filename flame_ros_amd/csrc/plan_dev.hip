@@ -1494,6 +1494,9 @@ bool DevPlanner::eligible(const PlanOptions& opt, int32_t V, int32_t E, int32_t 
   const int ntiles = (V + tile_own - 1) / std::max(tile_own, 1);
   if (ntiles < 2 || ntiles > kSegCap) return false;
   const int64_t lds2 = (int64_t)kSortPad * 8 + ((V + 31) / 32) * 4ll + kCapExt * 4 + kHash * 8;
+  // the tile passes and the subtree kernel opt in to (almost) all of gfx950's 160 KiB of LDS: a
+  // device / option set with less is the host builder's
+  if ((int64_t)kSubLdsBytes > lds_bytes || 160 * 1024 - 512 > lds_bytes) return false;
   return lds2 <= lds_bytes;
 }
 

@@ -171,7 +171,10 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
  * synchronisation: the two costs (in the solver's units, i.e. before scale_back is applied), then
  * the state times scale_back (1 = leave it; rescale_data: the scale flame_hip_graph_sync returned),
  * the idepths x (V), the per-triangle stage (vtx_normals 3V, tri_valid T) and the edge list derived
- * by flame_hip_graph_sync (2E).  Any output pointer may be NULL.  Synchronises. */
+ * by flame_hip_graph_sync (2E).  Any output pointer may be NULL.  Synchronises.  The un-scaling is
+ * applied to the resident state in place and only ONCE per upload: on a state that is already back
+ * in the caller's units (an earlier call, or flame_hip_scale_state) scale_back is ignored and asking
+ * for the costs returns FLAME_HIP_ERR_STATE. */
 int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float scale_back,
                             const float Kinv[9], const flame_hip_tri_params* tp, double* smooth,
                             double* data, float* x, float* vtx_normals, uint8_t* tri_valid,
