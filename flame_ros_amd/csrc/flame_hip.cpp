@@ -224,6 +224,17 @@ struct flame_hip_graph {
   float* map_idm = nullptr;
   float* map_dm = nullptr;
   float* map_cloud = nullptr;
+  uint32_t* map_cov = nullptr;   // per-block covered-pixel counts of the last raster (stat key coverage)
+  char* fr_dev = nullptr;        // output arena of flame_hip_frame_results (one D2H per frame)
+  uint32_t* dbg_key = nullptr;   // debug images: winning-primitive key map, BGR8 output, staged features
+  uint8_t* dbg_bgr = nullptr;
+  float* dbg_feat = nullptr;
+  // which raster the map buffers hold: the solver state it was made from (state_serial), the
+  // filter parameters, filtered or not -- dense maps, coverage and the debug images share it
+  uint64_t state_serial = 1, raster_serial = 0;
+  int raster_filtered = -1;
+  flame_hip_tri_params raster_tp;
+  float raster_kinv[9];
   // graph filter scratch (row a9)
   float* filter_tmp = nullptr;
   // mesh output (row f1)
@@ -299,7 +310,7 @@ struct flame_hip_graph {
 
 extern "C" {
 
-int flame_hip_version(void) { return 200; }
+int flame_hip_version(void) { return 300; }
 
 const char* flame_hip_strerror(int code) {
   switch (code) {
@@ -375,6 +386,7 @@ static hipError_t wait_last_solve(flame_hip_graph* g) {
 // (the device-plan upload returns with k_init_state still in flight).
 static hipError_t mark_state(flame_hip_graph* g) {
   g->state_pending = true;
+  g->state_serial++;
   return hipEventRecord(g->ev_state, g->stream);
 }
 static hipError_t order_after_state(flame_hip_graph* g, hipStream_t s) {
@@ -978,6 +990,7 @@ int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float*
                            g->A[g->cur], g->B[g->cur], nullptr, E > 0 ? E : 1, g->q[g->cur], nullptr));
   HIPCHK(hipStreamSynchronize(g->stream));
   g->state_scale = 1.0f;
+  g->state_serial++;
   return 0;
 }
 
@@ -998,6 +1011,7 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
   HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
   if ((rc = ensure_host_perms(g))) return rc;
+  g->state_serial++;
   if (x || w1 || w2 || xb || w1b || w2b) {
     std::vector<float4> hA(V), hB(V);
     if (V > 0) {
@@ -1123,6 +1137,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
     }
   }
   g->cur = cur_out;
+  g->state_serial++;
   g->last_launches = launches;
   g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
@@ -1216,17 +1231,61 @@ static void fill_tri_params(const float Kinv[9], const flame_hip_tri_params* tp,
   for (int k = 0; k < 9; ++k) d->Kinv[k] = Kinv[k];
 }
 
+// Triangle stage + dense raster of the CURRENT solver state into the handle's map buffers
+// (owner, idepthmap; depth map / cloud on request), enqueued on the handle's stream; skipped when
+// the buffers already hold exactly that raster (same state, parameters, filtered flag) -- the stat
+// key `coverage`, the dense-map getters and the debug images all come from one rasterisation.
+// fo (optional): the frame's per-vertex / per-triangle outputs, written by the triangle stage's own
+// two launches.  The per-block covered-pixel counts land in g->map_cov (raster_num_blocks() words).
+static int ensure_raster(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp, int filtered,
+                         float min_depth, float max_depth, bool want_dm, bool want_cloud, const FrameOut* fo = nullptr,
+                         uint32_t* cov_dst = nullptr) {
+  int rc;
+  const int32_t V = g->V, T = g->plan.T;
+  const int64_t npix = (int64_t)tp->width * tp->height;
+  if (npix != g->map_pixels) {
+    if ((rc = dev_alloc(g->caps, &g->map_owner, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->map_idm, (size_t)npix)) ||
+        (rc = dev_alloc(g->caps, &g->map_dm, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->map_cloud, 3 * (size_t)npix)) ||
+        (rc = dev_alloc(g->caps, &g->map_cov, (size_t)raster_num_blocks(tp->width, tp->height))))
+      return rc;
+    g->map_pixels = npix;
+    g->raster_serial = 0;
+  }
+  // (cov_dst: the caller wants the covered-pixel counts in its own buffer => always rasterise)
+  const bool cached = !cov_dst && g->raster_serial == g->state_serial && g->raster_filtered == filtered &&
+                      std::memcmp(&g->raster_tp, tp, sizeof(*tp)) == 0 && std::memcmp(g->raster_kinv, Kinv, 36) == 0;
+  if (cached && !want_dm && !want_cloud && !fo) return 0;
+  TriParamsDev d;
+  fill_tri_params(Kinv, tp, &d);
+  hipStream_t s = g->stream;
+  HIPCHK(launch_triangles(s, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d, g->tri_normals, g->tri_valid,
+                          g->vtx_normals, fo));
+  if (cached && !want_dm && !want_cloud) return 0;
+  HIPCHK(launch_raster(s, T, tp->width, tp->height, g->pos, g->A[g->cur], g->tris, g->tri_valid, filtered, d, min_depth,
+                       max_depth, g->map_owner, g->map_idm, (want_dm || want_cloud) ? g->map_dm : nullptr,
+                       want_cloud ? g->map_cloud : nullptr, cov_dst ? cov_dst : g->map_cov));
+  g->raster_serial = g->state_serial;
+  g->raster_filtered = filtered;
+  g->raster_tp = *tp;
+  std::memcpy(g->raster_kinv, Kinv, 36);
+  return 0;
+}
+
 // Everything flame::Flame::update() reads back after the solve, in ONE call with ONE stream
-// synchronisation (each of costs / download / triangles / graph_edges alone pays its own).
+// synchronisation (each of costs / download / triangles / graph_edges alone pays its own).  r03: the
+// kernels write their results straight into ONE device arena in the caller's order (cost partials |
+// x | vertex normals | triangle validity) that leaves with ONE copy; the edge list (constant since
+// the graph sync) is fetched on the staging stream while the iterations still run.
 int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float scale_back,
                             const float Kinv[9], const flame_hip_tri_params* tp, double* smooth, double* data,
-                            float* x, float* vtx_normals, uint8_t* tri_valid, int32_t* edges) {
+                            float* x, float* vtx_normals, uint8_t* tri_valid, int32_t* edges, float* coverage) {
   RoctxRange roctx_("flame_hip_frame_results");
   int rc = require_device(g);
   if (rc) return rc;
-  if (((smooth || data) && !p) || ((vtx_normals || tri_valid) && (!Kinv || !tp)) || !std::isfinite(scale_back))
+  if (((smooth || data) && !p) || ((vtx_normals || tri_valid || coverage) && (!Kinv || !tp)) || !std::isfinite(scale_back))
     return FLAME_HIP_ERR_ARG;
-  if (g->plan.T <= 0 && g->T > 0 && (vtx_normals || tri_valid)) return FLAME_HIP_ERR_STATE;
+  if (coverage && (tp->width < 1 || tp->height < 1)) return FLAME_HIP_ERR_ARG;
+  if (g->plan.T <= 0 && g->T > 0 && (vtx_normals || tri_valid || coverage)) return FLAME_HIP_ERR_STATE;
   if (edges && !g->synced) return FLAME_HIP_ERR_STATE;
   // The un-scaling is applied to the resident state in place, ONCE per upload: a second call on the
   // same frame does not scale again, and cannot report costs any more (they are defined in the
@@ -1240,43 +1299,107 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
   if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));  // a solve on a caller's stream
   const int32_t V = g->V, E = g->E, T = g->plan.T;
   const int nb = costs_num_blocks(V, E);
-  std::vector<double> h(2 * (size_t)nb);
-  HIPCHK(g->pout.reserve(sizeof(double) * h.size() + sizeof(float) * 4 * (size_t)V + (size_t)std::max(T, 0) +
-                         sizeof(int2) * (size_t)E + 64 * 8));
-  D2HBatch out(g->pout, s);
-  if (smooth || data) {  // costs are taken BEFORE the state goes back to the caller's units
-    HIPCHK(launch_costs(s, V, E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], p->data_factor, g->partials));
-    HIPCHK(out.add(h.data(), g->partials, sizeof(double) * h.size()));
+  const bool tri_stage = (vtx_normals || tri_valid || coverage) || (x && Kinv && tp);
+  const int ncb = coverage ? raster_num_blocks(tp->width, tp->height) : 0;
+  // ---- arena layout (device and page-locked mirror) ----
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t off_part = 0, off_x = al(sizeof(double) * 2 * (size_t)nb);
+  const size_t off_n = off_x + al(sizeof(float) * (tri_stage ? 1 : 3) * (size_t)V);
+  const size_t off_tv = off_n + al(sizeof(float) * 3 * (size_t)V);
+  const size_t off_cov = off_tv + al((size_t)std::max(T, 0));
+  const size_t off_edges = off_cov + al(sizeof(uint32_t) * (size_t)ncb);
+  const size_t dev_bytes = off_edges, total = off_edges + al(sizeof(int2) * (size_t)E);
+  if ((rc = dev_alloc(g->caps, &g->fr_dev, dev_bytes))) return rc;
+  HIPCHK(g->pout.reserve(total + 64));
+  char* host = g->pout.base;
+  const bool dev_edges = edges && E > 0 && g->sync_on_device;
+  if (dev_edges) {  // not ordered behind the solve: in_edges has been final since the graph sync
+    HIPCHK(hipMemcpyAsync(host + off_edges, g->in_edges, sizeof(int2) * (size_t)E, hipMemcpyDeviceToHost, g->stream_in));
   }
+  if (smooth || data)  // costs are taken BEFORE the state goes back to the caller's units
+    HIPCHK(launch_costs(s, V, E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], p->data_factor,
+                        reinterpret_cast<double*>(g->fr_dev + off_part)));
   if (scale_back != 1.0f) {
     HIPCHK(launch_scale_state(s, V, g->A[g->cur], g->B[g->cur], scale_back));
     g->state_scale *= scale_back;
     HIPCHK(mark_state(g));
   }
-  if (x && V > 0) {
-    HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], g->dl_v));
-    HIPCHK(out.add(x, g->dl_v, sizeof(float) * (size_t)V));
-  }
-  if (vtx_normals || tri_valid) {
-    TriParamsDev d;
-    fill_tri_params(Kinv, tp, &d);
-    HIPCHK(launch_triangles(s, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d, g->tri_normals,
-                            g->tri_valid, g->vtx_normals));
-    if (vtx_normals && V > 0) {
-      HIPCHK(launch_download_rows3(s, V, g->v_o2i_dev, g->vtx_normals, g->dl_n));
-      HIPCHK(out.add(vtx_normals, g->dl_n, sizeof(float) * 3 * (size_t)V));
+  if (tri_stage) {
+    FrameOut fo;
+    fo.v_i2o = g->v_i2o_dev;
+    fo.x = x ? reinterpret_cast<float*>(g->fr_dev + off_x) : nullptr;
+    fo.normals = vtx_normals ? reinterpret_cast<float*>(g->fr_dev + off_n) : nullptr;
+    fo.tri_valid = tri_valid ? reinterpret_cast<uint8_t*>(g->fr_dev + off_tv) : nullptr;
+    if (coverage) {  // + the filtered dense raster (kept for the map getters / debug images)
+      if ((rc = ensure_raster(g, Kinv, tp, 1, 0.f, 0.f, false, false, &fo, reinterpret_cast<uint32_t*>(g->fr_dev + off_cov))))
+        return rc;
+    } else {
+      TriParamsDev d;
+      fill_tri_params(Kinv, tp, &d);
+      HIPCHK(launch_triangles(s, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d, g->tri_normals,
+                              g->tri_valid, g->vtx_normals, &fo));
     }
-    if (tri_valid && T > 0) HIPCHK(out.add(tri_valid, g->tri_valid, (size_t)T));
+  } else if (x && V > 0) {  // no camera / filter parameters given: plain permuted download (3 planes, x first)
+    HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], reinterpret_cast<float*>(g->fr_dev + off_x)));
   }
+  HIPCHK(hipMemcpyAsync(host, g->fr_dev, dev_bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (dev_edges) HIPCHK(hipStreamSynchronize(g->stream_in));
+  if (smooth || data) {
+    const double* h = reinterpret_cast<const double*>(host + off_part);
+    double sm = 0.0, da = 0.0;
+    for (int b = 0; b < nb; ++b) { sm += h[2 * b]; da += h[2 * b + 1]; }
+    if (smooth) *smooth = sm;
+    if (data) *data = da;
+  }
+  if (x && V > 0) std::memcpy(x, host + off_x, sizeof(float) * (size_t)V);
+  if (vtx_normals && V > 0) std::memcpy(vtx_normals, host + off_n, sizeof(float) * 3 * (size_t)V);
+  if (tri_valid && T > 0) std::memcpy(tri_valid, host + off_tv, (size_t)T);
   if (edges && E > 0) {
-    if (g->sync_on_device) HIPCHK(out.add(edges, g->in_edges, sizeof(int2) * (size_t)E));
+    if (dev_edges) std::memcpy(edges, host + off_edges, sizeof(int2) * (size_t)E);
     else std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)E);
   }
+  if (coverage) {
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(host + off_cov);
+    uint64_t covered = 0;
+    for (int b = 0; b < ncb; ++b) covered += c[b];
+    *coverage = (float)covered / (float)((int64_t)tp->width * tp->height);
+  }
+  return 0;
+}
+
+int flame_hip_debug_image(flame_hip_graph* g, int32_t kind, const float Kinv[9], const flame_hip_tri_params* tp,
+                          float scene_color_scale, int32_t n_feat, const float* feat_pos, const float* feat_mu,
+                          uint8_t* bgr) {
+  RoctxRange roctx_("flame_hip_debug_image");
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (kind < 0 || kind > 3 || !Kinv || !tp || tp->width < 1 || tp->height < 1 || !bgr || n_feat < 0 ||
+      (kind == FLAME_HIP_IMG_FEATURES && n_feat > 0 && (!feat_pos || !feat_mu)))
+    return FLAME_HIP_ERR_ARG;
+  if (g->plan.T <= 0 && g->T > 0) return FLAME_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = g->stream;
+  if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));
+  if ((rc = ensure_raster(g, Kinv, tp, 1, 0.f, 0.f, false, false))) return rc;
+  const int64_t npix = (int64_t)tp->width * tp->height;
+  if ((rc = dev_alloc(g->caps, &g->dbg_key, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->dbg_bgr, 3 * (size_t)npix)))
+    return rc;
+  if (kind != FLAME_HIP_IMG_FEATURES) n_feat = 0;
+  HIPCHK(g->pout.reserve(3 * (size_t)npix + 12 * (size_t)n_feat + 256));
+  if (n_feat > 0) {  // {u, v, mu} records through the page-locked arena
+    if ((rc = dev_alloc(g->caps, &g->dbg_feat, 3 * (size_t)n_feat))) return rc;
+    float* st = reinterpret_cast<float*>(g->pout.base);
+    for (int32_t f = 0; f < n_feat; ++f) { st[3 * f] = feat_pos[2 * f]; st[3 * f + 1] = feat_pos[2 * f + 1]; st[3 * f + 2] = feat_mu[f]; }
+    g->pout.used = 12 * (size_t)n_feat;
+    HIPCHK(hipMemcpyAsync(g->dbg_feat, st, 12 * (size_t)n_feat, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(launch_debug_image(s, kind, g->plan.T, tp->width, tp->height, g->pos, g->A[g->cur], g->tris, g->tri_valid,
+                            g->map_owner, g->map_idm, g->vtx_normals, n_feat, g->dbg_feat, scene_color_scale, g->dbg_key,
+                            g->dbg_bgr));
+  D2HBatch out(g->pout, s);
+  HIPCHK(out.add(bgr, g->dbg_bgr, 3 * (size_t)npix));
   HIPCHK(out.finish());
-  double sm = 0.0, da = 0.0;
-  for (int b = 0; b < nb; ++b) { sm += h[2 * b]; da += h[2 * b + 1]; }
-  if (smooth) *smooth = sm;
-  if (data) *data = da;
   return 0;
 }
 
@@ -1351,21 +1474,9 @@ int flame_hip_depthmaps(flame_hip_graph* g, const float Kinv[9], const flame_hip
   if (!Kinv || !tp || tp->width < 1 || tp->height < 1) return FLAME_HIP_ERR_ARG;
   if (g->plan.T <= 0 && g->T > 0) return FLAME_HIP_ERR_STATE;
   if ((rc = flame_hip_sync(g))) return rc;
-  const int32_t V = g->V, T = g->plan.T;
   const int64_t npix = (int64_t)tp->width * tp->height;
-  if (npix != g->map_pixels) {
-    if ((rc = dev_alloc(g->caps, &g->map_owner, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->map_idm, (size_t)npix)) ||
-        (rc = dev_alloc(g->caps, &g->map_dm, (size_t)npix)) || (rc = dev_alloc(g->caps, &g->map_cloud, 3 * (size_t)npix)))
-      return rc;
-    g->map_pixels = npix;
-  }
-  TriParamsDev d;
-  fill_tri_params(Kinv, tp, &d);
-  HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
-                          g->tri_normals, g->tri_valid, g->vtx_normals));
-  HIPCHK(launch_raster(g->stream, T, tp->width, tp->height, g->pos, g->A[g->cur], g->tris,
-                       g->tri_valid, filtered, d, min_depth, max_depth, g->map_owner, g->map_idm,
-                       depthmap || cloud ? g->map_dm : nullptr, cloud ? g->map_cloud : nullptr));
+  if ((rc = ensure_raster(g, Kinv, tp, filtered ? 1 : 0, min_depth, max_depth, depthmap != nullptr, cloud != nullptr)))
+    return rc;
   HIPCHK(hipStreamSynchronize(g->stream));
   if (idepthmap) HIPCHK(memcpy_sync(g->stream, idepthmap, g->map_idm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
   if (depthmap) HIPCHK(memcpy_sync(g->stream, depthmap, g->map_dm, sizeof(float) * (size_t)npix, hipMemcpyDeviceToHost));
@@ -1467,6 +1578,7 @@ int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* st
   HIPCHK(order_after_state(g, s));
   HIPCHK(launch_halo_unpack(s, g->n_recv_v, g->n_recv_e, g->halo_recv_v, g->halo_recv_e,
                             (const float*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
+  g->state_serial++;
   return 0;
 }
 

@@ -56,10 +56,18 @@ struct TriParamsDev {
   float cos_thresh, diff_factor, diff_abs, max_len2, min_idepth;
   float Kinv[9];
 };
+// fo (optional): the frame's outputs in the CALLER's vertex order (x V floats, normals 3V floats,
+// any may be null) and a copy of tri_valid, written by the same two launches
+struct FrameOut {
+  const int32_t* v_i2o;
+  float* x;
+  float* normals;
+  uint8_t* tri_valid;
+};
 hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* pos,
                             const float4* A, const int32_t* tris, const int32_t* trow,
                             const int32_t* tinc, TriParamsDev tp, float4* tri_normals,
-                            uint8_t* tri_valid, float4* vtx_normals);
+                            uint8_t* tri_valid, float4* vtx_normals, const FrameOut* fo = nullptr);
 
 // ---- row a9: graph median (kind 0) / low-pass (kind 1) filter, one Jacobi pass ----
 hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int32_t* grow,
@@ -87,6 +95,15 @@ hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4
 hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height, const float2* pos,
                          const float4* A, const int32_t* tris, const uint8_t* tri_valid,
                          int32_t filtered, TriParamsDev tp, float min_depth, float max_depth,
-                         uint32_t* owner, float* idm, float* dm, float* cloud);
+                         uint32_t* owner, float* idm, float* dm, float* cloud, uint32_t* covered = nullptr);
+// covered (optional): raster_num_blocks() per-block counts of the pixels that are not NaN
+int raster_num_blocks(int32_t width, int32_t height);
+
+// ---- debug images (BGR8) rendered on the device: kind 0 wireframe, 1 features, 2 normals, 3 idepthmap;
+// owner / idm = the FILTERED raster of launch_raster; feat = n_feat x {u, v, mu}; key = W x H scratch ----
+hipError_t launch_debug_image(hipStream_t s, int32_t kind, int32_t T, int32_t width, int32_t height, const float2* pos,
+                              const float4* A, const int32_t* tris, const uint8_t* tri_valid, const uint32_t* owner,
+                              const float* idm, const float4* vtx_normals, int32_t n_feat, const float* feat,
+                              float scale, uint32_t* key, uint8_t* bgr);
 
 }  // namespace flamehip

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict
                                              const float4* __restrict__ A,
                                              const int32_t* __restrict__ tris, TriParamsDev tp,
                                              float4* __restrict__ tri_normals,
-                                             uint8_t* __restrict__ tri_valid) {
+                                             uint8_t* __restrict__ tri_valid, uint8_t* __restrict__ valid_out) {
   const int32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict
   if (!ok) {
     tri_normals[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     tri_valid[t] = 0;
+    if (valid_out) valid_out[t] = 0;
     return;
   }
   const float2 pa = pos[a], pb = pos[b], pc = pos[c];
@@ -584,12 +585,15 @@ __global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict
   }
   tri_normals[t] = make_float4(nx, ny, nz, 0.f);
   tri_valid[t] = valid;
+  if (valid_out) valid_out[t] = valid;
 }
 
 __global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* __restrict__ trow,
                                                      const int32_t* __restrict__ tinc,
                                                      const float4* __restrict__ tri_normals,
-                                                     float4* __restrict__ vtx_normals) {
+                                                     float4* __restrict__ vtx_normals,
+                                                     const int32_t* __restrict__ i2o, const float4* __restrict__ A,
+                                                     float* __restrict__ out_x, float* __restrict__ out_n) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
   float nx = 0.f, ny = 0.f, nz = 0.f;
@@ -600,6 +604,13 @@ __global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* _
   const float len = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
   if (len > 0.0f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = -1.f; }
   vtx_normals[v] = make_float4(nx, ny, nz, 0.f);
+  // the frame's results leave in the CALLER's vertex order, written here instead of by two more
+  // launches (flame_hip_frame_results: every dependent launch of a small frame costs ~5 us)
+  if (i2o) {
+    const int32_t o = i2o[v];
+    if (out_x) out_x[o] = A[v].x;
+    if (out_n) { out_n[3 * (size_t)o] = nx; out_n[3 * (size_t)o + 1] = ny; out_n[3 * (size_t)o + 2] = nz; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -786,11 +797,11 @@ __global__ __launch_bounds__(256) void k_raster_fill(int32_t width, int32_t heig
                                                      const uint32_t* __restrict__ owner,
                                                      TriParamsDev tp, float min_depth, float max_depth,
                                                      float* __restrict__ idm, float* __restrict__ dm,
-                                                     float* __restrict__ cloud) {
+                                                     float* __restrict__ cloud, uint32_t* __restrict__ covered) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= (int64_t)width * height) return;
-  const int jj = (int)(k % width), ii = (int)(k / width);
-  const uint32_t t = owner[k];
+  const bool inside = k < (int64_t)width * height;
+  const int jj = inside ? (int)(k % width) : 0, ii = inside ? (int)(k / width) : 0;
+  const uint32_t t = inside ? owner[k] : 0xffffffffu;
   float id = __builtin_nanf("");
   if (t != 0xffffffffu) {
     const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
@@ -802,6 +813,15 @@ __global__ __launch_bounds__(256) void k_raster_fill(int32_t width, int32_t heig
     const float num = fmaf(wc, A[c].x, fmaf(wb, A[b].x, wa * A[a].x));
     id = num / ((wa + wb) + wc);
   }
+  if (covered) {  // stat key `coverage`: pixels of the map that are not NaN, one count per block
+    // (summed on the host; a same-address atomic per wave serialised this kernel to ~60 us)
+    __shared__ uint32_t wcnt[4];
+    const unsigned long long m = __ballot(inside && !isnan(id));
+    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) covered[blockIdx.x] = (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);
+  }
+  if (!inside) return;
   idm[k] = id;
   float depth = __builtin_nanf("");
   if (!isnan(id) && id > 0.0f) depth = 1.0f / id;
@@ -818,6 +838,128 @@ __global__ __launch_bounds__(256) void k_raster_fill(int32_t width, int32_t heig
     }
     cloud[3 * k] = ox; cloud[3 * k + 1] = oy; cloud[3 * k + 2] = oz;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Debug images of flame::Flame (reference src/flame_offline_tum.cc:731-766; what each shows:
+// cfg/flame_offline_tum.yaml:58-64), rendered on the device into a BGR8 buffer so that update()
+// never draws on the host; the rules are stated in oracle/nltgv2_oracle.c (nltgv2_debug_image).
+// "Later primitive overwrites earlier ones" is made order-free by a key map: every primitive
+// atomicMax-es its index + 1 into the pixels it covers, a second pass colours each pixel from the
+// winning primitive.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ramp01(float v) { return fmaxf(0.0f, fminf(1.0f, v)); }
+__device__ __forceinline__ void put_jet(uint8_t* o, float v) {  // jet(v, 0, 2), BGR
+  float t = (v - 0.0f) / (2.0f - 0.0f);
+  t = ramp01(t);
+  const float r = ramp01(1.5f - fabsf(4.0f * t - 3.0f));
+  const float g = ramp01(1.5f - fabsf(4.0f * t - 2.0f));
+  const float b = ramp01(1.5f - fabsf(4.0f * t - 1.0f));
+  o[0] = (uint8_t)(255.0f * b + 0.5f);
+  o[1] = (uint8_t)(255.0f * g + 0.5f);
+  o[2] = (uint8_t)(255.0f * r + 0.5f);
+}
+__device__ __forceinline__ int round_px(float v) { return (int)(v + (v >= 0.0f ? 0.5f : -0.5f)); }
+
+// one thread per triangle side: Bresenham between the rounded end points
+__global__ __launch_bounds__(256) void k_dbg_lines(int32_t T, int32_t W, int32_t H, const float2* __restrict__ pos,
+                                                   const int32_t* __restrict__ tris,
+                                                   const uint8_t* __restrict__ tri_valid, uint32_t* __restrict__ key) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * T) return;
+  const int32_t t = i / 3, k = i - 3 * t;
+  if (!tri_valid[t]) return;
+  const float2 pa = pos[tris[3 * t + k]], pb = pos[tris[3 * t + (k + 1) % 3]];
+  int x0 = round_px(pa.x), y0 = round_px(pa.y);
+  const int x1 = round_px(pb.x), y1 = round_px(pb.y);
+  const int dx = abs(x1 - x0), dy = -abs(y1 - y0);
+  const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+  int err = dx + dy;
+  for (int guard = 0; guard < 4 * (W + H); ++guard) {
+    if (x0 >= 0 && y0 >= 0 && x0 < W && y0 < H) atomicMax(key + (size_t)y0 * W + x0, (uint32_t)i + 1u);
+    if (x0 == x1 && y0 == y1) break;
+    const int e2 = 2 * err;
+    if (e2 >= dy) { err += dy; x0 += sx; }
+    if (e2 <= dx) { err += dx; y0 += sy; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dbg_wire_color(int64_t npix, const uint32_t* __restrict__ key,
+                                                        const int32_t* __restrict__ tris,
+                                                        const float4* __restrict__ A, float scale,
+                                                        uint8_t* __restrict__ bgr) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  uint8_t* o = bgr + 3 * p;
+  const uint32_t kk = key[p];
+  if (kk == 0) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+  const int32_t i = (int32_t)(kk - 1), t = i / 3, k = i - 3 * t;
+  const float xa = A[tris[3 * t + k]].x, xb = A[tris[3 * t + (k + 1) % 3]].x;
+  put_jet(o, (0.5f * (xa + xb)) * scale);
+}
+
+// feat = n x {u, v, mu}
+__global__ __launch_bounds__(256) void k_dbg_feat_mark(int32_t n, int32_t W, int32_t H, const float* __restrict__ feat,
+                                                       uint32_t* __restrict__ key) {
+  const int32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= n) return;
+  const int px = round_px(feat[3 * f]), py = round_px(feat[3 * f + 1]);
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int x = px + dx, y = py + dy;
+      if (x >= 0 && y >= 0 && x < W && y < H) atomicMax(key + (size_t)y * W + x, (uint32_t)f + 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dbg_feat_color(int64_t npix, const uint32_t* __restrict__ key,
+                                                        const float* __restrict__ feat, float scale,
+                                                        uint8_t* __restrict__ bgr) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  uint8_t* o = bgr + 3 * p;
+  const uint32_t kk = key[p];
+  if (kk == 0) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+  put_jet(o, feat[3 * (size_t)(kk - 1) + 2] * scale);
+}
+
+__global__ __launch_bounds__(256) void k_dbg_idm_color(int64_t npix, const float* __restrict__ idm, float scale,
+                                                       uint8_t* __restrict__ bgr) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  uint8_t* o = bgr + 3 * p;
+  const float id = idm[p];
+  if (isnan(id)) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+  put_jet(o, id * scale);
+}
+
+// "Image colored by interpolated normal vectors" (cfg/flame_offline_tum.yaml:62): barycentric blend
+// of the three vertex normals of the pixel's owner triangle (owner map of the FILTERED raster)
+__global__ __launch_bounds__(256) void k_dbg_normals(int32_t W, int32_t H, const float2* __restrict__ pos,
+                                                     const int32_t* __restrict__ tris,
+                                                     const uint32_t* __restrict__ owner,
+                                                     const float4* __restrict__ vn, uint8_t* __restrict__ bgr) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)W * H) return;
+  uint8_t* o = bgr + 3 * p;
+  const uint32_t t = owner[p];
+  if (t == 0xffffffffu) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+  const int jj = (int)(p % W), ii = (int)(p / W);
+  const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+  const float2 Pa = pos[a], Pb = pos[b], Pc = pos[c];
+  const float px = (float)jj, py = (float)ii;
+  const float wa = edge_fn(Pb.x, Pb.y, Pc.x, Pc.y, px, py);
+  const float wb = edge_fn(Pc.x, Pc.y, Pa.x, Pa.y, px, py);
+  const float wc = edge_fn(Pa.x, Pa.y, Pb.x, Pb.y, px, py);
+  const float s = (wa + wb) + wc;
+  const float4 na = vn[a], nb = vn[b], nc = vn[c];
+  float nx = fmaf(wc, nc.x, fmaf(wb, nb.x, wa * na.x)) / s;
+  float ny = fmaf(wc, nc.y, fmaf(wb, nb.y, wa * na.y)) / s;
+  float nz = fmaf(wc, nc.z, fmaf(wb, nb.z, wa * na.z)) / s;
+  const float len = sqrtf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)));
+  if (len > 0.0f) { nx /= len; ny /= len; nz /= len; } else { nx = 0.f; ny = 0.f; nz = -1.f; }
+  o[0] = (uint8_t)(255.0f * (0.5f * nz + 0.5f) + 0.5f);
+  o[1] = (uint8_t)(255.0f * (0.5f * ny + 0.5f) + 0.5f);
+  o[2] = (uint8_t)(255.0f * (0.5f * nx + 0.5f) + 0.5f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -924,7 +1066,7 @@ hipError_t launch_mesh(hipStream_t s, int32_t V, const float2* pos, const float4
 hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height, const float2* pos,
                          const float4* A, const int32_t* tris, const uint8_t* tri_valid,
                          int32_t filtered, TriParamsDev tp, float min_depth, float max_depth,
-                         uint32_t* owner, float* idm, float* dm, float* cloud) {
+                         uint32_t* owner, float* idm, float* dm, float* cloud, uint32_t* covered) {
   const int64_t npix = (int64_t)width * height;
   if (npix <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(owner, 0xff, sizeof(uint32_t) * (size_t)npix, s);
@@ -935,7 +1077,32 @@ hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_raster_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, width, height,
-                     pos, A, tris, owner, tp, min_depth, max_depth, idm, dm, cloud);
+                     pos, A, tris, owner, tp, min_depth, max_depth, idm, dm, cloud, covered);
+  return hipGetLastError();
+}
+
+hipError_t launch_debug_image(hipStream_t s, int32_t kind, int32_t T, int32_t width, int32_t height, const float2* pos,
+                              const float4* A, const int32_t* tris, const uint8_t* tri_valid, const uint32_t* owner,
+                              const float* idm, const float4* vtx_normals, int32_t n_feat, const float* feat,
+                              float scale, uint32_t* key, uint8_t* bgr) {
+  const int64_t npix = (int64_t)width * height;
+  if (npix <= 0) return hipSuccess;
+  const dim3 gp((unsigned)((npix + 255) / 256)), b(256);
+  hipError_t e;
+  if (kind == 0 || kind == 1) {
+    if ((e = hipMemsetAsync(key, 0, sizeof(uint32_t) * (size_t)npix, s)) != hipSuccess) return e;
+    if (kind == 0) {
+      if (T > 0) hipLaunchKernelGGL(k_dbg_lines, dim3((3 * T + 255) / 256), b, 0, s, T, width, height, pos, tris, tri_valid, key);
+      hipLaunchKernelGGL(k_dbg_wire_color, gp, b, 0, s, npix, key, tris, A, scale, bgr);
+    } else {
+      if (n_feat > 0) hipLaunchKernelGGL(k_dbg_feat_mark, dim3((n_feat + 255) / 256), b, 0, s, n_feat, width, height, feat, key);
+      hipLaunchKernelGGL(k_dbg_feat_color, gp, b, 0, s, npix, key, feat, scale, bgr);
+    }
+  } else if (kind == 2) {
+    hipLaunchKernelGGL(k_dbg_normals, gp, b, 0, s, width, height, pos, tris, owner, vtx_normals, bgr);
+  } else {
+    hipLaunchKernelGGL(k_dbg_idm_color, gp, b, 0, s, npix, idm, scale, bgr);
+  }
   return hipGetLastError();
 }
 
@@ -1007,17 +1174,21 @@ hipError_t launch_costs(hipStream_t s, int32_t V, int32_t E, const int2* eij, co
 hipError_t launch_triangles(hipStream_t s, int32_t V, int32_t T, const float2* pos,
                             const float4* A, const int32_t* tris, const int32_t* trow,
                             const int32_t* tinc, TriParamsDev tp, float4* tri_normals,
-                            uint8_t* tri_valid, float4* vtx_normals) {
+                            uint8_t* tri_valid, float4* vtx_normals, const FrameOut* fo) {
   if (T > 0) {
-    hipLaunchKernelGGL(k_tri, dim3((T + 255) / 256), dim3(256), 0, s, T, pos, A, tris, tp, tri_normals, tri_valid);
+    hipLaunchKernelGGL(k_tri, dim3((T + 255) / 256), dim3(256), 0, s, T, pos, A, tris, tp, tri_normals, tri_valid,
+                       fo ? fo->tri_valid : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   if (V > 0) {
-    hipLaunchKernelGGL(k_vtx_normals, dim3((V + 255) / 256), dim3(256), 0, s, V, trow, tinc, tri_normals, vtx_normals);
+    hipLaunchKernelGGL(k_vtx_normals, dim3((V + 255) / 256), dim3(256), 0, s, V, trow, tinc, tri_normals, vtx_normals,
+                       fo ? fo->v_i2o : nullptr, A, fo ? fo->x : nullptr, fo ? fo->normals : nullptr);
     return hipGetLastError();
   }
   return hipSuccess;
 }
+
+int raster_num_blocks(int32_t width, int32_t height) { return (int)(((int64_t)width * height + 255) / 256); }
 
 }  // namespace flamehip

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libflame_hip.so")
 
 ERR_ARG, ERR_STATE, ERR_NAN, ERR_ALLOC, ERR_NODEVICE, ERR_HIP = -1, -2, -3, -4, -5, -1000
 PATH_AUTO, PATH_GLOBAL, PATH_TILE = 0, 1, 2
+IMG_WIREFRAME, IMG_FEATURES, IMG_NORMALS, IMG_IDEPTHMAP = 0, 1, 2, 3
 
 
 class Params(C.Structure):
@@ -65,7 +66,9 @@ SYMBOLS = {
     "flame_hip_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flame_hip_triangles": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _VP, _VP, _VP]),
     "flame_hip_frame_results": (C.c_int, [_VP, C.POINTER(Params), C.c_float, _VP, C.POINTER(TriParams),
-                                          C.POINTER(C.c_double), C.POINTER(C.c_double), _VP, _VP, _VP, _VP]),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), _VP, _VP, _VP, _VP,
+                                          C.POINTER(C.c_float)]),
+    "flame_hip_debug_image": (C.c_int, [_VP, _I32, _VP, C.POINTER(TriParams), C.c_float, _I32, _VP, _VP, _VP]),
     "flame_hip_mesh": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _VP, _VP, C.POINTER(_I32)]),
     "flame_hip_depthmaps": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _I32, C.c_float, C.c_float, _VP, _VP, _VP]),
     "flame_hip_download": (C.c_int, [_VP] + [_VP] * 4),

@@ -250,19 +250,34 @@ class GraphRegularizer:
                                                _ptr(tv), _ptr(tn)), "flame_hip_triangles")
         return tn, tv, vn
 
-    def frame_results(self, params, Kinv, tri_params, scale_back=1.0, with_edges=False):
+    def frame_results(self, params, Kinv, tri_params, scale_back=1.0, with_edges=False, with_coverage=False):
         """What flame::Flame::update() reads back after the solve, with one synchronisation:
-        (smooth, data, x[V], vtx_normals[V,3], tri_valid[T], edges[E,2] or None)."""
+        (smooth, data, x[V], vtx_normals[V,3], tri_valid[T], edges[E,2] or None[, coverage])."""
         Kinv = _f32(Kinv).reshape(9)
         x = np.empty(self.V, np.float32)
         vn = np.empty((self.V, 3), np.float32)
         tv = np.empty(self.T, np.uint8)
         e = np.empty((self.E, 2), np.int32) if with_edges else None
         s, d = C.c_double(), C.c_double()
+        cov = C.c_float()
         _l.check(self._lib.flame_hip_frame_results(self._h, C.byref(params), float(scale_back), _ptr(Kinv),
                                                    C.byref(tri_params), C.byref(s), C.byref(d), _ptr(x), _ptr(vn),
-                                                   _ptr(tv), _ptr(e)), "flame_hip_frame_results")
+                                                   _ptr(tv), _ptr(e), C.byref(cov) if with_coverage else None),
+                 "flame_hip_frame_results")
+        if with_coverage:
+            return s.value, d.value, x, vn, tv, e, cov.value
         return s.value, d.value, x, vn, tv, e
+
+    def debug_image(self, kind, Kinv, tri_params, scene_color_scale=1.0, feat_pos=None, feat_mu=None):
+        """Debug image of flame::Flame rendered on the device: BGR8 [H,W,3] (kind: lib.IMG_*)."""
+        Kinv = _f32(Kinv).reshape(9)
+        fp = None if feat_pos is None else _f32(feat_pos).reshape(-1, 2)
+        fm = None if feat_mu is None else _f32(feat_mu)
+        out = np.empty((tri_params.height, tri_params.width, 3), np.uint8)
+        _l.check(self._lib.flame_hip_debug_image(self._h, int(kind), _ptr(Kinv), C.byref(tri_params),
+                                                 float(scene_color_scale), 0 if fm is None else len(fm), _ptr(fp),
+                                                 _ptr(fm), _ptr(out)), "flame_hip_debug_image")
+        return out
 
     def mesh(self, Kinv, tri_params):
         """Row f1: (points[V,12] PointNormalUV layout, faces[F,3] reversed winding)."""

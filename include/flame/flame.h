@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <mutex>
@@ -83,12 +84,12 @@ class Flame {
     toRowMajor(K, K_);
     toRowMajor(Kinv, Kinv_);
     const Vec3b black(0, 0, 0);
-    debug_wireframe_ = Image3b(height, width, black);
-    debug_features_ = Image3b(height, width, black);
+    debug_wireframe_.img = Image3b(height, width, black);
+    debug_features_.img = Image3b(height, width, black);
     debug_detections_ = Image3b(height, width, black);
     debug_matches_ = Image3b(height, width, black);
-    debug_normals_ = Image3b(height, width, black);
-    debug_idepthmap_ = Image3b(height, width, black);
+    debug_normals_.img = Image3b(height, width, black);
+    debug_idepthmap_.img = Image3b(height, width, black);
   }
   Flame(const Flame&) = delete;
   Flame& operator=(const Flame&) = delete;
@@ -188,17 +189,30 @@ class Flame {
     return true;
   }
 
-  // Debug images, BGR8, width x height (reference src/flame_offline_tum.cc:731-766).  Wireframe:
-  // edges of the valid triangles coloured by idepth; Features: the raw features coloured by
-  // idepth; InverseDepthMap: jet colormap of the filtered dense idepthmap; all three on black
-  // (the input image is not kept).  Detections / Matches / Normals belong to the feature
-  // pipeline / are not drawn here: black images of the right size.
-  const Image3b& getDebugImageWireframe() const { return debug_wireframe_; }
-  const Image3b& getDebugImageFeatures() const { return debug_features_; }
+  // Debug images, BGR8, width x height (reference src/flame_offline_tum.cc:731-766; what each
+  // shows: cfg/flame_offline_tum.yaml:58-64).  Wireframe: sides of the valid triangles coloured by
+  // idepth; Features: the raw features coloured by idepth; Normals: "image colored by interpolated
+  // normal vectors"; InverseDepthMap: jet colormap of the filtered dense idepthmap; all on black
+  // (the input image is not kept).  They are rendered ON THE GPU (flame_hip_debug_image) and only
+  // when a getter asks: update() itself draws nothing -- the first call of a getter after an
+  // update renders that image from the frame's device state and copies it out, later calls return
+  // the cached image.  A disabled image (Params::debug_draw_*) stays black.  Detections / Matches
+  // belong to the feature pipeline: black images of the right size.  text_overlay / flip_images
+  // are not applied.
+  const Image3b& getDebugImageWireframe() const {
+    return debugImage(FLAME_HIP_IMG_WIREFRAME, params_.debug_draw_wireframe, &debug_wireframe_);
+  }
+  const Image3b& getDebugImageFeatures() const {
+    return debugImage(FLAME_HIP_IMG_FEATURES, params_.debug_draw_features, &debug_features_);
+  }
   const Image3b& getDebugImageDetections() const { return debug_detections_; }
   const Image3b& getDebugImageMatches() const { return debug_matches_; }
-  const Image3b& getDebugImageNormals() const { return debug_normals_; }
-  const Image3b& getDebugImageInverseDepthMap() const { return debug_idepthmap_; }
+  const Image3b& getDebugImageNormals() const {
+    return debugImage(FLAME_HIP_IMG_NORMALS, params_.debug_draw_normals, &debug_normals_);
+  }
+  const Image3b& getDebugImageInverseDepthMap() const {
+    return debugImage(FLAME_HIP_IMG_IDEPTHMAP, params_.debug_draw_idepthmap, &debug_idepthmap_);
+  }
 
   // reference src/flame_nodelet.cc:474-475 (called from the ROS callback thread): forwarded to the
   // front end under the same mutex update() holds.
@@ -300,6 +314,22 @@ class Flame {
       rc = reg::step(params_.rparams, &graph_, params_.nltgv2_iterations, /*wait=*/false);
       if (rc) return fail(rc);
     }
+    // ---- optional graph filters (row a9; regularization/do_median_filter, do_lowpass_filter,
+    // cfg/flame_offline_tum.yaml:85-86; timing keys src/utils.cc:155-156), on the regularised idepths ----
+    if (params_.do_median_filter) {
+      stats_.tick("median_filter");
+      rc = flame_hip_graph_filter(graph_.handle(), 0, 1);
+      if (!rc) rc = flame_hip_sync(graph_.handle());
+      stats_.tock("median_filter");
+      if (rc) return fail(rc);
+    }
+    if (params_.do_lowpass_filter) {
+      stats_.tick("lowpass_filter");
+      rc = flame_hip_graph_filter(graph_.handle(), 1, 1);
+      if (!rc) rc = flame_hip_sync(graph_.handle());
+      stats_.tock("lowpass_filter");
+      if (rc) return fail(rc);
+    }
     // ---- costs (a6), idepths back in the caller's units, per-triangle stage (a8), edge list: one
     // library call, one synchronisation.  Everything downstream (triangle filters, mesh, maps) works
     // on un-scaled inverse depths with the un-scaled thresholds. ----
@@ -310,8 +340,9 @@ class Flame {
     std::vector<float> normals(3 * static_cast<size_t>(V), 0.0f);
     std::vector<uint8_t> tri_valid(T, 0);
     const flame_hip_tri_params tp = triParams();
+    float coverage = 0.0f;
     rc = flame_hip_frame_results(graph_.handle(), &cp, scale, Kinv_, &tp, &smooth, &data, idepths.data(),
-                                 normals.data(), tri_valid.data(), eidx.data());
+                                 normals.data(), tri_valid.data(), eidx.data(), &coverage);
     if (rc) return fail(rc);
     stats_.tock("nltgv2");
     stats_.setTiming("interpolate", 0.0);  // folded into the call above (device time: see nltgv2_device)
@@ -327,13 +358,14 @@ class Flame {
     if (raw) { raw_vtx_ = raw->vtx; raw_mu_ = raw->idepth_mu; raw_var_ = raw->idepth_var; }
     else { raw_vtx_ = vtx; raw_mu_ = idepth_mu; raw_var_ = idepth_var; }
     device_frame_valid_ = true;
-    drawDebugImages();
+    ++frame_serial_;  // the debug images of earlier frames are stale (rendered on demand, see debugImage)
 
     // ---- stats (keys read at reference src/utils.cc:117-156) ----
     stats_.set("num_feats", static_cast<double>(raw_vtx_.size()));
     stats_.set("num_vtx", V);
     stats_.set("num_tris", T);
     stats_.set("num_edges", E);
+    stats_.set("coverage", coverage);  // share of the image the filtered dense map covers (src/utils.cc:122)
     stats_.set("nltgv2_total_smoothness_cost", smooth);
     stats_.set("nltgv2_avg_smoothness_cost", V ? smooth / V : 0.0);
     stats_.set("nltgv2_total_data_cost", data);
@@ -395,58 +427,31 @@ class Flame {
     return false;
   }
 
-  // ---- debug drawing (not on the path; plain CPU loops over the committed results) ----
-  Vec3b idepthColor(float id) const {
-    return utils::jet(id * params_.scene_color_scale, 0.0f, 2.0f);
-  }
-  void putPixel(Image3b* img, int x, int y, const Vec3b& c) const {
-    if (x >= 0 && y >= 0 && x < width_ && y < height_) (*img)(y, x) = c;
-  }
-  void drawLine(Image3b* img, int x0, int y0, int x1, int y1, const Vec3b& c) const {
-    const int dx = std::abs(x1 - x0), dy = -std::abs(y1 - y0);
-    const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
-    int err = dx + dy;
-    for (int guard = 0; guard < 4 * (width_ + height_); ++guard) {
-      putPixel(img, x0, y0, c);
-      if (x0 == x1 && y0 == y1) break;
-      const int e2 = 2 * err;
-      if (e2 >= dy) { err += dy; x0 += sx; }
-      if (e2 <= dx) { err += dx; y0 += sy; }
+  // ---- debug images: rendered by the library on the device, on demand ----
+  struct DebugImage {
+    Image3b img;
+    uint64_t serial = 0;  // frame_serial_ the image was rendered for
+  };
+  const Image3b& debugImage(int kind, bool enabled, DebugImage* d) const {
+    std::lock_guard<std::mutex> lock(mtx_);
+    if (!enabled || !device_frame_valid_ || d->serial == frame_serial_) return d->img;
+    const flame_hip_tri_params tp = triParams();
+    dbg_buf_.resize(3 * static_cast<size_t>(width_) * height_);
+    const bool feats = kind == FLAME_HIP_IMG_FEATURES;
+    if (feats) {
+      dbg_fpos_.resize(2 * raw_vtx_.size());
+      for (size_t v = 0; v < raw_vtx_.size(); ++v) { dbg_fpos_[2 * v] = raw_vtx_[v].x; dbg_fpos_[2 * v + 1] = raw_vtx_[v].y; }
     }
-  }
-  void drawDebugImages() {
-    const Vec3b black(0, 0, 0);
-    if (params_.debug_draw_wireframe) {
-      debug_wireframe_ = Image3b(height_, width_, black);
-      for (size_t t = 0; t < tris_.size(); ++t) {
-        if (!tri_valid_[t]) continue;
-        for (int k = 0; k < 3; ++k) {
-          const int a = tris_[t][k], b = tris_[t][(k + 1) % 3];
-          drawLine(&debug_wireframe_, utils::fast_roundf(vtx_[a].x), utils::fast_roundf(vtx_[a].y),
-                   utils::fast_roundf(vtx_[b].x), utils::fast_roundf(vtx_[b].y),
-                   idepthColor(0.5f * (idepths_[a] + idepths_[b])));
-        }
-      }
-    }
-    if (params_.debug_draw_features) {
-      debug_features_ = Image3b(height_, width_, black);
-      for (size_t v = 0; v < raw_vtx_.size(); ++v) {
-        const int x = utils::fast_roundf(raw_vtx_[v].x), y = utils::fast_roundf(raw_vtx_[v].y);
-        const Vec3b c = idepthColor(raw_mu_[v]);
-        for (int dy = -1; dy <= 1; ++dy)
-          for (int dx = -1; dx <= 1; ++dx) putPixel(&debug_features_, x + dx, y + dy, c);
-      }
-    }
-    if (params_.debug_draw_idepthmap) {
-      debug_idepthmap_ = Image3b(height_, width_, black);
-      std::vector<float> idm;
-      if (mapsLocked(1, &idm, nullptr, nullptr, 0.f, 0.f))
-        for (int i = 0; i < height_; ++i)
-          for (int j = 0; j < width_; ++j) {
-            const float id = idm[static_cast<size_t>(i) * width_ + j];
-            if (!std::isnan(id)) debug_idepthmap_(i, j) = idepthColor(id);
-          }
-    }
+    if (flame_hip_debug_image(graph_.handle(), kind, Kinv_, &tp, params_.scene_color_scale,
+                              feats ? static_cast<int32_t>(raw_vtx_.size()) : 0, feats ? dbg_fpos_.data() : nullptr,
+                              feats ? raw_mu_.data() : nullptr, dbg_buf_.data()))
+      return d->img;  // the previous image stays
+    static_assert(sizeof(Vec3b) == 3, "BGR8 pixels are packed");
+    for (int i = 0; i < height_; ++i)  // rows of both image types are contiguous
+      std::memcpy(static_cast<void*>(&d->img(i, 0)), dbg_buf_.data() + 3 * static_cast<size_t>(i) * width_,
+                  3 * static_cast<size_t>(width_));
+    d->serial = frame_serial_;
+    return d->img;
   }
 
   int width_, height_;
@@ -462,7 +467,11 @@ class Flame {
   std::vector<Triangle> tris_;
   std::vector<Edge> edges_;
   std::vector<uint8_t> tri_valid_;
-  Image3b debug_wireframe_, debug_features_, debug_detections_, debug_matches_, debug_normals_, debug_idepthmap_;
+  uint64_t frame_serial_ = 0;        // successful updates so far
+  Image3b debug_detections_, debug_matches_;
+  mutable DebugImage debug_wireframe_, debug_features_, debug_normals_, debug_idepthmap_;
+  mutable std::vector<uint8_t> dbg_buf_;
+  mutable std::vector<float> dbg_fpos_;
 };
 
 }  // namespace flame

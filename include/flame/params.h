@@ -58,12 +58,21 @@ struct Params {
   InverseDepthFilterParams zparams;
   FeatureDetectionParams fparams;
   // regulariser (:234-249, yaml :84-99)
+  // do_median_filter / do_lowpass_filter: YAML keys regularization/do_median_filter, do_lowpass_filter
+  // (cfg/flame_offline_tum.yaml:85-86) that flame_ros never reads => upstream defaults (off); one
+  // Jacobi pass of the graph filter on the regularised idepths (row a9)
+  bool do_median_filter = false;
+  bool do_lowpass_filter = false;
   bool do_nltgv2 = true;
   bool adaptive_data_weights = false;
   bool rescale_data = false;
   bool init_with_prediction = true;
   float idepth_var_max_graph = 0.01f;
   optimizers::nltgv2_l1_graph_regularizer::Params rparams;
+  // min_height / max_height ("height of features that are added to graph", yaml :97-98) and
+  // check_sticky_obstacles (:99) gate FEATURES, upstream of the variance gate, in the feature
+  // pipeline that is not rebuilt here: carried for the frontends and a registered FrontEnd,
+  // IGNORED by the GPU tail (the reference defaults +-1e14 / false disable them anyway).
   float min_height = -1e14f, max_height = 1e14f;
   bool check_sticky_obstacles = false;
   // not in the reference: regulariser iterations per update (an upstream constant that no

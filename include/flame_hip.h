@@ -171,14 +171,30 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
  * synchronisation: the two costs (in the solver's units, i.e. before scale_back is applied), then
  * the state times scale_back (1 = leave it; rescale_data: the scale flame_hip_graph_sync returned),
  * the idepths x (V), the per-triangle stage (vtx_normals 3V, tri_valid T) and the edge list derived
- * by flame_hip_graph_sync (2E).  Any output pointer may be NULL.  Synchronises.  The un-scaling is
+ * by flame_hip_graph_sync (2E), and the stat key `coverage` (reference src/utils.cc:122): the share
+ * of the tp->width x tp->height pixels the FILTERED dense idepthmap covers (not NaN).  Any output
+ * pointer may be NULL.  Synchronises.  The un-scaling is
  * applied to the resident state in place and only ONCE per upload: on a state that is already back
  * in the caller's units (an earlier call, or flame_hip_scale_state) scale_back is ignored and asking
  * for the costs returns FLAME_HIP_ERR_STATE. */
 int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float scale_back,
                             const float Kinv[9], const flame_hip_tri_params* tp, double* smooth,
                             double* data, float* x, float* vtx_normals, uint8_t* tri_valid,
-                            int32_t* edges);
+                            int32_t* edges, float* coverage);
+
+/* Debug images of flame::Flame rendered ON THE DEVICE (reference src/flame_offline_tum.cc:731-766;
+ * what each shows: cfg/flame_offline_tum.yaml:58-64): BGR8, tp->width x tp->height, row-major, on
+ * black.  WIREFRAME: sides of the valid triangles coloured by idepth; FEATURES: 3x3 squares at the
+ * n_feat raw features (feat_pos 2 n_feat, feat_mu n_feat; ignored by the other kinds) coloured by
+ * idepth; NORMALS: "image colored by interpolated normal vectors" over the filtered dense map;
+ * IDEPTHMAP: jet of the filtered dense idepthmap.  Colour = jet(idepth * scene_color_scale, 0, 2)
+ * (output/scene_color_scale, cfg/flame_offline_tum.yaml:35).  The exact rules are stated in
+ * oracle/nltgv2_oracle.c (nltgv2_debug_image).  Nothing is drawn on the host; the dense raster is
+ * shared with flame_hip_frame_results' coverage and flame_hip_depthmaps.  Synchronises. */
+enum { FLAME_HIP_IMG_WIREFRAME = 0, FLAME_HIP_IMG_FEATURES = 1, FLAME_HIP_IMG_NORMALS = 2, FLAME_HIP_IMG_IDEPTHMAP = 3 };
+int flame_hip_debug_image(flame_hip_graph* g, int32_t kind, const float Kinv[9],
+                          const flame_hip_tri_params* tp, float scene_color_scale, int32_t n_feat,
+                          const float* feat_pos, const float* feat_mu, uint8_t* bgr);
 
 /* "Next" row f1: the mesh as flame_ros publishes it on /flame/mesh.  Replaces the
  * vertex loop and face loop of publishDepthMesh (reference src/utils.cc:184-230): points = V x 12

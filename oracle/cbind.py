@@ -258,3 +258,34 @@ def depthmaps(width, height, pos, x, tris, tri_valid, filtered, Kinv, min_depth,
     L.nltgv2_depth_and_cloud(C.c_int32(width), C.c_int32(height), vp(idm), vp(Kinv),
                              C.c_float(min_depth), C.c_float(max_depth), vp(dm), vp(cl))
     return idm, dm, cl
+
+
+def coverage(idepthmap_filtered):
+    """Stat key `coverage`: non-NaN share of the filtered dense idepthmap (float32)."""
+    idm = _f32(idepthmap_filtered)
+    H, W = idm.shape
+    L = _load()
+    L.nltgv2_coverage.restype = C.c_float
+    return float(L.nltgv2_coverage(C.c_int32(W), C.c_int32(H), idm.ctypes.data_as(C.c_void_p)))
+
+
+IMG_WIREFRAME, IMG_FEATURES, IMG_NORMALS, IMG_IDEPTHMAP = 0, 1, 2, 3
+
+
+def debug_image(kind, width, height, scene_color_scale, pos, x, tris, tri_valid, vtx_normals=None,
+                idepthmap_filtered=None, feat_pos=None, feat_mu=None):
+    """The debug images of flame::Flame (BGR8 [H,W,3]); rules stated in nltgv2_oracle.c."""
+    pos = _f32(pos).reshape(-1, 2)
+    x = _f32(x)
+    tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    tv = np.ascontiguousarray(tri_valid, dtype=np.uint8)
+    vn = None if vtx_normals is None else _f32(vtx_normals).reshape(-1, 3)
+    idm = None if idepthmap_filtered is None else _f32(idepthmap_filtered)
+    fp = None if feat_pos is None else _f32(feat_pos).reshape(-1, 2)
+    fm = None if feat_mu is None else _f32(feat_mu)
+    out = np.empty((height, width, 3), np.uint8)
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    _load().nltgv2_debug_image(C.c_int32(kind), C.c_int32(width), C.c_int32(height), C.c_float(scene_color_scale),
+                               C.c_int32(len(x)), vp(pos), vp(x), C.c_int32(len(tris)), vp(tris), vp(tv), vp(vn),
+                               vp(idm), C.c_int32(0 if fm is None else len(fm)), vp(fp), vp(fm), vp(out))
+    return out

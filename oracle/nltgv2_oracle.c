@@ -437,6 +437,130 @@ void nltgv2_depth_and_cloud(int32_t width, int32_t height, const float* idepthma
     }
 }
 
+/* ---- stat key `coverage` (read at reference src/utils.cc:122, msg/FlameStats.msg:11) and the
+ * debug images flame_ros publishes (reference src/flame_offline_tum.cc:731-766; what each shows is
+ * stated at cfg/flame_offline_tum.yaml:58-64: "Mesh wireframe colored by idepth", "Features colored
+ * by idepth", "Image colored by interpolated normal vectors", "Colored idepthmap").  Upstream's
+ * drawing code is not in the reference tree; this is the build's precise statement.  All images
+ * are BGR8 (published as "bgr8", src/flame_offline_tum.cc:730), drawn on black (the input image
+ * is not kept), W x H, row-major.
+ *   coverage  : (number of pixels of the FILTERED dense idepthmap that are not NaN) / (W * H),
+ *               one float32 division of the two integers converted to float32
+ *   colour(id): jet(id * scene_color_scale, 0, 2) -- include/flame/utils/visualization.h jet()
+ *   wireframe : for every valid triangle t in ascending t, sides k = 0,1,2 (vertices tris[3t+k],
+ *               tris[3t+(k+1)%3]): Bresenham line between the rounded (half away from zero)
+ *               vertex positions, clipped per pixel, colour(0.5 * (x_a + x_b)); later lines
+ *               overwrite earlier ones
+ *   features  : for every raw feature f in ascending f a 3x3 square around its rounded position,
+ *               colour(mu_f); later features overwrite earlier ones
+ *   idepthmap : colour(idepthmap_filtered(p)) where that is not NaN, else black
+ *   normals   : for every pixel covered by the filtered dense map (same owner rule: the lowest-index
+ *               valid covering triangle), n = sum_k w_k * vtx_normal_k / ((wa + wb) + wc) with the
+ *               barycentric edge functions of nltgv2_idepthmap, normalised (a zero vector reads
+ *               (0, 0, -1)); channel c = (uint8)(255 * (0.5 * n_c + 0.5) + 0.5), stored B = n_z,
+ *               G = n_y, R = n_x; uncovered pixels black. ---- */
+float nltgv2_coverage(int32_t width, int32_t height, const float* idepthmap_filtered) {
+  int64_t cnt = 0;
+  for (int64_t k = 0; k < (int64_t)width * height; ++k) cnt += !isnan(idepthmap_filtered[k]);
+  return (float)cnt / (float)((int64_t)width * height);
+}
+
+static inline float ramp01(float v) { return fmaxf(0.0f, fminf(1.0f, v)); }
+static void jet_bgr(float v, float vmin, float vmax, uint8_t* bgr) {
+  float t = (vmax > vmin) ? (v - vmin) / (vmax - vmin) : 0.0f;
+  t = ramp01(t);
+  const float r = ramp01(1.5f - fabsf(4.0f * t - 3.0f));
+  const float g = ramp01(1.5f - fabsf(4.0f * t - 2.0f));
+  const float b = ramp01(1.5f - fabsf(4.0f * t - 1.0f));
+  bgr[0] = (uint8_t)(255.0f * b + 0.5f);
+  bgr[1] = (uint8_t)(255.0f * g + 0.5f);
+  bgr[2] = (uint8_t)(255.0f * r + 0.5f);
+}
+static inline int32_t round_px(float v) { return (int32_t)(v + (v >= 0.0f ? 0.5f : -0.5f)); }
+static inline void put_px(uint8_t* img, int32_t W, int32_t H, int32_t x, int32_t y, const uint8_t* c) {
+  if (x < 0 || y < 0 || x >= W || y >= H) return;
+  uint8_t* o = img + 3 * ((int64_t)y * W + x);
+  o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+}
+
+void nltgv2_debug_image(int32_t kind, int32_t W, int32_t H, float scene_color_scale, int32_t V,
+                        const float* pos, const float* x, int32_t T, const int32_t* tris,
+                        const uint8_t* tri_valid, const float* vtx_normals,
+                        const float* idepthmap_filtered, int32_t n_feat, const float* feat_pos,
+                        const float* feat_mu, uint8_t* bgr) {
+  (void)V;
+  memset(bgr, 0, 3 * (size_t)W * H);
+  uint8_t c[3];
+  if (kind == 0) { /* wireframe */
+    for (int32_t t = 0; t < T; ++t) {
+      if (!tri_valid[t]) continue;
+      for (int k = 0; k < 3; ++k) {
+        const int32_t a = tris[3 * t + k], b = tris[3 * t + (k + 1) % 3];
+        jet_bgr((0.5f * (x[a] + x[b])) * scene_color_scale, 0.0f, 2.0f, c);
+        int32_t x0 = round_px(pos[2 * a]), y0 = round_px(pos[2 * a + 1]);
+        const int32_t x1 = round_px(pos[2 * b]), y1 = round_px(pos[2 * b + 1]);
+        const int32_t dx = abs(x1 - x0), dy = -abs(y1 - y0);
+        const int32_t sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+        int32_t err = dx + dy;
+        for (int32_t guard = 0; guard < 4 * (W + H); ++guard) {
+          put_px(bgr, W, H, x0, y0, c);
+          if (x0 == x1 && y0 == y1) break;
+          const int32_t e2 = 2 * err;
+          if (e2 >= dy) { err += dy; x0 += sx; }
+          if (e2 <= dx) { err += dx; y0 += sy; }
+        }
+      }
+    }
+  } else if (kind == 1) { /* features */
+    for (int32_t f = 0; f < n_feat; ++f) {
+      jet_bgr(feat_mu[f] * scene_color_scale, 0.0f, 2.0f, c);
+      const int32_t px = round_px(feat_pos[2 * f]), py = round_px(feat_pos[2 * f + 1]);
+      for (int32_t dy = -1; dy <= 1; ++dy)
+        for (int32_t dx = -1; dx <= 1; ++dx) put_px(bgr, W, H, px + dx, py + dy, c);
+    }
+  } else if (kind == 3) { /* idepthmap */
+    for (int64_t k = 0; k < (int64_t)W * H; ++k) {
+      const float id = idepthmap_filtered[k];
+      if (isnan(id)) continue;
+      jet_bgr(id * scene_color_scale, 0.0f, 2.0f, bgr + 3 * k);
+    }
+  } else if (kind == 2) { /* normals: the raster rule of nltgv2_idepthmap, filtered */
+    for (int32_t t = T - 1; t >= 0; --t) {
+      if (!tri_valid[t]) continue;
+      const int32_t a = tris[3 * t], b = tris[3 * t + 1], cc = tris[3 * t + 2];
+      const float ax = pos[2 * a], ay = pos[2 * a + 1], bx = pos[2 * b], by = pos[2 * b + 1];
+      const float cx = pos[2 * cc], cy = pos[2 * cc + 1];
+      const float area = edge_fn(ax, ay, bx, by, cx, cy);
+      if (!(area != 0.0f)) continue;
+      int32_t x0 = (int32_t)ceilf(fminf(ax, fminf(bx, cx))), x1 = (int32_t)floorf(fmaxf(ax, fmaxf(bx, cx)));
+      int32_t y0 = (int32_t)ceilf(fminf(ay, fminf(by, cy))), y1 = (int32_t)floorf(fmaxf(ay, fmaxf(by, cy)));
+      if (x0 < 0) x0 = 0;
+      if (y0 < 0) y0 = 0;
+      if (x1 > W - 1) x1 = W - 1;
+      if (y1 > H - 1) y1 = H - 1;
+      for (int32_t ii = y0; ii <= y1; ++ii)
+        for (int32_t jj = x0; jj <= x1; ++jj) {
+          const float px = (float)jj, py = (float)ii;
+          const float wa = edge_fn(bx, by, cx, cy, px, py);
+          const float wb = edge_fn(cx, cy, ax, ay, px, py);
+          const float wc = edge_fn(ax, ay, bx, by, px, py);
+          const int in = (wa >= 0.0f && wb >= 0.0f && wc >= 0.0f) || (wa <= 0.0f && wb <= 0.0f && wc <= 0.0f);
+          if (!in) continue;
+          const float s = (wa + wb) + wc;
+          float n[3];
+          for (int r = 0; r < 3; ++r)
+            n[r] = fmaf(wc, vtx_normals[3 * cc + r], fmaf(wb, vtx_normals[3 * b + r], wa * vtx_normals[3 * a + r])) / s;
+          const float len = sqrtf(fmaf(n[2], n[2], fmaf(n[1], n[1], n[0] * n[0])));
+          if (len > 0.0f) { n[0] /= len; n[1] /= len; n[2] /= len; } else { n[0] = 0.f; n[1] = 0.f; n[2] = -1.f; }
+          uint8_t* o = bgr + 3 * ((int64_t)ii * W + jj);
+          o[0] = (uint8_t)(255.0f * (0.5f * n[2] + 0.5f) + 0.5f);
+          o[1] = (uint8_t)(255.0f * (0.5f * n[1] + 0.5f) + 0.5f);
+          o[2] = (uint8_t)(255.0f * (0.5f * n[0] + 0.5f) + 0.5f);
+        }
+    }
+  }
+}
+
 /* ---- row a9: optional graph median / low-pass filters of the vertex idepths.
  * Evidence that they exist: timing stat keys median_filter / lowpass_filter (reference
  * msg/FlameStats.msg:45-46, src/utils.cc:155-156) and YAML keys regularization/do_median_filter,

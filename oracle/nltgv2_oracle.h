@@ -128,6 +128,16 @@ void nltgv2_depth_and_cloud(int32_t width, int32_t height, const float* idepthma
                             const float Kinv[9], float min_depth, float max_depth,
                             float* depthmap, float* cloud);
 
+/* stat key `coverage` (reference src/utils.cc:122) and the debug images (reference
+ * src/flame_offline_tum.cc:731-766); kind 0 wireframe, 1 features, 2 normals, 3 idepthmap; bgr =
+ * 3 W H bytes.  The rules are stated above nltgv2_coverage in nltgv2_oracle.c. */
+float nltgv2_coverage(int32_t width, int32_t height, const float* idepthmap_filtered);
+void nltgv2_debug_image(int32_t kind, int32_t W, int32_t H, float scene_color_scale, int32_t V,
+                        const float* pos, const float* x, int32_t T, const int32_t* tris,
+                        const uint8_t* tri_valid, const float* vtx_normals,
+                        const float* idepthmap_filtered, int32_t n_feat, const float* feat_pos,
+                        const float* feat_mu, uint8_t* bgr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "flame/flame.h"
@@ -40,6 +41,7 @@ int main(int argc, char** argv) {
   params.rparams.step_x = 0.001f;
   params.rparams.step_q = 125.0f;
   params.rparams.theta = 0.25f;
+  params.debug_draw_normals = true;  // (reference default false, cfg/flame_offline_tum.yaml:62)
   flame::Matrix3f K, Kinv;  // cfg/kinect.yaml: 525/525/319.5/239.5
   K(0, 0) = 525.f; K(0, 1) = 0.f; K(0, 2) = 319.5f; K(1, 0) = 0.f; K(1, 1) = 525.f; K(1, 2) = 239.5f;
   K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
@@ -107,11 +109,26 @@ int main(int argc, char** argv) {
   std::fclose(f);
   f = std::fopen(argv[2], "w");
   if (!f) return 16;
-  std::fprintf(f, "%d %.17g %.17g %.17g %.17g\n", static_cast<int>(edges.size()),
+  std::fprintf(f, "%d %.17g %.17g %.17g %.17g %.9g\n", static_cast<int>(edges.size()),
                sensor->stats().stats("nltgv2_total_smoothness_cost"),
                sensor->stats().stats("nltgv2_total_data_cost"),
                sensor->stats().stats("nltgv2_avg_smoothness_cost"),
-               sensor->stats().timings("update"));
+               sensor->stats().timings("update"), sensor->stats().stats("coverage"));
   std::fclose(f);
+  // the debug images (reference src/flame_offline_tum.cc:731-766), rendered on demand: wireframe,
+  // features, normals, idepthmap as 4 x H x W x 3 bytes behind the binary outputs
+  f = std::fopen((std::string(argv[1]) + ".img").c_str(), "wb");
+  if (!f) return 15;
+  const flame::Image3b* imgs[4] = {&sensor->getDebugImageWireframe(), &sensor->getDebugImageFeatures(),
+                                   &sensor->getDebugImageNormals(), &sensor->getDebugImageInverseDepthMap()};
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 480; ++i)
+      for (int j = 0; j < 640; ++j) {
+        const flame::Vec3b c = (*imgs[k])(i, j);
+        unsigned char b[3] = {c[0], c[1], c[2]};
+        std::fwrite(b, 1, 3, f);
+      }
+  std::fclose(f);
+  if (sensor->getDebugImageDetections().rows != 480 || sensor->getDebugImageMatches().cols != 640) return 20;
   return 0;
 }

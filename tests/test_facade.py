@@ -22,7 +22,8 @@ import pytest
 
 from flame_ros_amd import lib
 from oracle import COracle
-from oracle.cbind import (SyncParams as OSync, TriParams, default_params, graph_sync as oracle_sync,
+from oracle.cbind import (SyncParams as OSync, TriParams, coverage as oracle_coverage, debug_image as oracle_image,
+                          default_params, depthmaps as oracle_depthmaps, graph_sync as oracle_sync,
                           triangles as oracle_triangles)
 from tests.util import assert_bit_equal, graphgen
 
@@ -146,7 +147,9 @@ def read_outputs(ob, ot, g):
     x = np.frombuffer(raw[:4 * g.V], np.float32)
     vn = np.frombuffer(raw[4 * g.V:16 * g.V], np.float32).reshape(-1, 3)
     tv = np.frombuffer(raw[16 * g.V:], np.uint8)
-    nE, smooth, data, avg_smooth, upd_ms = open(ot).read().split()
+    nE, smooth, data, avg_smooth, upd_ms, cov = open(ot).read().split()
+    read_outputs.coverage = float(cov)
+    read_outputs.images = np.fromfile(ob + ".img", np.uint8).reshape(4, 480, 640, 3)
     return x, vn, tv, int(nE), float(smooth), float(data), float(avg_smooth), float(upd_ms)
 
 
@@ -171,6 +174,12 @@ def test_facade_matches_oracle_on_gpu(gpu, exe, tmp_path):
     _, tv_o, vn_o = oracle_triangles(tp, KINV, g.pos, o.x, g.tris)
     assert np.array_equal(tv, tv_o)
     assert_bit_equal(vn, vn_o, "normals")
+    # stat key coverage + the debug images (rendered on the GPU when the getter is called)
+    idm_o, _, _ = oracle_depthmaps(640, 480, g.pos, o.x, g.tris, tv_o, True, KINV, 0.1, 100.0)
+    assert np.float32(read_outputs.coverage) == np.float32(oracle_coverage(idm_o))
+    for k, kind in enumerate((0, 1, 2, 3)):  # file order: wireframe, features, normals, idepthmap
+        want = oracle_image(kind, 640, 480, 1.0, g.pos, o.x, g.tris, tv_o, vn_o, idm_o, g.pos, g.z)
+        assert np.array_equal(read_outputs.images[k], want), "debug image %d" % kind
 
 
 @pytest.mark.gpu
@@ -197,7 +206,9 @@ def test_facade_sync_switches_and_frame_stream_on_gpu(gpu, exe, tmp_path, flags)
     # the GPU handle survives the stream: after the first frame (context, allocations, kernel
     # attributes) an update of a few thousand vertices is a matter of milliseconds
     ms = [float(l.split("update_ms=")[1].split()[0]) for l in p.stdout.splitlines() if "update_ms=" in l]
-    assert len(ms) == 3 and max(ms[1:]) < 60.0 and max(ms[1:]) < ms[0], ms
+    # (r02: 60 ms; the debug draws left update() in r03 -- a 3 k-vertex frame of 90 iterations is
+    # below a millisecond, 3 ms leaves room for one buffer re-allocation on the growing frame)
+    assert len(ms) == 3 and max(ms[1:]) < 3.0 and max(ms[1:]) < ms[0], ms
     g, var = frames[-1]
     x, vn, tv, nE, smooth, data, _, _ = read_outputs(ob, ot, g)
     s = oracle_sync(OSync(flags & 1, (flags >> 1) & 1, 1, 0.01), g.pos, g.z, var, g.tris)
@@ -221,3 +232,19 @@ def test_callsites_run_on_gpu(gpu, callsite_exe):
     p = subprocess.run([callsite_exe, "0"], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
     assert "frames_failed=0 hip_error=0" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,bound_ms", [("tum", 1.2), ("euroc", 2.0), ("50k", 4.4)])
+def test_facade_update_latency(gpu, workload, bound_ms):
+    """Median flame::Flame::update latency of a 40-frame stream with the reference's default
+    parameters (debug draws enabled, cfg/flame_offline_tum.yaml:58-64) at the BASELINE sizes: at
+    most 2x the round-3 targets (0.6 / 1.0 / 2.2 ms).  The mesh getter and the
+    three default debug images are fetched after every update, outside the timed update."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import facade_bench
+    r = facade_bench.run(workload, repeats=10, getters=2)
+    assert r["frames"] == 40 and r["coverage"] > 0.5, r
+    assert r["update_ms"]["p50"] < bound_ms, r
+    assert r["checksum"] > 0  # the getters really rendered something

@@ -1,0 +1,126 @@
+// tools/facade_bench.cc -- latency of the REAL integration path: a frame stream through
+// flame::Flame::updateGraph (include/flame/flame.h) with the reference's default parameters
+// (reference cfg/flame_offline_tum.yaml:19-99: wireframe / features / idepthmap debug draws ON,
+// all triangle filters ON), the way flame_offline_tum drives it (reference
+// src/flame_offline_tum.cc:565-782): update, then the mesh getter, stats, and -- optionally -- the
+// debug image getters a frontend with debug publishing enabled would call.
+//
+// Usage: facade_bench <width> <height> <iters> <repeats> <getters> frame0.bin [frame1.bin ...]
+//   frame files: the format of tests/cpp/facade_conformance.cc (header V, T, iters, device, flags;
+//   pos, mu, [var], tris), written by tools/facade_frames.py.  The frames are fed round-robin
+//   `repeats` times to ONE flame::Flame (every frame is a new graph for the library: nothing of a
+//   previous frame's topology is reused).  getters: 0 = update only, 1 = + getInverseDepthMesh,
+//   2 = + the three default debug images.  Prints one JSON line.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "flame/flame.h"
+
+namespace {
+struct Frame {
+  std::vector<flame::Point2f> vtx;
+  std::vector<float> mu, var;
+  std::vector<flame::Triangle> tris;
+};
+
+bool load(const char* path, Frame* f) {
+  FILE* fp = std::fopen(path, "rb");
+  if (!fp) return false;
+  std::fseek(fp, 0, SEEK_END);
+  const long n = std::ftell(fp);
+  std::fseek(fp, 0, SEEK_SET);
+  std::vector<char> buf(n);
+  const bool ok = std::fread(buf.data(), 1, n, fp) == static_cast<size_t>(n);
+  std::fclose(fp);
+  if (!ok) return false;
+  const int32_t* hdr = reinterpret_cast<const int32_t*>(buf.data());
+  const int V = hdr[0], T = hdr[1];
+  const float* pos = reinterpret_cast<const float*>(hdr + 5);
+  const float* mu = pos + 2 * V;
+  const float* varp = (hdr[4] & 4) ? mu + V : nullptr;
+  const int32_t* tri = reinterpret_cast<const int32_t*>(mu + V + (varp ? V : 0));
+  f->vtx.resize(V); f->mu.assign(mu, mu + V); f->var.assign(V, 1e-4f); f->tris.resize(T);
+  for (int v = 0; v < V; ++v) { f->vtx[v] = flame::Point2f(pos[2 * v], pos[2 * v + 1]); if (varp) f->var[v] = varp[v]; }
+  for (int t = 0; t < T; ++t) f->tris[t] = flame::Triangle(tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]);
+  return true;
+}
+
+double pct(std::vector<double> v, double p) {
+  if (v.empty()) return 0.0;
+  std::sort(v.begin(), v.end());
+  return v[std::min(v.size() - 1, static_cast<size_t>(p * (v.size() - 1) + 0.5))];
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 7) { std::fprintf(stderr, "usage: %s W H iters repeats getters frame.bin...\n", argv[0]); return 10; }
+  const int W = std::atoi(argv[1]), H = std::atoi(argv[2]), iters = std::atoi(argv[3]);
+  const int repeats = std::atoi(argv[4]), getters = std::atoi(argv[5]);
+  std::vector<Frame> frames(argc - 6);
+  for (int a = 6; a < argc; ++a)
+    if (!load(argv[a], &frames[a - 6])) return 11;
+
+  flame::Params params;  // defaults = reference cfg/flame_offline_tum.yaml
+  params.nltgv2_iterations = iters;
+  if (const char* e = std::getenv("FLAME_BENCH_NO_DEBUG")) {  // A/B: the debug draws off
+    if (e[0] == '1') params.debug_draw_wireframe = params.debug_draw_features = params.debug_draw_idepthmap = false;
+  }
+  flame::Matrix3f K, Kinv;  // cfg/kinect.yaml: 525/525/319.5/239.5
+  K(0, 0) = 525.f; K(0, 1) = 0.f; K(0, 2) = 319.5f; K(1, 0) = 0.f; K(1, 1) = 525.f; K(1, 2) = 239.5f;
+  K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
+  Kinv(0, 0) = 1.f / 525.f; Kinv(0, 1) = 0.f; Kinv(0, 2) = -319.5f / 525.f;
+  Kinv(1, 0) = 0.f; Kinv(1, 1) = 1.f / 525.f; Kinv(1, 2) = -239.5f / 525.f;
+  Kinv(2, 0) = 0.f; Kinv(2, 1) = 0.f; Kinv(2, 2) = 1.f;
+  std::shared_ptr<flame::Flame> sensor = std::make_shared<flame::Flame>(W, H, K, Kinv, params);
+
+  std::vector<double> upd, sync, solve, wall, get;
+  std::vector<flame::Point2f> ovtx;
+  std::vector<float> oid;
+  std::vector<flame::Vector3f> normals;
+  std::vector<flame::Triangle> otris;
+  std::vector<bool> validity;
+  std::vector<flame::Edge> edges;
+  const int warm = 3;
+  int n = 0;
+  unsigned long checksum = 0;
+  for (int r = 0; r < repeats + warm; ++r)
+    for (size_t k = 0; k < frames.size(); ++k, ++n) {
+      const Frame& f = frames[k];
+      const auto t0 = std::chrono::steady_clock::now();
+      const bool ok = sensor->updateGraph(0.033 * n, static_cast<uint32_t>(n), f.vtx, f.mu, f.var, f.tris);
+      const auto t1 = std::chrono::steady_clock::now();
+      if (!ok) {
+        std::printf("{\"error\": \"update failed\", \"hip_error\": %d}\n", static_cast<int>(sensor->stats().stats("hip_error")));
+        return 3;
+      }
+      if (getters >= 1) sensor->getInverseDepthMesh(&ovtx, &oid, &normals, &otris, &validity, &edges);
+      if (getters >= 2) {
+        const flame::Image3b& a = sensor->getDebugImageWireframe();
+        const flame::Image3b& b = sensor->getDebugImageFeatures();
+        const flame::Image3b& c = sensor->getDebugImageInverseDepthMap();
+        checksum += a(H / 2, W / 2)[0] + b(H / 2, W / 2)[1] + c(H / 2, W / 2)[2];
+      }
+      const auto t2 = std::chrono::steady_clock::now();
+      if (r < warm) continue;
+      upd.push_back(sensor->stats().timings("update"));
+      sync.push_back(sensor->stats().timings("sync_graph"));
+      solve.push_back(sensor->stats().timings("nltgv2"));
+      wall.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+      get.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
+  std::printf(
+      "{\"V\": %d, \"T\": %d, \"E\": %d, \"iters\": %d, \"frames\": %d, \"getters\": %d, "
+      "\"update_ms\": {\"p50\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"max\": %.4f}, "
+      "\"update_wall_ms_p50\": %.4f, \"sync_graph_ms_p50\": %.4f, \"nltgv2_ms_p50\": %.4f, "
+      "\"nltgv2_device_ms\": %.4f, \"getters_ms_p50\": %.4f, \"coverage\": %.6f, \"checksum\": %lu}\n",
+      static_cast<int>(frames[0].vtx.size()), static_cast<int>(frames[0].tris.size()),
+      static_cast<int>(sensor->stats().stats("num_edges")), iters, static_cast<int>(upd.size()), getters,
+      pct(upd, 0.5), pct(upd, 0.1), pct(upd, 0.9), pct(upd, 1.0), pct(wall, 0.5), pct(sync, 0.5), pct(solve, 0.5),
+      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum);
+  return 0;
+}
