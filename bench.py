@@ -95,10 +95,86 @@ def profiled_counters(workload, kernel):
     return best
 
 
+def tile_phase_split(g, iters, device, opts, launch_us):
+    """In-kernel timeline of ONE tile launch (s_memtime stamps written by the kernel when the handle
+    has profile=1; tools/tile_timeline.py prints the long form): p50 over tiles of the load phase,
+    the iterations (phase D + phase P), the store phase, in shader-clock cycles; what is left of the
+    measured launch period is the kernel boundary (launch gap + end-of-kernel release)."""
+    import numpy as np
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+    o = dict(opts, profile=1, use_graph=0)
+    with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=device, **o) as r:
+        pr = default_params()
+        r.step(pr, iters)
+        r.step(pr, iters)  # (lane order applied from the second solve on)
+        d = r.info("tile_depth")
+        if d <= 0:
+            return None
+        r.step(pr, d)
+        t = r.plan_array("profile", np.uint64).reshape(-1, 36).astype(np.int64)
+        mhz = r.info("clock_khz") / 1e3
+    t = t[t[:, 35] > 0]
+    if not len(t):
+        return None
+    load = t[:, 1] - t[:, 0]
+    it = t[:, 2 * d + 1] - t[:, 1]
+    store = t[:, 35] - t[:, 2 * d + 1]
+    tot = t[:, 35] - t[:, 0]
+    med = lambda a: float(np.median(a))  # noqa: E731
+    in_us = med(tot) / mhz
+    return {"unit": "shader-clock cycles, p50 over tiles of one launch", "iterations_in_launch": int(d),
+            "load": med(load), "iterate": med(it), "store": med(store), "in_kernel": med(tot),
+            "in_kernel_slowest_tile": float(tot.max()),
+            "clock_mhz_assumed": mhz, "in_kernel_us_at_assumed_clock": in_us,
+            "boundary_us": max(0.0, launch_us - float(tot.max()) / mhz),
+            "load_frac": med(load) / med(tot), "iterate_frac": med(it) / med(tot), "store_frac": med(store) / med(tot),
+            "iterate_frac_of_launch": (med(it) / mhz) / launch_us,
+            "note": "boundary_us = measured launch period - slowest tile's in-kernel time at the assumed clock"}
+
+
+def facade_frames(workloads=("tum", "euroc", "50k")):
+    """Median flame::Flame::update latency (C++, tools/facade_bench.cc) of a frame stream with the
+    reference's default parameters (cfg/flame_offline_tum.yaml:19-99, debug draws enabled)."""
+    sys.path.insert(0, ROOT)
+    from tools import facade_bench
+    out = {}
+    for w in workloads:
+        try:
+            r = facade_bench.run(w, repeats=10, getters=1)
+            out[w] = {"V": r["V"], "iters": r["iters"], "update_ms_p50": r["update_ms"]["p50"],
+                      "update_ms_p90": r["update_ms"]["p90"], "sync_graph_ms_p50": r["sync_graph_ms_p50"],
+                      "nltgv2_ms_p50": r["nltgv2_ms_p50"], "frames": r["frames"]}
+        except Exception as e:  # noqa: BLE001 -- the bench line must not die on the side measurement
+            out[w] = {"error": str(e)[:200]}
+    return out
+
+
+def frames_axis(device, batch=256, win=16, steps=5):
+    """Frames axis: `batch` independent TUM-shaped graphs (640x480, one feature per win x win cell) in
+    ONE handle, one LDS-resident tile (one CU) per frame, 200 PD iterations each per step."""
+    from flame_ros_amd import graphgen
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+    frames = [graphgen.dataset_shaped(640, 480, win, seed=b) for b in range(batch)]
+    with GraphRegularizer.from_batch(frames, device=device) as rb:
+        pr = default_params()
+        for _ in range(3):
+            rb.step(pr, 200, sync=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rb.step(pr, 200, sync=False)
+        rb.sync()
+        dt = time.perf_counter() - t0
+    return {"batch": batch, "win": win, "vertices_per_frame": frames[0].V, "iters": 200,
+            "frames_per_s": batch * steps / dt, "frame_iterations_per_s": batch * steps * 200 / dt,
+            "r01_frame_iterations_per_s": 1.01e8,
+            "note": "one workgroup (one CU) per frame, all 200 iterations in one launch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=0,
+                    help="timed steps (0 = as many as make the timed window >= 0.25 s, at least 20)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="50k", choices=["5k", "50k", "200k", "tum", "euroc"])
     ap.add_argument("--iters", type=int, default=0, help="PD iterations per step (0 = config)")
@@ -113,6 +189,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="extra library option (flame_hip_graph_set_option), repeatable")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-facade", action="store_true", help="skip the facade frame-latency and frames-axis side measurements")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "partition"],
                     help="N>1: independent frames per GPU (default) or ONE graph cut into N "
@@ -205,6 +282,18 @@ def main():
     # two priming solves put capture/instantiate outside the timed region whatever --warmup is
     for _ in range(2):
         r.step(p, iters, sync=True)
+    if args.steps <= 0:  # default: a timed window of >= 0.25 s (r02's 20 steps were a 20 ms window)
+        r.sync()
+        te = time.perf_counter()
+        for _ in range(5):
+            r.step(p, iters, sync=False)
+        r.sync()
+        step_s = (time.perf_counter() - te) / 5
+        args.steps = int(max(20, min(5000, -(-0.25 // step_s))))
+        if world > 1:  # every rank must time the same number of steps
+            t = torch.tensor([args.steps], device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            args.steps = int(t.item())
     for _ in range(args.warmup):
         r.step(p, iters, sync=False)
     barrier()
@@ -306,17 +395,18 @@ def main():
                          "note": "the same K-step window repeated after the timed one"} if repeat_ips else None),
             "frames_per_s": (1 if partition else world) * args.steps * nfr / elapsed,
             "us_per_iteration": elapsed / (args.steps * iters) * 1e6,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm" if path != 2 else "lds+latency", "contract_bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "k_tile" if path == 2 else "k_dual+k_primal",
                          "launch_us": launch_us, "iters_per_launch": iters_per_launch,
                          "alg_bytes_per_iter": alg_bytes_iter,
-                         "note": "achieved = (84E+60V) x iterations per launch / mean launch "
-                                 "duration (HIP events on the solve stream, incl. launch gaps): the "
-                                 "contract's figure. The tile path keeps state in LDS across iterations, "
-                                 "so it is NOT HBM-bound: see measured_hbm_gbps (PMC traffic / launch "
-                                 "time), blocked_floor_bytes_per_launch and the lds block for what "
-                                 "limits it."},
+                         "note": "achieved / frac = (84E+60V) x iterations per launch / mean launch "
+                                 "duration (HIP events on the solve stream, incl. launch gaps) against the HBM "
+                                 "peak: the contract's figure (contract_bound). The tile path keeps state in "
+                                 "LDS across iterations, so HBM does not bound it (measured_hbm_frac); `bound` "
+                                 "names what does: the LDS pipeline inside an iteration and load / kernel-"
+                                 "boundary latency around it (phase_split, lds_frac, iterate_frac)."},
         }
         if part_info:
             out["partition"] = part_info
@@ -359,12 +449,25 @@ def main():
                              "issue_floor_cycles_per_cu_launch": 4.0 * L.get("SQ_INSTS_LDS", 0.0) / min(ntl, cus),
                              "note": "SQ_* from a separate rocprofv3 --pmc pass; floor = 4 LDS-array cycles per "
                                      "wave-instruction (ds_read_b128, conflict-free; MI355X guide LDS table)"}
+        if path == 2 and not args.batch and not partition:
+            ps_ = tile_phase_split(g, iters, local_rank, opts, launch_us)
+            if ps_:
+                rl["phase_split"] = ps_
+                rl["iterate_frac"] = ps_["iterate_frac_of_launch"]
+                if rl.get("lds"):
+                    rl["lds_frac"] = rl["lds"]["idx_active_cycles_per_cu_launch"] / max(launch_us * ps_["clock_mhz_assumed"], 1.0)
         if args.batch:
             out["metric"] = "primal-dual iterations/sec over a batch of %d independent %d-vertex graphs" % (
                 args.batch, frames[0].V)
             out["config"]["workload"] = "batch of %d feature-grid graphs (640x480, win %d), %d PD iterations each" % (
                 args.batch, args.batch_win, iters)
             out["roofline"]["note"] += " Batch mode: value counts frame-iterations."
+        if world == 1 and not args.batch and not args.no_facade:
+            out["facade_frame_ms"] = facade_frames()
+            out["facade_frame_ms"]["note"] = ("median flame::Flame::update of a 40-frame stream through the C++ "
+                                              "facade with reference-default params (debug draws enabled), "
+                                              "tools/facade_bench.cc; targets 0.6 / 1.0 / 2.2 ms")
+            out["frames_axis"] = frames_axis(local_rank)
         if not args.no_cpu and world == 1:  # contract: rank 0 at N=1 only
             cb = cpu_baseline(args.workload, args.batch_win if args.batch else 0, iters, args.cpu_budget)
             out["cpu_baseline"] = cb

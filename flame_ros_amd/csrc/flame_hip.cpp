@@ -472,6 +472,11 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "device") *value = g->device;
   else if (k == "plan_on_device") *value = P.on_device ? 1 : 0;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
+  else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
+    int khz = 0;
+    if (g->device < 0 || hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, g->device) != hipSuccess) return FLAME_HIP_ERR_NODEVICE;
+    *value = khz;
+  }
   else return FLAME_HIP_ERR_ARG;
   return 0;
 }
