@@ -440,6 +440,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->opt.single_max = value;
   } else if (k == "debug_sub_cap") {
     g->opt.debug_sub_cap = value;
+  } else if (k == "d_sign") {
+    if (value != 1 && value != -1) return FLAME_HIP_ERR_ARG;
+    g->opt.d_sign = value;
   } else if (k == "plan_device") {
     g->plan_device = value != 0;
   } else if (k == "profile") {
@@ -896,7 +899,10 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
   // graphs that become one isolated tile (host plan) are synced on the host as well (E <= 3V bounds
   // the edge count of a triangulation before it is known)
   const bool lone_tile = plan_sizing(g->opt, V, (int32_t)std::min<int64_t>(3ll * V, INT32_MAX)).single;
-  if (g->device >= 0 && g->plan_device && V >= 2 && T > 0 && !lone_tile && g->opt.path != FLAME_HIP_PATH_GLOBAL) {
+  if (sp->edge_weight_rule < 0 || sp->edge_weight_rule > 3 || !std::isfinite(sp->alpha_gain) || !std::isfinite(sp->beta_gain))
+    return FLAME_HIP_ERR_ARG;
+  if (g->device >= 0 && g->plan_device && V >= 2 && T > 0 && !lone_tile && g->opt.path != FLAME_HIP_PATH_GLOBAL &&
+      !sync_weights_custom(*sp)) {
     // ---- on the device: edges of the triangulation, alpha, data terms; then the device plan ----
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(wait_last_solve(g));
@@ -952,8 +958,8 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
   const int32_t E = (int32_t)(g->sync.edges.size() / 2);
   if ((rc = flame_hip_graph_resize(g, V, E, T))) return rc;
   const SyncOut& S = g->sync;
-  rc = flame_hip_graph_upload(g, pos, S.edges.data(), S.alpha.data(), S.alpha.data(), S.z.data(),
-                              S.wgt.data(), S.x0.data(), T > 0 ? tris : nullptr);
+  rc = flame_hip_graph_upload(g, pos, S.edges.data(), S.alpha.data(), S.beta.empty() ? S.alpha.data() : S.beta.data(),
+                              S.z.data(), S.wgt.data(), S.x0.data(), T > 0 ? tris : nullptr);
   if (rc) return rc;
   g->synced = true;
   if (scale) *scale = S.scale;
@@ -1657,6 +1663,10 @@ int64_t flame_hip_debug_plan_array(const flame_hip_graph* g, const char* name, v
   else if (k == "tinc") { src = P.tinc.data(); n = (int64_t)P.tinc.size(); }
   else if (k == "sync_edges") { src = g->sync.edges.data(); n = (int64_t)g->sync.edges.size(); }
   else if (k == "sync_alpha") { src = g->sync.alpha.data(); n = (int64_t)g->sync.alpha.size(); }
+  else if (k == "sync_beta") {
+    const std::vector<float>& b = g->sync.beta.empty() ? g->sync.alpha : g->sync.beta;
+    src = b.data(); n = (int64_t)b.size();
+  }
   else if (k == "sync_z") { src = g->sync.z.data(); n = (int64_t)g->sync.z.size(); }
   else if (k == "sync_wgt") { src = g->sync.wgt.data(); n = (int64_t)g->sync.wgt.size(); }
   else if (k == "sync_x0") { src = g->sync.x0.data(); n = (int64_t)g->sync.x0.size(); }

@@ -401,7 +401,8 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       const int32_t e = eorder[k];
       const int32_t io = edges[2 * e], jo = edges[2 * e + 1];
       P.eij[k] = {P.v_o2i[io], P.v_o2i[jo]};
-      P.ew[k] = {alpha[e], beta[e], pos[2 * io] - pos[2 * jo], pos[2 * io + 1] - pos[2 * jo + 1]};
+      const float ds = opt.d_sign < 0 ? -1.0f : 1.0f;  // (a multiplication by +-1 is exact)
+      P.ew[k] = {alpha[e], beta[e], ds * (pos[2 * io] - pos[2 * jo]), ds * (pos[2 * io + 1] - pos[2 * jo + 1])};
     }
     lap("edge order");
     // ---- incidence CSR, ascending ORIGINAL edge id per vertex ----

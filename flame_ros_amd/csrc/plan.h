@@ -26,6 +26,7 @@ struct PlanOptions {
   // 60 us of GPU time at 50 k vertices, more on the host): 0 never; 1 when a plan is solved a
   // SECOND time (a frame stream that solves every graph once never pays for it); 2 at build time
   int lane_order = 1;
+  int d_sign = 1;        // [UPSTREAM-RECALL] switch: the edge vector is d_sign * (pos_i - pos_j)
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
                          // this many vertices on its first try (exercises the recovery path)

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
                                                      const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
                                                      int32_t* e_o2i, int2* eij, float4* ew, int32_t V, int32_t ntiles,
                                                      const int32_t* __restrict__ tlo,
-                                                     const int32_t* __restrict__ off, int32_t* estart) {
+                                                     const int32_t* __restrict__ off, int32_t* estart, float dsign) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   // estart[t] = first internal edge owned by tile t = where its first bucket starts
   if (k < ntiles) estart[k] = off[2 * max(0, min(tlo[k], V))];
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
   e_i2o[k] = e;
   e_o2i[e] = k;
   eij[k] = make_int2(si, sj);
-  ew[k] = make_float4(alpha[e], beta[e], pi.x - pj.x, pi.y - pj.y);
+  ew[k] = make_float4(alpha[e], beta[e], dsign * (pi.x - pj.x), dsign * (pi.y - pj.y));
 }
 
 
@@ -1730,7 +1730,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                        ecur, esorted);
     hipLaunchKernelGGL(k_csr_rows<false>, grid1(2 * (int64_t)V), dim3(256), 0, s, 2 * V, eoff, nullptr, esorted);
     hipLaunchKernelGGL(k_edge_gather, grid1(std::max<int64_t>(E, ntiles + 1)), dim3(256), 0, s, E, esorted, in.edges, in.alpha,
-                       in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, V, ntiles, leaf.lo, eoff, estart_);
+                       in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, V, ntiles, leaf.lo, eoff, estart_,
+                       opt.d_sign < 0 ? -1.0f : 1.0f);
   } else {
     HIPRET(hipMemsetAsync(estart_, 0, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   }

@@ -44,12 +44,23 @@ int graph_sync_host(const flame_hip_sync_params& sp, int32_t V, int32_t T, const
   }
   const int32_t E = (int32_t)(out->edges.size() / 2);
   out->alpha.resize(E);
+  const bool custom = sync_weights_custom(sp);
+  out->beta.clear();
+  if (custom) out->beta.resize(E);
+  const int32_t rule = sp.edge_weight_rule;
   for (int32_t e = 0; e < E; ++e) {
     const int32_t i = out->edges[2 * e], j = out->edges[2 * e + 1];
     const float dx = pos[2 * i] - pos[2 * j], dy = pos[2 * i + 1] - pos[2 * j + 1];
     // this file is compiled with -ffp-contract=off: dx*dx + dy*dy is two roundings, as the
     // oracle states it
-    out->alpha[e] = 1.0f / std::sqrt(dx * dx + dy * dy);
+    const float inv = 1.0f / std::sqrt(dx * dx + dy * dy);
+    if (!custom) { out->alpha[e] = inv; continue; }
+    float a = (rule == 1 || rule == 3) ? 1.0f : inv;
+    float b = (rule == 1 || rule == 2) ? 1.0f : inv;
+    if (sp.alpha_gain != 0.0f) a *= sp.alpha_gain;
+    if (sp.beta_gain != 0.0f) b *= sp.beta_gain;
+    out->alpha[e] = a;
+    out->beta[e] = b;
   }
   float scale = 1.0f;
   if (sp.rescale_data && V > 0) {

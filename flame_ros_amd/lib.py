@@ -32,7 +32,9 @@ class TriParams(C.Structure):
 class SyncParams(C.Structure):
     """flame_hip_sync_params (reference src/flame_offline_tum.cc:234-249, yaml :89-92)."""
     _fields_ = [("adaptive_data_weights", C.c_int32), ("rescale_data", C.c_int32),
-                ("init_with_prediction", C.c_int32), ("idepth_var_max_graph", C.c_float)]
+                ("init_with_prediction", C.c_int32), ("idepth_var_max_graph", C.c_float),
+                # [UPSTREAM-RECALL] switches, all-zero = default (include/flame_hip.h)
+                ("edge_weight_rule", C.c_int32), ("alpha_gain", C.c_float), ("beta_gain", C.c_float)]
 
 
 class TileDesc(C.Structure):

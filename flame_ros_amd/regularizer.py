@@ -24,10 +24,11 @@ def default_tri_params(width=640, height=480):
 
 
 def default_sync_params(adaptive_data_weights=False, rescale_data=False, init_with_prediction=True,
-                        idepth_var_max_graph=0.01):
-    """Defaults of cfg/flame_offline_tum.yaml:89-92 (reference)."""
+                        idepth_var_max_graph=0.01, edge_weight_rule=0, alpha_gain=0.0, beta_gain=0.0):
+    """Defaults of cfg/flame_offline_tum.yaml:89-92 (reference); the last three are the
+    [UPSTREAM-RECALL] switches of include/flame_hip.h (0 = the build's default statement)."""
     return SyncParams(int(adaptive_data_weights), int(rescale_data), int(init_with_prediction),
-                      idepth_var_max_graph)
+                      idepth_var_max_graph, int(edge_weight_rule), float(alpha_gain), float(beta_gain))
 
 
 def feature_gate(idepth_var, var_max):

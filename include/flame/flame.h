@@ -301,9 +301,12 @@ class Flame {
     sp.rescale_data = params_.rescale_data;
     sp.init_with_prediction = params_.init_with_prediction;
     sp.idepth_var_max_graph = params_.idepth_var_max_graph;
+    sp.edge_weight_rule = params_.edge_weight_rule;
+    sp.alpha_gain = params_.edge_alpha_gain;
+    sp.beta_gain = params_.edge_beta_gain;
     float scale = 1.0f;
     int rc = graph_.sync(params_.hip_device, sp, V, T, pos.data(), idepth_mu.data(), idepth_var.data(),
-                         tidx.data(), prediction ? prediction->data() : nullptr, &scale);
+                         tidx.data(), prediction ? prediction->data() : nullptr, &scale, params_.edge_d_sign);
     if (rc) return fail(rc);
     const int32_t E = graph_.numEdges();
     stats_.tock("sync_graph");

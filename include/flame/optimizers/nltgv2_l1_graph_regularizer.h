@@ -34,6 +34,7 @@ class Graph {
     if (g_) flame_hip_graph_destroy(g_);
     g_ = nullptr;
     device_ = -1;
+    d_sign_ = 1;
     V_ = E_ = T_ = 0;
     resident_ = false;
   }
@@ -57,9 +58,13 @@ class Graph {
   // Graph sync (row a7) in the library: features + triangulation in, graph resident on the GPU.
   int sync(int device, const flame_hip_sync_params& sp, int32_t V, int32_t T, const float* pos,
            const float* idepth_mu, const float* idepth_var, const int32_t* tris,
-           const float* prediction, float* scale) {
+           const float* prediction, float* scale, int d_sign = 1) {
     int rc = acquire(device);
     if (rc) return rc;
+    if (d_sign != d_sign_) {
+      if ((rc = flame_hip_set_option(g_, "d_sign", d_sign))) return rc;
+      d_sign_ = d_sign;
+    }
     V_ = E_ = T_ = 0;
     resident_ = false;
     if ((rc = flame_hip_graph_sync(g_, &sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, scale)))
@@ -92,6 +97,7 @@ class Graph {
   }
   flame_hip_graph* g_ = nullptr;
   int device_ = -1;
+  int d_sign_ = 1;
   int32_t V_ = 0, E_ = 0, T_ = 0;
   bool resident_ = false;
 };

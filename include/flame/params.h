@@ -75,6 +75,12 @@ struct Params {
   // IGNORED by the GPU tail (the reference defaults +-1e14 / false disable them anyway).
   float min_height = -1e14f, max_height = 1e14f;
   bool check_sticky_obstacles = false;
+  // [UPSTREAM-RECALL] switches (not in the reference; defaults = the build's statement, see
+  // include/flame_hip.h flame_hip_sync_params and option "d_sign"): flipped when a state dump of a
+  // real robustrobotics/flame build disagrees (tools/pin_upstream/)
+  int edge_weight_rule = 0;
+  float edge_alpha_gain = 0.0f, edge_beta_gain = 0.0f;
+  int edge_d_sign = 1;
   // not in the reference: regulariser iterations per update (an upstream constant that no
   // flame_ros YAML key exposes) and the GPU to run on
   int nltgv2_iterations = 200;

@@ -84,8 +84,9 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
  * 512, up to 2048), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
- * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile".
- * Unknown key -> FLAME_HIP_ERR_ARG. */
+ * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile",
+ * "d_sign" ([UPSTREAM-RECALL] switch: +1 (default) the edge vector entering K1 is d = pos_i - pos_j,
+ * -1 it is pos_j - pos_i).  Unknown key -> FLAME_HIP_ERR_ARG. */
 int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value);
 int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value);
 
@@ -110,6 +111,12 @@ typedef struct {
   int32_t rescale_data;          /* .../rescale_data */
   int32_t init_with_prediction;  /* .../init_with_prediction */
   float idepth_var_max_graph;    /* .../idepth_var_max */
+  /* [UPSTREAM-RECALL] switches; an all-zero tail is the default.  edge_weight_rule 0: alpha = beta =
+   * 1/|pos_i - pos_j|; 1: alpha = beta = 1; 2: alpha = 1/len, beta = 1; 3: alpha = 1, beta = 1/len.
+   * alpha_gain / beta_gain multiply the rule's value (0 reads 1).  Any non-default value takes the
+   * host sync path.  (Caller-supplied weights: flame_hip_graph_upload.) */
+  int32_t edge_weight_rule;
+  float alpha_gain, beta_gain;
 } flame_hip_sync_params;
 int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, int32_t V, int32_t T,
                          const float* pos, const float* idepth_mu, const float* idepth_var,

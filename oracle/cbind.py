@@ -172,7 +172,8 @@ class COracle:
 class SyncParams(C.Structure):
     """nltgv2_sync_params (reference cfg/flame_offline_tum.yaml:89-92)."""
     _fields_ = [("adaptive_data_weights", C.c_int32), ("rescale_data", C.c_int32),
-                ("init_with_prediction", C.c_int32), ("idepth_var_max_graph", C.c_float)]
+                ("init_with_prediction", C.c_int32), ("idepth_var_max_graph", C.c_float),
+                ("edge_weight_rule", C.c_int32), ("alpha_gain", C.c_float), ("beta_gain", C.c_float)]
 
 
 def feature_gate(var, var_max):

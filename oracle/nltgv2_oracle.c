@@ -611,7 +611,8 @@ void nltgv2_graph_filter(nltgv2_graph* g, const int32_t* row, const int32_t* inc
  *   gate    : feature v may enter the graph iff var_v < idepth_var_max_graph (strict)
  *   edges   : the unique undirected edges of the triangulation, oriented i < j, in lexicographic
  *             order of (i, j); alpha_e = beta_e = 1 / sqrt(dx^2 + dy^2) in float32, dx^2 + dy^2 NOT
- *             fused ([UPSTREAM-RECALL] reciprocal pixel edge length)
+ *             fused ([UPSTREAM-RECALL] reciprocal pixel edge length; edge_weight_rule / alpha_gain /
+ *             beta_gain select the alternatives listed in nltgv2_oracle.h)
  *   scale   : rescale_data ? (float)(sum_v (double)mu_v / V) : 1; a scale that is not > 0 reads 1
  *   z_v     = mu_v / scale;  wgt_v = adaptive ? 1 / var_v : 1
  *   x0_v    = (init_with_prediction && prediction && isfinite(prediction_v)) ? prediction_v / scale
@@ -652,8 +653,14 @@ int32_t nltgv2_graph_sync(const nltgv2_sync_params* sp, int32_t V, int32_t T, co
     const int32_t i = edges[2 * e], j = edges[2 * e + 1];
     const float dx = pos[2 * i] - pos[2 * j], dy = pos[2 * i + 1] - pos[2 * j + 1];
     const float len = sqrtf(dx * dx + dy * dy);
-    alpha[e] = 1.0f / len;
-    beta[e] = alpha[e];
+    const float inv = 1.0f / len;
+    const int32_t rule = sp->edge_weight_rule;
+    float a = (rule == 1 || rule == 3) ? 1.0f : inv;
+    float b = (rule == 1 || rule == 2) ? 1.0f : inv;
+    if (sp->alpha_gain != 0.0f) a *= sp->alpha_gain;
+    if (sp->beta_gain != 0.0f) b *= sp->beta_gain;
+    alpha[e] = a;
+    beta[e] = b;
   }
   float scale = 1.0f;
   if (sp->rescale_data && V > 0) {

@@ -104,6 +104,12 @@ typedef struct {
   int32_t rescale_data;          /* :90 */
   int32_t init_with_prediction;  /* :91 */
   float idepth_var_max_graph;    /* :92 */
+  /* [UPSTREAM-RECALL] switches (all-zero = the build's default statement), so that a mismatch
+   * against a state dump of a real robustrobotics/flame build is a flag flip, not a rewrite:
+   * edge_weight_rule 0: alpha = beta = 1/len; 1: alpha = beta = 1; 2: alpha = 1/len, beta = 1;
+   * 3: alpha = 1, beta = 1/len.  alpha_gain / beta_gain multiply the rule's value (0 reads 1). */
+  int32_t edge_weight_rule;
+  float alpha_gain, beta_gain;
 } nltgv2_sync_params;
 int32_t nltgv2_feature_gate(int32_t n, const float* var, float var_max, uint8_t* keep);
 /* edges capacity 2*3T ints, alpha/beta capacity 3T; returns E */

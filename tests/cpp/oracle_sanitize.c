@@ -32,7 +32,7 @@ int main(void) {
   int32_t* edges = malloc(sizeof(int32_t) * 2 * 3 * T);
   float *alpha = malloc(sizeof(float) * 3 * T), *beta = malloc(sizeof(float) * 3 * T);
   float z[V], wgt[V], x0[V], scale = 0.f;
-  nltgv2_sync_params sp = {1, 1, 1, 0.01f};
+  nltgv2_sync_params sp = {1, 1, 1, 0.01f, 0, 0.0f, 0.0f};
   uint8_t keep[V];
   if (nltgv2_feature_gate(V, var, sp.idepth_var_max_graph, keep) != V) return 2;
   const int32_t E = nltgv2_graph_sync(&sp, V, T, pos, mu, var, tris, pred, edges, alpha, beta, z, wgt, x0, &scale);

@@ -47,6 +47,42 @@ def test_sync_matches_oracle(adaptive, rescale, init_pred):
     r.close()
 
 
+@pytest.mark.parametrize("rule,ag,bg", [(1, 0.0, 0.0), (2, 0.0, 0.5), (3, 2.0, 0.0), (0, 1.0, 3.0)])
+def test_sync_upstream_recall_switches(rule, ag, bg):
+    """The [UPSTREAM-RECALL] edge-weight switches (include/flame_hip.h flame_hip_sync_params tail):
+    alternatives to alpha = beta = 1/len, identical in the library and in the oracle."""
+    g, var, pred = features(1500, 5)
+    want = oracle_sync(OSync(0, 0, 1, 0.01, rule, ag, bg), g.pos, g.z, var, g.tris, pred)
+    r = GraphRegularizer.empty(device=-1)
+    r.sync_features(g.pos, g.z, var, g.tris, default_sync_params(0, 0, 1, 0.01, rule, ag, bg), prediction=pred)
+    assert_bit_equal(r.plan_array("sync_alpha", np.float32), want["alpha"], "alpha")
+    assert_bit_equal(r.plan_array("sync_beta", np.float32), want["beta"], "beta")
+    inv = g.alpha
+    a = (np.ones_like(inv) if rule in (1, 3) else inv) * np.float32(ag if ag else 1.0)
+    b = (np.ones_like(inv) if rule in (1, 2) else inv) * np.float32(bg if bg else 1.0)
+    assert_bit_equal(want["alpha"], a, "alpha rule")
+    assert_bit_equal(want["beta"], b, "beta rule")
+    # the solver sees them: t_ew / ew of the plan carry (alpha, beta)
+    ew = r.plan_array("ew", np.float32).reshape(-1, 4)
+    e_i2o = r.plan_array("e_i2o", np.int32)
+    assert_bit_equal(ew[:, 0], want["alpha"][e_i2o], "plan alpha")
+    assert_bit_equal(ew[:, 1], want["beta"][e_i2o], "plan beta")
+    r.close()
+    with pytest.raises(FlameHipError):
+        GraphRegularizer.empty(device=-1).sync_features(g.pos, g.z, var, g.tris, default_sync_params(edge_weight_rule=7))
+
+
+def test_d_sign_option_flips_the_edge_vectors():
+    g = graphgen.synthetic(800, seed=2)
+    ews = []
+    for ds in (1, -1):
+        r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, d_sign=ds)
+        ews.append(r.plan_array("ew", np.float32).reshape(-1, 4))
+        r.close()
+    assert_bit_equal(ews[0][:, :2], ews[1][:, :2], "weights")
+    assert_bit_equal(ews[0][:, 2:], -ews[1][:, 2:], "d")
+
+
 def test_feature_gate():
     var = np.float32([0.0, 0.00999, 0.01, 0.02, np.inf, np.nan, 1e-9])
     keep = feature_gate(var, 0.01)
