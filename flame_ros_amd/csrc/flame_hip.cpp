@@ -267,6 +267,7 @@ struct flame_hip_graph {
   bool host_perms = true;  // plan.v_i2o / v_o2i / e_i2o / e_o2i / tris are valid on the host
   // costs
   double* partials = nullptr;
+  uint8_t* cost_mask = nullptr;  // flame_hip_costs_masked: V vertex flags then E edge flags, internal order
   // halo exchange lists (internal ids), see flame_hip_halo_register
   int32_t n_send_v = 0, n_send_e = 0, n_recv_v = 0, n_recv_e = 0;
   int32_t* halo_send_v = nullptr;
@@ -1179,14 +1180,31 @@ int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches) {
 }
 
 int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smooth, double* data) {
+  return flame_hip_costs_masked(g, p, nullptr, nullptr, smooth, data);
+}
+
+int flame_hip_costs_masked(flame_hip_graph* g, const flame_hip_params* p, const uint8_t* vmask,
+                           const uint8_t* emask, double* smooth, double* data) {
   RoctxRange roctx_("flame_hip_costs");
   int rc = require_device(g);
   if (rc) return rc;
   if (!p) return FLAME_HIP_ERR_ARG;
   if ((rc = flame_hip_sync(g))) return rc;
   const int nb = costs_num_blocks(g->V, g->E);
+  uint8_t *dvm = nullptr, *dem = nullptr;
+  if (vmask || emask) {  // masks arrive in the caller's order: permuted to the internal one here
+    if ((rc = ensure_host_perms(g))) return rc;
+    const Plan& P = g->plan;
+    if ((rc = dev_alloc(g->caps, &g->cost_mask, (size_t)g->V + (size_t)g->E + 64))) return rc;
+    std::vector<uint8_t> h((size_t)g->V + (size_t)g->E, 1);
+    if (vmask) for (int32_t k = 0; k < g->V; ++k) h[k] = vmask[P.v_i2o[k]] ? 1 : 0;
+    if (emask) for (int32_t k = 0; k < g->E; ++k) h[(size_t)g->V + k] = emask[P.e_i2o[k]] ? 1 : 0;
+    if (!h.empty()) HIPCHK(memcpy_sync(g->stream, g->cost_mask, h.data(), h.size(), hipMemcpyHostToDevice));
+    if (vmask) dvm = g->cost_mask;
+    if (emask) dem = g->cost_mask + g->V;
+  }
   HIPCHK(launch_costs(g->stream, g->V, g->E, g->eij, g->ew, g->A[g->cur], g->B[g->cur],
-                      p->data_factor, g->partials));
+                      p->data_factor, g->partials, dem, dvm));
   std::vector<double> h(2 * (size_t)nb);
   HIPCHK(hipMemcpyAsync(h.data(), g->partials, sizeof(double) * h.size(), hipMemcpyDeviceToHost, g->stream));
   HIPCHK(hipStreamSynchronize(g->stream));

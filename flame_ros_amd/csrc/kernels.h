@@ -40,8 +40,10 @@ hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes);
 
 // ---- costs: per-block float64 partial sums (partials[2*b] smooth, [2*b+1] data) ----
 int costs_num_blocks(int32_t V, int32_t E);
+// emask / vmask (optional, INTERNAL order): only the flagged edges / vertices are summed
 hipError_t launch_costs(hipStream_t s, int32_t V, int32_t E, const int2* eij, const float4* ew,
-                        const float4* A, const float4* B, float lambda, double* partials);
+                        const float4* A, const float4* B, float lambda, double* partials,
+                        const uint8_t* emask = nullptr, const uint8_t* vmask = nullptr);
 
 // ---- halo exchange pack / unpack (multi-GPU subdomains) ----
 hipError_t launch_halo_pack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,

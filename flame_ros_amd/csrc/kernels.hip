@@ -486,10 +486,13 @@ __global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2*
                                                const float4* __restrict__ ew,
                                                const float4* __restrict__ A,
                                                const float4* __restrict__ B, float lambda,
-                                               double* __restrict__ partials) {
+                                               double* __restrict__ partials,
+                                               const uint8_t* __restrict__ emask,
+                                               const uint8_t* __restrict__ vmask) {
   __shared__ double red[2][4];
   double s = 0.0, d = 0.0;
   for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
+    if (emask && !emask[e]) continue;  // multi-GPU subdomain: only the edges this rank owns
     const int2 ij = eij[e];
     const float4 w = ew[e];
     const float4 ai = A[ij.x], aj = A[ij.y];
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2*
     s += (double)t1 + (double)t2 + (double)t3;
   }
   for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+    if (vmask && !vmask[v]) continue;
     const float4 a = A[v];
     const float c = (lambda * B[v].w) * fabsf(a.x - a.w);
     d += (double)c;
@@ -1166,8 +1170,9 @@ hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes) {
 int costs_num_blocks(int32_t, int32_t) { return kCostBlocks; }
 
 hipError_t launch_costs(hipStream_t s, int32_t V, int32_t E, const int2* eij, const float4* ew,
-                        const float4* A, const float4* B, float lambda, double* partials) {
-  hipLaunchKernelGGL(k_costs, dim3(kCostBlocks), dim3(256), 0, s, V, E, eij, ew, A, B, lambda, partials);
+                        const float4* A, const float4* B, float lambda, double* partials,
+                        const uint8_t* emask, const uint8_t* vmask) {
+  hipLaunchKernelGGL(k_costs, dim3(kCostBlocks), dim3(256), 0, s, V, E, eij, ew, A, B, lambda, partials, emask, vmask);
   return hipGetLastError();
 }
 

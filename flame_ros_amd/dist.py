@@ -136,31 +136,35 @@ class PartitionedSolver:
         self.solver = make_solver(sub, pos[sub.vid], sub.edges, f(alpha)[sub.eid], f(beta)[sub.eid],
                                   f(z)[sub.vid], f(wgt)[sub.vid],
                                   None if x0 is None else f(x0)[sub.vid])
-        # tell every owner which of its vertices / edges (global ids) this rank needs
-        want = {r: (sub.vid[v].tolist(), sub.eid[sub.recv_e.get(r, np.zeros(0, np.int32))].tolist())
-                for r, v in sub.recv_v.items()}
-        for r, e in sub.recv_e.items():
-            want.setdefault(r, ([], sub.eid[e].tolist()))
+        # tell every owner which of its vertices / edges (GLOBAL ids, int64 arrays) this rank needs;
+        # the owner maps them to its local numbering with a binary search (own vertices and the local
+        # edge list are ascending in global id): no per-element Python anywhere
+        none = np.zeros(0, np.int32)
+        want = {int(r): (sub.vid[sub.recv_v.get(r, none)], sub.eid[sub.recv_e.get(r, none)])
+                for r in set(sub.recv_v) | set(sub.recv_e)}
         allwant = [None] * self.world
         dist.all_gather_object(allwant, want)
-        g2l_v = {int(g): i for i, g in enumerate(sub.vid[:sub.n_own])}
-        g2l_e = {int(g): i for i, g in enumerate(sub.eid)}
+        own_gid = sub.vid[:sub.n_own]
         self.peers = sorted(set(want) | {r for r in range(self.world) if self.rank in allwant[r]})
         send_v, send_e, recv_v, recv_e = [], [], [], []
         self.send_cnt, self.recv_cnt = {}, {}
         for r in self.peers:
-            wv, we = allwant[r].get(self.rank, ([], []))
-            sv = [g2l_v[g] for g in wv]
-            se = [g2l_e[g] for g in we]
-            rv = sub.recv_v.get(r, np.zeros(0, np.int32)).tolist()
-            re_ = sub.recv_e.get(r, np.zeros(0, np.int32)).tolist()
+            wv, we = allwant[r].get(self.rank, (np.zeros(0, np.int64), np.zeros(0, np.int64)))
+            sv = np.searchsorted(own_gid, wv).astype(np.int32)
+            se = np.searchsorted(sub.eid, we).astype(np.int32)
+            assert np.array_equal(own_gid[sv], wv) and np.array_equal(sub.eid[se], we), "request for state this rank does not own"
+            rv, re_ = sub.recv_v.get(r, none), sub.recv_e.get(r, none)
             self.send_cnt[r] = (len(sv), len(se))
             self.recv_cnt[r] = (len(rv), len(re_))
-            send_v += sv; send_e += se; recv_v += rv; recv_e += re_
+            send_v.append(sv); send_e.append(se); recv_v.append(rv); recv_e.append(re_)
+        cat = lambda a: np.concatenate(a).astype(np.int32) if a else none  # noqa: E731
+        send_v, send_e, recv_v, recv_e = cat(send_v), cat(send_e), cat(recv_v), cat(recv_e)
         self.n_send = (len(send_v), len(send_e))
         self.n_recv = (len(recv_v), len(recv_e))
-        i32 = lambda a: np.asarray(a, np.int32)  # noqa: E731
-        self.solver.halo_register(i32(send_v), i32(send_e), i32(recv_v), i32(recv_e))
+        self.solver.halo_register(send_v, send_e, recv_v, recv_e)
+        self._rings_left = depth  # a fresh upload holds exact state on every ring
+        self._sbuf = self._rbuf = None  # persistent exchange buffers, allocated on the first exchange
+        self._ops_cache = None
 
     # packed buffer layout: all vertex records (VREC floats each, peers in order) then all edge
     # records (EREC floats each, peers in order) -> per-peer messages are two slices each
@@ -183,39 +187,74 @@ class PartitionedSolver:
             return self._exchange()
 
     def _exchange(self):
+        """pack -> P2P -> unpack.  The send and receive buffers are allocated ONCE (first exchange) and
+        the P2POp list is built once; with the nccl backend everything is enqueued on the solver's
+        stream (Work.wait() of an NCCL op orders the stream, it does not block the host), so a step()
+        returns without a host synchronisation -- only download() / costs() synchronise."""
         dist = self.dist
-        sbuf = self.solver.halo_pack()
-        # gloo has no device-to-device path: stage through the host (tests with several ranks on ONE
-        # GPU; the product backend is nccl = RCCL, device buffers straight into ncclSend/ncclRecv)
-        staged = sbuf.is_cuda and dist.get_backend() == "gloo"
-        dev = sbuf.device
-        if staged:
-            sbuf = sbuf.cpu()
-        rbuf = sbuf.new_empty(VREC * self.n_recv[0] + EREC * self.n_recv[1])
-        ops, ssl, rsl = [], self._slices(self.send_cnt, self.n_send), self._slices(self.recv_cnt, self.n_recv)
-        for r in self.peers:
-            for a, b in ssl[r]:
-                if b > a:
-                    ops.append(dist.P2POp(dist.isend, sbuf[a:b], r))
-            for a, b in rsl[r]:
-                if b > a:
-                    ops.append(dist.P2POp(dist.irecv, rbuf[a:b], r))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
+        if self._sbuf is None:
+            first = self.solver.halo_pack()  # (a solver without persistent buffers returns a new one)
+            # gloo has no device-to-device path: stage through the host (tests with several ranks on
+            # ONE GPU; the product backend is nccl = RCCL, device buffers straight into ncclSend/Recv)
+            self._staged = first.is_cuda and dist.get_backend() == "gloo"
+            self._dev = first.device
+            self._sbuf = first.cpu() if self._staged else first
+            self._rbuf = self._sbuf.new_empty(VREC * self.n_recv[0] + EREC * self.n_recv[1])
+            self._rdev = self._rbuf.to(self._dev) if self._staged else self._rbuf
+            ops, ssl, rsl = [], self._slices(self.send_cnt, self.n_send), self._slices(self.recv_cnt, self.n_recv)
+            for r in self.peers:
+                for a, b in ssl[r]:
+                    if b > a:
+                        ops.append(dist.P2POp(dist.isend, self._sbuf[a:b], r))
+                for a, b in rsl[r]:
+                    if b > a:
+                        ops.append(dist.P2POp(dist.irecv, self._rbuf[a:b], r))
+            self._ops_cache = ops
+            self._pack_into = getattr(self.solver, "halo_pack_into", None)
+        elif self._pack_into is not None and not self._staged:
+            self._pack_into(self._sbuf)  # in place: no allocation
+        else:
+            packed = self.solver.halo_pack()
+            self._sbuf.copy_(packed)  # (gloo test path / solvers without halo_pack_into)
+        if self._ops_cache:
+            for w in dist.batch_isend_irecv(self._ops_cache):
                 w.wait()
-        if staged:
-            rbuf = rbuf.to(dev)
-        self.solver.halo_unpack(rbuf)
+        if self._staged:
+            self._rdev.copy_(self._rbuf)
+        self.solver.halo_unpack(self._rdev)
 
     def step(self, params, num_iters):
+        """Every local iteration invalidates one halo ring: `_rings_left` counts how many more
+        iterations the halo still supports; an exchange (exact state from the owners) resets it to
+        the halo depth.  Successive step() calls continue where the previous one stopped."""
         done = 0
         while done < num_iters:
-            n = min(self.depth, num_iters - done)
-            self.solver.step(params, n)
-            done += n
-            if done < num_iters:
+            if self._rings_left == 0:
                 self.exchange()
-        self._stale = True
+                self._rings_left = self.depth
+            n = min(self._rings_left, num_iters - done)
+            self.solver.step(params, n)
+            self._rings_left -= n
+            done += n
+
+    def costs(self, params):
+        """nltgv2_total_smoothness_cost / nltgv2_total_data_cost of the WHOLE graph (the stat keys read
+        at reference src/utils.cc:131-136): every rank sums the edges and vertices it owns, one
+        all-reduce of 2 doubles (SURVEY.md 8e "final cost reduction")."""
+        import torch
+        s = self.sub
+        if self._rings_left == 0 and self.depth > 0:  # an owned edge reads its target in ring 1
+            self.exchange()
+            self._rings_left = self.depth
+        vmask = np.zeros(len(s.vid), np.uint8)
+        vmask[:s.n_own] = 1
+        sm, da = self.solver.costs_owned(params, vmask, s.e_owned.astype(np.uint8))
+        t = torch.tensor([sm, da], dtype=torch.float64)
+        if self.world > 1:
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t[0]), float(t[1])
 
     def gather_solution(self):
         """x, w1, w2 (V) and q (E,3) of the whole graph on every rank (verification helper)."""
@@ -271,9 +310,18 @@ class HipSubdomainSolver:
         with self.stream_context():
             buf = self.torch.empty(VREC * self.n_send[0] + EREC * self.n_send[1],
                                    dtype=self.torch.float32, device=self.device)
+        return self.halo_pack_into(buf)
+
+    def halo_pack_into(self, buf):
+        """Pack into a caller-owned (persistent) device buffer: no allocation per exchange."""
+        assert buf.is_cuda and buf.dtype == self.torch.float32 and buf.is_contiguous()
         self._l.check(self.reg._lib.flame_hip_halo_pack(self.reg._h, self._C.c_void_p(buf.data_ptr()),
                                                         self._stream()), "flame_hip_halo_pack")
         return buf
+
+    def costs_owned(self, params, vmask, emask):
+        self.stream.synchronize()
+        return self.reg.costs_masked(params, vmask, emask)
 
     def halo_unpack(self, buf):
         assert buf.is_cuda and buf.dtype == self.torch.float32 and buf.is_contiguous()

@@ -66,6 +66,7 @@ SYMBOLS = {
     "flame_hip_sync": (C.c_int, [_VP]),
     "flame_hip_last_solve_ms": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(_I32)]),
     "flame_hip_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "flame_hip_costs_masked": (C.c_int, [_VP, C.POINTER(Params), _VP, _VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flame_hip_triangles": (C.c_int, [_VP, _VP, C.POINTER(TriParams), _VP, _VP, _VP]),
     "flame_hip_frame_results": (C.c_int, [_VP, C.POINTER(Params), C.c_float, _VP, C.POINTER(TriParams),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), _VP, _VP, _VP, _VP,

@@ -223,6 +223,16 @@ class GraphRegularizer:
                  "flame_hip_costs")
         return s.value, d.value
 
+    def costs_masked(self, params, vmask=None, emask=None):
+        """Costs over the flagged vertices / edges only (caller's order; None = all): what a
+        multi-GPU subdomain owns."""
+        vm = None if vmask is None else np.ascontiguousarray(vmask, np.uint8)
+        em = None if emask is None else np.ascontiguousarray(emask, np.uint8)
+        s, d = C.c_double(), C.c_double()
+        _l.check(self._lib.flame_hip_costs_masked(self._h, C.byref(params), _ptr(vm), _ptr(em), C.byref(s),
+                                                  C.byref(d)), "flame_hip_costs_masked")
+        return s.value, d.value
+
     def smoothnessCost(self, params):
         return self.costs(params)[0]
 

@@ -168,6 +168,11 @@ int flame_hip_graph_filter(flame_hip_graph* g, int32_t kind, int32_t passes);
 /* Replaces: smoothnessCost()/dataCost() behind the stat keys nltgv2_total_smoothness_cost and
  * nltgv2_total_data_cost (reference src/utils.cc:131-136).  Synchronises. */
 int flame_hip_costs(flame_hip_graph* g, const flame_hip_params* p, double* smooth, double* data);
+/* The same sums restricted to flagged vertices (vmask, V bytes, caller's order, NULL = all) and
+ * edges (emask, E bytes, NULL = all): a multi-GPU subdomain sums what it OWNS and the
+ * ranks all-reduce the two doubles ("final cost reduction: one ncclAllReduce of 2 doubles"). */
+int flame_hip_costs_masked(flame_hip_graph* g, const flame_hip_params* p, const uint8_t* vmask,
+                           const uint8_t* emask, double* smooth, double* data);
 
 /* Replaces: the per-triangle stage feeding getInverseDepthMesh (row a8).  Kinv row-major 3x3.
  * Outputs (any may be NULL): vtx_normals 3V, tri_valid T, tri_normals 3T.  Synchronises. */

@@ -26,14 +26,13 @@ def run_subdomains_one_gpu(g, world, depth, iters):
             send[(o, r)] = (send[(o, r)][0], s.eid[e].tolist())
     offs = []
     for r, s in enumerate(subs):
-        lv = {int(x): i for i, x in enumerate(s.vid[:s.n_own])}
-        le = {int(x): i for i, x in enumerate(s.eid)}
         sv, se, rv, re_ = [], [], [], []
         for o in range(world):
             if o == r:
                 continue
-            sv += [lv[x] for x in send[(r, o)][0]]
-            se += [le[x] for x in send[(r, o)][1]]
+            # global ids -> this rank's local numbering by binary search (both lists ascending)
+            sv += np.searchsorted(s.vid[:s.n_own], np.asarray(send[(r, o)][0], np.int64)).tolist()
+            se += np.searchsorted(s.eid, np.asarray(send[(r, o)][1], np.int64)).tolist()
             rv += s.recv_v.get(o, np.zeros(0, np.int32)).tolist()
             re_ += s.recv_e.get(o, np.zeros(0, np.int32)).tolist()
         i32 = lambda a: np.asarray(a, np.int32)  # noqa: E731

@@ -46,6 +46,21 @@ class OracleSubdomainSolver:
     def download(self):
         return self.o.x, self.o.w1, self.o.w2, self.o.q
 
+    def costs_owned(self, params, vmask, emask):
+        # the oracle's cost terms over the owned vertices / edges (float32 terms, float64 sums)
+        o = self.o
+        e = np.flatnonzero(emask)
+        i, j = o.edges[e, 0], o.edges[e, 1]
+        d = o.pos[i] - o.pos[j]
+        t = o.x[i] - o.x[j]
+        t = np.float32(t - o.w1[i] * d[:, 0])  # (test-side arithmetic: compared with a tolerance)
+        t = np.float32(t - o.w2[i] * d[:, 1])
+        sm = (o.alpha[e] * np.abs(t)).astype(np.float64) + (o.beta[e] * np.abs(o.w1[i] - o.w1[j])).astype(np.float64) \
+            + (o.beta[e] * np.abs(o.w2[i] - o.w2[j])).astype(np.float64)
+        v = np.flatnonzero(vmask)
+        da = ((np.float32(params.data_factor) * o.wgt[v]) * np.abs(o.x[v] - o.z[v])).astype(np.float64)
+        return float(sm.sum()), float(da.sum())
+
 
 def _free_port():
     s = socket.socket()
@@ -64,15 +79,18 @@ def _worker(rank, world, port, V, depth, iters, out):
         ps = fdist.PartitionedSolver(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt,
                                      lambda *a: OracleSubdomainSolver(*a), depth=depth)
         assert ps.sub.n_own > 0 and len(ps.peers) >= 1
-        ps.step(p, iters)
+        # two step() calls: the second continues on whatever halo rings the first left valid
+        ps.step(p, iters // 2)
+        ps.step(p, iters - iters // 2)
         x, w1, w2, q = ps.gather_solution()
+        sm, da = ps.costs(p)  # owned sums + one all-reduce of 2 doubles
         # replicas mode: frames are sharded round-robin, aggregate = max time over ranks
         frames = fdist.shard_frames(7, rank, world)
         t = torch.tensor([float(len(frames))])
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         assert int(t.item()) == 7
         if rank == 0:
-            np.savez(out, x=x, w1=w1, w2=w2, q=q, halo=len(ps.sub.vid) - ps.sub.n_own)
+            np.savez(out, x=x, w1=w1, w2=w2, q=q, halo=len(ps.sub.vid) - ps.sub.n_own, costs=np.array([sm, da]))
     finally:
         dist.destroy_process_group()
 
@@ -89,6 +107,8 @@ def test_partitioned_solve_matches_serial_oracle(tmp_path, world, depth, iters, 
     assert int(r["halo"]) > 0
     for k, want in (("x", o.x), ("w1", o.w1), ("w2", o.w2), ("q", o.q)):
         assert np.array_equal(r[k].view(np.uint32), want.view(np.uint32)), k
+    so, do = o.costs(default_params())  # whole-graph costs = all-reduced owned sums
+    assert abs(r["costs"][0] - so) <= 1e-6 * so and abs(r["costs"][1] - do) <= 1e-6 * do, (r["costs"], so, do)
 
 
 def test_rcb_and_subdomain_structure():

@@ -66,6 +66,38 @@ def test_config5_200k_eight_subdomains(gpu, g200k):
         sv.reg.close()
 
 
+def test_config4_50k_two_subdomains_full_size(gpu):
+    """BASELINE config 4 at FULL size: the 50 000-vertex graph cut 2-way (RCB; METIS is absent from the
+    image), halo depth 16, 500 PD iterations, both subdomains through the real kernels on this one GPU
+    (what RCCL moves between two MI355X travels through device buffers here): own state bit-exact
+    against the oracle, and the owned-cost sums add up to the whole graph's costs (the all-reduce of
+    2 doubles of partition mode)."""
+    g, iters = graphgen.named("50k")
+    assert g.V == 50000 and iters == 500
+    o = make_oracle(g)
+    o.solve(oracle_params(), iters)
+    subs, solvers = run_subdomains_one_gpu(g, 2, 16, iters)
+    sm = da = 0.0
+    for r, s in enumerate(subs):
+        x, w1, w2, q = solvers[r].download()
+        own = slice(0, s.n_own)
+        assert 24000 < s.n_own < 26000 and len(s.vid) - s.n_own > 1000  # a real cut with a deep halo
+        assert_bit_equal(x[own], o.x[s.vid[own]], "subdomain %d x" % r)
+        assert_bit_equal(w1[own], o.w1[s.vid[own]], "subdomain %d w1" % r)
+        oe = np.flatnonzero(s.e_owned)
+        assert_bit_equal(q[oe], o.q[s.eid[oe]], "subdomain %d q" % r)
+        # 500 = 31 x 16 + 4: the last chunk left 12 halo rings exact, so owned edges see exact targets
+        vmask = np.zeros(len(s.vid), np.uint8)
+        vmask[own] = 1
+        a, b = solvers[r].costs_owned(default_params(), vmask, s.e_owned.astype(np.uint8))
+        sm += a
+        da += b
+    so, do = o.costs(oracle_params())
+    assert abs(sm - so) <= 1e-9 * so and abs(da - do) <= 1e-9 * do, (sm, so, da, do)
+    for sv in solvers:
+        sv.reg.close()
+
+
 def test_config3_euroc_10k(gpu):
     g, iters = graphgen.named("euroc")
     assert g.V == 10000

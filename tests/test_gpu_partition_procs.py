@@ -41,10 +41,12 @@ def _worker(rank, world, port, V, depth, iters, out):
         g = graphgen.synthetic(V, seed=31)
         ps = fdist.PartitionedSolver(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, fdist.make_hip_solver(0),
                                      depth=depth)
-        ps.step(default_params(), iters)
+        ps.step(default_params(), iters // 2)          # two calls: the second continues on the halo
+        ps.step(default_params(), iters - iters // 2)   # rings the first left valid
         x, w1, w2, q = ps.gather_solution()
+        sm, da = ps.costs(default_params())             # owned sums (k_costs, masked) + all-reduce
         if rank == 0:
-            np.savez(out, x=x, w1=w1, w2=w2, q=q)
+            np.savez(out, x=x, w1=w1, w2=w2, q=q, costs=np.array([sm, da]))
     finally:
         dist.destroy_process_group()
 
@@ -60,6 +62,8 @@ def test_partitioned_hip_solver_processes(gpu, tmp_path, world, depth, iters):
     r = np.load(out)
     for k, want in (("x", o.x), ("w1", o.w1), ("w2", o.w2), ("q", o.q)):
         assert np.array_equal(r[k].view(np.uint32), want.view(np.uint32)), k
+    so, do = o.costs(oracle_params())
+    assert abs(r["costs"][0] - so) <= 1e-9 * so and abs(r["costs"][1] - do) <= 1e-9 * do, (r["costs"], so, do)
 
 
 @pytest.mark.parametrize("mode", ["replicas", "partition"])
