@@ -639,6 +639,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
                             &index_error, g->dflags, &nan_flag, stage_rest));
     if (nan_flag & 1) return FLAME_HIP_ERR_NAN;
     if (index_error) return FLAME_HIP_ERR_ARG;
+    const bool tiles_valid = ok;  // every tile was built (it may still be too large for LDS / a kernel config)
     if (ok) {
       int e_max = 0, upd_max = 0;
       lds_max = 0;
@@ -649,6 +650,15 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       }
       ok = lds_max <= g->opt.lds_bytes &&
            pick_tile_config(g->opt.tile_threads, e_max, upd_max, &cfg_nt, &cfg_ept, &cfg_vpt);
+    }
+    // Only the LARGEST tile decides whether a partition fits, and before the cost balance that is a
+    // border tile (long hull edges => a halo up to 1.5 x the median): balance first, shrink only
+    // if the balanced partition does not fit either.
+    if (!ok && tiles_valid && g->opt.balance && !balanced && ntiles >= 16) {
+      balanced = true;
+      refine_left = kBalanceRefinePasses;
+      HIPCHK(g->planner.weights_from_tiles(s, V, A));
+      continue;
     }
     if (ok && g->opt.balance && !balanced && ntiles >= 16) {
       balanced = true;

@@ -622,8 +622,23 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     }
     lap("concat");
     TileCfg cfg{};
+    const bool tiles_valid = ok;
     if (ok && lds_max > lds_cap) ok = false;
     if (ok && !pick_cfg(opt.tile_threads, e_max, upd_max, &cfg)) ok = false;
+    // only the LARGEST tile decides whether a partition fits, and before the cost balance that is a
+    // border tile: balance first, shrink only if the balanced partition does not fit either
+    // (same rule in flame_hip.cpp upload_device_plan)
+    if (!ok && tiles_valid && opt.balance && !balanced && !batch && !single && ntiles >= 16) {
+      balanced = true;
+      refine_left = kBalanceRefinePasses;
+      vweight.assign(V, 1);
+      for (int t = 0; t < ntiles; ++t) {
+        const TileDesc& D = P.tiles[t];
+        const int32_t wt = tile_weight(D);
+        for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k) vweight[P.v_i2o[k]] = wt;
+      }
+      continue;
+    }
     // Refinement passes of the cost balance (first upload only; a frame stream refines through the
     // cost-density grid from frame to frame): every vertex weight is scaled by its tile's cost over
     // the mean tile cost and the bisection is redone.  Integer arithmetic, see plan_dev.hip
