@@ -249,6 +249,10 @@ struct flame_hip_graph {
   float* dl_n = nullptr;  // 3V floats (vertex normals of flame_hip_frame_results)
   // device plan builder (row f3) and the staged inputs it reads (caller's order)
   int plan_device = 1;
+  int plan_reuse = 1;          // frame streams: partition from the previous frame's tile map
+  bool plan_reused = false;    // the current plan's partition came from the map
+  int reuse_tile_own_opt = 0;  // the "tile_own" option the map was made with
+  int reuse_backoff = 0, reuse_skip = 0;  // frames to sit out after a rejected reuse (doubles, <= 16)
   DevPlanner planner;
   float2* in_pos = nullptr;
   int2* in_edges = nullptr;
@@ -446,6 +450,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->opt.d_sign = value;
   } else if (k == "plan_device") {
     g->plan_device = value != 0;
+  } else if (k == "plan_reuse") {
+    g->plan_reuse = value != 0;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -475,6 +481,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "tile_loc_edges") { int64_t s = 0; for (auto& t : P.tiles) s += t.e_loc; *value = s; }
   else if (k == "device") *value = g->device;
   else if (k == "plan_on_device") *value = P.on_device ? 1 : 0;
+  else if (k == "plan_reused") *value = (P.on_device && g->plan_reused) ? 1 : 0;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
     int khz = 0;
@@ -619,13 +626,24 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   int ntiles = 0, cfg_nt = 0, cfg_ept = 0, cfg_vpt = 0;
   int64_t lds_max = 0;
   std::vector<TileDesc>& tiles = P.tiles;
-  for (int attempt = 0; attempt < 7 + kBalanceRefinePasses && !built; ++attempt) {
-    ntiles = (V + tile_own - 1) / tile_own;
+  // A frame stream re-uses the previous frame's PARTITION (the tile of every spatial cell) while the
+  // frames stay alike: no sorts, no bisection (option "plan_reuse", default on; results are the
+  // oracle's bits on any partition).  One try; a frame it does not suit is bisected as usual.
+  bool try_reuse = g->plan_reuse && g->opt.balance && g->planner.map_usable(V, depth) &&
+                   g->opt.tile_own == g->reuse_tile_own_opt;
+  if (try_reuse && g->reuse_skip > 0) { --g->reuse_skip; try_reuse = false; }  // back-off after rejections
+  g->plan_reused = false;
+  for (int attempt = 0; attempt < 8 + kBalanceRefinePasses && !built; ++attempt) {
+    const bool reusing = try_reuse;
+    try_reuse = false;
+    ntiles = reusing ? g->planner.map_tiles() : (V + tile_own - 1) / tile_own;
     if (ntiles < 2) return 0;
     // every retry halves tile_own: the tile count may have outgrown the builder's segment tables
     // (kSegCap) -- the host builder shrinks safely in that case
-    if (attempt > 0 && !DevPlanner::eligible(g->opt, V, E, T, tile_own, depth, false, g->opt.lds_bytes)) return 0;
-    if (!balanced) {
+    if (attempt > 0 && !reusing && !DevPlanner::eligible(g->opt, V, E, T, tile_own, depth, false, g->opt.lds_bytes)) return 0;
+    if (reusing) {
+      g->planner.reuse_partition();
+    } else if (!balanced) {
       if (g->opt.balance && ntiles >= 16 && g->planner.grid_tiles() == ntiles) {
         g->planner.set_weights_from_grid();  // a frame stream balances in ONE pass
         balanced = true;
@@ -650,6 +668,14 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       }
       ok = lds_max <= g->opt.lds_bytes &&
            pick_tile_config(g->opt.tile_threads, e_max, upd_max, &cfg_nt, &cfg_ept, &cfg_vpt);
+    }
+    if (reusing) {
+      if (ok) { built = true; g->plan_reused = true; g->reuse_backoff = 0; break; }
+      g->planner.drop_map();  // scene change / does not fit: exact bisection from here on
+      g->reuse_backoff = std::min(16, std::max(1, 2 * g->reuse_backoff));  // a wasted attempt costs a build:
+      g->reuse_skip = g->reuse_backoff;                                     // try again 1, 2, 4 ... 16 frames later
+      balanced = false;
+      continue;
     }
     // Only the LARGEST tile decides whether a partition fits, and before the cost balance that is a
     // border tile (long hull edges => a halo up to 1.5 x the median): balance first, shrink only
@@ -682,7 +708,13 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   }
   if (!built) return 0;
   lap("plan build");
-  if (g->opt.balance && ntiles >= 16) HIPCHK(g->planner.update_grid(s, V, ntiles, in, A));
+  if (g->opt.balance && ntiles >= 16) {
+    HIPCHK(g->planner.update_grid(s, V, ntiles, in, A));  // cost-density grid + the tile map of this frame
+    g->planner.set_map_depth(depth);
+    g->reuse_tile_own_opt = g->opt.tile_own;
+  } else {
+    g->planner.drop_map();
+  }
   // ---- host-side description of the plan ----
   P.V = V; P.E = E; P.T = T;
   P.on_device = true;

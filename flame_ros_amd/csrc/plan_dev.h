@@ -104,12 +104,33 @@ class DevPlanner {
   int grid_tiles() const { return grid_tiles_; }
   void drop_grid() { grid_tiles_ = 0; }
 
+  // Partition reuse on a frame stream (plan_dev.hip "Partition REUSE"): update_grid() also records
+  // the tile of every vertex in a pyramid of spatial cells; while the next frames hold about as many
+  // vertices (within 1/8) at the same halo depth, reuse_partition() makes the NEXT build() read its
+  // partition from that map (map_tiles() tiles) instead of bisecting.  A build that rejects the
+  // reused partition drops the map (the caller then bisects as usual).
+  int map_tiles() const { return map_tiles_; }
+  bool map_usable(int32_t V, int depth) const {
+    return map_tiles_ >= 2 && depth == map_depth_ && V >= 2 * map_tiles_ &&
+           8ll * (V > map_V_ ? V - map_V_ : map_V_ - V) <= map_V_;
+  }
+  void reuse_partition() { reuse_next_ = true; }
+  void set_map_depth(int depth) { map_depth_ = depth; }
+  void drop_map() { map_tiles_ = 0; }
+  bool last_build_reused() const { return last_reused_; }
+
  private:
   hipError_t reserve(int32_t V, int32_t E, int32_t T, int ntiles);
+  hipError_t scan_i32(hipStream_t s, int lane, const int32_t* in, int32_t* out, int64_t n, bool inclusive,
+                      void* cub_tmp, size_t cub_bytes);
   void release();
 
   int weight_mode_ = 0;
   int grid_tiles_ = 0;
+  int map_tiles_ = 0, map_depth_ = 0;
+  int32_t map_V_ = 0;
+  bool reuse_next_ = false, last_reused_ = false;
+  int32_t* cell_pyr_ = nullptr;    // tile + 1 of the vertices in every cell of a 128/32/8/1 pyramid
   bool use_subtree_ = true;  // deep bisection levels in one LDS kernel
   int sub_extra_levels_ = 0; // hand-over level pushed down after a subtree overflow
   bool attr_set_ = false, sub_attr_set_ = false;  // dynamic-LDS opt-in done on this handle's device
@@ -133,6 +154,11 @@ class DevPlanner {
   int32_t* tile_ext_ = nullptr;  // ntiles * kCapExt (pass-1 vertex lists)
   int32_t* tile_meta_ = nullptr; // ntiles * kMetaWords (pass-1 counts, ring ends, offsets)
   int32_t* flags_ = nullptr;     // error / totals words
+  // look-back state of the single-launch scans (plan_dev.hip "Single-launch prefix sums"): one set per
+  // stream the builder scans on; a flag matches only the launch (epoch) that wrote it
+  unsigned long long* scan_agg_[2] = {nullptr, nullptr};
+  uint32_t* scan_flag_[2] = {nullptr, nullptr};
+  uint32_t scan_epoch_[2] = {0, 0};
   long long* grid_sum_ = nullptr;  // kGrid^2
   int32_t* grid_cnt_ = nullptr;    // kGrid^2
   int32_t* grid_w_ = nullptr;      // kGrid^2

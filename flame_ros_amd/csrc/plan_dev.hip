@@ -247,6 +247,106 @@ inline void zero4(hipStream_t s, int32_t* a, int64_t na, int32_t* b = nullptr, i
   hipLaunchKernelGGL(k_zero4, dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (m + 255) / 256))), dim3(256), 0, s, j);
 }
 
+// exclusive prefix of one value per thread over the workgroup (a[] = scratch of >= 16 entries):
+// shuffle scan inside the wave, the 16 wave totals through LDS -- two barriers
+template <class T>
+__device__ __forceinline__ T block_exclusive(T v, T* a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const T u = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += u;
+  }
+  if (lane == 63) a[wave] = inc;
+  __syncthreads();
+  T base = 0;
+  for (int w = 0; w < wave; ++w) base += a[w];
+  __syncthreads();
+  return base + inc - v;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Single-launch prefix sums.  hipcub's device scan is two launches (look-back state init + scan) and
+// a plan build has a dozen scans of a few 10^4..10^5 items on its critical path, every dependent
+// launch ~4-5 us of host-bound latency: here a scan is ONE launch.  A block scans its tile of
+// kScanTile items, publishes its total {value, then -- after s_waitcnt vmcnt(0) -- the launch's epoch
+// as the flag; agent-scope (sc1) stores} and reads the totals of the blocks before it (sc1 loads,
+// polling the flag).  No reset between launches (a flag only ever matches the launch that wrote it);
+// all blocks are co-resident (grid <= kScanMaxBlocks <= 2 blocks per CU), so polling cannot starve
+// the producer; the poll is bounded all the same (flags word, bit 32: the build is then rejected and
+// redone by the host builder).  The input of a tile comes through a functor, so the level loop's
+// gather / flag kernels are fused into their scans.
+// ------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kScanItems;
+constexpr int kScanMaxBlocks = 448;
+struct ScanState {
+  unsigned long long* agg;  // kScanMaxBlocks block totals
+  uint32_t* flag;           // kScanMaxBlocks: epoch of the launch that published agg[b]
+  uint32_t epoch;
+  int32_t* err;             // builder flags word
+};
+
+template <class T>
+__device__ __forceinline__ T scan_lookback(T block_total, const ScanState& st, T* sh /* >= 1 entry */) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    __hip_atomic_store(&st.agg[b], (unsigned long long)block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop its own wait: MI355X guide, hand-offs)
+    __hip_atomic_store(&st.flag[b], st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 64) {
+    T acc = 0;
+    for (int j = tid; j < b; j += 64) {
+      int spin = 0;
+      while (__hip_atomic_load(&st.flag[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != st.epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spin > (1 << 22)) { atomicOr(st.err, 32); break; }
+      }
+      acc += (T)__hip_atomic_load(&st.agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (tid == 0) sh[0] = acc;
+  }
+  __syncthreads();
+  return sh[0];
+}
+
+// out[i] = sum of load(j) for j < i (exclusive) or j <= i (inclusive); store(i, item, prefix)
+template <class T, bool INCLUSIVE, class Load, class Store>
+__device__ __forceinline__ void scan_tile(int64_t n, const ScanState& st, Load load, Store store) {
+  __shared__ T sh_a[16];
+  __shared__ T sh_p[2];
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * kScanItems;
+  T v[kScanItems];
+  T sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? load(base + k) : (T)0;
+    sum += v[k];
+  }
+  const T ex = block_exclusive<T>(sum, sh_a);
+  if (tid == kScanThreads - 1) sh_p[1] = ex + sum;
+  __syncthreads();
+  const T before = scan_lookback<T>(sh_p[1], st, sh_p);
+  T run = before + ex;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) store(base + k, v[k], INCLUSIVE ? run + v[k] : run);
+    run += v[k];
+  }
+}
+
+template <bool INCLUSIVE>
+__global__ __launch_bounds__(kScanThreads) void k_scan_i32(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                           int64_t n, ScanState st) {
+  scan_tile<int32_t, INCLUSIVE>(n, st, [&](int64_t i) { return in[i]; },
+                                [&](int64_t i, int32_t, int32_t p) { out[i] = p; });
+}
+
 // ---- global bisection levels on two presorted lists ----
 // lx / ly = the vertex ids sorted along x / along y in the total order (coordinate, id), both grouped
 // by segment (a segment is the same position range [lo, hi) in both).  A level never sorts: the box
@@ -277,6 +377,16 @@ __global__ __launch_bounds__(256) void k_lvl_wgather(int32_t V, const int32_t* _
   wsort[p] = w_int[axis[seg_pos[p]] ? ly[p] : lx[p]];
 }
 
+// the same fused into its inclusive scan (one launch instead of gather + two scan launches)
+__global__ __launch_bounds__(kScanThreads) void k_lvl_wscan(int32_t V, const int32_t* __restrict__ seg_pos,
+                                                            const int32_t* __restrict__ axis,
+                                                            const uint32_t* __restrict__ lx, const uint32_t* __restrict__ ly,
+                                                            const int32_t* __restrict__ w_int, long long* wsort,
+                                                            long long* wscan, ScanState st) {
+  scan_tile<long long, true>(V, st, [&](int64_t p) { return (long long)w_int[axis[seg_pos[p]] ? ly[p] : lx[p]]; },
+                             [&](int64_t p, long long w, long long inc) { wsort[p] = w; wscan[p] = inc; });
+}
+
 // side of every vertex (1 = right child) = its position along its segment's axis against the split
 __global__ __launch_bounds__(256) void k_lvl_side(int32_t V, const int32_t* __restrict__ seg_pos,
                                                   const int32_t* __restrict__ axis,
@@ -296,6 +406,15 @@ __global__ __launch_bounds__(256) void k_lvl_flags(int32_t V, const uint32_t* __
   const int32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= V) return;
   flags[p] = (long long)side[lx[p]] | ((long long)side[ly[p]] << 32);
+}
+
+// the flags fused into their inclusive scan
+__global__ __launch_bounds__(kScanThreads) void k_lvl_fscan(int32_t V, const uint32_t* __restrict__ lx,
+                                                            const uint32_t* __restrict__ ly,
+                                                            const int32_t* __restrict__ side, long long* flags,
+                                                            long long* scan, ScanState st) {
+  scan_tile<long long, true>(V, st, [&](int64_t p) { return (long long)side[lx[p]] | ((long long)side[ly[p]] << 32); },
+                             [&](int64_t p, long long f, long long inc) { flags[p] = f; scan[p] = inc; });
 }
 
 // stable partition of both lists + the segment of every position on the next level
@@ -352,25 +471,6 @@ constexpr size_t kSubLdsBytes = (size_t)kSubCap * (2 + 2 + 4 + 1 + 1) + (size_t)
                                 (size_t)kSubLeaves * (8 + 5) * 4 + (size_t)kSubLeaves * 2 * 8 + kSubSortBytes + 64;
 
 static_assert(kSubLdsBytes <= 160 * 1024 - 256, "subtree kernel LDS");
-
-// exclusive prefix of one value per thread over the workgroup (a[] = scratch of >= 16 entries):
-// shuffle scan inside the wave, the 16 wave totals through LDS -- two barriers
-template <class T>
-__device__ __forceinline__ T block_exclusive(T v, T* a) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  T inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const T u = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += u;
-  }
-  if (lane == 63) a[wave] = inc;
-  __syncthreads();
-  T base = 0;
-  for (int w = 0; w < wave; ++w) base += a[w];
-  __syncthreads();
-  return base + inc - v;
-}
 
 __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg_cur, SegTab cur, SegTab out,
                                                              int32_t* nseg_out, int32_t ntiles, int32_t* perm,
@@ -661,8 +761,10 @@ __global__ __launch_bounds__(256) void k_tile_order(int32_t V, int32_t ntiles, c
     if (p < n) {
       const int32_t v = v_i2o[lo + p];
       const float2 q = pos[v];
-      const uint32_t qx = (uint32_t)(65535.0f * (q.x - mnx) / fmaxf(mxx - mnx, 1e-20f));
-      const uint32_t qy = (uint32_t)(65535.0f * (q.y - mny) / fmaxf(mxy - mny, 1e-20f));
+      // (clamped: identity for a box that is this frame's own; a reused partition keeps the box of
+      // the frame it was made from)
+      const uint32_t qx = (uint32_t)(65535.0f * (fminf(fmaxf(q.x, mnx), mxx) - mnx) / fmaxf(mxx - mnx, 1e-20f));
+      const uint32_t qy = (uint32_t)(65535.0f * (fminf(fmaxf(q.y, mny), mxy) - mny) / fmaxf(mxy - mny, 1e-20f));
       k = ((uint64_t)(spread16(qx) | (spread16(qy) << 1)) << 32) | (uint32_t)v;
     }
     keys[p] = k;
@@ -1328,6 +1430,87 @@ __device__ __forceinline__ int grid_cell_dev(const float* b, float2 q) {
   return cy * Plan::kGrid + cx;
 }
 
+// ------------------------------------------------------------------------------------------
+// Partition REUSE on a frame stream.  The solver's results do not depend on the partition (every
+// path produces the oracle's bits), the partition only has to be spatially compact and balanced --
+// and consecutive frames of a camera see almost the same feature distribution.  After every build the
+// tile of each vertex is rasterised into a pyramid of spatial cells (256^2 ... 8^2, 1 cells over the
+// frame's bounding box; value = tile + 1, the larger id wins a shared cell: integer atomicMax on the
+// three finest levels, order-free; the coarser ones are reduced from those).  The NEXT frame looks its vertices up in that pyramid (finest non-empty
+// level), counts the tiles, and a stable counting pass groups the vertices by tile: three short
+// kernels instead of two device sorts, the level loop and the subtree kernel (~0.3 ms at 50 k).
+// Inside a tile the Morton order of stage B applies as ever.  A frame whose tiles come out empty or
+// much larger than planned (scene change) is rebuilt by exact bisection.
+// ------------------------------------------------------------------------------------------
+constexpr int kPyrLevels = 7;
+constexpr int kPyrAtomicLevels = 3;  // written per vertex (>= 4096 cells: no contended atomics); the coarser
+                                     // levels are reduced from level 2 by k_grid_final
+__device__ constexpr int kPyrDims[kPyrLevels] = {256, 128, 64, 32, 16, 8, 1};
+__device__ constexpr int kPyrOff[kPyrLevels] = {0, 65536, 65536 + 16384, 65536 + 16384 + 4096, 65536 + 16384 + 4096 + 1024,
+                                                65536 + 16384 + 4096 + 1024 + 256, 65536 + 16384 + 4096 + 1024 + 256 + 64};
+constexpr int kPyrCells = 65536 + 16384 + 4096 + 1024 + 256 + 64 + 1;
+constexpr int kPyrAtomicCells = 65536 + 16384 + 4096;
+
+__device__ __forceinline__ int pyr_cell(const float* b, float2 q, int level) {
+  const int d = kPyrDims[level];
+  const float fx = (q.x - b[0]) / fmaxf(b[2] - b[0], 1e-20f);
+  const float fy = (q.y - b[1]) / fmaxf(b[3] - b[1], 1e-20f);
+  const int cx = max(0, min(d - 1, (int)(fx * (float)d)));
+  const int cy = max(0, min(d - 1, (int)(fy * (float)d)));
+  return kPyrOff[level] + cy * d + cx;
+}
+
+// tile of every vertex of the NEW frame from the previous frame's pyramid; tile counts
+__global__ __launch_bounds__(256) void k_reuse_assign(int32_t V, int32_t ntiles, const float2* __restrict__ pos,
+                                                      const float* __restrict__ bounds,
+                                                      const int32_t* __restrict__ pyr, int32_t* vt, int32_t* tile_cnt) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const float2 q = pos[v];
+  int32_t t = 0;
+  for (int l = 0; l < kPyrLevels; ++l) {
+    const int32_t c = pyr[pyr_cell(bounds, q, l)];
+    if (c > 0) { t = c - 1; break; }
+  }
+  t = max(0, min(t, ntiles - 1));
+  vt[v] = t;
+  atomicAdd(&tile_cnt[t], 1);
+}
+
+// one block: tile ranges from the counts; a tile that is empty or above `cap` vertices rejects the reuse
+__global__ __launch_bounds__(kSegCap) void k_reuse_offsets(int32_t V, int32_t ntiles, int32_t cap,
+                                                           const int32_t* __restrict__ tile_cnt, SegTab t, int32_t* nseg,
+                                                           int32_t* flags) {
+  __shared__ int32_t sc[kSegCap];
+  const int s = threadIdx.x;
+  const int32_t c = s < ntiles ? tile_cnt[s] : 0;
+  sc[s] = c;
+  __syncthreads();
+  for (int off = 1; off < kSegCap; off <<= 1) {
+    const int32_t v = s >= off ? sc[s - off] : 0;
+    __syncthreads();
+    sc[s] += v;
+    __syncthreads();
+  }
+  if (s < ntiles) {
+    t.lo[s] = sc[s] - c; t.hi[s] = sc[s]; t.leaves[s] = 1; t.first[s] = s;
+    if (c < 1 || c > cap) atomicOr(&flags[0], 64);
+  }
+  if (s == 0) nseg[0] = ntiles;
+  if (s == kSegCap - 1 && sc[s] != V) atomicOr(&flags[0], 64);
+}
+
+__global__ __launch_bounds__(256) void k_reuse_scatter(int32_t V, const int32_t* __restrict__ vt,
+                                                       const int32_t* __restrict__ tlo, int32_t* cursor, int32_t* perm,
+                                                       int32_t* seg_pos) {
+  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const int32_t t = vt[v];
+  const int32_t p = tlo[t] + atomicAdd(&cursor[t], 1);  // (order inside a tile is set by stage B)
+  perm[p] = v;
+  seg_pos[p] = t;
+}
+
 __global__ __launch_bounds__(256) void k_weights_from_grid(int32_t V, const float2* __restrict__ pos,
                                                            const float* __restrict__ bounds,
                                                            const int32_t* __restrict__ grid_w, int32_t* w_int) {
@@ -1340,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
                                                     const int32_t* __restrict__ tile_of_int,
                                                     const TileDesc* __restrict__ tiles,
                                                     const float* __restrict__ bounds,
-                                                    unsigned long long* sum, int32_t* cnt) {
+                                                    unsigned long long* sum, int32_t* cnt, int32_t* pyr) {
   // vertices that are neighbours in internal order (same tile, Morton order) fall into the same
   // cell: accumulate per workgroup in LDS, flush the touched cells once (integer sums: any order)
   __shared__ unsigned long long s_sum[Plan::kGrid * Plan::kGrid];
@@ -1349,9 +1532,15 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
   __syncthreads();
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k < V) {
-    const int c = grid_cell_dev(bounds, pos[v_i2o[k]]);
+    const float2 q = pos[v_i2o[k]];
+    const int c = grid_cell_dev(bounds, q);
     atomicAdd(&s_sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]]));
     atomicAdd(&s_cnt[c], 1);
+    if (pyr) {  // the tile map the next frame's partition is read from (partition reuse)
+      const int32_t tv = tile_of_int[k] + 1;
+#pragma unroll
+      for (int l = 0; l < kPyrAtomicLevels; ++l) atomicMax(&pyr[pyr_cell(bounds, q, l)], tv);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < Plan::kGrid * Plan::kGrid; c += 256)
@@ -1360,8 +1549,21 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
 
 __global__ __launch_bounds__(1024) void k_grid_final(int32_t V, const unsigned long long* sum,
                                                      const int32_t* cnt, int32_t* grid_w, const float* gbbox,
-                                                     float* bounds) {
+                                                     float* bounds, int32_t* pyr) {
   if (threadIdx.x < 4) bounds[threadIdx.x] = gbbox[threadIdx.x];  // the frame the grid was made from
+  if (pyr) {  // coarse levels of the tile map: max over the 2 x 2 (last step 8 x 8) children, level by level
+    for (int l = kPyrAtomicLevels; l < kPyrLevels; ++l) {
+      const int d = kPyrDims[l], dc = kPyrDims[l - 1], r = dc / d;
+      for (int c = threadIdx.x; c < d * d; c += 1024) {
+        const int cx = c % d, cy = c / d;
+        int32_t m = 0;
+        for (int yy = 0; yy < r; ++yy)
+          for (int xx = 0; xx < r; ++xx) m = max(m, pyr[kPyrOff[l - 1] + (cy * r + yy) * dc + cx * r + xx]);
+        pyr[kPyrOff[l] + c] = m;
+      }
+      __syncthreads();
+    }
+  }
   __shared__ unsigned long long s_tot[1024];
   const int c = threadIdx.x;  // kGrid * kGrid == 1024
   s_tot[c] = sum[c];
@@ -1467,9 +1669,12 @@ DevPlanner::~DevPlanner() { release(); }
 void DevPlanner::release() {
   void* ptrs[] = {cub_tmp_, keys_a_, keys_b_, vals_a_, vals_b_, seg_pos_, tile_of_int_, w_int_, wsort_, wscan_,
                   counts_, seg_tab_, estart_, tile_ext_, tile_meta_, flags_, grid_sum_, grid_cnt_, grid_w_,
-                  grid_bounds_, gbbox_, tcub_tmp_, tcnt_};
+                  grid_bounds_, gbbox_, tcub_tmp_, tcnt_, scan_agg_[0], scan_agg_[1], scan_flag_[0], scan_flag_[1],
+                  cell_pyr_};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  scan_agg_[0] = scan_agg_[1] = nullptr; scan_flag_[0] = scan_flag_[1] = nullptr;
+  cell_pyr_ = nullptr; map_tiles_ = 0; map_V_ = 0;
   if (hpin_) (void)hipHostFree(hpin_);
   hpin_ = nullptr; hpin_bytes_ = 0;
   if (s2_) (void)hipStreamDestroy(s2_);
@@ -1498,6 +1703,38 @@ bool DevPlanner::eligible(const PlanOptions& opt, int32_t V, int32_t E, int32_t 
   // device / option set with less is the host builder's
   if ((int64_t)kSubLdsBytes > lds_bytes || 160 * 1024 - 512 > lds_bytes) return false;
   return lds2 <= lds_bytes;
+}
+
+// the look-back state of the next scan launch on a lane (epochs never repeat between resets)
+static hipError_t scan_state(hipStream_t s, unsigned long long* agg, uint32_t* flag, uint32_t* epoch, int32_t* err,
+                             ScanState* st) {
+  if (*epoch == 0xfffffff0u) {  // wrap: forget every flag written so far
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t) * kScanMaxBlocks, s);
+    if (e != hipSuccess) return e;
+    *epoch = 0;
+  }
+  st->agg = agg; st->flag = flag; st->epoch = ++*epoch; st->err = err;
+  return hipSuccess;
+}
+
+// One-launch exclusive / inclusive prefix sum of n int32 (falls back to hipcub beyond the co-resident
+// grid).  `lane` selects the look-back state: 0 = the builder's main stream, 1 = its second stream
+// (two scans may be in flight at once, one per stream).
+hipError_t DevPlanner::scan_i32(hipStream_t s, int lane, const int32_t* in, int32_t* out, int64_t n, bool inclusive,
+                                void* cub_tmp, size_t cub_bytes) {
+  if (n <= 0) return hipSuccess;
+  const int64_t nb = (n + kScanTile - 1) / kScanTile;
+  static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B
+  if (nb > kScanMaxBlocks || !scan_agg_[lane] || force_cub) {
+    size_t tb = cub_bytes;
+    return inclusive ? hipcub::DeviceScan::InclusiveSum(cub_tmp, tb, in, out, (int)n, s)
+                     : hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, in, out, (int)n, s);
+  }
+  ScanState st;
+  HIPRET(scan_state(s, scan_agg_[lane], scan_flag_[lane], &scan_epoch_[lane], flags_, &st));
+  if (inclusive) hipLaunchKernelGGL(k_scan_i32<true>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, in, out, n, st);
+  else hipLaunchKernelGGL(k_scan_i32<false>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, in, out, n, st);
+  return hipGetLastError();
 }
 
 hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
@@ -1544,10 +1781,17 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     // 2 tables x 4 arrays, bbox (4), mid_raw x 2, child_base, mid_out, nseg x 2 (+ pad), axis
     HIPRET(dalloc(&seg_tab_, (size_t)kSegCap * 17 + 32));
     HIPRET(dalloc(&flags_, 8));
+    for (int l = 0; l < 2; ++l) {
+      HIPRET(dalloc(&scan_agg_[l], (size_t)kScanMaxBlocks));
+      HIPRET(dalloc(&scan_flag_[l], (size_t)kScanMaxBlocks));
+      HIPRET(hipMemset(scan_flag_[l], 0, sizeof(uint32_t) * kScanMaxBlocks));
+      scan_epoch_[l] = 0;
+    }
     HIPRET(dalloc(&grid_sum_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_cnt_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_w_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_bounds_, 4)); HIPRET(dalloc(&gbbox_, 4));
+    HIPRET(dalloc(&cell_pyr_, (size_t)kPyrCells));
   }
   {  // D2H copies land in page-locked memory (a copy into pageable memory is staged and waited for)
     const size_t need = 256 + sizeof(TileDesc) * (size_t)std::max<int64_t>(ntiles + ntiles / 4, 64);
@@ -1610,10 +1854,28 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // flags; the vertex order outputs (every entry is an index for the later stages, whatever the
   // partition); the triangle stage's counts and cursors
   zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, (T > 0 && in.tris) ? tcnt_ : nullptr, 2 * (int64_t)V + 2);
-  if (weight_mode_ == 2)  // (mode 1: w_int_ already holds the weights, see weights_from_tiles / _scale_)
+  const bool reuse = reuse_next_;  // the caller asked for the previous frame's partition (map_usable())
+  reuse_next_ = false;
+  last_reused_ = false;
+  if (weight_mode_ == 2 && !reuse)  // (mode 1: w_int_ already holds the weights, see weights_from_tiles / _scale_)
     hipLaunchKernelGGL(k_weights_from_grid, grid1(V), dim3(256), 0, s, V, in.pos, grid_bounds_, grid_w_, w_int_);
 
   // ---- stage A ----
+  int cur = 0;
+  if (reuse) {
+    // partition from the previous frame's tile map: lookup + counts, ranges, counting scatter
+    int32_t* tile_cnt = st + 12 * kSegCap;   // (mid_raw[0] / mid_raw[1]: free in this path)
+    int32_t* cursor = st + 13 * kSegCap;
+    int32_t* vt = w_int_;                    // (no weights in this path)
+    HIPRET(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * 2 * kSegCap, s));
+    hipLaunchKernelGGL(k_reuse_assign, grid1(V), dim3(256), 0, s, V, ntiles, in.pos, gbbox_, cell_pyr_, vt, tile_cnt);
+    // (cost-balanced partitions hold 0.5..1.8 x the mean on purpose; a tile that is too LARGE for LDS or
+    // a kernel configuration is found by the fit check of the caller like on any other partition)
+    const int32_t cap = (int32_t)std::min<int64_t>(kOrderCap, ((int64_t)V * 3) / ntiles + 16);
+    hipLaunchKernelGGL(k_reuse_offsets, dim3(1), dim3(kSegCap), 0, s, V, ntiles, cap, tile_cnt, tab[0], nseg, flags_);
+    hipLaunchKernelGGL(k_reuse_scatter, grid1(V), dim3(256), 0, s, V, vt, tab[0].lo, cursor, perm, seg_pos_);
+    last_reused_ = true;
+  } else {
   int levels = 0;
   while ((1 << levels) < ntiles) ++levels;
   // deep levels in LDS: from the first level whose segments hold <= kSubCap vertices (1.5 x margin
@@ -1651,22 +1913,39 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
   }
   hipLaunchKernelGGL(k_rcb_init, grid1(V), dim3(256), 0, s, V, ntiles, perm, seg_pos_, tab[0], nseg, bbox, mid_raw[0]);
-  int cur = 0, lb = 0;
+  int lb = 0;
   for (int lev = 0; lev < sub_level; ++lev, cur ^= 1, lb ^= 1) {
     hipLaunchKernelGGL(k_lvl_axis, dim3((unsigned)(((1 << lev) + 255) / 256)), dim3(256), 0, s, nseg + cur, tab[cur], LX[lb], LY[lb],
                        in.pos, axis, lev == 0 ? gbbox_ : nullptr);
+    const int64_t scan_blocks = ((int64_t)V + kScanTile - 1) / kScanTile;
+    static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B
+    const bool one_launch_scans = scan_blocks <= kScanMaxBlocks && !force_cub;
     if (weighted) {
-      hipLaunchKernelGGL(k_lvl_wgather, grid1(V), dim3(256), 0, s, V, seg_pos_, axis, LX[lb], LY[lb], w_int_, wsort_);
-      size_t tb = cub_bytes_;
-      HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+      if (one_launch_scans) {  // gather + inclusive scan in one launch
+        ScanState st;
+        HIPRET(scan_state(s, scan_agg_[0], scan_flag_[0], &scan_epoch_[0], flags_, &st));
+        hipLaunchKernelGGL(k_lvl_wscan, dim3((unsigned)scan_blocks), dim3(kScanThreads), 0, s, V, seg_pos_, axis, LX[lb],
+                           LY[lb], w_int_, wsort_, wscan_, st);
+      } else {
+        hipLaunchKernelGGL(k_lvl_wgather, grid1(V), dim3(256), 0, s, V, seg_pos_, axis, LX[lb], LY[lb], w_int_, wsort_);
+        size_t tb = cub_bytes_;
+        HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+      }
       hipLaunchKernelGGL(k_rcb_mid, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], wsort_, wscan_, mid_raw[cur]);
     }
     hipLaunchKernelGGL(k_rcb_split, dim3(1), dim3(kSegCap), 0, s, nseg + cur, nseg + (cur ^ 1), tab[cur], tab[cur ^ 1],
                        mid_raw[cur], mid_raw[cur ^ 1], weighted ? 1 : 0, child_base, mid_out, bbox);
     hipLaunchKernelGGL(k_lvl_side, grid1(V), dim3(256), 0, s, V, seg_pos_, axis, tab[cur].leaves, mid_out, LX[lb], LY[lb], side);
-    hipLaunchKernelGGL(k_lvl_flags, grid1(V), dim3(256), 0, s, V, LX[lb], LY[lb], side, wsort_);
-    size_t tb = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+    if (one_launch_scans) {  // side flags + inclusive scan in one launch
+      ScanState st;
+      HIPRET(scan_state(s, scan_agg_[0], scan_flag_[0], &scan_epoch_[0], flags_, &st));
+      hipLaunchKernelGGL(k_lvl_fscan, dim3((unsigned)scan_blocks), dim3(kScanThreads), 0, s, V, LX[lb], LY[lb], side, wsort_,
+                         wscan_, st);
+    } else {
+      hipLaunchKernelGGL(k_lvl_flags, grid1(V), dim3(256), 0, s, V, LX[lb], LY[lb], side, wsort_);
+      size_t tb = cub_bytes_;
+      HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+    }
     hipLaunchKernelGGL(k_lvl_scatter, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], mid_out, child_base, wsort_, wscan_,
                        LX[lb], LY[lb], LX[lb ^ 1], LY[lb ^ 1]);
   }
@@ -1687,6 +1966,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                        flags_);
     cur ^= 1;
   }
+  }  // (exact bisection)
   hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
   const SegTab leaf = tab[cur];  // lo = vstart, hi = vstart + n_own per tile
   lap("A rcb");
@@ -1706,8 +1986,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     int32_t* tcursor = tcnt_ + V + 1;
     hipLaunchKernelGGL(k_tri_count, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->v_o2i, A->tris, tcnt_,
                        flags_);
-    size_t tb2 = tcub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(tcub_tmp_, tb2, tcnt_, A->trow, V + 1, s2_));
+    HIPRET(scan_i32(s2_, 1, tcnt_, A->trow, (int64_t)V + 1, false, tcub_tmp_, tcub_bytes_));
     hipLaunchKernelGGL(k_tri_fill, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->tris, A->trow, tcursor,
                        reinterpret_cast<uint32_t*>(A->tinc));
     hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s2_, V, A->trow, nullptr,
@@ -1724,8 +2003,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     zero4(s, ecnt, 4 * (int64_t)V + 1, counts_, (int64_t)V + 1, reinterpret_cast<int32_t*>(wsort_), V);
     hipLaunchKernelGGL(k_edge_count, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, ecnt,
                        flags_);
-    size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, ecnt, eoff, 2 * V + 1, s));
+    HIPRET(scan_i32(s, 0, ecnt, eoff, 2 * (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
     hipLaunchKernelGGL(k_edge_fill, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, eoff,
                        ecur, esorted);
     hipLaunchKernelGGL(k_csr_rows<false>, grid1(2 * (int64_t)V), dim3(256), 0, s, 2 * V, eoff, nullptr, esorted);
@@ -1740,8 +2018,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (E > 0) {
     int32_t* cursor = reinterpret_cast<int32_t*>(wsort_);  // (the weight scratch of stage A is free)
     hipLaunchKernelGGL(k_csr_count, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, counts_);
-    size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb2, counts_, A->grow, V + 1, s));
+    HIPRET(scan_i32(s, 0, counts_, A->grow, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
     hipLaunchKernelGGL(k_csr_fill, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, A->grow, cursor,
                        reinterpret_cast<uint32_t*>(A->ginc));
     hipLaunchKernelGGL(k_csr_rows<true>, grid1(V), dim3(256), 0, s, V, A->grow, A->e_o2i,
@@ -1768,6 +2045,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (user_flags_dev && user_flags_host) *user_flags_host = *huser;
   lap("F pass1+sync");
   if (user_flags_dev && user_flags_host && *user_flags_host) return hipSuccess;
+  if (hflags[0] & 32) return hipSuccess;  // a scan's look-back timed out (never seen): not ok -> host builder
+  if (hflags[0] & 64) { map_tiles_ = 0; return hipSuccess; }  // the reused partition does not suit this frame: not ok
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
   if (hflags[0] & 16) {  // a subtree outgrew its workgroup (uneven weighted splits): hand over one
     // level later from now on; after three such steps every level goes through the global kernels
@@ -1788,7 +2067,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   HIPRET(hipGetLastError());
   tiles_host->assign(htiles, htiles + ntiles);
   lap("G pass2+sync");
-  if (hflags[0] & 8) return hipSuccess;
+  if (hflags[0] & (8 | 32)) return hipSuccess;
   *ok = true;
   return hipGetLastError();
 }
@@ -1823,18 +2102,17 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
   HIPRET(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (2 * (size_t)V + 1), s));
   hipLaunchKernelGGL(k_he_count, grid1(n), dim3(256), 0, s, n, V, tris, cnt, flags_);
-  size_t tb = cub_bytes_;
-  HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, cnt, off, V + 1, s));
+  HIPRET(scan_i32(s, 0, cnt, off, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
   hipLaunchKernelGGL(k_he_fill, grid1(n), dim3(256), 0, s, n, V, tris, off, cursor, out);
   hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s, V, off, nullptr, out);
   hipLaunchKernelGGL(k_he_mark, grid1(V), dim3(256), 0, s, V, off, out, f);
-  tb = cub_bytes_;
-  HIPRET(hipcub::DeviceScan::ExclusiveSum(cub_tmp_, tb, f, idx, n, s));
+  HIPRET(scan_i32(s, 0, f, idx, n, false, cub_tmp_, cub_bytes_));
   hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, flags_ + 4);
   int32_t* h = reinterpret_cast<int32_t*>(hpin_);  // (page-locked, see reserve())
   HIPRET(hipMemcpyAsync(h, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
+  if (h[0] & 32) return hipErrorUnknown;  // a scan's look-back timed out (never seen)
   if (h[0] & 2) { *index_error = true; return hipSuccess; }
   *E_out = h[4];
   return hipSuccess;
@@ -1850,11 +2128,12 @@ hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, cons
 hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in,
                                    const DevPlanArrays& A) {
   const int n = Plan::kGrid * Plan::kGrid;
-  zero4(s, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n);
+  zero4(s, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
   hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, s, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, gbbox_,
-                     reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_);
+                     reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_);
+  map_tiles_ = ntiles; map_V_ = V;
   hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, s, V, reinterpret_cast<unsigned long long*>(grid_sum_),
-                     grid_cnt_, grid_w_, gbbox_, grid_bounds_);
+                     grid_cnt_, grid_w_, gbbox_, grid_bounds_, cell_pyr_);
   grid_tiles_ = ntiles;
   return hipGetLastError();
 }

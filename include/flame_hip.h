@@ -81,6 +81,9 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
 /* Options are set BEFORE upload.  Keys: "path" (enum above), "tile_own" (target own vertices
  * per tile), "tile_depth" (halo depth = iterations per launch), "tile_threads", "use_graph"
  * (replay launches from a hipGraph), "plan_device" (1 = build halo-tile plans on the GPU, default),
+ * "plan_reuse" (1 = default: on a frame stream the device builder takes the PARTITION of a frame from
+ * the previous frame's tile map while the frames hold about as many vertices, instead of sorting and
+ * bisecting again; results do not depend on the partition; flame_hip_get_info "plan_reused"),
  * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
  * 512, up to 2048), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),

@@ -178,7 +178,9 @@ def test_device_plan_frame_stream(gpu):
         g = graphgen.synthetic(V, seed=40 + k)
         if host is None:
             host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
-            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+            # (plan_reuse=0: the partition-reuse shortcut of frame streams is the device builder's own;
+            # the array-for-array comparison is about the exact bisection both builders implement)
+            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, plan_reuse=0)
         else:
             host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
             dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
@@ -192,6 +194,41 @@ def test_device_plan_frame_stream(gpu):
     host.close(); dev.close()
 
 
+def test_partition_reuse_on_a_frame_stream(gpu):
+    """Frame streams take the partition of a frame from the previous frame's tile map (plan_reuse, the
+    default): frames of similar size are not bisected again, the plan is valid (the solve is the
+    oracle's bits, as on any partition), a frame the map does not suit (scene change: all features in
+    one corner; a much larger frame) is rebuilt by exact bisection."""
+    dev = None
+    rng = np.random.default_rng(3)
+    sizes = [(20000, None), (20400, None), (19000, None), (20000, "corner"), (20100, None), (20300, None),
+             (9000, None), (9300, None)]
+    reused = []
+    for k, (V, kind) in enumerate(sizes):
+        g = graphgen.synthetic(V, seed=70 + k)
+        if kind == "corner":  # every feature inside the top-left eighth of the image
+            pos = (rng.random((V, 2)) * np.array([80.0, 60.0])).astype(np.float32)
+            g = graphgen.from_points(pos, 640, 480, np.random.Generator(np.random.PCG64(5)))
+        if dev is None:
+            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+        else:
+            dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+        assert dev.info("plan_on_device") == 1 and dev.info("path") == _l.PATH_TILE
+        reused.append(dev.info("plan_reused"))
+        o = make_oracle(g)
+        o.solve(oracle_params(), 25)
+        dev.step(default_params(), 25)
+        x, w1, w2, q = dev.download()
+        assert_bit_equal(x, o.x, "frame %d x" % k)
+        assert_bit_equal(q, o.q, "frame %d q" % k)
+        # the tiles cover the graph exactly once
+        td = dev.plan_array("tiles", np.int32).reshape(dev.info("num_tiles"), -1)
+        assert td[:, 1].sum() == g.V and td[:, 1].min() >= 1
+    #          first similar similar corner back(sits out one frame) similar smaller similar
+    assert reused == [0, 1, 1, 0, 0, 1, 0, 1], reused
+    dev.close()
+
+
 def test_device_plan_growing_frames(gpu):
     """Frames that grow threefold each on ONE handle: every scratch buffer of the builder (lists,
     counters, page-locked landing areas, tile arrays) is re-reserved on the way."""
@@ -200,7 +237,7 @@ def test_device_plan_growing_frames(gpu):
         g = graphgen.synthetic(V, seed=60 + k)
         if host is None:
             host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
-            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+            dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, plan_reuse=0)
         else:
             host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
             dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
@@ -218,7 +255,7 @@ def test_device_plan_subtree_overflow_recovery(gpu):
     one level later and the plan still equals the host builder's."""
     g, _ = graphgen.named("50k")
     host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
-    dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, debug_sub_cap=2000)
+    dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, debug_sub_cap=2000, plan_reuse=0)
     compare_plans(host, dev, "overflow recovery")
     host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
     dev.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
