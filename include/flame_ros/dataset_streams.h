@@ -12,9 +12,11 @@
 //         src/dataset_utils/utils.h:50-93 (greedy closest-first association, max_diff 0.02 s),
 //         src/dataset_utils/asl/dataset.h:83-103 (folder = sensor.yaml + data.csv, first line =
 //         column names)
-// Images are not decoded here (no decoder in this image): frames carry the image FILE PATHS, the
-// depth scale factor and the camera pose, which is all flame::Flame::update() needs besides the
-// pixels.  Header-only, C++11.
+// Frames carry the image FILE PATHS, the depth scale factor and the camera pose; the pixels come
+// through image_io.h (PNG / PNM decode, gray conversion, plumb-bob rectification, depth scaling --
+// what the reference does with cv::imread / rectifyImage / cv::undistort): loadFramePixels() below
+// turns a frame record into the cv::Mat1b / cv::Mat1f contents flame::Flame::update() receives.
+// Header-only, C++11.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -27,6 +29,8 @@
 #include <tuple>
 #include <unordered_set>
 #include <vector>
+
+#include "image_io.h"
 
 namespace flame_ros {
 namespace datasets {
@@ -425,6 +429,45 @@ class AslDataset {
   Quat q_pose_in_body_, q_cam_in_body_;
   double t_pose_in_body_[3], t_cam_in_body_[3];
 };
+
+// The pixels of one frame as the frontends hand them to flame::Flame::update(): the 8-bit gray
+// image (undistorted when `cam` is given: reference tum_rgbd_offline_stream.cc:196-200 rectifies both
+// images, asl_rgbd_offline_stream.cc:285-287 the colour image only) and, when the frame has one, the
+// depth image in metres (raw / depth_scale_factor; `rectify_depth` as the TUM stream does).
+// Returns false with *err set when a file is missing or not decodable.
+inline bool loadFramePixels(const std::string& rgb_file, const std::string& depth_file, float depth_scale_factor,
+                            const images::PlumbBob* cam, bool rectify_depth, int* width, int* height,
+                            std::vector<uint8_t>* gray, std::vector<float>* depth_m, std::string* err = nullptr) {
+  images::Image rgb;
+  if (!images::readImage(rgb_file, &rgb, err)) return false;
+  std::vector<uint8_t> g;
+  if (!images::toGray8(rgb, &g)) { if (err) *err = "unsupported channel count in " + rgb_file; return false; }
+  *width = rgb.width; *height = rgb.height;
+  if (cam) {
+    gray->resize(g.size());
+    images::undistort<uint8_t>(g.data(), rgb.width, rgb.height, 1, *cam, gray->data());
+  } else {
+    gray->swap(g);
+  }
+  depth_m->clear();
+  if (depth_file.empty()) return true;
+  images::Image d;
+  if (!images::readImage(depth_file, &d, err)) return false;
+  if (d.bit_depth != 16 || d.channels != 1 || d.width != rgb.width || d.height != rgb.height) {
+    if (err) *err = "depth image must be 16-bit gray of the colour image's size: " + depth_file;
+    return false;
+  }
+  std::vector<uint16_t> raw;
+  if (cam && rectify_depth) {
+    raw.resize(d.u16.size());
+    images::undistort<uint16_t>(d.u16.data(), d.width, d.height, 1, *cam, raw.data());
+  } else {
+    raw.swap(d.u16);
+  }
+  depth_m->resize(raw.size());
+  images::depthToFloat(raw.data(), raw.size(), depth_scale_factor, depth_m->data());
+  return true;
+}
 
 }  // namespace datasets
 }  // namespace flame_ros

@@ -4,8 +4,10 @@
 //   asl <id> <time> <qw qx qy qz> <tx ty tz> <rgb path> [<depth path>]
 // usage: dataset_streams_test tum <index file> <frame> | asl <pose dir> <rgb dir> <depth dir|-> <frame>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "flame_ros/dataset_streams.h"
 
@@ -29,6 +31,39 @@ int main(int argc, char** argv) {
                   f.pose_optical.q.x, f.pose_optical.q.y, f.pose_optical.q.z, f.pose_optical.t[0], f.pose_optical.t[1],
                   f.pose_optical.t[2], f.has_depth ? 1 : 0, f.rgb_file.c_str(), f.depth_file.c_str());
     return idx.empty() ? 0 : 2;
+  }
+  if (argc >= 5 && !std::strcmp(argv[1], "tumpix")) {
+    // pixels of every frame of a TUM sequence: <index> <frame> <out.bin> [fx fy cx cy k1 k2 p1 p2 k3]
+    ds::TumIndex idx(argv[2], frameOf(argv[3]));
+    flame_ros::images::PlumbBob cam;
+    const bool rect = argc >= 14;
+    if (rect) {
+      cam.fx = std::atof(argv[5]); cam.fy = std::atof(argv[6]); cam.cx = std::atof(argv[7]); cam.cy = std::atof(argv[8]);
+      cam.k1 = std::atof(argv[9]); cam.k2 = std::atof(argv[10]); cam.p1 = std::atof(argv[11]); cam.p2 = std::atof(argv[12]);
+      cam.k3 = std::atof(argv[13]);
+    }
+    FILE* f = std::fopen(argv[4], "wb");
+    if (!f) return 4;
+    uint32_t id;
+    ds::TumFrame fr;
+    while (idx.get(&id, &fr)) {
+      int w = 0, h = 0;
+      std::vector<uint8_t> gray;
+      std::vector<float> depth;
+      std::string err;
+      if (!ds::loadFramePixels(fr.rgb_file, fr.has_depth ? fr.depth_file : std::string(), idx.depthScaleFactor(),
+                               rect ? &cam : nullptr, true, &w, &h, &gray, &depth, &err)) {
+        std::fprintf(stderr, "%s\n", err.c_str());
+        std::fclose(f);
+        return 5;
+      }
+      const int32_t hdr[3] = {w, h, depth.empty() ? 0 : 1};
+      std::fwrite(hdr, 4, 3, f);
+      std::fwrite(gray.data(), 1, gray.size(), f);
+      std::fwrite(depth.data(), 4, depth.size(), f);
+    }
+    std::fclose(f);
+    return 0;
   }
   if (argc >= 6 && !std::strcmp(argv[1], "asl")) {
     ds::AslDataset d(argv[2], argv[3], std::strcmp(argv[4], "-") ? argv[4] : "", frameOf(argv[5]));

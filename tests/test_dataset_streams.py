@@ -4,8 +4,8 @@ tum_rgbd_offline_stream.cc:248-300) with every input frame convention (:145-194)
 folders (sensor.yaml + data.csv; reference src/dataset_utils/asl/dataset.h:83-103, types.h:37-120),
 timestamp association (src/dataset_utils/utils.h:50-93) and the pose-sensor -> body -> camera ->
 optical chain (reference src/ros_sensor_streams/asl_rgbd_offline_stream.cc:205-275).  Expected
-poses are computed here independently with SciPy rotations.  No images are decoded (none are
-needed to test the parsers)."""
+poses are computed here independently with SciPy rotations; the last test writes a three-frame
+TUM sequence WITH images (Pillow) and reads the pixels back through loadFramePixels()."""
 import os
 import subprocess
 
@@ -167,3 +167,44 @@ def test_asl_dataset_association_and_pose_chain(exe, tmp_path, world, with_depth
         assert r[10] == str(tmp_path / "cam0" / "data" / ("%d.png" % rgb_t[ri]))
         if with_depth:
             assert r[11] == str(tmp_path / "depth0" / "data" / ("%d.png" % rgb_t[ri]))
+
+
+def test_tum_sequence_with_pixels(exe, tmp_path):
+    """Index -> file names -> decoded gray image + depth in metres, as flame_offline_tum hands them
+    to update() (reference src/flame_offline_tum.cc:565-594; decode / rectify / scale:
+    src/ros_sensor_streams/tum_rgbd_offline_stream.cc:196-209)."""
+    PIL = pytest.importorskip("PIL.Image")
+    seq = tmp_path / "seq"
+    (seq / "rgb").mkdir(parents=True)
+    (seq / "depth").mkdir()
+    (seq / "index.txt").write_text("\n".join(TUM_LINES))
+    rng = np.random.default_rng(0)
+    imgs, depths = {}, {}
+    for name in "abc":
+        rgb = (rng.random((48, 64, 3)) * 255).astype(np.uint8)
+        rgb[10:30, 20:40] = 200
+        PIL.fromarray(rgb, mode="RGB").save(str(seq / "rgb" / (name + ".png")))
+        imgs[name] = rgb
+        if name != "c":  # the third index line has no depth image
+            d = (rng.random((48, 64)) * 20000).astype(np.uint16)
+            PIL.fromarray(d).save(str(seq / "depth" / (name + ".png")))
+            depths[name] = d
+    out = str(tmp_path / "pix.bin")
+    subprocess.run([exe, "tumpix", str(seq / "index.txt"), "RDF", out], check=True)
+    raw, off = open(out, "rb").read(), 0
+    for name in "abc":
+        w, h, has_d = np.frombuffer(raw, np.int32, 3, off)
+        off += 12
+        assert (w, h) == (64, 48) and bool(has_d) == (name in depths)
+        gray = np.frombuffer(raw, np.uint8, w * h, off).reshape(h, w)
+        off += w * h
+        r, g, b = (imgs[name][..., k].astype(np.int64) for k in range(3))
+        assert np.array_equal(gray, ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.uint8))
+        if has_d:
+            d = np.frombuffer(raw, np.float32, w * h, off).reshape(h, w)
+            off += 4 * w * h
+            assert np.array_equal(d, depths[name].astype(np.float32) / np.float32(5000))
+    assert off == len(raw)
+    # a missing image is an error, not a crash
+    os.remove(str(seq / "rgb" / "b.png"))
+    assert subprocess.run([exe, "tumpix", str(seq / "index.txt"), "RDF", out], capture_output=True).returncode == 5

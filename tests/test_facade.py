@@ -248,3 +248,38 @@ def test_facade_update_latency(gpu, workload, bound_ms):
     assert r["frames"] == 40 and r["coverage"] > 0.5, r
     assert r["update_ms"]["p50"] < bound_ms, r
     assert r["checksum"] > 0  # the getters really rendered something
+
+
+@pytest.fixture(scope="module")
+def threads_exe(tmp_path_factory):
+    lib.load()
+    out = str(tmp_path_factory.mktemp("threads") / "facade_threads")
+    subprocess.check_call(CXX + ["-O1", "-I" + os.path.join(ROOT, "include"),
+                                 os.path.join(ROOT, "tests", "cpp", "facade_threads.cc"), "-o", out] + LINK)
+    return out
+
+
+def _parse(stdout):
+    return {k: int(v) for k, v in (kv.split("=") for kv in stdout.split())}
+
+
+def test_facade_two_threads_without_gpu(threads_exe):
+    """The nodelet's pattern (reference src/flame_nodelet.cc:474-475 vs :634-635): update() on one
+    thread, pose-frame mutators + getters on another.  Without a GPU every update fails cleanly; the
+    mutex still serialises the front-end callbacks and no read is torn."""
+    if have_gpu():
+        pytest.skip("GPU present: covered by the gpu test")
+    p = subprocess.run([threads_exe, "0", "3000"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stdout, p.stderr)
+    r = _parse(p.stdout)
+    assert r["failed"] == 3000 and r["inconsistent"] == 0 and r["overlaps"] == 0 and r["hip_error"] == lib.ERR_NODEVICE
+
+
+@pytest.mark.gpu
+def test_facade_two_threads_on_gpu(gpu, threads_exe):
+    """update() (GPU tail included) against the pose-frame mutators and every getter, incl. a debug image
+    rendered on the device from the other thread: no torn mesh, no overlapping front-end callbacks."""
+    p = subprocess.run([threads_exe, "0", "150"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    r = _parse(p.stdout)
+    assert r["failed"] == 0 and r["inconsistent"] == 0 and r["overlaps"] == 0 and r["reads"] > 5 and r["pf_calls"] > 10, r
