@@ -964,14 +964,24 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
         (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)) ||
         (rc = dev_alloc(g->caps, &g->in_edges, 3 * (size_t)T)) || (rc = dev_alloc(g->caps, &g->in_alpha, 3 * (size_t)T)))
       return rc;
+    static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+      if (!timing) return;
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[sync] %-16s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+      t_prev = now;
+    };
     HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->in_mu, idepth_mu, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->in_var, idepth_var, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
     if (prediction) HIPCHK(hipMemcpyAsync(g->in_pred, prediction, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
+    lap("H2D enqueue");
     int32_t E = 0;
     bool index_error = false;
     HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error));
+    lap("edges_from_tris");
     if (index_error) return FLAME_HIP_ERR_ARG;
     const bool use_pred = sp->init_with_prediction && prediction;
     HIPCHK(g->planner.sync_data(s, V, g->in_mu, g->in_var, use_pred ? g->in_pred : nullptr, sc,
