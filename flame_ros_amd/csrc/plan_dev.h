@@ -130,6 +130,8 @@ class DevPlanner {
   int map_tiles_ = 0, map_depth_ = 0;
   int32_t map_V_ = 0;
   bool reuse_next_ = false, last_reused_ = false;
+  int32_t spec_nv_ = 0, spec_ne_ = 0, spec_ns_ = 0;  // tile-array totals (+1/8) of the previous build: the next
+  int spec_tiles_ = 0;                                //   build allocates for them and skips a host round trip
   int32_t* cell_pyr_ = nullptr;    // tile + 1 of the vertices in every cell of a 128/32/8/1 pyramid
   bool use_subtree_ = true;  // deep bisection levels in one LDS kernel
   int sub_extra_levels_ = 0; // hand-over level pushed down after a subtree overflow

@@ -1137,7 +1137,8 @@ __global__ __launch_bounds__(kP1Threads) void k_tile_pass1(TileGraph G, const in
 }
 
 // exclusive scans of (n_ext, e_loc, n_upd) over the tiles; totals and the fail flag
-__global__ __launch_bounds__(kSegCap) void k_tile_offsets(int ntiles, int32_t* meta, int32_t* flags) {
+__global__ __launch_bounds__(kSegCap) void k_tile_offsets(int ntiles, int32_t* meta, int32_t* flags, int32_t cap_nv,
+                                                          int32_t cap_ne, int32_t cap_ns) {
   __shared__ int32_t sc[3][kSegCap];
   const int t = threadIdx.x;
   int32_t v[3] = {0, 0, 0};
@@ -1159,7 +1160,11 @@ __global__ __launch_bounds__(kSegCap) void k_tile_offsets(int ntiles, int32_t* m
     int32_t* m = meta + (size_t)t * kMetaWords;
     for (int c = 0; c < 3; ++c) m[21 + c] = sc[c][t] - v[c];
   }
-  if (t == kSegCap - 1) { flags[1] = sc[0][t]; flags[2] = sc[1][t]; flags[3] = sc[2][t]; }
+  if (t == kSegCap - 1) {
+    flags[1] = sc[0][t]; flags[2] = sc[1][t]; flags[3] = sc[2][t];
+    // speculative tile arrays (sized from the previous frame, no host round trip before pass 2): too small?
+    if (cap_nv > 0 && (sc[0][t] > cap_nv || sc[1][t] > cap_ne || sc[2][t] > cap_ns)) atomicOr(&flags[0], 128);
+  }
 }
 
 // Lane order inside one block of 64 local edges (plan.cpp assign_lanes(), the identical greedy),
@@ -1244,6 +1249,10 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
   __shared__ int32_t s_ring_end[kMaxDepth + 1], s_level_end[kMaxDepth + 1];
   __shared__ int32_t s_gw[kCapExt / 64], s_gbase[kCapExt / 64 + 1];
   const int t = blockIdx.x, tid = threadIdx.x;
+  // a build that has already failed (bad indices, a tile that does not fit, a rejected partition, tile
+  // arrays too small for a speculative launch: every bit but pass 2's own 8) must not be continued:
+  // the host used to stop before this launch; without the round trip the kernel stops itself
+  if (__builtin_amdgcn_readfirstlane(flags[0]) & ~8) return;
   TileLds L;
   uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
   L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
@@ -1784,8 +1793,8 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     for (int l = 0; l < 2; ++l) {
       HIPRET(dalloc(&scan_agg_[l], (size_t)kScanMaxBlocks));
       HIPRET(dalloc(&scan_flag_[l], (size_t)kScanMaxBlocks));
-      HIPRET(hipMemset(scan_flag_[l], 0, sizeof(uint32_t) * kScanMaxBlocks));
-      scan_epoch_[l] = 0;
+      scan_epoch_[l] = 0xfffffff0u;  // = "wrapped": the first scan on the lane zeroes the flags on ITS stream
+                                     // (a legacy-stream hipMemset here collides with another thread's capture)
     }
     HIPRET(dalloc(&grid_sum_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_cnt_, (size_t)Plan::kGrid * Plan::kGrid));
@@ -2030,20 +2039,37 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // ---- stage F ----
   TileGraph G;
   G.V = V; G.depth = depth; G.grow = A->grow; G.ginc = A->ginc; G.eij = A->eij; G.e_i2o = A->e_i2o; G.e_o2i = A->e_o2i;
+  // The tile arrays are sized from the totals pass 1 counts.  A frame stream does not wait for them:
+  // the arrays are allocated for 9/8 of the PREVIOUS build's totals, pass 2 is launched right behind
+  // pass 1 and the one synchronisation at the end tells whether the guess held (flags bit 128: the
+  // exact sizes are known by then and pass 2 is simply run again).  First build on a handle: one more
+  // round trip, as before.
+  const bool spec = spec_nv_ > 0 && spec_tiles_ >= ntiles;
+  if (spec && alloc_tiles(alloc_ctx, (size_t)spec_tiles_, (size_t)spec_nv_, (size_t)spec_ne_, (size_t)spec_ns_) != 0)
+    return hipErrorOutOfMemory;
   hipLaunchKernelGGL(k_tile_pass1, dim3(ntiles), dim3(kP1Threads), lds1, s, G, leaf.lo, leaf.hi, tile_ext_, tile_meta_);
-  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_);
+  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_, spec ? spec_nv_ : 0,
+                     spec ? spec_ne_ : 0, spec ? spec_ns_ : 0);
   if (tri_stage) HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
   lap("E tris (joined)");
   int32_t* hflags = reinterpret_cast<int32_t*>(hpin_);
   int32_t* huser = reinterpret_cast<int32_t*>(hpin_ + 64);
   TileDesc* htiles = reinterpret_cast<TileDesc*>(hpin_ + 256);
+  auto launch_pass2 = [&]() -> hipError_t {
+    hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
+                       tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_,
+                       opt.lane_order == 2 ? 1 : 0);
+    HIPRET(hipMemcpyAsync(htiles, A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
+    return hipGetLastError();
+  };
+  if (spec) HIPRET(launch_pass2());
   HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (user_flags_dev && user_flags_host)  // the caller's own check word rides on the same sync
     HIPRET(hipMemcpyAsync(huser, user_flags_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
   if (user_flags_dev && user_flags_host) *user_flags_host = *huser;
-  lap("F pass1+sync");
+  lap(spec ? "F+G pass1+2+sync" : "F pass1+sync");
   if (user_flags_dev && user_flags_host && *user_flags_host) return hipSuccess;
   if (hflags[0] & 32) return hipSuccess;  // a scan's look-back timed out (never seen): not ok -> host builder
   if (hflags[0] & 64) { map_tiles_ = 0; return hipSuccess; }  // the reused partition does not suit this frame: not ok
@@ -2055,18 +2081,21 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                  user_flags_dev, user_flags_host, nullptr);  // (the caller's arrays are staged by now)
   }
   if (hflags[0] & 5) return hipSuccess;  // a tile does not fit (or the partition is inconsistent): not ok
-  if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)
-    return hipErrorOutOfMemory;
-  // ---- stage G ----
-  hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
-                     tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_,
-                     opt.lane_order == 2 ? 1 : 0);
-  HIPRET(hipMemcpyAsync(htiles, A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
-  HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIPRET(hipStreamSynchronize(s));
-  HIPRET(hipGetLastError());
+  // the next build on this handle speculates on these totals
+  spec_tiles_ = std::max(ntiles, spec_tiles_);
+  spec_nv_ = hflags[1] + hflags[1] / 8 + 1024; spec_ne_ = hflags[2] + hflags[2] / 8 + 1024; spec_ns_ = hflags[3] + hflags[3] / 8 + 1024;
+  if (!spec || (hflags[0] & 128)) {
+    if (alloc_tiles(alloc_ctx, (size_t)ntiles, (size_t)hflags[1], (size_t)hflags[2], (size_t)hflags[3]) != 0)
+      return hipErrorOutOfMemory;
+    // ---- stage G (first build on a handle, or the speculative arrays were too small) ----
+    if (hflags[0] & 128) HIPRET(hipMemsetAsync(flags_, 0, sizeof(int32_t), s));  // (nothing else was set: checked above)
+    HIPRET(launch_pass2());
+    HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPRET(hipStreamSynchronize(s));
+    HIPRET(hipGetLastError());
+    lap("G pass2+sync");
+  }
   tiles_host->assign(htiles, htiles + ntiles);
-  lap("G pass2+sync");
   if (hflags[0] & (8 | 32)) return hipSuccess;
   *ok = true;
   return hipGetLastError();

@@ -6,6 +6,7 @@
 // never run concurrently with each other (the facade's mutex serialises them).
 // Usage: facade_threads <device> <frames>; exit 0 = ok, 3 = update() failed (no device).
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -104,8 +105,12 @@ int main(int argc, char** argv) {
   });
   flame::Image1b img(480, 640);
   int failed = 0;
-  for (int k = 0; k < nframes; ++k)
+  for (int k = 0; k < nframes; ++k) {
     if (!sensor->update(0.033 * k, static_cast<uint32_t>(k), flame::SE3f(), img, (k % 10) == 0)) ++failed;
+    // frames arrive at camera rate, not back to back (std::mutex is not fair: a worker that re-locks
+    // at once would starve the callback thread and the test would exercise nothing)
+    std::this_thread::sleep_for(std::chrono::microseconds(500));
+  }
   done.store(true);
   callback.join();
   std::printf("frames=%d failed=%d reads=%d inconsistent=%d overlaps=%d pf_calls=%d hip_error=%d\n", nframes, failed,
