@@ -552,12 +552,8 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   };
   // ---- stage the caller's arrays ----
   if (staged) {
-    if ((rc = dev_alloc(g->caps, &g->dflags, 8))) return rc;
-    HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
-    HIPCHK(launch_check_finite(s, V, g->in_z, g->dflags));
-    HIPCHK(launch_check_finite(s, V, g->in_wgt, g->dflags));
-    HIPCHK(launch_check_finite(s, E, g->in_alpha, g->dflags));
-    if (have_x0) HIPCHK(launch_check_finite(s, V, g->in_x0, g->dflags));
+    // (g->dflags was zeroed by flame_hip_graph_sync and carries the non-finite check of the kernels
+    // that derived z / wgt / x0 / alpha there)
   } else {
   if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_edges, (size_t)E)) ||
       (rc = dev_alloc(g->caps, &g->in_alpha, (size_t)E)) || (rc = dev_alloc(g->caps, &g->in_beta, (size_t)E)) ||
@@ -972,6 +968,8 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
       std::fprintf(stderr, "[sync] %-16s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
       t_prev = now;
     };
+    if ((rc = dev_alloc(g->caps, &g->dflags, 8))) return rc;
+    HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
     HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(g->in_mu, idepth_mu, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
@@ -980,12 +978,12 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     lap("H2D enqueue");
     int32_t E = 0;
     bool index_error = false;
-    HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error));
+    HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error, g->dflags));
     lap("edges_from_tris");
     if (index_error) return FLAME_HIP_ERR_ARG;
     const bool use_pred = sp->init_with_prediction && prediction;
     HIPCHK(g->planner.sync_data(s, V, g->in_mu, g->in_var, use_pred ? g->in_pred : nullptr, sc,
-                                sp->adaptive_data_weights, sp->init_with_prediction, g->in_z, g->in_wgt, g->in_x0));
+                                sp->adaptive_data_weights, sp->init_with_prediction, g->in_z, g->in_wgt, g->in_x0, g->dflags));
     g->V = V; g->E = E; g->T = T;
     g->uploaded = false;
     g->n_send_v = g->n_send_e = g->n_recv_v = g->n_recv_e = 0;

@@ -84,11 +84,14 @@ class DevPlanner {
 
   // Graph sync on the device (row a7): unique undirected edges (i < j, lexicographic) of a
   // triangulation + alpha = 1 / |pos_i - pos_j|; edges / alpha need 3T entries.  Synchronises (E).
+  // nan_flag (optional device word): bit 0 is set when a derived value is not finite (the upload's
+  // non-finite-input check, done where the values are made instead of by launches of its own)
   hipError_t edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
-                             int2* edges, float* alpha, int32_t* E_out, bool* index_error);
+                             int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag = nullptr);
   // z = mu / scale, wgt = 1 or 1 / var, x0 = prediction / scale where finite (else z)
   hipError_t sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
-                       float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0);
+                       float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0,
+                       int32_t* nan_flag = nullptr);
 
   // weights for the next build: none / from the tiles of the last build / from the cost-density grid
   void set_weights_none() { weight_mode_ = 0; }

@@ -1631,7 +1631,7 @@ __global__ __launch_bounds__(256) void k_he_mark(int32_t V, const int32_t* __res
 __global__ __launch_bounds__(256) void k_he_compact(int32_t V, const int32_t* __restrict__ off,
                                                     const uint32_t* __restrict__ out, const int32_t* __restrict__ f,
                                                     const int32_t* __restrict__ idx, const float2* __restrict__ pos,
-                                                    int2* edges, float* alpha, int32_t* total) {
+                                                    int2* edges, float* alpha, int32_t* total, int32_t* nan_flag) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
   if (v == V - 1) { const int32_t n = off[V]; total[0] = n > 0 ? idx[n - 1] + f[n - 1] : 0; }
@@ -1642,20 +1642,26 @@ __global__ __launch_bounds__(256) void k_he_compact(int32_t V, const int32_t* __
     const float2 pj = pos[j];
     const float dx = pi.x - pj.x, dy = pi.y - pj.y;
     edges[idx[k]] = make_int2(v, j);
-    alpha[idx[k]] = 1.0f / sqrtf(dx * dx + dy * dy);  // -ffp-contract=off: two roundings, as the oracle
+    const float a = 1.0f / sqrtf(dx * dx + dy * dy);  // -ffp-contract=off: two roundings, as the oracle
+    alpha[idx[k]] = a;
+    if (nan_flag && !isfinite(a)) atomicOr(nan_flag, 1);  // (two features on one pixel)
   }
 }
 
 __global__ __launch_bounds__(256) void k_sync_data(int32_t V, const float* __restrict__ mu,
                                                    const float* __restrict__ var, const float* __restrict__ pred,
                                                    float scale, int adaptive, int init_pred, float* z, float* wgt,
-                                                   float* x0) {
+                                                   float* x0, int32_t* nan_flag) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
   const float zi = mu[v] / scale;
+  const float wi = adaptive ? 1.0f / var[v] : 1.0f;
+  const float xi = (init_pred && pred && isfinite(pred[v])) ? pred[v] / scale : zi;
   z[v] = zi;
-  wgt[v] = adaptive ? 1.0f / var[v] : 1.0f;
-  x0[v] = (init_pred && pred && isfinite(pred[v])) ? pred[v] / scale : zi;
+  wgt[v] = wi;
+  x0[v] = xi;
+  // the non-finite-input check of the upload rides here (it was three more launches per frame)
+  if (nan_flag && !(isfinite(zi) && isfinite(wi) && isfinite(xi))) atomicOr(nan_flag, 1);
 }
 
 template <class T>
@@ -2116,7 +2122,7 @@ hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntil
 }
 
 hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
-                                       int2* edges, float* alpha, int32_t* E_out, bool* index_error) {
+                                       int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag) {
   *E_out = 0;
   *index_error = false;
   if (T <= 0) return hipSuccess;
@@ -2136,7 +2142,7 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s, V, off, nullptr, out);
   hipLaunchKernelGGL(k_he_mark, grid1(V), dim3(256), 0, s, V, off, out, f);
   HIPRET(scan_i32(s, 0, f, idx, n, false, cub_tmp_, cub_bytes_));
-  hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, flags_ + 4);
+  hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, flags_ + 4, nan_flag);
   int32_t* h = reinterpret_cast<int32_t*>(hpin_);  // (page-locked, see reserve())
   HIPRET(hipMemcpyAsync(h, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
@@ -2148,9 +2154,11 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
 }
 
 hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
-                                 float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0) {
+                                 float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0,
+                                 int32_t* nan_flag) {
   if (V <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_sync_data, grid1(V), dim3(256), 0, s, V, mu, var, pred, scale, adaptive, init_pred, z, wgt, x0);
+  hipLaunchKernelGGL(k_sync_data, grid1(V), dim3(256), 0, s, V, mu, var, pred, scale, adaptive, init_pred, z, wgt, x0,
+                     nan_flag);
   return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_
 from oracle import COracle
 from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync, triangles as oracle_triangles, TriParams as OTri
 from tests.test_graph_sync import features
-from tests.util import assert_bit_equal, oracle_params
+from tests.util import assert_bit_equal, graphgen, oracle_params
 
 pytestmark = pytest.mark.gpu
 
@@ -81,3 +81,25 @@ def test_frame_results_one_call(gpu, rescale):
         assert_bit_equal(vn, vn_o, "vertex normals")
         assert np.array_equal(tv, tv_o) and np.array_equal(e, s["edges"])
         r.close()
+
+
+def test_device_sync_flags_non_finite_derived_values(gpu):
+    """The non-finite-input check rides in the kernels that derive the values (r03): a zero variance
+    under adaptive weights (wgt = 1/var = inf) and two features on one pixel (alpha = 1/0 = inf) must
+    still come back as FLAME_HIP_ERR_NAN from the device path, and the handle stays usable."""
+    from flame_ros_amd import lib
+    from flame_ros_amd.regularizer import FlameHipError
+    g = graphgen.synthetic(6000, seed=21)
+    var = np.full(g.V, 1e-4, np.float32)
+    r = GraphRegularizer.empty(device=0)
+    bad = var.copy(); bad[17] = 0.0
+    with pytest.raises(FlameHipError) as e:
+        r.sync_features(g.pos, g.z, bad, g.tris, default_sync_params(adaptive_data_weights=True))
+    assert e.value.code == lib.ERR_NAN
+    pos = g.pos.copy(); pos[g.tris[5, 1]] = pos[g.tris[5, 0]]   # an edge of length zero
+    with pytest.raises(FlameHipError) as e:
+        r.sync_features(pos, g.z, var, g.tris, default_sync_params())
+    assert e.value.code == lib.ERR_NAN
+    r.sync_features(g.pos, g.z, var, g.tris, default_sync_params())  # a good frame afterwards
+    assert r.info("plan_on_device") == 1 and r.E == g.E
+    r.close()
