@@ -928,11 +928,18 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
   RoctxRange roctx_("flame_hip_graph_sync");
   if (!g || !sp || V < 0 || T < 0) return FLAME_HIP_ERR_ARG;
   if ((V > 0 && (!pos || !idepth_mu || !idepth_var)) || (T > 0 && !tris)) return FLAME_HIP_ERR_ARG;
-  if (!all_finite(pos, 2 * (size_t)V) || !all_finite(idepth_mu, V)) return FLAME_HIP_ERR_NAN;
-  for (int32_t v = 0; v < V; ++v) {
-    if (std::isnan(idepth_var[v])) return FLAME_HIP_ERR_NAN;
-    if (!(idepth_var[v] < sp->idepth_var_max_graph)) return FLAME_HIP_ERR_ARG;  // fails the gate
-  }
+  const auto t_entry = std::chrono::steady_clock::now();
+  // input validation on the host: non-finite positions / idepths, NaN variances, the variance gate.
+  // On the device path it runs WHILE the GPU already derives the edges (every kernel there is safe on
+  // unvalidated input: indices are range-checked, non-finite values only set a flag).
+  auto validate = [&]() -> int {
+    if (!all_finite(pos, 2 * (size_t)V) || !all_finite(idepth_mu, V)) return FLAME_HIP_ERR_NAN;
+    for (int32_t v = 0; v < V; ++v) {
+      if (std::isnan(idepth_var[v])) return FLAME_HIP_ERR_NAN;
+      if (!(idepth_var[v] < sp->idepth_var_max_graph)) return FLAME_HIP_ERR_ARG;  // fails the gate
+    }
+    return 0;
+  };
   int rc;
   g->sync_on_device = false;
   // graphs that become one isolated tile (host plan) are synced on the host as well (E <= 3V bounds
@@ -947,13 +954,6 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     HIPCHK(wait_last_solve(g));
     hipStream_t s = g->stream;
     HIPCHK(hipStreamSynchronize(s));
-    float sc = 1.0f;
-    if (sp->rescale_data) {  // mean in the oracle's order (sequential, float64)
-      double acc = 0.0;
-      for (int32_t v = 0; v < V; ++v) acc += (double)idepth_mu[v];
-      sc = (float)(acc / (double)V);
-      if (!(sc > 0.0f)) sc = 1.0f;
-    }
     if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_tris, 3 * (size_t)T)) ||
         (rc = dev_alloc(g->caps, &g->in_mu, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_var, (size_t)V)) ||
         (rc = dev_alloc(g->caps, &g->in_pred, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) ||
@@ -961,13 +961,14 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
         (rc = dev_alloc(g->caps, &g->in_edges, 3 * (size_t)T)) || (rc = dev_alloc(g->caps, &g->in_alpha, 3 * (size_t)T)))
       return rc;
     static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
+    auto t_prev = t_entry;
     auto lap = [&](const char* what) {
       if (!timing) return;
       const auto now = std::chrono::steady_clock::now();
       std::fprintf(stderr, "[sync] %-16s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
       t_prev = now;
     };
+    lap("checks+allocs");
     if ((rc = dev_alloc(g->caps, &g->dflags, 8))) return rc;
     HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
     HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
@@ -978,8 +979,21 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     lap("H2D enqueue");
     int32_t E = 0;
     bool index_error = false;
-    HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error, g->dflags));
+    int vrc = 0;
+    float sc = 1.0f;
+    HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error, g->dflags,
+                                      [&]() {
+                                        vrc = validate();
+                                        if (vrc == 0 && sp->rescale_data) {  // mean in the oracle's order (sequential, float64)
+                                          double acc = 0.0;
+                                          for (int32_t v = 0; v < V; ++v) acc += (double)idepth_mu[v];
+                                          sc = (float)(acc / (double)V);
+                                          if (!(sc > 0.0f)) sc = 1.0f;
+                                        }
+                                      }));
     lap("edges_from_tris");
+    if (vrc || index_error) g->uploaded = false;  // (the staged inputs of the previous graph are gone)
+    if (vrc) return vrc;
     if (index_error) return FLAME_HIP_ERR_ARG;
     const bool use_pred = sp->init_with_prediction && prediction;
     HIPCHK(g->planner.sync_data(s, V, g->in_mu, g->in_var, use_pred ? g->in_pred : nullptr, sc,
@@ -1004,6 +1018,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     }
     // not eligible for the device plan (e.g. one isolated tile): fall through to the host builder
   }
+  if ((rc = validate())) return rc;
   rc = graph_sync_host(*sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, &g->sync);
   if (rc) return rc;
   const int32_t E = (int32_t)(g->sync.edges.size() / 2);

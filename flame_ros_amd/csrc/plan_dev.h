@@ -87,7 +87,8 @@ class DevPlanner {
   // nan_flag (optional device word): bit 0 is set when a derived value is not finite (the upload's
   // non-finite-input check, done where the values are made instead of by launches of its own)
   hipError_t edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
-                             int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag = nullptr);
+                             int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag = nullptr,
+                             const std::function<void()>& while_running = nullptr);
   // z = mu / scale, wgt = 1 or 1 / var, x0 = prediction / scale where finite (else z)
   hipError_t sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
                        float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0,

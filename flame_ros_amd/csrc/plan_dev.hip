@@ -2122,7 +2122,8 @@ hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntil
 }
 
 hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
-                                       int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag) {
+                                       int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag,
+                                       const std::function<void()>& while_running) {
   *E_out = 0;
   *index_error = false;
   if (T <= 0) return hipSuccess;
@@ -2145,6 +2146,7 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, flags_ + 4, nan_flag);
   int32_t* h = reinterpret_cast<int32_t*>(hpin_);  // (page-locked, see reserve())
   HIPRET(hipMemcpyAsync(h, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (while_running) while_running();  // host work of the caller overlaps the kernels above
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
   if (h[0] & 32) return hipErrorUnknown;  // a scan's look-back timed out (never seen)
