@@ -291,11 +291,12 @@ class Flame {
 
     // ---- graph sync (row a7), in the library ----
     stats_.tick("sync_graph");
-    std::vector<float> pos(2 * static_cast<size_t>(V));
-    std::vector<int32_t> tidx(3 * static_cast<size_t>(T));
-    for (int32_t v = 0; v < V; ++v) { pos[2 * v] = vtx[v].x; pos[2 * v + 1] = vtx[v].y; }
-    for (int32_t t = 0; t < T; ++t)
-      for (int k = 0; k < 3; ++k) tidx[3 * t + k] = triangles[t][k];
+    // cv::Point2f / cv::Vec3i (and the fallback structs) ARE the library's input layout -- {float u, v}
+    // per vertex, three int32 vertex ids per triangle: no conversion pass over the frame
+    static_assert(sizeof(Point2f) == 2 * sizeof(float) && sizeof(Triangle) == 3 * sizeof(int32_t) &&
+                      sizeof(Edge) == 2 * sizeof(int32_t), "boundary types are packed");
+    const float* pos = V ? reinterpret_cast<const float*>(vtx.data()) : nullptr;
+    const int32_t* tidx = T ? reinterpret_cast<const int32_t*>(triangles.data()) : nullptr;
     flame_hip_sync_params sp;
     sp.adaptive_data_weights = params_.adaptive_data_weights;
     sp.rescale_data = params_.rescale_data;
@@ -305,8 +306,8 @@ class Flame {
     sp.alpha_gain = params_.edge_alpha_gain;
     sp.beta_gain = params_.edge_beta_gain;
     float scale = 1.0f;
-    int rc = graph_.sync(params_.hip_device, sp, V, T, pos.data(), idepth_mu.data(), idepth_var.data(),
-                         tidx.data(), prediction ? prediction->data() : nullptr, &scale, params_.edge_d_sign);
+    int rc = graph_.sync(params_.hip_device, sp, V, T, pos, idepth_mu.data(), idepth_var.data(), tidx,
+                         prediction ? prediction->data() : nullptr, &scale, params_.edge_d_sign);
     if (rc) return fail(rc);
     const int32_t E = graph_.numEdges();
     stats_.tock("sync_graph");
@@ -338,28 +339,34 @@ class Flame {
     // on un-scaled inverse depths with the un-scaled thresholds. ----
     const flame_hip_params cp = reg::toC(params_.rparams);
     double smooth = 0.0, data = 0.0;
-    std::vector<int32_t> eidx(2 * static_cast<size_t>(E));
-    std::vector<float> idepths(V, 0.0f);
-    std::vector<float> normals(3 * static_cast<size_t>(V), 0.0f);
-    std::vector<uint8_t> tri_valid(T, 0);
+    // Host-side copies of the frame (what the getters hand out) are made WHILE the GPU iterates: the
+    // solve above is asynchronous, the call below is the frame's one synchronisation.  They go into
+    // staging members and are swapped in only when the frame succeeded (atomic commit).
+    st_vtx_ = vtx;
+    st_tris_ = triangles;
+    if (raw) { st_raw_vtx_ = raw->vtx; st_raw_mu_ = raw->idepth_mu; st_raw_var_ = raw->idepth_var; }
+    else { st_raw_vtx_ = vtx; st_raw_mu_ = idepth_mu; st_raw_var_ = idepth_var; }
+    st_edges_.resize(E);
+    st_idepths_.resize(V);
+    st_normals_.resize(3 * static_cast<size_t>(V));
+    st_tri_valid_.resize(T);
     const flame_hip_tri_params tp = triParams();
     float coverage = 0.0f;
-    rc = flame_hip_frame_results(graph_.handle(), &cp, scale, Kinv_, &tp, &smooth, &data, idepths.data(),
-                                 normals.data(), tri_valid.data(), eidx.data(), &coverage);
+    rc = flame_hip_frame_results(graph_.handle(), &cp, scale, Kinv_, &tp, &smooth, &data, st_idepths_.data(),
+                                 st_normals_.data(), st_tri_valid_.data(),
+                                 E ? reinterpret_cast<int32_t*>(st_edges_.data()) : nullptr, &coverage);
     if (rc) return fail(rc);
     stats_.tock("nltgv2");
     stats_.setTiming("interpolate", 0.0);  // folded into the call above (device time: see nltgv2_device)
 
     // ---- commit: every cached output changes together ----
-    vtx_ = vtx;
-    tris_ = triangles;
-    idepths_.swap(idepths);
-    normals_flat_.swap(normals);
-    tri_valid_.swap(tri_valid);
-    edges_.resize(E);
-    for (int32_t e = 0; e < E; ++e) edges_[e] = Edge(eidx[2 * e], eidx[2 * e + 1]);
-    if (raw) { raw_vtx_ = raw->vtx; raw_mu_ = raw->idepth_mu; raw_var_ = raw->idepth_var; }
-    else { raw_vtx_ = vtx; raw_mu_ = idepth_mu; raw_var_ = idepth_var; }
+    vtx_.swap(st_vtx_);
+    tris_.swap(st_tris_);
+    idepths_.swap(st_idepths_);
+    normals_flat_.swap(st_normals_);
+    tri_valid_.swap(st_tri_valid_);
+    edges_.swap(st_edges_);
+    raw_vtx_.swap(st_raw_vtx_); raw_mu_.swap(st_raw_mu_); raw_var_.swap(st_raw_var_);
     device_frame_valid_ = true;
     ++frame_serial_;  // the debug images of earlier frames are stale (rendered on demand, see debugImage)
 
@@ -470,6 +477,12 @@ class Flame {
   std::vector<Triangle> tris_;
   std::vector<Edge> edges_;
   std::vector<uint8_t> tri_valid_;
+  // staging of the frame in flight (filled while the GPU iterates, swapped in on success)
+  std::vector<Point2f> st_vtx_, st_raw_vtx_;
+  std::vector<float> st_raw_mu_, st_raw_var_, st_idepths_, st_normals_;
+  std::vector<Triangle> st_tris_;
+  std::vector<Edge> st_edges_;
+  std::vector<uint8_t> st_tri_valid_;
   uint64_t frame_serial_ = 0;        // successful updates so far
   Image3b debug_detections_, debug_matches_;
   mutable DebugImage debug_wireframe_, debug_features_, debug_normals_, debug_idepthmap_;
