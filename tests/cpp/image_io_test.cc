@@ -26,6 +26,16 @@ static bool dump(const char* path, const Image& im) {
 
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
+  if (std::string(argv[1]) == "inflate") {  // <zlib stream file> <out.bin>: raw inflate of a whole file
+    std::vector<uint8_t> in, out;
+    if (!readFile(argv[2], &in)) return 3;
+    if (!inflate(in.data(), in.size(), &out)) return 6;
+    FILE* f = std::fopen(argv[3], "wb");
+    if (!f) return 4;
+    std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    return 0;
+  }
   Image im;
   std::string err;
   if (!readImage(argv[2], &im, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 3; }

@@ -166,3 +166,29 @@ def test_corrupt_files_are_rejected(exe, tmp_path):
         open(bad, "wb").write(data)
         p = subprocess.run([exe, "decode", bad, str(tmp_path / "o.bin")], capture_output=True)
         assert p.returncode == 3, name
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_inflate_against_zlib_streams(exe, tmp_path, seed):
+    """The header-only inflate against streams zlib produced with every strategy / level / window size
+    that changes the block structure (stored, fixed Huffman, dynamic Huffman, RLE, long distances),
+    incl. the empty input and inputs that span many deflate blocks."""
+    rng = np.random.default_rng(seed)
+    kinds = [b"", bytes(rng.integers(0, 256, 70000, dtype=np.uint8)),                      # incompressible
+             bytes(rng.integers(0, 4, 200000, dtype=np.uint8)),                            # low entropy
+             (b"flame_ros " * 5000) + bytes(rng.integers(0, 256, 999, dtype=np.uint8)),   # long matches
+             bytes(np.repeat(rng.integers(0, 256, 300, dtype=np.uint8), rng.integers(1, 400, 300)))]  # runs
+    data = kinds[seed % len(kinds)] if seed < len(kinds) else b"".join(kinds)
+    for level, strategy, wbits in ((0, zlib.Z_DEFAULT_STRATEGY, 15), (1, zlib.Z_DEFAULT_STRATEGY, 15),
+                                   (9, zlib.Z_DEFAULT_STRATEGY, 15), (6, zlib.Z_FIXED, 15), (6, zlib.Z_RLE, 15),
+                                   (6, zlib.Z_HUFFMAN_ONLY, 15), (9, zlib.Z_FILTERED, 9)):
+        co = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+        z = co.compress(data) + co.flush()
+        src, out = str(tmp_path / "z.bin"), str(tmp_path / "o.bin")
+        open(src, "wb").write(z)
+        p = subprocess.run([exe, "inflate", src, out], capture_output=True)
+        assert p.returncode == 0, (level, strategy, wbits, len(data))
+        assert open(out, "rb").read() == data, (level, strategy, wbits)
+    # a truncated stream is rejected
+    open(src, "wb").write(z[:max(3, len(z) // 2)])
+    assert subprocess.run([exe, "inflate", src, out], capture_output=True).returncode in (6,) or len(data) == 0
