@@ -253,6 +253,12 @@ struct flame_hip_graph {
   bool plan_reused = false;    // the current plan's partition came from the map
   int reuse_tile_own_opt = 0;  // the "tile_own" option the map was made with
   int reuse_backoff = 0, reuse_skip = 0;  // frames to sit out after a rejected reuse (doubles, <= 16)
+  // graph sync without waiting for the edge count: E is predicted (V + T + euler_off, -1 for a
+  // triangulated disk) and checked at the plan builder's first synchronisation
+  bool spec_edges = false;     // the current upload_device_plan() runs on a predicted count
+  int32_t true_edges = 0;      // ... and this is what the device counted when the prediction failed
+  int32_t euler_off = -1;      // E - V - T of the last frame
+  int euler_skip = 0, euler_backoff = 0;
   DevPlanner planner;
   float2* in_pos = nullptr;
   int2* in_edges = nullptr;
@@ -648,10 +654,13 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       }
     }
     bool ok = false, index_error = false;
-    int32_t nan_flag = 0;  // the finite-check word rides on the builder's first sync
+    int32_t uflags[2] = {0, 0};  // the finite-check word and the derived edge count ride on the builder's first sync
+    g->planner.expect_edges(g->spec_edges ? E : -1);
     HIPCHK(g->planner.build(s, g->opt, V, E, T, ntiles, depth, in, &A, alloc_tile_arrays, &ctx, &tiles, &ok,
-                            &index_error, g->dflags, &nan_flag, stage_rest));
-    if (nan_flag & 1) return FLAME_HIP_ERR_NAN;
+                            &index_error, g->dflags, uflags, stage_rest));
+    g->planner.expect_edges(-1);
+    if (g->spec_edges && uflags[1] != E) { g->true_edges = uflags[1]; return 2; }  // the predicted edge count was wrong
+    if (uflags[0] & 1) return FLAME_HIP_ERR_NAN;
     if (index_error) return FLAME_HIP_ERR_ARG;
     const bool tiles_valid = ok;  // every tile was built (it may still be too large for LDS / a kernel config)
     if (ok) {
@@ -981,6 +990,14 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     bool index_error = false;
     int vrc = 0;
     float sc = 1.0f;
+    // The edge count of a triangulation is known before the device has derived the edges: Euler's
+    // formula, E = V + T - 1 for a triangulated disk (what a Delaunay triangulation is); for meshes
+    // with holes / several components the offset of the previous frame.  The frame goes on without
+    // the round trip; the plan builder's first synchronisation brings the true count and a wrong
+    // guess only costs a second build (then the handle waits 1, 2, 4 ... frames before guessing again).
+    int32_t expected_E = -1;
+    if (g->euler_skip > 0) --g->euler_skip;
+    else if ((int64_t)V + T + g->euler_off > 0 && (int64_t)V + T + g->euler_off <= 3ll * T) expected_E = V + T + g->euler_off;
     HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error, g->dflags,
                                       [&]() {
                                         vrc = validate();
@@ -990,7 +1007,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
                                           sc = (float)(acc / (double)V);
                                           if (!(sc > 0.0f)) sc = 1.0f;
                                         }
-                                      }));
+                                      }, expected_E));
     lap("edges_from_tris");
     if (vrc || index_error) g->uploaded = false;  // (the staged inputs of the previous graph are gone)
     if (vrc) return vrc;
@@ -1005,7 +1022,20 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     g->solves_since_upload = 0;
     g->lanes_applied = false;
     g->beta_is_alpha = true;
+    g->spec_edges = expected_E >= 0;
     rc = upload_device_plan(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, true);
+    g->spec_edges = false;
+    if (rc == 2) {  // the predicted edge count was wrong: the device has the true one by now -- build again
+      E = g->true_edges;
+      g->euler_backoff = std::min(16, std::max(1, 2 * g->euler_backoff));
+      g->euler_skip = g->euler_backoff;
+      if (E < 0 || E > 3 * (int64_t)T) return FLAME_HIP_ERR_ARG;
+      g->E = E;
+      rc = upload_device_plan(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, true);
+    } else if (expected_E >= 0) {
+      g->euler_backoff = 0;
+    }
+    if (rc == 1 || rc == 0) g->euler_off = (int32_t)((int64_t)g->E - V - T);
     if (rc <= 0) (void)hipStreamSynchronize(s);  // the H2D copies of the caller's arrays end here
     if (rc < 0) return rc;
     if (rc == 1) {

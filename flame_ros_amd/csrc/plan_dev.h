@@ -70,8 +70,8 @@ class DevPlanner {
   // buffers; alloc_tiles(nv, ne, ns) is called once (after a stream sync) and must fill the tile
   // array pointers of `arrays` for those element counts.  On success *tiles_host receives the tile
   // descriptors and *ok tells whether every tile could be built (false = the caller retries with
-  // smaller tiles or falls back to the host builder).  user_flags_dev (optional): one device word of
-  // the caller (e.g. a non-finite-input flag) copied to *user_flags_host with the builder's first
+  // smaller tiles or falls back to the host builder).  user_flags_dev (optional): TWO device words of
+  // the caller (a non-finite-input flag; the derived edge count) copied to user_flags_host[0..1] with the builder's first
   // sync; a non-zero word ends the build early (ok = false).  after_partition (optional) is called
   // once stages A and B -- which read only `in.pos` -- are enqueued: the caller stages its other
   // arrays there, so the host-side copies overlap the partition kernels.  Returns a hipError_t.
@@ -88,7 +88,11 @@ class DevPlanner {
   // non-finite-input check, done where the values are made instead of by launches of its own)
   hipError_t edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
                              int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag = nullptr,
-                             const std::function<void()>& while_running = nullptr);
+                             const std::function<void()>& while_running = nullptr, int32_t expected_E = -1);
+  // expected_E >= 0 (needs nan_flag): do not wait for the count -- *E_out = expected_E, the true count is
+  // written to nan_flag[1]; expect_edges(E) makes the NEXT build() check it at its first synchronisation
+  // (user_flags_host[1] then holds the true count; a mismatch ends the build with ok = false)
+  void expect_edges(int32_t E) { expect_E_ = E; }
   // z = mu / scale, wgt = 1 or 1 / var, x0 = prediction / scale where finite (else z)
   hipError_t sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
                        float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0,
@@ -134,6 +138,7 @@ class DevPlanner {
   int map_tiles_ = 0, map_depth_ = 0;
   int32_t map_V_ = 0;
   bool reuse_next_ = false, last_reused_ = false;
+  int32_t expect_E_ = -1;  // >= 0: the build was launched on a predicted edge count (checked at its first sync)
   int32_t spec_nv_ = 0, spec_ne_ = 0, spec_ns_ = 0;  // tile-array totals (+1/8) of the previous build: the next
   int spec_tiles_ = 0;                                //   build allocates for them and skips a host round trip
   int32_t* cell_pyr_ = nullptr;    // tile + 1 of the vertices in every cell of a 128/32/8/1 pyramid

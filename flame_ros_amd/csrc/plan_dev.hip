@@ -2071,12 +2071,15 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (spec) HIPRET(launch_pass2());
   HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (user_flags_dev && user_flags_host)  // the caller's own check word rides on the same sync
-    HIPRET(hipMemcpyAsync(huser, user_flags_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPRET(hipMemcpyAsync(huser, user_flags_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
-  if (user_flags_dev && user_flags_host) *user_flags_host = *huser;
+  if (user_flags_dev && user_flags_host) { user_flags_host[0] = huser[0]; user_flags_host[1] = huser[1]; }
   lap(spec ? "F+G pass1+2+sync" : "F pass1+sync");
-  if (user_flags_dev && user_flags_host && *user_flags_host) return hipSuccess;
+  // word 0: the caller's failure flag; word 1: the number of edges the graph sync derived -- a build
+  // that was launched on a PREDICTED edge count and got it wrong is worthless whatever else it says
+  if (user_flags_dev && user_flags_host && (user_flags_host[0] || (expect_E_ >= 0 && user_flags_host[1] != expect_E_)))
+    return hipSuccess;
   if (hflags[0] & 32) return hipSuccess;  // a scan's look-back timed out (never seen): not ok -> host builder
   if (hflags[0] & 64) { map_tiles_ = 0; return hipSuccess; }  // the reused partition does not suit this frame: not ok
   if (hflags[0] & 2) { *index_error = true; return hipSuccess; }
@@ -2123,7 +2126,7 @@ hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntil
 
 hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
                                        int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag,
-                                       const std::function<void()>& while_running) {
+                                       const std::function<void()>& while_running, int32_t expected_E) {
   *E_out = 0;
   *index_error = false;
   if (T <= 0) return hipSuccess;
@@ -2143,7 +2146,16 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s, V, off, nullptr, out);
   hipLaunchKernelGGL(k_he_mark, grid1(V), dim3(256), 0, s, V, off, out, f);
   HIPRET(scan_i32(s, 0, f, idx, n, false, cub_tmp_, cub_bytes_));
-  hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, flags_ + 4, nan_flag);
+  hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha,
+                     (expected_E >= 0 && nan_flag) ? nan_flag + 1 : flags_ + 4, nan_flag);
+  if (expected_E >= 0 && nan_flag) {
+    // No round trip: the caller goes on with the edge count it predicted (Euler: E = V + T - 1 for a
+    // triangulated disk); the true count lands in nan_flag[1] and comes back with the plan builder's
+    // first synchronisation, which rejects the build when the prediction was wrong.
+    if (while_running) while_running();
+    *E_out = expected_E;
+    return hipGetLastError();
+  }
   int32_t* h = reinterpret_cast<int32_t*>(hpin_);  // (page-locked, see reserve())
   HIPRET(hipMemcpyAsync(h, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (while_running) while_running();  // host work of the caller overlaps the kernels above

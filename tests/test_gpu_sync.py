@@ -103,3 +103,38 @@ def test_device_sync_flags_non_finite_derived_values(gpu):
     r.sync_features(g.pos, g.z, var, g.tris, default_sync_params())  # a good frame afterwards
     assert r.info("plan_on_device") == 1 and r.E == g.E
     r.close()
+
+
+def test_edge_count_is_predicted_and_verified(gpu):
+    """The device graph sync does not wait for the edge count: E = V + T + (offset of the previous
+    frame, -1 for a triangulated disk = Euler) is assumed and checked at the plan builder's first
+    synchronisation; a wrong guess (a mesh with holes after a Delaunay frame and vice versa) costs a
+    second build and must give the same result: edges, alpha and the solve equal the oracle's."""
+    r = GraphRegularizer.empty(device=0)
+    rng = np.random.default_rng(4)
+    kinds = ["disk", "disk", "holes", "holes", "holes", "disk", "disk", "two_parts"]
+    for k, kind in enumerate(kinds):
+        g = graphgen.synthetic(6000 + 50 * k, seed=90 + k)
+        tris = g.tris
+        if kind == "holes":      # drop a fifth of the triangles: holes and notches, E != V + T - 1
+            tris = tris[rng.random(len(tris)) > 0.2]
+        elif kind == "two_parts":  # keep only triangles left of x = 300 and right of x = 340: two components
+            cx = g.pos[tris].mean(1)[:, 0]
+            tris = tris[(cx < 300) | (cx > 340)]
+        var = np.full(g.V, 1e-4, np.float32)
+        s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, tris, None)
+        E = len(s["edges"])
+        if kind == "disk":
+            assert E == g.V + len(tris) - 1
+        else:
+            assert E != g.V + len(tris) - 1
+        r.sync_features(g.pos, g.z, var, tris, default_sync_params())
+        assert r.info("plan_on_device") == 1 and r.E == E, (kind, r.E, E)
+        assert np.array_equal(r.edges(), s["edges"])
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+        o.solve(oracle_params(), 20)
+        r.step(default_params(), 20)
+        x, w1, w2, q = r.download()
+        assert_bit_equal(x, o.x, "frame %d (%s) x" % (k, kind))
+        assert_bit_equal(q, o.q, "frame %d (%s) q" % (k, kind))
+    r.close()
