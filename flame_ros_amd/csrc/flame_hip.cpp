@@ -895,7 +895,9 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     g->cur = 0;
     if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)P.T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)P.T)))
       return rc;
-      HIPCHK(hipStreamSynchronize(g->stream));  // the staged host arrays (hA, hB, hpos) end here
+    // (no synchronisation here: the transfer reads the page-locked arena, which is only rewritten by
+    // the next upload -- behind that upload's own stream synchronisation; the solve is ordered behind
+    // the copy on the stream, a caller's stream through the state event of finish_upload)
   }
   return finish_upload(g);
 }
