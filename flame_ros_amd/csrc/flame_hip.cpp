@@ -1327,6 +1327,7 @@ int flame_hip_triangles(flame_hip_graph* g, const float Kinv[9], const flame_hip
   fill_tri_params(Kinv, tp, &d);
   HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
                           g->tri_normals, g->tri_valid, g->vtx_normals));
+  g->raster_serial = 0;  // tri_valid / vtx_normals were rewritten (maybe with other filter parameters)
   HIPCHK(hipStreamSynchronize(g->stream));
   if (vtx_normals && V > 0) {
     HIPCHK(launch_download_rows3(g->stream, V, g->v_o2i_dev, g->vtx_normals, g->dl_v));
@@ -1464,6 +1465,7 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
       fill_tri_params(Kinv, tp, &d);
       HIPCHK(launch_triangles(s, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d, g->tri_normals,
                               g->tri_valid, g->vtx_normals, &fo));
+      g->raster_serial = 0;
     }
   } else if (x && V > 0) {  // no camera / filter parameters given: plain permuted download (3 planes, x first)
     HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], reinterpret_cast<float*>(g->fr_dev + off_x)));
@@ -1542,6 +1544,7 @@ int flame_hip_mesh(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_
   fill_tri_params(Kinv, tp, &d);
   HIPCHK(launch_triangles(g->stream, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d,
                           g->tri_normals, g->tri_valid, g->vtx_normals));
+  g->raster_serial = 0;  // (as in flame_hip_triangles)
   HIPCHK(launch_mesh(g->stream, V, g->pos, g->A[g->cur], g->vtx_normals, g->v_i2o_dev, d, tp->width,
                      tp->height, g->mesh_pts));
   HIPCHK(hipStreamSynchronize(g->stream));
