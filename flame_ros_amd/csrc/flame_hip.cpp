@@ -1471,8 +1471,15 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     HIPCHK(launch_download_vertex(s, V, g->v_o2i_dev, g->A[g->cur], reinterpret_cast<float*>(g->fr_dev + off_x)));
   }
   HIPCHK(hipMemcpyAsync(host, g->fr_dev, dev_bytes, hipMemcpyDeviceToHost, s));
+  if (edges && E > 0) {  // the edge list is copied out WHILE the iterations still run on the main stream
+    if (dev_edges) {
+      HIPCHK(hipStreamSynchronize(g->stream_in));
+      std::memcpy(edges, host + off_edges, sizeof(int2) * (size_t)E);
+    } else {
+      std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)E);
+    }
+  }
   HIPCHK(hipStreamSynchronize(s));
-  if (dev_edges) HIPCHK(hipStreamSynchronize(g->stream_in));
   if (smooth || data) {
     const double* h = reinterpret_cast<const double*>(host + off_part);
     double sm = 0.0, da = 0.0;
@@ -1483,10 +1490,6 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
   if (x && V > 0) std::memcpy(x, host + off_x, sizeof(float) * (size_t)V);
   if (vtx_normals && V > 0) std::memcpy(vtx_normals, host + off_n, sizeof(float) * 3 * (size_t)V);
   if (tri_valid && T > 0) std::memcpy(tri_valid, host + off_tv, (size_t)T);
-  if (edges && E > 0) {
-    if (dev_edges) std::memcpy(edges, host + off_edges, sizeof(int2) * (size_t)E);
-    else std::memcpy(edges, g->sync.edges.data(), sizeof(int32_t) * 2 * (size_t)E);
-  }
   if (coverage) {
     const uint32_t* c = reinterpret_cast<const uint32_t*>(host + off_cov);
     uint64_t covered = 0;
