@@ -197,8 +197,9 @@ class Flame {
   // when a getter asks: update() itself draws nothing -- the first call of a getter after an
   // update renders that image from the frame's device state and copies it out, later calls return
   // the cached image.  A disabled image (Params::debug_draw_*) stays black.  Detections / Matches
-  // belong to the feature pipeline: black images of the right size.  text_overlay / flip_images
-  // are not applied.
+  // belong to the feature pipeline: black images of the right size.  debug_flip_images rotates the
+  // rendered images by 180 degrees (cfg/flame_offline_tum.yaml:65); debug_draw_text_overlay is not
+  // applied (no font rendering here).
   const Image3b& getDebugImageWireframe() const {
     return debugImage(FLAME_HIP_IMG_WIREFRAME, params_.debug_draw_wireframe, &debug_wireframe_);
   }
@@ -426,8 +427,8 @@ class Flame {
     const bool ok = maps(filtered, &v, nullptr, nullptr, 0.f, 0.f);
     *out = Image1f(height_, width_, std::numeric_limits<float>::quiet_NaN());
     if (!ok) return;
-    for (int i = 0; i < height_; ++i)
-      for (int j = 0; j < width_; ++j) (*out)(i, j) = v[static_cast<size_t>(i) * width_ + j];
+    for (int i = 0; i < height_; ++i)  // (rows of both image types are contiguous)
+      std::memcpy(static_cast<void*>(&(*out)(i, 0)), v.data() + static_cast<size_t>(i) * width_, sizeof(float) * width_);
   }
   bool fail(int code) {
     stats_.set("hip_error", code);
@@ -457,6 +458,12 @@ class Flame {
                               feats ? raw_mu_.data() : nullptr, dbg_buf_.data()))
       return d->img;  // the previous image stays
     static_assert(sizeof(Vec3b) == 3, "BGR8 pixels are packed");
+    if (params_.debug_flip_images) {  // "Rotated debug images by 180 degrees for display" (yaml :65)
+      uint8_t* b = dbg_buf_.data();
+      const size_t n = static_cast<size_t>(width_) * height_;
+      for (size_t lo = 0, hi = n - 1; lo < hi; ++lo, --hi)
+        for (int c = 0; c < 3; ++c) std::swap(b[3 * lo + c], b[3 * hi + c]);
+    }
     for (int i = 0; i < height_; ++i)  // rows of both image types are contiguous
       std::memcpy(static_cast<void*>(&d->img(i, 0)), dbg_buf_.data() + 3 * static_cast<size_t>(i) * width_,
                   3 * static_cast<size_t>(width_));

@@ -5,7 +5,7 @@
 // input is one frame (header V, T, iters, device, flags; pos, mu, [var], tris) fed to the SAME
 // flame::Flame object in turn (a frame stream on one GPU handle); idepths / validity / normals /
 // costs of the LAST frame are written back.  flags: 1 = adaptive_data_weights, 2 = rescale_data,
-// 4 = a var array follows mu.  Exit code 0 = ok, 3 = update returned false (no device).
+// 4 = a var array follows mu, 8 = debug_flip_images.  Exit code 0 = ok, 3 = update returned false (no device).
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -42,6 +42,7 @@ int main(int argc, char** argv) {
   params.rparams.step_q = 125.0f;
   params.rparams.theta = 0.25f;
   params.debug_draw_normals = true;  // (reference default false, cfg/flame_offline_tum.yaml:62)
+  params.debug_flip_images = (hdr0[4] & 8) != 0;  // debug/flip_images (yaml :65)
   flame::Matrix3f K, Kinv;  // cfg/kinect.yaml: 525/525/319.5/239.5
   K(0, 0) = 525.f; K(0, 1) = 0.f; K(0, 2) = 319.5f; K(1, 0) = 0.f; K(1, 1) = 525.f; K(1, 2) = 239.5f;
   K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;

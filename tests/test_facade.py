@@ -177,9 +177,18 @@ def test_facade_matches_oracle_on_gpu(gpu, exe, tmp_path):
     # stat key coverage + the debug images (rendered on the GPU when the getter is called)
     idm_o, _, _ = oracle_depthmaps(640, 480, g.pos, o.x, g.tris, tv_o, True, KINV, 0.1, 100.0)
     assert np.float32(read_outputs.coverage) == np.float32(oracle_coverage(idm_o))
+    wants = []
     for k, kind in enumerate((0, 1, 2, 3)):  # file order: wireframe, features, normals, idepthmap
         want = oracle_image(kind, 640, 480, 1.0, g.pos, o.x, g.tris, tv_o, vn_o, idm_o, g.pos, g.z)
         assert np.array_equal(read_outputs.images[k], want), "debug image %d" % kind
+        wants.append(want)
+    # debug/flip_images (reference cfg/flame_offline_tum.yaml:65): the same images rotated by 180 degrees
+    write_input(inp, g, iters, 0, flags=8)
+    p = subprocess.run([exe, ob, ot, inp], capture_output=True, text=True)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    read_outputs(ob, ot, g)
+    for k in range(4):
+        assert np.array_equal(read_outputs.images[k], wants[k][::-1, ::-1]), "flipped debug image %d" % k
 
 
 @pytest.mark.gpu
