@@ -373,6 +373,7 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
   if (g->device >= 0) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    (void)g->planner.wait_maps();
     g->free_device();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -792,6 +793,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     HIPCHK(wait_last_solve(g));
     HIPCHK(hipStreamSynchronize(g->stream));
     HIPCHK(hipStreamSynchronize(g->stream_in));
+    HIPCHK(g->planner.wait_maps());  // (the previous frame's maps read its positions / tiles on the builder's stream)
     g->drop_execs();  // captured launches hold the old grid / pointers
     g->solves_since_upload = 0;
     g->lanes_applied = false;
@@ -965,6 +967,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     HIPCHK(wait_last_solve(g));
     hipStream_t s = g->stream;
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(g->planner.wait_maps());
     if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_tris, 3 * (size_t)T)) ||
         (rc = dev_alloc(g->caps, &g->in_mu, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_var, (size_t)V)) ||
         (rc = dev_alloc(g->caps, &g->in_pred, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) ||
@@ -982,12 +985,21 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     lap("checks+allocs");
     if ((rc = dev_alloc(g->caps, &g->dflags, 8))) return rc;
     HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
-    HIPCHK(hipMemcpyAsync(g->in_pos, pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(g->in_mu, idepth_mu, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(g->in_var, idepth_var, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-    if (prediction) HIPCHK(hipMemcpyAsync(g->in_pred, prediction, sizeof(float) * (size_t)V, hipMemcpyHostToDevice, s));
-    lap("H2D enqueue");
+    // The copies from the caller's (pageable) arrays block the host, so they are issued in the order
+    // the kernels need them, each batch of kernels enqueued before the next copy starts: triangles ->
+    // half-edge count / scan / fill; positions -> unique edges + alpha; idepths -> data terms.
+    // They go through the staging stream (a copy on the solve stream would wait for the kernels queued
+    // there, and the host with it); the solve stream waits for an event behind each batch.
+    hipStream_t sin = g->stream_in;
+    auto stage = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, sin); };
+    auto staged_for = [&]() {
+      hipError_t e = hipEventRecord(g->ev_in, sin);
+      return e != hipSuccess ? e : hipStreamWaitEvent(s, g->ev_in, 0);
+    };
+    HIPCHK(stage(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T));
+    HIPCHK(staged_for());
+    lap("H2D triangles");
+    hipError_t stage_err = hipSuccess;
     int32_t E = 0;
     bool index_error = false;
     int vrc = 0;
@@ -1002,6 +1014,11 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     else if ((int64_t)V + T + g->euler_off > 0 && (int64_t)V + T + g->euler_off <= 3ll * T) expected_E = V + T + g->euler_off;
     HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error, g->dflags,
                                       [&]() {
+                                        stage_err = stage(g->in_mu, idepth_mu, sizeof(float) * (size_t)V);
+                                        if (stage_err == hipSuccess) stage_err = stage(g->in_var, idepth_var, sizeof(float) * (size_t)V);
+                                        if (stage_err == hipSuccess && prediction)
+                                          stage_err = stage(g->in_pred, prediction, sizeof(float) * (size_t)V);
+                                        if (stage_err == hipSuccess) stage_err = staged_for();
                                         vrc = validate();
                                         if (vrc == 0 && sp->rescale_data) {  // mean in the oracle's order (sequential, float64)
                                           double acc = 0.0;
@@ -1009,7 +1026,12 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
                                           sc = (float)(acc / (double)V);
                                           if (!(sc > 0.0f)) sc = 1.0f;
                                         }
-                                      }, expected_E));
+                                      }, expected_E,
+                                      [&]() {
+                                        hipError_t e = stage(g->in_pos, pos, sizeof(float2) * (size_t)V);
+                                        return e != hipSuccess ? e : staged_for();
+                                      }));
+    HIPCHK(stage_err);
     lap("edges_from_tris");
     if (vrc || index_error) g->uploaded = false;  // (the staged inputs of the previous graph are gone)
     if (vrc) return vrc;

@@ -88,7 +88,10 @@ class DevPlanner {
   // non-finite-input check, done where the values are made instead of by launches of its own)
   hipError_t edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
                              int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag = nullptr,
-                             const std::function<void()>& while_running = nullptr, int32_t expected_E = -1);
+                             const std::function<void()>& while_running = nullptr, int32_t expected_E = -1,
+                             const std::function<hipError_t()>& before_positions = nullptr);
+  // before_positions: called once the kernels that read ONLY the triangles are enqueued and before the
+  // first one that reads `pos` -- a caller that still has to stage the positions does it there
   // expected_E >= 0 (needs nan_flag): do not wait for the count -- *E_out = expected_E, the true count is
   // written to nan_flag[1]; expect_edges(E) makes the NEXT build() check it at its first synchronisation
   // (user_flags_host[1] then holds the true count; a mismatch ends the build with ok = false)
@@ -109,6 +112,9 @@ class DevPlanner {
   // records the cost-density grid of the last build (device side, integer); grid_tiles() then
   // returns the tile count it was made for
   hipError_t update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in, const DevPlanArrays& arrays);
+  // update_grid() works on the builder's second stream, beside the caller's iterations: host-side wait
+  // before anything it reads (positions, tile descriptors, vertex order) or writes is touched again
+  hipError_t wait_maps();
   int grid_tiles() const { return grid_tiles_; }
   void drop_grid() { grid_tiles_ = 0; }
 
@@ -160,6 +166,9 @@ class DevPlanner {
   long long* wsort_ = nullptr;   // V
   long long* wscan_ = nullptr;   // V
   int32_t* counts_ = nullptr;    // V + 2 (degree / triangle counts)
+  int32_t* rank_ = nullptr;      // 2E + 3T places inside the counting CSRs' rows (what the counting atomics returned)
+  int32_t* rank_tri_ = nullptr;  // = rank_ + 2 capE_
+  int32_t* reuse_cnt_ = nullptr; // tile counters of the partition-reuse pass, one per 128-byte line
   int32_t* seg_tab_ = nullptr;   // segment tables + bbox + mids (see plan_dev.hip)
   int32_t* estart_ = nullptr;    // ntiles + 1
   int32_t* tile_ext_ = nullptr;  // ntiles * kCapExt (pass-1 vertex lists)
@@ -180,11 +189,12 @@ class DevPlanner {
   char* hpin_ = nullptr;         // page-locked landing area of the builder's D2H copies (flags, descriptors)
   size_t hpin_bytes_ = 0;
   hipStream_t s2_ = nullptr;
-  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_grid_ = nullptr;
+  bool grid_pending_ = false;    // update_grid()'s kernels may still run on s2_
   int64_t capV2_ = 0;
   size_t tcub_bytes_ = 0;
   void* tcub_tmp_ = nullptr;     // scan scratch of the triangle stage
-  int32_t* tcnt_ = nullptr;      // V + 1 counts, then V cursors
+  int32_t* tcnt_ = nullptr;      // V + 1 counts (2V + 2 allocated)
 };
 
 // Conflict-avoiding lane order applied to a finished plan on the device (plan.h PlanOptions::

@@ -805,21 +805,24 @@ __global__ __launch_bounds__(256) void k_edge_count(int32_t E, int32_t V, const 
                                                     const int32_t* __restrict__ v_o2i,
                                                     const int32_t* __restrict__ tile_of_int,
                                                     const int32_t* __restrict__ tlo, const int32_t* __restrict__ thi,
-                                                    int32_t* cnt, int32_t* flags) {
+                                                    int32_t* cnt, int32_t* rank, int32_t* flags) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
-  atomicAdd(&cnt[edge_bucket(edges[e], V, v_o2i, tile_of_int, tlo, thi, flags)], 1);
+  // the value the count returns is the entry's place in its bucket: the fill needs no second atomic
+  // (the order inside a bucket is arbitrary either way; k_csr_rows sorts it)
+  rank[e] = atomicAdd(&cnt[edge_bucket(edges[e], V, v_o2i, tile_of_int, tlo, thi, flags)], 1);
 }
 
 __global__ __launch_bounds__(256) void k_edge_fill(int32_t E, int32_t V, const int2* __restrict__ edges,
                                                    const int32_t* __restrict__ v_o2i,
                                                    const int32_t* __restrict__ tile_of_int,
                                                    const int32_t* __restrict__ tlo, const int32_t* __restrict__ thi,
-                                                   const int32_t* __restrict__ off, int32_t* cursor, uint32_t* out) {
+                                                   const int32_t* __restrict__ off,
+                                                   const int32_t* __restrict__ rank, uint32_t* out) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   const int32_t b = edge_bucket(edges[e], V, v_o2i, tile_of_int, tlo, thi, nullptr);
-  out[off[b] + atomicAdd(&cursor[b], 1)] = (uint32_t)e;
+  out[off[b] + rank[e]] = (uint32_t)e;
 }
 
 
@@ -863,47 +866,52 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
 // thread.  The result is the one the stable sort by vertex gave (rows in ascending original edge /
 // triangle id), in 7 short launches instead of the ~20 of a library merge sort of 2E or 3T keys. ----
 __global__ __launch_bounds__(256) void k_csr_count(int32_t E, const int2* __restrict__ eij,
-                                                   const int32_t* __restrict__ e_o2i, int32_t* cnt) {
+                                                   const int32_t* __restrict__ e_o2i, int32_t* cnt, int2* rank) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   const int2 ij = eij[e_o2i[e]];
-  atomicAdd(&cnt[ij.x], 1);
-  atomicAdd(&cnt[ij.y], 1);
+  int2 r;
+  r.x = atomicAdd(&cnt[ij.x], 1);
+  r.y = atomicAdd(&cnt[ij.y], 1);
+  rank[e] = r;
 }
 
 // entry = (original edge id << 1) | role (1: the vertex is the target): ascending entry = ascending
 // original id, the summation order of the arithmetic contract
 __global__ __launch_bounds__(256) void k_csr_fill(int32_t E, const int2* __restrict__ eij,
                                                   const int32_t* __restrict__ e_o2i,
-                                                  const int32_t* __restrict__ row, int32_t* cursor, uint32_t* out) {
+                                                  const int32_t* __restrict__ row,
+                                                  const int2* __restrict__ rank, uint32_t* out) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
   if (e >= E) return;
   const int2 ij = eij[e_o2i[e]];
-  out[row[ij.x] + atomicAdd(&cursor[ij.x], 1)] = (uint32_t)e << 1;
-  out[row[ij.y] + atomicAdd(&cursor[ij.y], 1)] = ((uint32_t)e << 1) | 1u;
+  const int2 r = rank[e];
+  out[row[ij.x] + r.x] = (uint32_t)e << 1;
+  out[row[ij.y] + r.y] = ((uint32_t)e << 1) | 1u;
 }
 
 __global__ __launch_bounds__(256) void k_tri_count(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
                                                    const int32_t* __restrict__ v_o2i, int32_t* tris_int,
-                                                   int32_t* cnt, int32_t* flags) {
+                                                   int32_t* cnt, int32_t* rank, int32_t* flags) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
   const int32_t vo = tris[k];
   if (vo < 0 || vo >= V) { atomicOr(&flags[0], 2); tris_int[k] = 0; return; }
   const int32_t v = v_o2i[vo];
   tris_int[k] = v;
-  atomicAdd(&cnt[v], 1);
+  rank[k] = atomicAdd(&cnt[v], 1);
 }
 
 __global__ __launch_bounds__(256) void k_tri_fill(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
                                                   const int32_t* __restrict__ tris_int,
-                                                  const int32_t* __restrict__ row, int32_t* cursor, uint32_t* out) {
+                                                  const int32_t* __restrict__ row,
+                                                  const int32_t* __restrict__ rank, uint32_t* out) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
   const int32_t vo = tris[k];
   if (vo < 0 || vo >= V) return;  // (flagged by k_tri_count: the plan is rejected after the next sync)
   const int32_t v = tris_int[k];
-  out[row[v] + atomicAdd(&cursor[v], 1)] = (uint32_t)(k / 3);
+  out[row[v] + rank[k]] = (uint32_t)(k / 3);
 }
 
 // one thread per row: ascending order (insertion sort; heap sort for long rows, so that a vertex of
@@ -1235,116 +1243,95 @@ __global__ __launch_bounds__(256) void k_assign_lanes(const TileDesc* __restrict
   assign_lanes_block(threadIdx.x & 63, b0, D.e_loc, D.erec_off, D.nslots, t_eij, t_ew, t_emap);
 }
 
-__global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const int32_t* __restrict__ vstart_tab,
-                                                           const int32_t* __restrict__ vend_tab,
-                                                           const int32_t* __restrict__ estart,
-                                                           const int32_t* __restrict__ tile_ext,
-                                                           const int32_t* __restrict__ meta,
-                                                           const float4* __restrict__ ew, TileDesc* tiles,
-                                                           int32_t* t_vmap, int32_t* t_emap, uint2* t_eij,
-                                                           float4* t_ew, uint32_t* t_srow, int32_t* flags,
-                                                           int lane_order) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_fail, s_ecnt;
-  __shared__ int32_t s_ring_end[kMaxDepth + 1], s_level_end[kMaxDepth + 1];
-  __shared__ int32_t s_gw[kCapExt / 64], s_gbase[kCapExt / 64 + 1];
-  const int t = blockIdx.x, tid = threadIdx.x;
-  // a build that has already failed (bad indices, a tile that does not fit, a rejected partition, tile
-  // arrays too small for a speculative launch: every bit but pass 2's own 8) must not be continued:
-  // the host used to stop before this launch; without the round trip the kernel stops itself
-  if (__builtin_amdgcn_readfirstlane(flags[0]) & ~8) return;
-  TileLds L;
-  uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
-  L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
-  L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
-  L.hkey = L.ext + kCapExt;
-  L.hval = L.hkey + kHash;
-  const int32_t* m = meta + (size_t)t * kMetaWords;
-  const int n_ext = m[0], e_loc = m[1], n_upd = m[2];
-  const int32_t voff = m[21], eoff = m[22], soff = m[23];
-  const int32_t vstart = vstart_tab[t], n_own = vend_tab[t] - vstart;
-  const int32_t es = estart[t], e_own = estart[t + 1] - es;
-  if (tid == 0) { s_fail = m[3]; s_ecnt = 0; }
-  if (tid <= kMaxDepth) { s_ring_end[tid] = m[4 + tid]; s_level_end[tid] = 0; }
-  if (tid < kCapExt / 64) s_gw[tid] = 1;
-  const int bm_words = (G.V + 31) >> 5;
-  for (int i = tid; i < bm_words; i += kP2Threads) L.bitmap[i] = 0u;
-  __syncthreads();
-  if (m[3]) {  // pass 1 already failed this tile: leave a descriptor that says so
-    if (tid == 0) { TileDesc D = {}; D.n_ext = -1; tiles[t] = D; }
-    return;
-  }
-  for (int l = tid; l < n_ext; l += kP2Threads) {
-    const int32_t v = tile_ext[(size_t)t * kCapExt + l];
-    L.ext[l] = v;
-    atomicOr(&L.bitmap[v >> 5], 1u << (v & 31));
-    t_vmap[voff + l] = v;
-  }
-  __syncthreads();
-  tile_hash_build<kP2Threads>(L, n_ext);
-  // ---- local edges: every local vertex contributes its outgoing incidences ----
-  for (int it = tid; it < n_ext * kRowLanes; it += kP2Threads) {
+// what a tile's workgroup shares while it is being built
+struct TileShared {
+  int fail, ecnt, n;
+  int32_t ring_end[kMaxDepth + 1], level_end[kMaxDepth + 1];
+  int32_t gw[kCapExt / 64], gbase[kCapExt / 64 + 1];
+};
+
+// local edges: every local vertex contributes its outgoing incidences (keys into ekeys, count in S.ecnt)
+template <int NTB>
+__device__ __forceinline__ void tile_collect_keys(const TileGraph& G, const TileLds& L, TileShared& S, uint64_t* ekeys,
+                                                  int n_ext) {
+  const int tid = threadIdx.x;
+  for (int it = tid; it < n_ext * kRowLanes; it += NTB) {
     const int lv = it / kRowLanes;
     const int32_t v = L.ext[lv];
-    const int rv = ring_of(s_ring_end, lv);
+    const int rv = ring_of(S.ring_end, lv);
     for (int32_t s = G.grow[v] + it % kRowLanes; s < G.grow[v + 1]; s += kRowLanes) {
       const int32_t ent = G.ginc[s];
-      if (ent < 0) continue;
+      if (ent < 0) continue;  // v is the target; the source adds the edge
       uint64_t key;
-      if (local_edge_key(G, L, s_ring_end, ent, lv, rv, G.eij[ent].y, &key)) {
-        const int pos = atomicAdd(&s_ecnt, 1);
+      if (local_edge_key(G, L, S.ring_end, ent, lv, rv, G.eij[ent].y, &key)) {
+        const int pos = atomicAdd(&S.ecnt, 1);
         if (pos < kSortPad) ekeys[pos] = key;
       }
     }
   }
   __syncthreads();
-  if (s_ecnt != e_loc) { if (tid == 0) s_fail = 1; }
+}
+
+// everything behind the key list: sorted local edges, gather records, incidence slots, descriptor.
+// Expects L (ext, bitmap, hash), S.ring_end, S.fail, the keys and S.gw[] = 1, S.level_end[] = 0.
+struct TileOut {
+  const float4* ew; TileDesc* tiles; int32_t* t_vmap; int32_t* t_emap; uint2* t_eij; float4* t_ew; uint32_t* t_srow;
+  int32_t* flags; int lane_order;
+};
+
+template <int NTB>
+__device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, TileShared& S, uint64_t* ekeys, int t,
+                                          int32_t vstart, int32_t n_own, int32_t es, int32_t e_own, int n_ext,
+                                          int e_loc, int n_upd, int32_t voff, int32_t eoff, int32_t soff,
+                                          const TileOut& O) {
+  const int tid = threadIdx.x;
+  for (int l = tid; l < n_ext; l += NTB) O.t_vmap[voff + l] = L.ext[l];
   const int msort = next_pow2(max(e_loc, 1));
-  for (int i = e_loc + tid; i < msort; i += kP2Threads) ekeys[i] = ~0ull;
+  for (int i = e_loc + tid; i < msort; i += NTB) ekeys[i] = ~0ull;
   __syncthreads();
-  bitonic_sort<kP2Threads, uint64_t>(ekeys, msort);
+  bitonic_sort<NTB, uint64_t>(ekeys, msort);
   // ---- gather lists, local records, level ends, owned prefix check ----
-  if (e_own > e_loc && tid == 0) s_fail = 1;
-  for (int le = tid; le < e_loc; le += kP2Threads) {
+  if (e_own > e_loc && tid == 0) S.fail = 1;
+  for (int le = tid; le < e_loc; le += NTB) {
     const uint64_t key = ekeys[le];
     const int32_t k = G.e_o2i[(int32_t)(key & 0xffffffffu)];
     const int lvl = (int)(key >> 49);
     const int nxt = le + 1 < e_loc ? (int)(ekeys[le + 1] >> 49) : kMaxDepth + 1;
-    for (int l = lvl; l < nxt && l <= kMaxDepth; ++l) s_level_end[l] = le + 1;
-    if (le < e_own && k != es + le) s_fail = 1;  // owned edges = the prefix, in internal order
+    for (int l = lvl; l < nxt && l <= kMaxDepth; ++l) S.level_end[l] = le + 1;
+    if (le < e_own && k != es + le) S.fail = 1;  // owned edges = the prefix, in internal order
     const uint32_t li = (uint32_t)((key >> 32) & 0xffffu);
     const uint32_t lj = (uint32_t)hash_lookup(L, G.eij[k].y);
-    t_emap[eoff + le] = k;
-    t_eij[eoff + le] = make_uint2(li | (lj << 16), 0xffffffffu);
-    t_ew[eoff + le] = ew[k];
+    O.t_emap[eoff + le] = k;
+    O.t_eij[eoff + le] = make_uint2(li | (lj << 16), 0xffffffffu);
+    O.t_ew[eoff + le] = O.ew[k];
   }
   // ---- incidence slots: one row per updated vertex, odd pitch per 64-vertex group ----
-  for (int lv = tid; lv < n_upd; lv += kP2Threads) {
+  for (int lv = tid; lv < n_upd; lv += NTB) {
     const int32_t v = L.ext[lv];
-    atomicMax(&s_gw[lv >> 6], G.grow[v + 1] - G.grow[v]);
+    atomicMax(&S.gw[lv >> 6], G.grow[v + 1] - G.grow[v]);
   }
   __syncthreads();
   if (tid == 0) {
     int32_t base = 0;
     const int ng = (n_upd + 63) >> 6;
     for (int g = 0; g < ng; ++g) {
-      const int32_t w = s_gw[g] | 1;
-      s_gw[g] = w;
-      s_gbase[g] = base;
-      if (base + 64 * w + kDummySlots > 65535) { s_fail = 1; break; }
+      const int32_t w = S.gw[g] | 1;
+      S.gw[g] = w;
+      S.gbase[g] = base;
+      if (base + 64 * w + kDummySlots > 65535) { S.fail = 1; break; }
       base += 64 * w;
     }
-    s_gbase[kCapExt / 64] = base;
+    S.gbase[kCapExt / 64] = base;
   }
   __syncthreads();
-  for (int it = tid; it < n_upd * kRowLanes; it += kP2Threads) {
+  for (int it = tid; it < n_upd * kRowLanes; it += NTB) {
     const int lv = it / kRowLanes, sub = it % kRowLanes;
     const int32_t v = L.ext[lv];
     const int32_t deg = G.grow[v + 1] - G.grow[v];
     const int g = lv >> 6;
-    const int32_t s0 = s_gbase[g] + (lv - (g << 6)) * s_gw[g];
-    if (sub == 0) t_srow[soff + lv] = (uint32_t)s0 | ((uint32_t)deg << 16);
-    const int rv = ring_of(s_ring_end, lv);
+    const int32_t s0 = S.gbase[g] + (lv - (g << 6)) * S.gw[g];
+    if (sub == 0) O.t_srow[soff + lv] = (uint32_t)s0 | ((uint32_t)deg << 16);
+    const int rv = ring_of(S.ring_end, lv);
     int j = sub;
     for (int32_t s = G.grow[v] + sub; s < G.grow[v + 1]; s += kRowLanes, j += kRowLanes) {
       const int32_t ent = G.ginc[s];
@@ -1354,12 +1341,12 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
       uint64_t key = 0;
       bool ok;
       if (!role) {
-        ok = local_edge_key(G, L, s_ring_end, k, lv, rv, ij.y, &key);
+        ok = local_edge_key(G, L, S.ring_end, k, lv, rv, ij.y, &key);
       } else {
         ok = ((L.bitmap[ij.x >> 5] >> (ij.x & 31)) & 1u) != 0;
         if (ok) {
           const int ls = hash_lookup(L, ij.x);
-          const int rs = ring_of(s_ring_end, ls);
+          const int rs = ring_of(S.ring_end, ls);
           ok = !(G.depth > 0 && min(rs, rv) >= G.depth);
           const uint64_t lvl = (uint64_t)max(rs, rv);
           const uint64_t notown = (lvl <= 1 && rs != 0) ? 1 : 0;
@@ -1376,16 +1363,16 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
           if (km < key) lo = mid + 1; else hi = mid - 1;
         }
       }
-      if (le < 0) { s_fail = 1; continue; }  // halo closure invariant
-      reinterpret_cast<unsigned short*>(&t_eij[eoff + le].y)[role] = (unsigned short)(s0 + j);
+      if (le < 0) { S.fail = 1; continue; }  // halo closure invariant
+      reinterpret_cast<unsigned short*>(&O.t_eij[eoff + le].y)[role] = (unsigned short)(s0 + j);
     }
   }
   __syncthreads();
   // ---- lane order at build time (lane_order = 2): plan.cpp assign_lanes(), the identical greedy ----
-  if (lane_order && !s_fail) {
-    const int32_t nslots = s_gbase[kCapExt / 64];
-    for (int b0 = (tid >> 6) * 64; b0 < e_loc; b0 += (kP2Threads / 64) * 64)
-      assign_lanes_block(tid & 63, b0, e_loc, eoff, nslots, t_eij, t_ew, t_emap);
+  if (O.lane_order && !S.fail) {
+    const int32_t nslots = S.gbase[kCapExt / 64];
+    for (int b0 = (tid >> 6) * 64; b0 < e_loc; b0 += (NTB / 64) * 64)
+      assign_lanes_block(tid & 63, b0, e_loc, eoff, nslots, O.t_eij, O.t_ew, O.t_emap);
   }
   if (tid == 0) {
     TileDesc D = {};
@@ -1393,11 +1380,138 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
     D.estart = es; D.e_own = e_own; D.e_loc = e_loc;
     D.n_upd = n_upd; D.depth = G.depth;
     D.vmap_off = voff; D.emap_off = eoff; D.erec_off = eoff; D.srow_off = soff;
-    D.nslots = s_gbase[kCapExt / 64];
-    for (int r = 0; r <= kMaxDepth; ++r) { D.ring_end[r] = s_ring_end[r]; D.level_end[r] = s_level_end[r]; }
-    if (s_fail) { D.n_ext = -1; atomicOr(&flags[0], 8); }
-    tiles[t] = D;
+    D.nslots = S.gbase[kCapExt / 64];
+    for (int r = 0; r <= kMaxDepth; ++r) { D.ring_end[r] = S.ring_end[r]; D.level_end[r] = S.level_end[r]; }
+    if (S.fail) { D.n_ext = -1; atomicOr(&O.flags[0], 8); }
+    O.tiles[t] = D;
   }
+}
+
+__global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const int32_t* __restrict__ vstart_tab,
+                                                           const int32_t* __restrict__ vend_tab,
+                                                           const int32_t* __restrict__ estart,
+                                                           const int32_t* __restrict__ tile_ext,
+                                                           const int32_t* __restrict__ meta, TileOut O) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ TileShared S;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  // a build that has already failed (bad indices, a tile that does not fit, a rejected partition, tile
+  // arrays too small for a speculative launch: every bit but pass 2's own 8) must not be continued:
+  // the host used to stop before this launch; without the round trip the kernel stops itself
+  if (__builtin_amdgcn_readfirstlane(O.flags[0]) & ~8) return;
+  TileLds L;
+  uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
+  L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
+  L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
+  L.hkey = L.ext + kCapExt;
+  L.hval = L.hkey + kHash;
+  const int32_t* m = meta + (size_t)t * kMetaWords;
+  const int n_ext = m[0], e_loc = m[1], n_upd = m[2];
+  const int32_t voff = m[21], eoff = m[22], soff = m[23];
+  const int32_t vstart = vstart_tab[t], n_own = vend_tab[t] - vstart;
+  const int32_t es = estart[t], e_own = estart[t + 1] - es;
+  if (tid == 0) { S.fail = m[3]; S.ecnt = 0; }
+  if (tid <= kMaxDepth) { S.ring_end[tid] = m[4 + tid]; S.level_end[tid] = 0; }
+  if (tid < kCapExt / 64) S.gw[tid] = 1;
+  const int bm_words = (G.V + 31) >> 5;
+  for (int i = tid; i < bm_words; i += kP2Threads) L.bitmap[i] = 0u;
+  __syncthreads();
+  if (m[3]) {  // pass 1 already failed this tile: leave a descriptor that says so
+    if (tid == 0) { TileDesc D = {}; D.n_ext = -1; O.tiles[t] = D; }
+    return;
+  }
+  for (int l = tid; l < n_ext; l += kP2Threads) {
+    const int32_t v = tile_ext[(size_t)t * kCapExt + l];
+    L.ext[l] = v;
+    atomicOr(&L.bitmap[v >> 5], 1u << (v & 31));
+  }
+  __syncthreads();
+  tile_hash_build<kP2Threads>(L, n_ext);
+  tile_collect_keys<kP2Threads>(G, L, S, ekeys, n_ext);
+  if (S.ecnt != e_loc) { if (tid == 0) S.fail = 1; }
+  tile_emit<kP2Threads>(G, L, S, ekeys, t, vstart, n_own, es, e_own, n_ext, e_loc, n_upd, voff, eoff, soff, O);
+}
+
+// Pass 1 + offsets + pass 2 in ONE launch (a frame stream with speculative tile arrays, tiles <=
+// kScanMaxBlocks): the rings, the hash and the key list are built once instead of twice, the three
+// running totals (local vertices, local edges, slot rows) come by look-back over the tiles before
+// this one, packed 22 | 22 | 20 bits.  Tiles are dispatched in index order and a tile only waits for
+// lower indices, so the grid may exceed the resident set.  tile_ext / meta are written all the same:
+// when the speculative arrays turn out too small (bit 128) the host re-runs plain pass 2 from them.
+__global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const int32_t* __restrict__ vstart_tab,
+                                                           const int32_t* __restrict__ vend_tab,
+                                                           const int32_t* __restrict__ estart, int32_t* tile_ext,
+                                                           int32_t* meta, TileOut O, ScanState st, int32_t cap_nv,
+                                                           int32_t cap_ne, int32_t cap_ns) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ TileShared S;
+  __shared__ unsigned long long sh_lb[2];
+  const int t = blockIdx.x, tid = threadIdx.x, ntiles = gridDim.x;
+  // failed before this launch (bits 4, 8, 128 are the launch's own: a tile must not leave on them,
+  // the tiles behind it wait for its totals)
+  // (it still publishes: a flag raised by the second stream while this launch runs is seen by some
+  // tiles and not by others)
+  if (__builtin_amdgcn_readfirstlane(O.flags[0]) & ~(4 | 8 | 128)) {
+    if (tid == 0) {
+      __hip_atomic_store(&st.agg[t], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&st.flag[t], st.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  TileLds L;
+  uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
+  L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
+  L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
+  L.hkey = L.ext + kCapExt;
+  L.hval = L.hkey + kHash;
+  if (tid == 0) { S.fail = 0; S.ecnt = 0; }
+  if (tid <= kMaxDepth) S.level_end[tid] = 0;
+  if (tid < kCapExt / 64) S.gw[tid] = 1;
+  __syncthreads();
+  const int32_t vstart = vstart_tab[t], n_own = vend_tab[t] - vstart;
+  const int32_t es = estart[t], e_own = estart[t + 1] - es;
+  tile_rings<kP2Threads>(G, L, vstart, n_own, &S.n, S.ring_end, &S.fail);
+  const int n_ext = S.n;
+  tile_hash_build<kP2Threads>(L, n_ext);
+  tile_collect_keys<kP2Threads>(G, L, S, ekeys, n_ext);
+  const int e_cnt = S.ecnt;
+  const int n_upd = G.depth == 0 ? n_ext : S.ring_end[G.depth - 1];
+  const bool bad = S.fail || e_cnt > kCapEdge;
+  __syncthreads();
+  const int e_loc = min(e_cnt, kSortPad);
+  const unsigned long long mine = (unsigned long long)n_ext | ((unsigned long long)e_loc << 22) | ((unsigned long long)n_upd << 44);
+  const unsigned long long before = scan_lookback<unsigned long long>(mine, st, sh_lb);
+  const int32_t voff = (int32_t)(before & 0x3fffffu), eoff = (int32_t)((before >> 22) & 0x3fffffu),
+                soff = (int32_t)(before >> 44);
+  int32_t* m = meta + (size_t)t * kMetaWords;
+  for (int l = tid; l < n_ext; l += kP2Threads) tile_ext[(size_t)t * kCapExt + l] = L.ext[l];
+  if (tid <= kMaxDepth) m[4 + tid] = S.ring_end[tid];
+  if (tid == 0) {
+    m[0] = n_ext; m[1] = e_cnt; m[2] = n_upd; m[3] = bad ? 1 : 0;
+    m[21] = voff; m[22] = eoff; m[23] = soff;
+    if (bad) atomicOr(&O.flags[0], 4);
+    if (t == ntiles - 1) { O.flags[1] = voff + n_ext; O.flags[2] = eoff + e_loc; O.flags[3] = soff + n_upd; }
+  }
+  const bool over = voff + n_ext > cap_nv || eoff + e_loc > cap_ne || soff + n_upd > cap_ns;
+  if (over && tid == 0) atomicOr(&O.flags[0], 128);
+  if (bad || over) {
+    if (tid == 0 && bad && !over) { TileDesc D = {}; D.n_ext = -1; O.tiles[t] = D; }
+    return;
+  }
+  tile_emit<kP2Threads>(G, L, S, ekeys, t, vstart, n_own, es, e_own, n_ext, e_loc, n_upd, voff, eoff, soff, O);
+}
+
+// What the host reads after a build -- the flags word, the caller's check word, the tile descriptors --
+// written straight into page-locked host memory by one launch (three small D2H copies were three
+// dependent blit launches, ~20 us of the frame's critical path)
+__global__ __launch_bounds__(256) void k_publish(const int32_t* __restrict__ flags, const int32_t* __restrict__ user,
+                                                 const int32_t* __restrict__ tiles, int32_t tile_words, int32_t* hflags,
+                                                 int32_t* huser, int32_t* htiles) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 8) hflags[i] = flags[i];
+  if (user && i < 2) huser[i] = user[i];
+  if (tiles && i < tile_words) htiles[i] = tiles[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1451,6 +1565,7 @@ __device__ __forceinline__ int grid_cell_dev(const float* b, float2 q) {
 // Inside a tile the Morton order of stage B applies as ever.  A frame whose tiles come out empty or
 // much larger than planned (scene change) is rebuilt by exact bisection.
 // ------------------------------------------------------------------------------------------
+constexpr int kCntStride = 32;  // ints between two tile counters of the reuse pass (one cache line each)
 constexpr int kPyrLevels = 7;
 constexpr int kPyrAtomicLevels = 3;  // written per vertex (>= 4096 cells: no contended atomics); the coarser
                                      // levels are reduced from level 2 by k_grid_final
@@ -1472,7 +1587,8 @@ __device__ __forceinline__ int pyr_cell(const float* b, float2 q, int level) {
 // tile of every vertex of the NEW frame from the previous frame's pyramid; tile counts
 __global__ __launch_bounds__(256) void k_reuse_assign(int32_t V, int32_t ntiles, const float2* __restrict__ pos,
                                                       const float* __restrict__ bounds,
-                                                      const int32_t* __restrict__ pyr, int32_t* vt, int32_t* tile_cnt) {
+                                                      const int32_t* __restrict__ pyr, int32_t* vt, int32_t* vrank,
+                                                      int32_t* tile_cnt) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
   const float2 q = pos[v];
@@ -1482,8 +1598,11 @@ __global__ __launch_bounds__(256) void k_reuse_assign(int32_t V, int32_t ntiles,
     if (c > 0) { t = c - 1; break; }
   }
   t = max(0, min(t, ntiles - 1));
+  // the count doubles as the vertex's rank inside its tile (any order will do: stage B sorts the tile),
+  // so the scatter needs no second round of contended atomics.  One counter per 128-byte line: a
+  // few hundred counters packed into 8 lines serialise every atomic of the launch on 8 L2 channels
   vt[v] = t;
-  atomicAdd(&tile_cnt[t], 1);
+  vrank[v] = atomicAdd(&tile_cnt[t * kCntStride], 1);
 }
 
 // one block: tile ranges from the counts; a tile that is empty or above `cap` vertices rejects the reuse
@@ -1492,7 +1611,7 @@ __global__ __launch_bounds__(kSegCap) void k_reuse_offsets(int32_t V, int32_t nt
                                                            int32_t* flags) {
   __shared__ int32_t sc[kSegCap];
   const int s = threadIdx.x;
-  const int32_t c = s < ntiles ? tile_cnt[s] : 0;
+  const int32_t c = s < ntiles ? tile_cnt[s * kCntStride] : 0;
   sc[s] = c;
   __syncthreads();
   for (int off = 1; off < kSegCap; off <<= 1) {
@@ -1510,12 +1629,13 @@ __global__ __launch_bounds__(kSegCap) void k_reuse_offsets(int32_t V, int32_t nt
 }
 
 __global__ __launch_bounds__(256) void k_reuse_scatter(int32_t V, const int32_t* __restrict__ vt,
-                                                       const int32_t* __restrict__ tlo, int32_t* cursor, int32_t* perm,
+                                                       const int32_t* __restrict__ vrank,
+                                                       const int32_t* __restrict__ tlo, int32_t* perm,
                                                        int32_t* seg_pos) {
   const int32_t v = blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
   const int32_t t = vt[v];
-  const int32_t p = tlo[t] + atomicAdd(&cursor[t], 1);  // (order inside a tile is set by stage B)
+  const int32_t p = tlo[t] + vrank[v];  // (order inside a tile is set by stage B)
   perm[p] = v;
   seg_pos[p] = t;
 }
@@ -1604,21 +1724,22 @@ __device__ __forceinline__ bool half_edge(int32_t k, int32_t V, const int32_t* _
 }
 
 __global__ __launch_bounds__(256) void k_he_count(int32_t n3, int32_t V, const int32_t* __restrict__ tris, int32_t* cnt,
-                                                  int32_t* flags) {
+                                                  int32_t* rank, int32_t* flags) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
   int32_t a, b;
   if (!half_edge(k, V, tris, &a, &b)) { atomicOr(&flags[0], 2); return; }
-  atomicAdd(&cnt[a], 1);
+  rank[k] = atomicAdd(&cnt[a], 1);
 }
 
 __global__ __launch_bounds__(256) void k_he_fill(int32_t n3, int32_t V, const int32_t* __restrict__ tris,
-                                                 const int32_t* __restrict__ off, int32_t* cursor, uint32_t* out) {
+                                                 const int32_t* __restrict__ off,
+                                                 const int32_t* __restrict__ rank, uint32_t* out) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= n3) return;
   int32_t a, b;
   if (!half_edge(k, V, tris, &a, &b)) return;
-  out[off[a] + atomicAdd(&cursor[a], 1)] = (uint32_t)b;
+  out[off[a] + rank[k]] = (uint32_t)b;
 }
 
 __global__ __launch_bounds__(256) void k_he_mark(int32_t V, const int32_t* __restrict__ off,
@@ -1646,6 +1767,52 @@ __global__ __launch_bounds__(256) void k_he_compact(int32_t V, const int32_t* __
     alpha[idx[k]] = a;
     if (nan_flag && !isfinite(a)) atomicOr(nan_flag, 1);  // (two features on one pixel)
   }
+}
+
+// rows + mark + scan + compact in ONE launch (graphs of up to kScanMaxBlocks * 256 vertices): a block
+// sorts its 256 rows in LDS, counts the distinct entries, gets the number of edges before it by
+// look-back and writes its edges -- the sorted rows never travel back to memory
+__global__ __launch_bounds__(256) void k_he_unique(int32_t V, const int32_t* __restrict__ off, uint32_t* out,
+                                                   const float2* __restrict__ pos, int2* edges, float* alpha,
+                                                   int32_t* total, int32_t* nan_flag, ScanState st) {
+  __shared__ uint32_t s_a[kRowsLds];
+  __shared__ int32_t sh_a[16];
+  __shared__ int32_t sh_p[2];
+  const int32_t v0 = blockIdx.x * 256, v1 = min(v0 + 256, V);
+  const int32_t r0 = off[v0], r1 = off[v1];
+  const int32_t v = v0 + threadIdx.x;
+  const bool lds = r1 - r0 <= kRowsLds;
+  if (lds) {
+    for (int32_t i = threadIdx.x; i < r1 - r0; i += 256) s_a[i] = out[r0 + i];
+    __syncthreads();
+  }
+  int d = 0, uniq = 0;
+  uint32_t* a = nullptr;
+  if (v < V) {
+    d = off[v + 1] - off[v];
+    a = lds ? s_a + (off[v] - r0) : out + off[v];
+    sort_row(a, d);
+    for (int k = 0; k < d; ++k) uniq += (k == 0 || a[k] != a[k - 1]) ? 1 : 0;
+  }
+  const int32_t ex = block_exclusive<int32_t>(uniq, sh_a);
+  if (threadIdx.x == 255) sh_p[1] = ex + uniq;
+  __syncthreads();
+  const int32_t before = scan_lookback<int32_t>(sh_p[1], st, sh_p);
+  if (v >= V) return;
+  int32_t idx = before + ex;
+  const float2 pi = pos[v];
+  for (int k = 0; k < d; ++k) {
+    if (k > 0 && a[k] == a[k - 1]) continue;
+    const int32_t j = (int32_t)a[k];
+    const float2 pj = pos[j];
+    const float dx = pi.x - pj.x, dy = pi.y - pj.y;
+    edges[idx] = make_int2(v, j);
+    const float al = 1.0f / sqrtf(dx * dx + dy * dy);  // -ffp-contract=off: two roundings, as the oracle
+    alpha[idx] = al;
+    if (nan_flag && !isfinite(al)) atomicOr(nan_flag, 1);  // (two features on one pixel)
+    ++idx;
+  }
+  if (v == V - 1) total[0] = idx;
 }
 
 __global__ __launch_bounds__(256) void k_sync_data(int32_t V, const float* __restrict__ mu,
@@ -1682,20 +1849,24 @@ static_assert(Plan::kGrid * Plan::kGrid == 1024, "k_grid_final assumes a 32 x 32
 DevPlanner::~DevPlanner() { release(); }
 
 void DevPlanner::release() {
+  (void)wait_maps();
   void* ptrs[] = {cub_tmp_, keys_a_, keys_b_, vals_a_, vals_b_, seg_pos_, tile_of_int_, w_int_, wsort_, wscan_,
                   counts_, seg_tab_, estart_, tile_ext_, tile_meta_, flags_, grid_sum_, grid_cnt_, grid_w_,
                   grid_bounds_, gbbox_, tcub_tmp_, tcnt_, scan_agg_[0], scan_agg_[1], scan_flag_[0], scan_flag_[1],
-                  cell_pyr_};
+                  cell_pyr_, rank_, reuse_cnt_};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   scan_agg_[0] = scan_agg_[1] = nullptr; scan_flag_[0] = scan_flag_[1] = nullptr;
   cell_pyr_ = nullptr; map_tiles_ = 0; map_V_ = 0;
+  rank_ = rank_tri_ = nullptr; reuse_cnt_ = nullptr;
   if (hpin_) (void)hipHostFree(hpin_);
   hpin_ = nullptr; hpin_bytes_ = 0;
   if (s2_) (void)hipStreamDestroy(s2_);
   if (ev_fork_) (void)hipEventDestroy(ev_fork_);
   if (ev_join_) (void)hipEventDestroy(ev_join_);
-  s2_ = nullptr; ev_fork_ = ev_join_ = nullptr;
+  if (ev_grid_) (void)hipEventDestroy(ev_grid_);
+  s2_ = nullptr; ev_fork_ = ev_join_ = ev_grid_ = nullptr;
+  grid_pending_ = false;
   tcub_tmp_ = nullptr; tcnt_ = nullptr;
   capV2_ = 0; tcub_bytes_ = 0;
   cub_tmp_ = nullptr; keys_a_ = keys_b_ = nullptr; vals_a_ = vals_b_ = nullptr;
@@ -1752,7 +1923,14 @@ hipError_t DevPlanner::scan_i32(hipStream_t s, int lane, const int32_t* in, int3
   return hipGetLastError();
 }
 
+hipError_t DevPlanner::wait_maps() {
+  if (!grid_pending_) return hipSuccess;
+  grid_pending_ = false;
+  return hipEventSynchronize(ev_grid_);
+}
+
 hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
+  HIPRET(wait_maps());  // (buffers may be re-allocated or rewritten from here on)
   const int64_t nk = std::max<int64_t>(std::max<int64_t>(V, 2 * (int64_t)E), 3 * (int64_t)T);
   if (V > capV_ || E > capE_ || T > capT_) {
     const int64_t v = std::max<int64_t>(V + V / 4, capV_), e = std::max<int64_t>(E + E / 4, capE_),
@@ -1763,6 +1941,10 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(dalloc(&seg_pos_, (size_t)v)); HIPRET(dalloc(&tile_of_int_, (size_t)v));
     HIPRET(dalloc(&w_int_, (size_t)v)); HIPRET(dalloc(&wsort_, (size_t)v)); HIPRET(dalloc(&wscan_, (size_t)v));
     HIPRET(dalloc(&counts_, (size_t)v + 2));
+    // places inside the counting CSRs' rows: [0, 2e) the edge stages (C: one per edge, D: one per edge
+    // end), [2e, 2e + 3t) the triangle stages (half edges, then stage E on the second stream)
+    HIPRET(dalloc(&rank_, (size_t)(2 * e + 3 * t) + 2));
+    rank_tri_ = rank_ + 2 * e;
     capV_ = v; capE_ = e; capT_ = t;
     // temp storage of the library sorts / scans at the largest sizes
     size_t need = 0, b = 0;
@@ -1791,6 +1973,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
     HIPRET(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     HIPRET(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    HIPRET(hipEventCreateWithFlags(&ev_grid_, hipEventDisableTiming));
   }
   if (!seg_tab_) {
     // 2 tables x 4 arrays, bbox (4), mid_raw x 2, child_base, mid_out, nseg x 2 (+ pad), axis
@@ -1807,6 +1990,7 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     HIPRET(dalloc(&grid_w_, (size_t)Plan::kGrid * Plan::kGrid));
     HIPRET(dalloc(&grid_bounds_, 4)); HIPRET(dalloc(&gbbox_, 4));
     HIPRET(dalloc(&cell_pyr_, (size_t)kPyrCells));
+    HIPRET(dalloc(&reuse_cnt_, (size_t)kSegCap * kCntStride));
   }
   {  // D2H copies land in page-locked memory (a copy into pageable memory is staged and waited for)
     const size_t need = 256 + sizeof(TileDesc) * (size_t)std::max<int64_t>(ntiles + ntiles / 4, 64);
@@ -1852,6 +2036,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (!attr_set_) {  // per planner (= per handle = per device), not per process
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     attr_set_ = true;
   }
   // segment tables
@@ -1868,7 +2053,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   const int vb = bits_for(V);
   // flags; the vertex order outputs (every entry is an index for the later stages, whatever the
   // partition); the triangle stage's counts and cursors
-  zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, (T > 0 && in.tris) ? tcnt_ : nullptr, 2 * (int64_t)V + 2);
+  zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, (T > 0 && in.tris) ? tcnt_ : nullptr, (int64_t)V + 2);
   const bool reuse = reuse_next_;  // the caller asked for the previous frame's partition (map_usable())
   reuse_next_ = false;
   last_reused_ = false;
@@ -1879,16 +2064,16 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   int cur = 0;
   if (reuse) {
     // partition from the previous frame's tile map: lookup + counts, ranges, counting scatter
-    int32_t* tile_cnt = st + 12 * kSegCap;   // (mid_raw[0] / mid_raw[1]: free in this path)
-    int32_t* cursor = st + 13 * kSegCap;
+    int32_t* tile_cnt = reuse_cnt_;          // one counter per cache line
     int32_t* vt = w_int_;                    // (no weights in this path)
-    HIPRET(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * 2 * kSegCap, s));
-    hipLaunchKernelGGL(k_reuse_assign, grid1(V), dim3(256), 0, s, V, ntiles, in.pos, gbbox_, cell_pyr_, vt, tile_cnt);
+    int32_t* vrank = counts_;                // (V + 2 ints, zeroed again by stage C before its own use)
+    HIPRET(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * kCntStride * (size_t)ntiles, s));
+    hipLaunchKernelGGL(k_reuse_assign, grid1(V), dim3(256), 0, s, V, ntiles, in.pos, gbbox_, cell_pyr_, vt, vrank, tile_cnt);
     // (cost-balanced partitions hold 0.5..1.8 x the mean on purpose; a tile that is too LARGE for LDS or
     // a kernel configuration is found by the fit check of the caller like on any other partition)
     const int32_t cap = (int32_t)std::min<int64_t>(kOrderCap, ((int64_t)V * 3) / ntiles + 16);
     hipLaunchKernelGGL(k_reuse_offsets, dim3(1), dim3(kSegCap), 0, s, V, ntiles, cap, tile_cnt, tab[0], nseg, flags_);
-    hipLaunchKernelGGL(k_reuse_scatter, grid1(V), dim3(256), 0, s, V, vt, tab[0].lo, cursor, perm, seg_pos_);
+    hipLaunchKernelGGL(k_reuse_scatter, grid1(V), dim3(256), 0, s, V, vt, vrank, tab[0].lo, perm, seg_pos_);
     last_reused_ = true;
   } else {
   int levels = 0;
@@ -1998,11 +2183,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (tri_stage) {
     HIPRET(hipEventRecord(ev_fork_, s));
     HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
-    int32_t* tcursor = tcnt_ + V + 1;
     hipLaunchKernelGGL(k_tri_count, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->v_o2i, A->tris, tcnt_,
-                       flags_);
+                       rank_tri_, flags_);
     HIPRET(scan_i32(s2_, 1, tcnt_, A->trow, (int64_t)V + 1, false, tcub_tmp_, tcub_bytes_));
-    hipLaunchKernelGGL(k_tri_fill, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->tris, A->trow, tcursor,
+    hipLaunchKernelGGL(k_tri_fill, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->tris, A->trow, rank_tri_,
                        reinterpret_cast<uint32_t*>(A->tinc));
     hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s2_, V, A->trow, nullptr,
                        reinterpret_cast<uint32_t*>(A->tinc));
@@ -2010,17 +2194,16 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   }
   // ---- stage C ----
   if (E > 0) {
-    int32_t* ecnt = reinterpret_cast<int32_t*>(keys_b_);     // 2V + 1 bucket counts, then 2V cursors (8-byte keys:
-    int32_t* ecur = ecnt + 2 * (size_t)V + 1;                //   room for 2 n >= 4 V + 1 ints)
+    int32_t* ecnt = reinterpret_cast<int32_t*>(keys_b_);     // 2V + 1 bucket counts
     int32_t* eoff = reinterpret_cast<int32_t*>(vals_b_);     // (the lists of stage A are dead)
     uint32_t* esorted = reinterpret_cast<uint32_t*>(keys_a_);
-    // stage C's bucket counts + cursors, stage D's counts and cursors
-    zero4(s, ecnt, 4 * (int64_t)V + 1, counts_, (int64_t)V + 1, reinterpret_cast<int32_t*>(wsort_), V);
+    // stage C's bucket counts, stage D's counts
+    zero4(s, ecnt, 2 * (int64_t)V + 1, counts_, (int64_t)V + 1, nullptr, 0);
     hipLaunchKernelGGL(k_edge_count, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, ecnt,
-                       flags_);
+                       rank_, flags_);
     HIPRET(scan_i32(s, 0, ecnt, eoff, 2 * (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
     hipLaunchKernelGGL(k_edge_fill, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, eoff,
-                       ecur, esorted);
+                       rank_, esorted);
     hipLaunchKernelGGL(k_csr_rows<false>, grid1(2 * (int64_t)V), dim3(256), 0, s, 2 * V, eoff, nullptr, esorted);
     hipLaunchKernelGGL(k_edge_gather, grid1(std::max<int64_t>(E, ntiles + 1)), dim3(256), 0, s, E, esorted, in.edges, in.alpha,
                        in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, V, ntiles, leaf.lo, eoff, estart_,
@@ -2031,10 +2214,10 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   lap("C edges");
   // ---- stage D ----
   if (E > 0) {
-    int32_t* cursor = reinterpret_cast<int32_t*>(wsort_);  // (the weight scratch of stage A is free)
-    hipLaunchKernelGGL(k_csr_count, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, counts_);
+    int2* rank2 = reinterpret_cast<int2*>(rank_);
+    hipLaunchKernelGGL(k_csr_count, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, counts_, rank2);
     HIPRET(scan_i32(s, 0, counts_, A->grow, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
-    hipLaunchKernelGGL(k_csr_fill, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, A->grow, cursor,
+    hipLaunchKernelGGL(k_csr_fill, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, A->grow, rank2,
                        reinterpret_cast<uint32_t*>(A->ginc));
     hipLaunchKernelGGL(k_csr_rows<true>, grid1(V), dim3(256), 0, s, V, A->grow, A->e_o2i,
                        reinterpret_cast<uint32_t*>(A->ginc));
@@ -2053,25 +2236,50 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   const bool spec = spec_nv_ > 0 && spec_tiles_ >= ntiles;
   if (spec && alloc_tiles(alloc_ctx, (size_t)spec_tiles_, (size_t)spec_nv_, (size_t)spec_ne_, (size_t)spec_ns_) != 0)
     return hipErrorOutOfMemory;
-  hipLaunchKernelGGL(k_tile_pass1, dim3(ntiles), dim3(kP1Threads), lds1, s, G, leaf.lo, leaf.hi, tile_ext_, tile_meta_);
-  hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_, spec ? spec_nv_ : 0,
-                     spec ? spec_ne_ : 0, spec ? spec_ns_ : 0);
-  if (tri_stage) HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
-  lap("E tris (joined)");
+  static const bool unfused = std::getenv("FLAME_HIP_TILE_UNFUSED") != nullptr;  // dev A/B
+  const bool fused = spec && ntiles <= kScanMaxBlocks && scan_agg_[0] && !unfused;
   int32_t* hflags = reinterpret_cast<int32_t*>(hpin_);
   int32_t* huser = reinterpret_cast<int32_t*>(hpin_ + 64);
   TileDesc* htiles = reinterpret_cast<TileDesc*>(hpin_ + 256);
+  auto tile_out = [&]() {
+    TileOut O;
+    O.ew = A->ew; O.tiles = A->tiles; O.t_vmap = A->t_vmap; O.t_emap = A->t_emap; O.t_eij = A->t_eij; O.t_ew = A->t_ew;
+    O.t_srow = A->t_srow; O.flags = flags_; O.lane_order = opt.lane_order == 2 ? 1 : 0;
+    return O;
+  };
   auto launch_pass2 = [&]() -> hipError_t {
     hipLaunchKernelGGL(k_tile_pass2, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
-                       tile_meta_, A->ew, A->tiles, A->t_vmap, A->t_emap, A->t_eij, A->t_ew, A->t_srow, flags_,
-                       opt.lane_order == 2 ? 1 : 0);
-    HIPRET(hipMemcpyAsync(htiles, A->tiles, sizeof(TileDesc) * (size_t)ntiles, hipMemcpyDeviceToHost, s));
+                       tile_meta_, tile_out());
     return hipGetLastError();
   };
-  if (spec) HIPRET(launch_pass2());
-  HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (user_flags_dev && user_flags_host)  // the caller's own check word rides on the same sync
-    HIPRET(hipMemcpyAsync(huser, user_flags_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  static_assert(sizeof(TileDesc) % 4 == 0, "descriptors are published as words");
+  bool tiles_built = false;
+  auto publish = [&]() -> hipError_t {
+    const int32_t words = tiles_built ? (int32_t)(sizeof(TileDesc) / 4) * ntiles : 0;
+    hipLaunchKernelGGL(k_publish, grid1(std::max(words, 8)), dim3(256), 0, s, flags_,
+                       (user_flags_dev && user_flags_host) ? user_flags_dev : nullptr,
+                       tiles_built ? reinterpret_cast<const int32_t*>(A->tiles) : nullptr, words, hflags, huser,
+                       reinterpret_cast<int32_t*>(htiles));
+    return hipGetLastError();
+  };
+  if (fused) {
+    // (the triangle stage on the second stream raises its flags on the same word: join first, so that
+    // every tile of the launch sees the same word at its start)
+    if (tri_stage) HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
+    ScanState st;
+    HIPRET(scan_state(s, scan_agg_[0], scan_flag_[0], &scan_epoch_[0], flags_, &st));
+    hipLaunchKernelGGL(k_tile_fused, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
+                       tile_meta_, tile_out(), st, spec_nv_, spec_ne_, spec_ns_);
+    tiles_built = true;
+  } else {
+    hipLaunchKernelGGL(k_tile_pass1, dim3(ntiles), dim3(kP1Threads), lds1, s, G, leaf.lo, leaf.hi, tile_ext_, tile_meta_);
+    hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_, spec ? spec_nv_ : 0,
+                       spec ? spec_ne_ : 0, spec ? spec_ns_ : 0);
+    if (tri_stage) HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
+    if (spec) { HIPRET(launch_pass2()); tiles_built = true; }
+  }
+  lap("E tris (joined)");
+  HIPRET(publish());  // (the caller's own check word rides on the same sync)
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
   if (user_flags_dev && user_flags_host) { user_flags_host[0] = huser[0]; user_flags_host[1] = huser[1]; }
@@ -2099,7 +2307,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     // ---- stage G (first build on a handle, or the speculative arrays were too small) ----
     if (hflags[0] & 128) HIPRET(hipMemsetAsync(flags_, 0, sizeof(int32_t), s));  // (nothing else was set: checked above)
     HIPRET(launch_pass2());
-    HIPRET(hipMemcpyAsync(hflags, flags_, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    tiles_built = true;
+    HIPRET(publish());
     HIPRET(hipStreamSynchronize(s));
     HIPRET(hipGetLastError());
     lap("G pass2+sync");
@@ -2126,7 +2335,8 @@ hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntil
 
 hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, const int32_t* tris, const float2* pos,
                                        int2* edges, float* alpha, int32_t* E_out, bool* index_error, int32_t* nan_flag,
-                                       const std::function<void()>& while_running, int32_t expected_E) {
+                                       const std::function<void()>& while_running, int32_t expected_E,
+                                       const std::function<hipError_t()>& before_positions) {
   *E_out = 0;
   *index_error = false;
   if (T <= 0) return hipSuccess;
@@ -2134,20 +2344,29 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   HIPRET(reserve(V, n, T, 1));  // E <= 3T
   int32_t* f = reinterpret_cast<int32_t*>(vals_a_);
   int32_t* idx = reinterpret_cast<int32_t*>(vals_b_);
-  int32_t* cnt = tcnt_;                                     // V + 1 counts, then V cursors
-  int32_t* cursor = tcnt_ + V + 1;
+  int32_t* cnt = tcnt_;                                     // V + 1 counts
   int32_t* off = counts_;                                   // V + 1 row offsets
   uint32_t* out = reinterpret_cast<uint32_t*>(keys_a_);     // 3T entries
   HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
-  HIPRET(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (2 * (size_t)V + 1), s));
-  hipLaunchKernelGGL(k_he_count, grid1(n), dim3(256), 0, s, n, V, tris, cnt, flags_);
+  HIPRET(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)V + 1), s));
+  hipLaunchKernelGGL(k_he_count, grid1(n), dim3(256), 0, s, n, V, tris, cnt, rank_tri_, flags_);
   HIPRET(scan_i32(s, 0, cnt, off, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
-  hipLaunchKernelGGL(k_he_fill, grid1(n), dim3(256), 0, s, n, V, tris, off, cursor, out);
-  hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s, V, off, nullptr, out);
-  hipLaunchKernelGGL(k_he_mark, grid1(V), dim3(256), 0, s, V, off, out, f);
-  HIPRET(scan_i32(s, 0, f, idx, n, false, cub_tmp_, cub_bytes_));
-  hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha,
-                     (expected_E >= 0 && nan_flag) ? nan_flag + 1 : flags_ + 4, nan_flag);
+  hipLaunchKernelGGL(k_he_fill, grid1(n), dim3(256), 0, s, n, V, tris, off, rank_tri_, out);
+  // (the half-edge kernels above read the triangles only: the caller stages the positions now, its
+  // host-synchronous copy runs beside them)
+  if (before_positions) HIPRET(before_positions());
+  int32_t* total = (expected_E >= 0 && nan_flag) ? nan_flag + 1 : flags_ + 4;
+  static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B: the unfused chain
+  if (((int64_t)V + 255) / 256 <= kScanMaxBlocks && scan_agg_[0] && !force_cub) {
+    ScanState st;
+    HIPRET(scan_state(s, scan_agg_[0], scan_flag_[0], &scan_epoch_[0], flags_, &st));
+    hipLaunchKernelGGL(k_he_unique, grid1(V), dim3(256), 0, s, V, off, out, pos, edges, alpha, total, nan_flag, st);
+  } else {
+    hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s, V, off, nullptr, out);
+    hipLaunchKernelGGL(k_he_mark, grid1(V), dim3(256), 0, s, V, off, out, f);
+    HIPRET(scan_i32(s, 0, f, idx, n, false, cub_tmp_, cub_bytes_));
+    hipLaunchKernelGGL(k_he_compact, grid1(V), dim3(256), 0, s, V, off, out, f, idx, pos, edges, alpha, total, nan_flag);
+  }
   if (expected_E >= 0 && nan_flag) {
     // No round trip: the caller goes on with the edge count it predicted (Euler: E = V + T - 1 for a
     // triangulated disk); the true count lands in nan_flag[1] and comes back with the plan builder's
@@ -2179,12 +2398,24 @@ hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, cons
 hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in,
                                    const DevPlanArrays& A) {
   const int n = Plan::kGrid * Plan::kGrid;
-  zero4(s, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
-  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, s, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, gbbox_,
+  // Only the NEXT build reads these maps: they are made on the second stream, beside the iterations
+  // of this frame instead of in front of them.  Every entry point that touches what they read or
+  // write (the next build, the next edge derivation, the caller's next upload) waits for ev_grid_.
+  hipStream_t g2 = s2_ ? s2_ : s;
+  if (s2_) {
+    HIPRET(hipEventRecord(ev_fork_, s));
+    HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
+  }
+  zero4(g2, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
+  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, g2, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, gbbox_,
                      reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_);
   map_tiles_ = ntiles; map_V_ = V;
-  hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, s, V, reinterpret_cast<unsigned long long*>(grid_sum_),
+  hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, g2, V, reinterpret_cast<unsigned long long*>(grid_sum_),
                      grid_cnt_, grid_w_, gbbox_, grid_bounds_, cell_pyr_);
+  if (s2_) {
+    HIPRET(hipEventRecord(ev_grid_, s2_));
+    grid_pending_ = true;
+  }
   grid_tiles_ = ntiles;
   return hipGetLastError();
 }
