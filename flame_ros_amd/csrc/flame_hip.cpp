@@ -250,6 +250,10 @@ struct flame_hip_graph {
   // device plan builder (row f3) and the staged inputs it reads (caller's order)
   int plan_device = 1;
   int plan_reuse = 1;          // frame streams: partition from the previous frame's tile map
+  int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
+                               // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
+                               // that is solved once pays for its plan, and that is cheapest at depth 4-5
+  int single_cap = 1 << 30;    // an isolated tile did not fit a graph of this many vertices + 1 on this handle
   bool plan_reused = false;    // the current plan's partition came from the map
   int reuse_tile_own_opt = 0;  // the "tile_own" option the map was made with
   int reuse_backoff = 0, reuse_skip = 0;  // frames to sit out after a rejected reuse (doubles, <= 16)
@@ -459,6 +463,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->plan_device = value != 0;
   } else if (k == "plan_reuse") {
     g->plan_reuse = value != 0;
+  } else if (k == "stream_depth") {
+    if (value < 0 || value > kMaxDepth) return FLAME_HIP_ERR_ARG;
+    g->stream_depth = value;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -489,6 +496,8 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "device") *value = g->device;
   else if (k == "plan_on_device") *value = P.on_device ? 1 : 0;
   else if (k == "plan_reused") *value = (P.on_device && g->plan_reused) ? 1 : 0;
+  else if (k == "single_cap") *value = g->single_cap;
+  else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
     int khz = 0;
@@ -534,6 +543,22 @@ int alloc_tile_arrays(void* ctx, size_t ntiles, size_t nv, size_t ne, size_t ns)
   return 0;
 }
 }  // namespace
+
+// Plan options as they apply to ONE graph of V vertices on this handle (entry points: upload, graph
+// sync): the isolated-tile limit capped by what failed to fit before, the stream depth for small
+// graphs.  Restores the handle's options when the entry point returns.
+struct GraphOptScope {
+  flame_hip_graph* g;
+  int saved_single_max, saved_depth;
+  GraphOptScope(flame_hip_graph* g_, int32_t V) : g(g_), saved_single_max(g_->opt.single_max), saved_depth(g_->opt.tile_depth) {
+    g->opt.single_max = std::min(g->opt.single_max, g->single_cap);
+    if (g->stream_depth > 0 && g->opt.tile_depth == 0 && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() && V <= 64 * 32)
+      g->opt.tile_depth = g->stream_depth;
+  }
+  ~GraphOptScope() { g->opt.single_max = saved_single_max; g->opt.tile_depth = saved_depth; }
+  GraphOptScope(const GraphOptScope&) = delete;
+  GraphOptScope& operator=(const GraphOptScope&) = delete;
+};
 
 static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_t* edges,
                               const float* alpha, const float* beta, const float* z, const float* wgt,
@@ -787,7 +812,16 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   if ((V > 0 && (!pos || !z || !wgt)) || (E > 0 && (!edges || !alpha || !beta)))
     return FLAME_HIP_ERR_ARG;
   g->uploaded = false;
+  const GraphOptScope opt_scope(g, V);
   int rc;
+  auto device_plan = [&]() -> int {
+    int r = upload_device_plan(g, pos, edges, alpha, beta, z, wgt, x0, tris);
+    if (r <= 0) {  // not built there: copies from the caller's arrays may still be in flight
+      (void)hipStreamSynchronize(g->stream);
+      (void)hipStreamSynchronize(g->stream_in);
+    }
+    return r;
+  };
   if (g->device >= 0) {
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(wait_last_solve(g));
@@ -797,24 +831,40 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     g->drop_execs();  // captured launches hold the old grid / pointers
     g->solves_since_upload = 0;
     g->lanes_applied = false;
-    rc = upload_device_plan(g, pos, edges, alpha, beta, z, wgt, x0, tris);
-    if (rc <= 0) {  // not built there: copies from the caller's arrays may still be in flight
-      (void)hipStreamSynchronize(g->stream);
-      (void)hipStreamSynchronize(g->stream_in);
-    }
+    rc = device_plan();
     if (rc < 0) return rc;
   } else {
     rc = 0;
   }
-  const bool dev_plan = rc == 1;
+  bool dev_plan = rc == 1;
   if (!dev_plan) {
     if (!all_finite(pos, 2 * (size_t)V) || !all_finite(z, V) || !all_finite(wgt, V) ||
         !all_finite(alpha, E) || !all_finite(beta, E) || (x0 && !all_finite(x0, V)))
       return FLAME_HIP_ERR_NAN;
     g->plan.on_device = false;
     g->host_perms = true;
+    // An isolated tile that was sized from (V, E) alone may not fit after all (its slot rows follow
+    // the degrees).  The host builder's own answer is a halo'd partition built on the host -- 4 ms at
+    // 1.3 k vertices; when the choice was automatic the graph goes to the device builder instead, and
+    // the handle remembers the size (flame_hip_get_info "single_cap").
+    const bool auto_single = g->device >= 0 && g->plan_device && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() &&
+                             plan_sizing(g->opt, V, E).single;
+    g->opt.single_only = auto_single;
     rc = build_plan(g->opt, V, E, g->T, pos, edges, alpha, beta, tris, &g->plan);
-    if (rc != 0) return rc;
+    g->opt.single_only = false;
+    if (rc == kPlanSingleNoFit) {
+      g->single_cap = std::min(g->single_cap, std::max(V - 1, 0));
+      g->opt.single_max = std::min(g->opt.single_max, g->single_cap);  // (restored by opt_scope)
+      rc = device_plan();
+      if (rc < 0) return rc;
+      dev_plan = rc == 1;
+      if (!dev_plan) {
+        g->plan.on_device = false;
+        g->host_perms = true;
+        rc = build_plan(g->opt, V, E, g->T, pos, edges, alpha, beta, tris, &g->plan);
+      }
+    }
+    if (!dev_plan && rc != 0) return rc;
   }
   const Plan& P = g->plan;
   if (!dev_plan) {
@@ -942,6 +992,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
   if (!g || !sp || V < 0 || T < 0) return FLAME_HIP_ERR_ARG;
   if ((V > 0 && (!pos || !idepth_mu || !idepth_var)) || (T > 0 && !tris)) return FLAME_HIP_ERR_ARG;
   const auto t_entry = std::chrono::steady_clock::now();
+  const GraphOptScope opt_scope(g, V);
   // input validation on the host: non-finite positions / idepths, NaN variances, the variance gate.
   // On the device path it runs WHILE the GPU already derives the edges (every kernel there is safe on
   // unvalidated input: indices are range-checked, non-finite values only set a flag).

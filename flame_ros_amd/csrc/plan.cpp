@@ -211,7 +211,10 @@ bool pick_cfg(int want_nt, int e_max, int upd_max, TileCfg* out) {
 PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   const int64_t lds_cap = opt.lds_bytes;
   // an isolated single tile holds the whole graph when it fits the largest kernel config
-  const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 32) <= lds_cap;
+  // (LDS of the tile: 16 B per vertex + 16 B per incidence slot; the slot rows of a 64-vertex group
+  // share the group's largest degree as pitch, measured 1.1-1.2 x the 2E incidences in degree order:
+  // priced at 1.19 x -- a tile that turns out too large after all is rebuilt as a halo'd partition)
+  const bool single_fits = V <= 2048 && E <= 6144 && ((int64_t)V * 16 + (int64_t)E * 38 + 1024) <= lds_cap;
   // Auto sizing (measured on MI355X, DESIGN.md "Tile sizing"): one tile per CU when the graph
   // allows it (256 CUs), never below 32 own vertices (halo overhead) or above 196 (LDS / threads);
   // when there are more tiles than CUs prefer the shallower halo whose tiles co-reside on a CU.
@@ -724,6 +727,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     P.wgrid.clear();
     // did not fit: shrink the tiles (a single tile becomes a halo'd partition) and retry
     P.tiles.clear();
+    if (single && opt.single_only) { P.has_tiles = false; return kPlanSingleNoFit; }
     if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }
     else tile_own = std::max(16, tile_own / 2);
   }

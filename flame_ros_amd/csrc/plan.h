@@ -28,11 +28,15 @@ struct PlanOptions {
   int lane_order = 1;
   int d_sign = 1;        // [UPSTREAM-RECALL] switch: the edge vector is d_sign * (pos_i - pos_j)
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
+  bool single_only = false;  // build_plan(): return kPlanSingleNoFit instead of falling back to a
+                             // halo'd partition when the isolated tile does not fit after all
   int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
                          // this many vertices on its first try (exercises the recovery path)
   // batch of independent graphs (frames axis): nb + 1 vertex offsets; graph b = one isolated tile
   std::vector<int32_t> batch_voff;
 };
+
+constexpr int kPlanSingleNoFit = 1;  // build_plan() with single_only: the caller partitions elsewhere
 
 struct Float4 { float x, y, z, w; };
 struct Int2 { int32_t x, y; };

@@ -105,5 +105,9 @@ def named(name, seed=0):
     if name in GRID:
         c = GRID[name]
         return dataset_shaped(c["width"], c["height"], c["win"], seed), c["iters"]
+    if name[0] == "v" and name[1:].isdigit():  # "v2000": that many uniform vertices on 640 x 480, 200 iterations
+        return synthetic(int(name[1:]), 640, 480, seed), 200
+    if name[0] == "g" and name[1:].isdigit():  # "g24": one jittered feature per 24-pixel cell of 640 x 480
+        return dataset_shaped(640, 480, int(name[1:]), seed), 200
     c = NAMED[name]
     return synthetic(c["num_vertices"], c["width"], c["height"], seed), c["iters"]

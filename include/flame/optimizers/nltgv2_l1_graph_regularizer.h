@@ -88,10 +88,14 @@ class Graph {
     reset();
     const int rc = flame_hip_graph_create(&g_, device, 0, 0, 0);
     if (rc) { g_ = nullptr; return rc; }
-    // A Graph is re-built every frame: graphs that fit one LDS tile (<= 2048 vertices) are then
-    // cheapest as ONE isolated tile (trivial plan; 0.77 ms vs 1.0 ms per frame at 1.2 k vertices),
-    // although a resident graph of that size iterates faster on a few dozen halo tiles.
-    (void)flame_hip_set_option(g_, "tile_single_max", 2048);
+    // A Graph is re-built every frame, so the plan is paid by ONE solve.  Measured per frame (graph
+    // sync + 200 iterations + results, tools/exp/small_frame_sweep.py): up to ~1 000 vertices ONE
+    // isolated tile wins (trivial host plan: 0.45 ms at 770, 0.51 ms at 910 vertices against 0.57 on
+    // halo tiles); above, a few dozen halo tiles planned on the GPU do (1 200 vertices: 0.57 vs
+    // 0.66 ms), and with halo depth 5 rather than the 8 a resident graph of <= 64 tiles gets
+    // (1.2-2 k vertices: 0.56-0.62 vs 0.60-0.70 ms).
+    (void)flame_hip_set_option(g_, "tile_single_max", 1024);
+    (void)flame_hip_set_option(g_, "stream_depth", 5);
     device_ = device;
     return 0;
   }

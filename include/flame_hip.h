@@ -85,7 +85,10 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * the previous frame's tile map while the frames hold about as many vertices, instead of sorting and
  * bisecting again; results do not depend on the partition; flame_hip_get_info "plan_reused"),
  * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
- * 512, up to 2048), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
+ * 512, up to 2048; a graph whose tile does not fit after all is partitioned, and the handle stops
+ * trying at that size: flame_hip_get_info "single_cap"), "stream_depth" (0 = off, default; > 0: halo
+ * depth of graphs of up to 2048 vertices in place of the automatic 8 -- for handles that solve every
+ * graph ONCE, where the plan of shallow tiles is cheaper than the launches deep tiles save), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
  * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile",
  * "d_sign" ([UPSTREAM-RECALL] switch: +1 (default) the edge vector entering K1 is d = pos_i - pos_j,

@@ -229,6 +229,72 @@ def test_partition_reuse_on_a_frame_stream(gpu):
     dev.close()
 
 
+def _quad_lattice(nx, ny, seed=0):
+    """nx x ny jittered lattice, horizontal + vertical edges only (degree 4: every slot row of an
+    isolated tile carries one pad slot in five)."""
+    rng = np.random.default_rng(seed)
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    pos = (np.stack([ix.ravel() * 10.0 + 5.0, iy.ravel() * 8.0 + 4.0], 1) + rng.uniform(-1, 1, (nx * ny, 2))).astype(np.float32)
+    vid = (iy * nx + ix)
+    eh = np.stack([vid[:, :-1].ravel(), vid[:, 1:].ravel()], 1)
+    ev = np.stack([vid[:-1, :].ravel(), vid[1:, :].ravel()], 1)
+    edges = np.concatenate([eh, ev]).astype(np.int32)
+    d = pos[edges[:, 0]] - pos[edges[:, 1]]
+    alpha = (1.0 / np.sqrt((d * d).sum(1))).astype(np.float32)
+    z = (0.5 + 0.001 * pos[:, 0] + rng.normal(0, 0.02, nx * ny)).astype(np.float32)
+    return pos, edges, alpha, z
+
+
+def test_isolated_tile_that_does_not_fit_goes_to_the_device_builder(gpu):
+    """Graphs between the isolated-tile limit and what really fits one tile.  (1) a 1 344-vertex feature
+    grid with tile_single_max = 2048: the sizing rule sees that it does not fit and plans halo tiles on
+    the GPU.  (2) a degree-4 lattice of 1 740 vertices passes the rule (it prices the slot rows from
+    (V, E)) and fails in the builder: the answer must not be a halo plan built on the host (4 ms) --
+    the graph goes to the device builder, the handle remembers the size, results are the oracle's."""
+    g = graphgen.named("g15")[0]
+    assert 1300 < g.V < 1400
+    dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_single_max=2048)
+    assert dev.info("num_tiles") > 1 and dev.info("plan_on_device") == 1
+    dev.close()
+
+    from oracle import COracle
+    pos, edges, alpha, z = _quad_lattice(30, 58)
+    V = len(pos)
+    wgt = np.ones(V, np.float32)
+    dev = GraphRegularizer(pos, edges, alpha, alpha, z, wgt, device=0, tile_single_max=2048)
+    assert dev.info("num_tiles") > 1 and dev.info("plan_on_device") == 1
+    assert dev.info("single_cap") == V - 1
+    o = COracle(pos, edges, alpha, alpha, z, wgt)
+    o.solve(oracle_params(), 30)
+    dev.step(default_params(), 30)
+    x, w1, w2, q = dev.download()
+    assert_bit_equal(x, o.x, "x")
+    assert_bit_equal(q, o.q, "q")
+    # the next graph of that size does not try the isolated tile again; a smaller one still gets it
+    pos2, edges2, alpha2, z2 = _quad_lattice(30, 58, seed=1)
+    dev.reupload(pos2, edges2, alpha2, alpha2, z2, wgt)
+    assert dev.info("num_tiles") > 1 and dev.info("plan_on_device") == 1
+    g3 = graphgen.named("g20")[0]
+    dev.reupload(g3.pos, g3.edges, g3.alpha, g3.beta, g3.z, g3.wgt, tris=g3.tris)
+    assert dev.info("num_tiles") == 1
+    dev.close()
+
+
+def test_stream_depth_option(gpu):
+    """stream_depth replaces the automatic depth 8 of small graphs (<= 2048 vertices) and nothing else."""
+    p = default_params()
+    for name, want in (("v2000", 5), ("5k", None)):
+        g = graphgen.named(name)[0]
+        a = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+        b = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, stream_depth=5)
+        assert b.info("tile_depth") == (want if want else a.info("tile_depth"))
+        if want:
+            assert a.info("tile_depth") == 8
+        a.step(p, 23); b.step(p, 23)
+        assert_bit_equal(a.download()[0], b.download()[0], name)
+        a.close(); b.close()
+
+
 def test_device_plan_growing_frames(gpu):
     """Frames that grow threefold each on ONE handle: every scratch buffer of the builder (lists,
     counters, page-locked landing areas, tile arrays) is re-reserved on the way."""
