@@ -766,31 +766,57 @@ __device__ __forceinline__ float edge_fn(float ax, float ay, float bx, float by,
   return fmaf(bx - ax, py - ay, -((by - ay) * (px - ax)));
 }
 
-__global__ __launch_bounds__(256) void k_raster_owner(int32_t T, int32_t width, int32_t height,
-                                                      const float2* __restrict__ pos,
-                                                      const int32_t* __restrict__ tris,
-                                                      const uint8_t* __restrict__ tri_valid,
-                                                      int32_t filtered, uint32_t* __restrict__ owner) {
-  const int32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (t >= T) return;
-  if (filtered && !tri_valid[t]) return;
-  const float2 A = pos[tris[3 * t]], B = pos[tris[3 * t + 1]], Cc = pos[tris[3 * t + 2]];
-  const float area = edge_fn(A.x, A.y, B.x, B.y, Cc.x, Cc.y);
-  if (!(area != 0.0f)) return;
-  int x0 = (int)ceilf(fminf(A.x, fminf(B.x, Cc.x))), x1 = (int)floorf(fmaxf(A.x, fmaxf(B.x, Cc.x)));
-  int y0 = (int)ceilf(fminf(A.y, fminf(B.y, Cc.y))), y1 = (int)floorf(fmaxf(A.y, fmaxf(B.y, Cc.y)));
-  x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, width - 1); y1 = min(y1, height - 1);
-  const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-  if (bw <= 0 || bh <= 0) return;
-  for (int k = lane; k < bw * bh; k += 64) {
+// LPT lanes per triangle: 64 for meshes of large triangles (1.2 k vertices on 640 x 480: ~130 pixels
+// each), 8 for dense ones (a 50 k-vertex mesh has 3-pixel triangles: a wave per triangle kept 9 lanes
+// of 64 busy); with 8, a triangle whose bounding box exceeds 256 pixels (hull slivers) is rasterised by
+// the whole wave afterwards.  The owner of a pixel is the smallest triangle id that covers it
+// (atomicMin): the same map in any order.
+__device__ __forceinline__ void raster_cover(float2 A, float2 B, float2 Cc, int x0, int y0, int bw, int n, int first,
+                                             int step, int32_t width, uint32_t t, uint32_t* __restrict__ owner) {
+  for (int k = first; k < n; k += step) {
     const int jj = x0 + k % bw, ii = y0 + k / bw;
     const float px = (float)jj, py = (float)ii;
     const float wa = edge_fn(B.x, B.y, Cc.x, Cc.y, px, py);
     const float wb = edge_fn(Cc.x, Cc.y, A.x, A.y, px, py);
     const float wc = edge_fn(A.x, A.y, B.x, B.y, px, py);
     const bool in = (wa >= 0.f && wb >= 0.f && wc >= 0.f) || (wa <= 0.f && wb <= 0.f && wc <= 0.f);
-    if (in) atomicMin(owner + (size_t)ii * width + jj, (uint32_t)t);
+    if (in) atomicMin(owner + (size_t)ii * width + jj, t);
+  }
+}
+
+template <int LPT>
+__global__ __launch_bounds__(256) void k_raster_owner(int32_t T, int32_t width, int32_t height,
+                                                      const float2* __restrict__ pos,
+                                                      const int32_t* __restrict__ tris,
+                                                      const uint8_t* __restrict__ tri_valid,
+                                                      int32_t filtered, uint32_t* __restrict__ owner) {
+  const int lane = threadIdx.x & 63, sub = lane % LPT;
+  const int32_t t = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPT) + lane / LPT;
+  bool live = t < T && !(filtered && !tri_valid[t]);
+  float2 A = make_float2(0.f, 0.f), B = A, Cc = A;
+  int x0 = 0, y0 = 0, bw = 0, bh = 0;
+  if (live) {
+    A = pos[tris[3 * t]]; B = pos[tris[3 * t + 1]]; Cc = pos[tris[3 * t + 2]];
+    const float area = edge_fn(A.x, A.y, B.x, B.y, Cc.x, Cc.y);
+    x0 = (int)ceilf(fminf(A.x, fminf(B.x, Cc.x)));
+    y0 = (int)ceilf(fminf(A.y, fminf(B.y, Cc.y)));
+    int x1 = (int)floorf(fmaxf(A.x, fmaxf(B.x, Cc.x))), y1 = (int)floorf(fmaxf(A.y, fmaxf(B.y, Cc.y)));
+    x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, width - 1); y1 = min(y1, height - 1);
+    bw = x1 - x0 + 1; bh = y1 - y0 + 1;
+    live = area != 0.0f && bw > 0 && bh > 0;
+  }
+  const int n = live ? bw * bh : 0;
+  if (LPT == 64 || n <= 256) raster_cover(A, B, Cc, x0, y0, bw, n, sub, LPT, width, (uint32_t)t, owner);
+  if (LPT == 64) return;
+  unsigned long long big = __ballot(n > 256 && sub == 0);
+  while (big) {  // wave-uniform: every lane takes the triangle of lane l
+    const int l = (int)__builtin_ctzll(big);
+    big &= big - 1;
+    const float2 a = make_float2(__shfl(A.x, l, 64), __shfl(A.y, l, 64));
+    const float2 b = make_float2(__shfl(B.x, l, 64), __shfl(B.y, l, 64));
+    const float2 c = make_float2(__shfl(Cc.x, l, 64), __shfl(Cc.y, l, 64));
+    raster_cover(a, b, c, __shfl(x0, l, 64), __shfl(y0, l, 64), __shfl(bw, l, 64), __shfl(n, l, 64), lane, 64, width,
+                 (uint32_t)__shfl(t, l, 64), owner);
   }
 }
 
@@ -1076,8 +1102,12 @@ hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height
   hipError_t e = hipMemsetAsync(owner, 0xff, sizeof(uint32_t) * (size_t)npix, s);
   if (e != hipSuccess) return e;
   if (T > 0) {
-    hipLaunchKernelGGL(k_raster_owner, dim3((T + 3) / 4), dim3(256), 0, s, T, width, height, pos, tris,
-                       tri_valid, filtered, owner);
+    if (npix / T >= 64)  // mean triangle area in pixels
+      hipLaunchKernelGGL(k_raster_owner<64>, dim3((T + 3) / 4), dim3(256), 0, s, T, width, height, pos, tris, tri_valid,
+                         filtered, owner);
+    else
+      hipLaunchKernelGGL(k_raster_owner<8>, dim3((T + 31) / 32), dim3(256), 0, s, T, width, height, pos, tris, tri_valid,
+                         filtered, owner);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_raster_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, width, height,
