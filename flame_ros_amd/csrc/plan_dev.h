@@ -91,7 +91,9 @@ class DevPlanner {
                              const std::function<void()>& while_running = nullptr, int32_t expected_E = -1,
                              const std::function<hipError_t()>& before_positions = nullptr);
   // before_positions: called once the kernels that read ONLY the triangles are enqueued and before the
-  // first one that reads `pos` -- a caller that still has to stage the positions does it there
+  // first one that reads `pos` -- a caller that still has to stage the positions does it there.
+  // With expected_E >= 0 the chain's own flags (bit 2 bad index, bit 32 look-back timeout) go to
+  // nan_flag[2], which build() reads through its 4 user-flag words.
   // expected_E >= 0 (needs nan_flag): do not wait for the count -- *E_out = expected_E, the true count is
   // written to nan_flag[1]; expect_edges(E) makes the NEXT build() check it at its first synchronisation
   // (user_flags_host[1] then holds the true count; a mismatch ends the build with ok = false)

@@ -234,16 +234,18 @@ __global__ __launch_bounds__(kSegCap) void k_rcb_split(const int32_t* nseg_cur, 
 
 
 // several scratch arrays zeroed by ONE launch (a build had a dozen separate memsets)
-struct ZeroJob { int32_t* p[4]; int64_t n[4]; };
+constexpr int kZeroJobs = 5;
+struct ZeroJob { int32_t* p[kZeroJobs]; int64_t n[kZeroJobs]; };
 __global__ __launch_bounds__(256) void k_zero4(ZeroJob j) {
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < kZeroJobs; ++a)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.n[a]; i += stride) j.p[a][i] = 0;
 }
 inline void zero4(hipStream_t s, int32_t* a, int64_t na, int32_t* b = nullptr, int64_t nb = 0, int32_t* c = nullptr,
-                  int64_t nc = 0, int32_t* d = nullptr, int64_t nd = 0) {
-  ZeroJob j = {{a, b, c, d}, {a ? na : 0, b ? nb : 0, c ? nc : 0, d ? nd : 0}};
-  const int64_t m = std::max(std::max(j.n[0], j.n[1]), std::max(j.n[2], j.n[3]));
+                  int64_t nc = 0, int32_t* d = nullptr, int64_t nd = 0, int32_t* e = nullptr, int64_t ne = 0) {
+  ZeroJob j = {{a, b, c, d, e}, {a ? na : 0, b ? nb : 0, c ? nc : 0, d ? nd : 0, e ? ne : 0}};
+  int64_t m = 0;
+  for (int k = 0; k < kZeroJobs; ++k) m = std::max(m, j.n[k]);
   hipLaunchKernelGGL(k_zero4, dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (m + 255) / 256))), dim3(256), 0, s, j);
 }
 
@@ -805,8 +807,9 @@ __global__ __launch_bounds__(256) void k_edge_count(int32_t E, int32_t V, const 
                                                     const int32_t* __restrict__ v_o2i,
                                                     const int32_t* __restrict__ tile_of_int,
                                                     const int32_t* __restrict__ tlo, const int32_t* __restrict__ thi,
-                                                    int32_t* cnt, int32_t* rank, int32_t* flags) {
+                                                    int32_t* cnt, int32_t* rank, int32_t* flags, int32_t* zero_me) {
   const int32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e <= V) zero_me[e] = 0;  // stage D's degree counts (V + 1), used two launches later (grid >= V + 1)
   if (e >= E) return;
   // the value the count returns is the entry's place in its bucket: the fill needs no second atomic
   // (the order inside a bucket is arbitrary either way; k_csr_rows sorts it)
@@ -826,36 +829,6 @@ __global__ __launch_bounds__(256) void k_edge_fill(int32_t E, int32_t V, const i
 }
 
 
-__global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* __restrict__ sorted_e,
-                                                     const int2* __restrict__ edges,
-                                                     const float* __restrict__ alpha,
-                                                     const float* __restrict__ beta,
-                                                     const float2* __restrict__ pos,
-                                                     const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
-                                                     int32_t* e_o2i, int2* eij, float4* ew, int32_t V, int32_t ntiles,
-                                                     const int32_t* __restrict__ tlo,
-                                                     const int32_t* __restrict__ off, int32_t* estart, float dsign) {
-  const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  // estart[t] = first internal edge owned by tile t = where its first bucket starts
-  if (k < ntiles) estart[k] = off[2 * max(0, min(tlo[k], V))];
-  if (k == ntiles) estart[k] = E;
-  if (k >= E) return;
-  const int32_t e = (int32_t)sorted_e[k];
-  const int2 ij = edges[e];
-  if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {
-    // flagged by k_edge_keys (the plan is rejected after the next sync); keep every index in range
-    e_i2o[k] = e; e_o2i[e] = k;
-    eij[k] = make_int2(0, 0);
-    ew[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
-  }
-  const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
-  const float2 pi = pos[ij.x], pj = pos[ij.y];
-  e_i2o[k] = e;
-  e_o2i[e] = k;
-  eij[k] = make_int2(si, sj);
-  ew[k] = make_float4(alpha[e], beta[e], dsign * (pi.x - pj.x), dsign * (pi.y - pj.y));
-}
 
 
 // ------------------------------------------------------------------------------------------
@@ -865,16 +838,6 @@ __global__ __launch_bounds__(256) void k_edge_gather(int32_t E, const uint32_t* 
 // per row (the order inside a row is whatever the atomics give) -> every row sorted by its own
 // thread.  The result is the one the stable sort by vertex gave (rows in ascending original edge /
 // triangle id), in 7 short launches instead of the ~20 of a library merge sort of 2E or 3T keys. ----
-__global__ __launch_bounds__(256) void k_csr_count(int32_t E, const int2* __restrict__ eij,
-                                                   const int32_t* __restrict__ e_o2i, int32_t* cnt, int2* rank) {
-  const int32_t e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
-  const int2 ij = eij[e_o2i[e]];
-  int2 r;
-  r.x = atomicAdd(&cnt[ij.x], 1);
-  r.y = atomicAdd(&cnt[ij.y], 1);
-  rank[e] = r;
-}
 
 // entry = (original edge id << 1) | role (1: the vertex is the target): ascending entry = ascending
 // original id, the summation order of the arithmetic contract
@@ -977,6 +940,60 @@ __global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __re
   }
 }
 
+
+// Stage C's last two launches and stage D's first in one: a block sorts its 256 buckets in LDS
+// (k_csr_rows), then gathers the edge records of exactly those entries (k_edge_gather) and counts the
+// degrees of their endpoints for the incidence CSR (k_csr_count; the count is the rank again).
+__global__ __launch_bounds__(256) void k_edge_rows_gather(int32_t nrows, const int32_t* __restrict__ off, uint32_t* sorted_e,
+                                                          const int2* __restrict__ edges,
+                                                          const float* __restrict__ alpha,
+                                                          const float* __restrict__ beta,
+                                                          const float2* __restrict__ pos,
+                                                          const int32_t* __restrict__ v_o2i, int32_t* e_i2o,
+                                                          int32_t* e_o2i, int2* eij, float4* ew, int32_t V, int32_t E,
+                                                          int32_t ntiles, const int32_t* __restrict__ tlo,
+                                                          int32_t* estart, float dsign, int32_t* deg_cnt, int2* rank2) {
+  __shared__ uint32_t s_a[kRowsLds];
+  const int32_t v0 = blockIdx.x * 256, v1 = min(v0 + 256, nrows);
+  const int32_t r0 = off[v0], r1 = off[v1];
+  const int32_t v = v0 + threadIdx.x;
+  const bool lds = r1 - r0 <= kRowsLds;  // the block's rows are one contiguous range of the array
+  if (lds) {
+    for (int32_t i = threadIdx.x; i < r1 - r0; i += 256) s_a[i] = sorted_e[r0 + i];
+    __syncthreads();
+  }
+  if (v < nrows) sort_row(lds ? s_a + (off[v] - r0) : sorted_e + off[v], off[v + 1] - off[v]);
+  __syncthreads();
+  // estart[t] = first internal edge owned by tile t = where its first bucket starts
+  const int32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g < ntiles) estart[g] = off[2 * max(0, min(tlo[g], V))];
+  if (g == ntiles) estart[g] = E;
+  for (int32_t k = r0 + threadIdx.x; k < r1; k += 256) {
+    const int32_t e = (int32_t)(lds ? s_a[k - r0] : sorted_e[k]);
+    if (lds) sorted_e[k] = (uint32_t)e;
+    const int2 ij = edges[e];
+    e_i2o[k] = e;
+    e_o2i[e] = k;
+    if (ij.x < 0 || ij.y < 0 || ij.x >= V || ij.y >= V || ij.x == ij.y) {
+      // flagged by the bucket count (the plan is rejected after the next sync); keep every index in range
+      eij[k] = make_int2(0, 0);
+      ew[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      int2 r0v;  // (counted at vertex 0 like any (0, 0) record, so that the fill stays inside the array)
+      r0v.x = atomicAdd(&deg_cnt[0], 1);
+      r0v.y = atomicAdd(&deg_cnt[0], 1);
+      rank2[e] = r0v;
+      continue;
+    }
+    const int32_t si = v_o2i[ij.x], sj = v_o2i[ij.y];
+    const float2 pi = pos[ij.x], pj = pos[ij.y];
+    eij[k] = make_int2(si, sj);
+    ew[k] = make_float4(alpha[e], beta[e], dsign * (pi.x - pj.x), dsign * (pi.y - pj.y));
+    int2 r;
+    r.x = atomicAdd(&deg_cnt[si], 1);
+    r.y = atomicAdd(&deg_cnt[sj], 1);
+    rank2[e] = r;
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // Stage F / G: tiles.  One workgroup per tile.
@@ -1510,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_publish(const int32_t* __restrict__ fla
                                                  int32_t* huser, int32_t* htiles) {
   const int32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < 8) hflags[i] = flags[i];
-  if (user && i < 2) huser[i] = user[i];
+  if (user && i < 4) huser[i] = user[i];
   if (tiles && i < tile_words) htiles[i] = tiles[i];
 }
 
@@ -1605,39 +1622,50 @@ __global__ __launch_bounds__(256) void k_reuse_assign(int32_t V, int32_t ntiles,
   vrank[v] = atomicAdd(&tile_cnt[t * kCntStride], 1);
 }
 
-// one block: tile ranges from the counts; a tile that is empty or above `cap` vertices rejects the reuse
-__global__ __launch_bounds__(kSegCap) void k_reuse_offsets(int32_t V, int32_t ntiles, int32_t cap,
-                                                           const int32_t* __restrict__ tile_cnt, SegTab t, int32_t* nseg,
-                                                           int32_t* flags) {
-  __shared__ int32_t sc[kSegCap];
-  const int s = threadIdx.x;
-  const int32_t c = s < ntiles ? tile_cnt[s * kCntStride] : 0;
-  sc[s] = c;
-  __syncthreads();
-  for (int off = 1; off < kSegCap; off <<= 1) {
-    const int32_t v = s >= off ? sc[s - off] : 0;
-    __syncthreads();
-    sc[s] += v;
-    __syncthreads();
-  }
-  if (s < ntiles) {
-    t.lo[s] = sc[s] - c; t.hi[s] = sc[s]; t.leaves[s] = 1; t.first[s] = s;
-    if (c < 1 || c > cap) atomicOr(&flags[0], 64);
-  }
-  if (s == 0) nseg[0] = ntiles;
-  if (s == kSegCap - 1 && sc[s] != V) atomicOr(&flags[0], 64);
-}
-
-__global__ __launch_bounds__(256) void k_reuse_scatter(int32_t V, const int32_t* __restrict__ vt,
+// Tile ranges from the counts + the counting scatter, one launch: every block scans the (<= 1024) tile
+// counts itself -- a few hundred LDS operations instead of a dependent single-block launch -- and
+// places its 256 vertices; block 0 also writes the segment table the later stages read (what the last
+// bisection level leaves behind: one leaf per segment, in tile order).  A tile that is empty or above
+// `cap` vertices rejects the reuse (flag 64).
+__global__ __launch_bounds__(256) void k_reuse_scatter(int32_t V, int32_t ntiles, int32_t cap,
+                                                       const int32_t* __restrict__ vt,
                                                        const int32_t* __restrict__ vrank,
-                                                       const int32_t* __restrict__ tlo, int32_t* perm,
-                                                       int32_t* seg_pos) {
-  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+                                                       const int32_t* __restrict__ tile_cnt, SegTab t, int32_t* nseg,
+                                                       int32_t* flags, int32_t* perm, int32_t* seg_pos) {
+  __shared__ int32_t s_lo[kSegCap];
+  __shared__ int32_t s_part[16];
+  static_assert(kSegCap == 4 * 256, "four counters per thread");
+  const int tid = threadIdx.x;
+  int32_t c[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * tid + k;
+    c[k] = i < ntiles ? tile_cnt[i * kCntStride] : 0;
+    sum += c[k];
+  }
+  int32_t run = block_exclusive<int32_t>(sum, s_part);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s_lo[4 * tid + k] = run; run += c[k]; }
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = 4 * tid + k;
+      if (i < ntiles) {
+        const int32_t lo = s_lo[i];
+        t.lo[i] = lo; t.hi[i] = lo + c[k]; t.leaves[i] = 1; t.first[i] = i;
+        if (c[k] < 1 || c[k] > cap) atomicOr(&flags[0], 64);
+      }
+    }
+    if (tid == 0) nseg[0] = ntiles;
+    if (tid == 255 && run != V) atomicOr(&flags[0], 64);
+  }
+  __syncthreads();
+  const int32_t v = blockIdx.x * 256 + tid;
   if (v >= V) return;
-  const int32_t t = vt[v];
-  const int32_t p = tlo[t] + vrank[v];  // (order inside a tile is set by stage B)
+  const int32_t tl = vt[v];
+  const int32_t p = s_lo[tl] + vrank[v];  // (order inside a tile is set by stage B)
   perm[p] = v;
-  seg_pos[p] = t;
+  seg_pos[p] = tl;
 }
 
 __global__ __launch_bounds__(256) void k_weights_from_grid(int32_t V, const float2* __restrict__ pos,
@@ -2021,7 +2049,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // FLAME_HIP_PLAN_TIMING=1: synchronise after every stage and print its wall time (dev aid)
   static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
   auto tprev = std::chrono::steady_clock::now();
-  static const bool timing_nosync = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '2';  // host enqueue time only
+  static const bool timing_nosync = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] >= '2';  // host enqueue time only
   auto lap = [&](const char* what) {
     if (!timing) return;
     if (!timing_nosync) (void)hipStreamSynchronize(s);
@@ -2031,6 +2059,14 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   };
   HIPRET(reserve(V, E, T, ntiles));
   lap("reserve");
+  // FLAME_HIP_PLAN_TIMING=3: device time of the build's launches (events on `s`) beside its host wall time
+  static const bool timing_dev = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '3';
+  static hipEvent_t tev[2] = {nullptr, nullptr};
+  const auto t_build0 = std::chrono::steady_clock::now();
+  if (timing_dev) {
+    if (!tev[0]) { (void)hipEventCreate(&tev[0]); (void)hipEventCreate(&tev[1]); }
+    (void)hipEventRecord(tev[0], s);
+  }
   const size_t lds1 = ((size_t)(V + 31) / 32) * 4 + kCapExt * 4 + kHash * 8;
   const size_t lds2 = lds1 + (size_t)kSortPad * 8;
   if (!attr_set_) {  // per planner (= per handle = per device), not per process
@@ -2053,8 +2089,12 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   const int vb = bits_for(V);
   // flags; the vertex order outputs (every entry is an index for the later stages, whatever the
   // partition); the triangle stage's counts and cursors
-  zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, (T > 0 && in.tris) ? tcnt_ : nullptr, (int64_t)V + 2);
   const bool reuse = reuse_next_;  // the caller asked for the previous frame's partition (map_usable())
+  // (the reuse path's tile counters and stage C's bucket counts ride along: their scratch is free from
+  // the start there, while the bisection stages still use it)
+  int32_t* ecnt0 = reinterpret_cast<int32_t*>(keys_b_);
+  zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, reuse ? reuse_cnt_ : nullptr, (int64_t)kCntStride * ntiles,
+        (reuse && E > 0) ? ecnt0 : nullptr, 2 * (int64_t)V + 1);
   reuse_next_ = false;
   last_reused_ = false;
   if (weight_mode_ == 2 && !reuse)  // (mode 1: w_int_ already holds the weights, see weights_from_tiles / _scale_)
@@ -2066,14 +2106,13 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     // partition from the previous frame's tile map: lookup + counts, ranges, counting scatter
     int32_t* tile_cnt = reuse_cnt_;          // one counter per cache line
     int32_t* vt = w_int_;                    // (no weights in this path)
-    int32_t* vrank = counts_;                // (V + 2 ints, zeroed again by stage C before its own use)
-    HIPRET(hipMemsetAsync(tile_cnt, 0, sizeof(int32_t) * kCntStride * (size_t)ntiles, s));
+    int32_t* vrank = reinterpret_cast<int32_t*>(wscan_);  // (the weight scratch of the bisection path)
     hipLaunchKernelGGL(k_reuse_assign, grid1(V), dim3(256), 0, s, V, ntiles, in.pos, gbbox_, cell_pyr_, vt, vrank, tile_cnt);
     // (cost-balanced partitions hold 0.5..1.8 x the mean on purpose; a tile that is too LARGE for LDS or
     // a kernel configuration is found by the fit check of the caller like on any other partition)
     const int32_t cap = (int32_t)std::min<int64_t>(kOrderCap, ((int64_t)V * 3) / ntiles + 16);
-    hipLaunchKernelGGL(k_reuse_offsets, dim3(1), dim3(kSegCap), 0, s, V, ntiles, cap, tile_cnt, tab[0], nseg, flags_);
-    hipLaunchKernelGGL(k_reuse_scatter, grid1(V), dim3(256), 0, s, V, vt, vrank, tab[0].lo, perm, seg_pos_);
+    hipLaunchKernelGGL(k_reuse_scatter, grid1(V), dim3(256), 0, s, V, ntiles, cap, vt, vrank, tile_cnt, tab[0], nseg, flags_,
+                       perm, seg_pos_);
     last_reused_ = true;
   } else {
   int levels = 0;
@@ -2167,7 +2206,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     cur ^= 1;
   }
   }  // (exact bisection)
-  hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
+  if (!reuse)  // (the reuse path writes the table of a finished bisection by construction)
+    hipLaunchKernelGGL(k_rcb_check, dim3(1), dim3(kSegCap), 0, s, nseg + cur, tab[cur], ntiles, flags_);
   const SegTab leaf = tab[cur];  // lo = vstart, hi = vstart + n_own per tile
   lap("A rcb");
 
@@ -2183,6 +2223,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   if (tri_stage) {
     HIPRET(hipEventRecord(ev_fork_, s));
     HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
+    zero4(s2_, tcnt_, (int64_t)V + 2);  // (on the second stream: not one more job of the build's first launch)
     hipLaunchKernelGGL(k_tri_count, grid1(3 * (int64_t)T), dim3(256), 0, s2_, 3 * T, V, in.tris, A->v_o2i, A->tris, tcnt_,
                        rank_tri_, flags_);
     HIPRET(scan_i32(s2_, 1, tcnt_, A->trow, (int64_t)V + 1, false, tcub_tmp_, tcub_bytes_));
@@ -2197,25 +2238,26 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     int32_t* ecnt = reinterpret_cast<int32_t*>(keys_b_);     // 2V + 1 bucket counts
     int32_t* eoff = reinterpret_cast<int32_t*>(vals_b_);     // (the lists of stage A are dead)
     uint32_t* esorted = reinterpret_cast<uint32_t*>(keys_a_);
-    // stage C's bucket counts, stage D's counts
-    zero4(s, ecnt, 2 * (int64_t)V + 1, counts_, (int64_t)V + 1, nullptr, 0);
-    hipLaunchKernelGGL(k_edge_count, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, ecnt,
-                       rank_, flags_);
+    // stage C's bucket counts (the reuse path zeroed them with its first launch); stage D's degree
+    // counts are zeroed by k_edge_count
+    if (!reuse) zero4(s, ecnt, 2 * (int64_t)V + 1);
+    hipLaunchKernelGGL(k_edge_count, grid1(std::max<int64_t>(E, (int64_t)V + 1)), dim3(256), 0, s, E, V, in.edges, A->v_o2i,
+                       tile_of_int_, leaf.lo, leaf.hi, ecnt, rank_, flags_, counts_);
     HIPRET(scan_i32(s, 0, ecnt, eoff, 2 * (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
     hipLaunchKernelGGL(k_edge_fill, grid1(E), dim3(256), 0, s, E, V, in.edges, A->v_o2i, tile_of_int_, leaf.lo, leaf.hi, eoff,
                        rank_, esorted);
-    hipLaunchKernelGGL(k_csr_rows<false>, grid1(2 * (int64_t)V), dim3(256), 0, s, 2 * V, eoff, nullptr, esorted);
-    hipLaunchKernelGGL(k_edge_gather, grid1(std::max<int64_t>(E, ntiles + 1)), dim3(256), 0, s, E, esorted, in.edges, in.alpha,
-                       in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, V, ntiles, leaf.lo, eoff, estart_,
-                       opt.d_sign < 0 ? -1.0f : 1.0f);
+    // bucket sort + edge records + degree counts of stage D (kSegCap tiles <= 2V rows / 256 blocks * 256: the
+    // grid covers estart[0 .. ntiles] as long as 2V >= ntiles + 1, i.e. always: a tile owns a vertex)
+    hipLaunchKernelGGL(k_edge_rows_gather, grid1(std::max<int64_t>(2 * (int64_t)V, ntiles + 1)), dim3(256), 0, s, 2 * V, eoff,
+                       esorted, in.edges, in.alpha, in.beta, in.pos, A->v_o2i, A->e_i2o, A->e_o2i, A->eij, A->ew, V, E, ntiles,
+                       leaf.lo, estart_, opt.d_sign < 0 ? -1.0f : 1.0f, counts_, reinterpret_cast<int2*>(rank_));
   } else {
     HIPRET(hipMemsetAsync(estart_, 0, sizeof(int32_t) * (size_t)(ntiles + 2), s));
   }
   lap("C edges");
   // ---- stage D ----
   if (E > 0) {
-    int2* rank2 = reinterpret_cast<int2*>(rank_);
-    hipLaunchKernelGGL(k_csr_count, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, counts_, rank2);
+    int2* rank2 = reinterpret_cast<int2*>(rank_);  // (degree counts and ranks: k_edge_rows_gather)
     HIPRET(scan_i32(s, 0, counts_, A->grow, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
     hipLaunchKernelGGL(k_csr_fill, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, A->grow, rank2,
                        reinterpret_cast<uint32_t*>(A->ginc));
@@ -2280,9 +2322,24 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   }
   lap("E tris (joined)");
   HIPRET(publish());  // (the caller's own check word rides on the same sync)
+  if (timing_dev) (void)hipEventRecord(tev[1], s);
+  const auto t_enq = std::chrono::steady_clock::now();
   HIPRET(hipStreamSynchronize(s));
   HIPRET(hipGetLastError());
-  if (user_flags_dev && user_flags_host) { user_flags_host[0] = huser[0]; user_flags_host[1] = huser[1]; }
+  if (timing_dev) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, tev[0], tev[1]);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[plan_dev] device %.3f ms; host: enqueued after %.3f ms, synchronised after %.3f ms\n", ms,
+                 std::chrono::duration<double, std::milli>(t_enq - t_build0).count(),
+                 std::chrono::duration<double, std::milli>(now - t_build0).count());
+  }
+  if (user_flags_dev && user_flags_host) {
+    for (int i = 0; i < 4; ++i) user_flags_host[i] = huser[i];
+    // word 2: the flags of the edge derivation in front of this build (edges_from_tris without a round trip)
+    if (user_flags_host[2] & 32) return hipSuccess;                          // look-back timeout: not ok
+    if (user_flags_host[2] & 2) { *index_error = true; return hipSuccess; }  // triangle index out of range
+  }
   lap(spec ? "F+G pass1+2+sync" : "F pass1+sync");
   // word 0: the caller's failure flag; word 1: the number of edges the graph sync derived -- a build
   // that was launched on a PREDICTED edge count and got it wrong is worthless whatever else it says
@@ -2342,24 +2399,30 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   if (T <= 0) return hipSuccess;
   const int32_t n = 3 * T;
   HIPRET(reserve(V, n, T, 1));  // E <= 3T
+  static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B: the unfused chain
+  const bool fused = ((int64_t)V + 255) / 256 <= kScanMaxBlocks && scan_agg_[0] && !force_cub;
+  // no round trip: the chain's flags (bit 2 bad index, bit 32 look-back timeout) go to the caller's word
+  // nan_flag[2] -- the build() that follows zeroes flags_ with its first launch and reads the caller's
+  // words at its first synchronisation
+  const bool own_flags = expected_E >= 0 && nan_flag;
+  int32_t* he_flags = own_flags ? nan_flag + 2 : flags_;
   int32_t* f = reinterpret_cast<int32_t*>(vals_a_);
   int32_t* idx = reinterpret_cast<int32_t*>(vals_b_);
   int32_t* cnt = tcnt_;                                     // V + 1 counts
   int32_t* off = counts_;                                   // V + 1 row offsets
   uint32_t* out = reinterpret_cast<uint32_t*>(keys_a_);     // 3T entries
-  HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
+  if (!own_flags) HIPRET(hipMemsetAsync(flags_, 0, 8 * sizeof(int32_t), s));
   HIPRET(hipMemsetAsync(cnt, 0, sizeof(int32_t) * ((size_t)V + 1), s));
-  hipLaunchKernelGGL(k_he_count, grid1(n), dim3(256), 0, s, n, V, tris, cnt, rank_tri_, flags_);
+  hipLaunchKernelGGL(k_he_count, grid1(n), dim3(256), 0, s, n, V, tris, cnt, rank_tri_, he_flags);
   HIPRET(scan_i32(s, 0, cnt, off, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
   hipLaunchKernelGGL(k_he_fill, grid1(n), dim3(256), 0, s, n, V, tris, off, rank_tri_, out);
   // (the half-edge kernels above read the triangles only: the caller stages the positions now, its
   // host-synchronous copy runs beside them)
   if (before_positions) HIPRET(before_positions());
   int32_t* total = (expected_E >= 0 && nan_flag) ? nan_flag + 1 : flags_ + 4;
-  static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B: the unfused chain
-  if (((int64_t)V + 255) / 256 <= kScanMaxBlocks && scan_agg_[0] && !force_cub) {
+  if (fused) {
     ScanState st;
-    HIPRET(scan_state(s, scan_agg_[0], scan_flag_[0], &scan_epoch_[0], flags_, &st));
+    HIPRET(scan_state(s, scan_agg_[0], scan_flag_[0], &scan_epoch_[0], he_flags, &st));
     hipLaunchKernelGGL(k_he_unique, grid1(V), dim3(256), 0, s, V, off, out, pos, edges, alpha, total, nan_flag, st);
   } else {
     hipLaunchKernelGGL(k_csr_rows<false>, grid1(V), dim3(256), 0, s, V, off, nullptr, out);
