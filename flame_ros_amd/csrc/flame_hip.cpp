@@ -1444,9 +1444,11 @@ static void fill_tri_params(const float Kinv[9], const flame_hip_tri_params* tp,
 // key `coverage`, the dense-map getters and the debug images all come from one rasterisation.
 // fo (optional): the frame's per-vertex / per-triangle outputs, written by the triangle stage's own
 // two launches.  The per-block covered-pixel counts land in g->map_cov (raster_num_blocks() words).
+// cost_lambda / cost_partials (optional, with fo and cov_dst = the frame's results stage): the cost
+// partials of the current state ride in the first launch (launch_frame_stage).
 static int ensure_raster(flame_hip_graph* g, const float Kinv[9], const flame_hip_tri_params* tp, int filtered,
                          float min_depth, float max_depth, bool want_dm, bool want_cloud, const FrameOut* fo = nullptr,
-                         uint32_t* cov_dst = nullptr) {
+                         uint32_t* cov_dst = nullptr, float cost_lambda = 0.f, double* cost_partials = nullptr) {
   int rc;
   const int32_t V = g->V, T = g->plan.T;
   const int64_t npix = (int64_t)tp->width * tp->height;
@@ -1465,6 +1467,20 @@ static int ensure_raster(flame_hip_graph* g, const float Kinv[9], const flame_hi
   TriParamsDev d;
   fill_tri_params(Kinv, tp, &d);
   hipStream_t s = g->stream;
+  if (!cached && V > 0 && T > 0 && npix > 0) {  // everything is due: three launches instead of five or six
+    HIPCHK(launch_frame_stage(s, V, g->E, T, tp->width, tp->height, g->pos, g->A[g->cur], g->B[g->cur], g->eij, g->ew, g->tris,
+                              g->trow, g->tinc, d, g->tri_normals, g->tri_valid, g->vtx_normals, fo, cost_lambda,
+                              cost_partials, filtered, min_depth, max_depth, g->map_owner, g->map_idm,
+                              (want_dm || want_cloud) ? g->map_dm : nullptr, want_cloud ? g->map_cloud : nullptr,
+                              cov_dst ? cov_dst : g->map_cov));
+    g->raster_serial = g->state_serial;
+    g->raster_filtered = filtered;
+    g->raster_tp = *tp;
+    std::memcpy(g->raster_kinv, Kinv, 36);
+    return 0;
+  }
+  if (cost_partials)
+    HIPCHK(launch_costs(s, V, g->E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], cost_lambda, cost_partials));
   HIPCHK(launch_triangles(s, V, T, g->pos, g->A[g->cur], g->tris, g->trow, g->tinc, d, g->tri_normals, g->tri_valid,
                           g->vtx_normals, fo));
   if (cached && !want_dm && !want_cloud) return 0;
@@ -1523,7 +1539,10 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
   if (dev_edges) {  // not ordered behind the solve: in_edges has been final since the graph sync
     HIPCHK(hipMemcpyAsync(host + off_edges, g->in_edges, sizeof(int2) * (size_t)E, hipMemcpyDeviceToHost, g->stream_in));
   }
-  if (smooth || data)  // costs are taken BEFORE the state goes back to the caller's units
+  // costs are taken BEFORE the state goes back to the caller's units; with no scaling pending and the
+  // raster due anyway they ride in the triangle stage's launch (ensure_raster)
+  const bool costs_ride = (smooth || data) && scale_back == 1.0f && tri_stage && coverage != nullptr;
+  if ((smooth || data) && !costs_ride)
     HIPCHK(launch_costs(s, V, E, g->eij, g->ew, g->A[g->cur], g->B[g->cur], p->data_factor,
                         reinterpret_cast<double*>(g->fr_dev + off_part)));
   if (scale_back != 1.0f) {
@@ -1538,7 +1557,9 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     fo.normals = vtx_normals ? reinterpret_cast<float*>(g->fr_dev + off_n) : nullptr;
     fo.tri_valid = tri_valid ? reinterpret_cast<uint8_t*>(g->fr_dev + off_tv) : nullptr;
     if (coverage) {  // + the filtered dense raster (kept for the map getters / debug images)
-      if ((rc = ensure_raster(g, Kinv, tp, 1, 0.f, 0.f, false, false, &fo, reinterpret_cast<uint32_t*>(g->fr_dev + off_cov))))
+      if ((rc = ensure_raster(g, Kinv, tp, 1, 0.f, 0.f, false, false, &fo, reinterpret_cast<uint32_t*>(g->fr_dev + off_cov),
+                              costs_ride ? p->data_factor : 0.f,
+                              costs_ride ? reinterpret_cast<double*>(g->fr_dev + off_part) : nullptr)))
         return rc;
     } else {
       TriParamsDev d;

@@ -100,6 +100,15 @@ hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height
                          uint32_t* owner, float* idm, float* dm, float* cloud, uint32_t* covered = nullptr);
 // covered (optional): raster_num_blocks() per-block counts of the pixels that are not NaN
 int raster_num_blocks(int32_t width, int32_t height);
+// One frame's results stage in three launches instead of six: {triangle stage | cost partials (partials
+// may be null) | owner map cleared}, {vertex normals + the frame's per-vertex outputs | owner pass},
+// fill pass.  Same results as launch_costs + launch_triangles + launch_raster.  Needs V, T, pixels > 0.
+hipError_t launch_frame_stage(hipStream_t s, int32_t V, int32_t E, int32_t T, int32_t width, int32_t height,
+                              const float2* pos, const float4* A, const float4* B, const int2* eij, const float4* ew,
+                              const int32_t* tris, const int32_t* trow, const int32_t* tinc, TriParamsDev tp,
+                              float4* tri_normals, uint8_t* tri_valid, float4* vtx_normals, const FrameOut* fo,
+                              float lambda, double* partials, int32_t filtered, float min_depth, float max_depth,
+                              uint32_t* owner, float* idm, float* dm, float* cloud, uint32_t* covered);
 
 // ---- debug images (BGR8) rendered on the device: kind 0 wireframe, 1 features, 2 normals, 3 idepthmap;
 // owner / idm = the FILTERED raster of launch_raster; feat = n_feat x {u, v, mu}; key = W x H scratch ----

@@ -482,16 +482,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2* __restrict__ eij,
-                                               const float4* __restrict__ ew,
-                                               const float4* __restrict__ A,
-                                               const float4* __restrict__ B, float lambda,
-                                               double* __restrict__ partials,
-                                               const uint8_t* __restrict__ emask,
-                                               const uint8_t* __restrict__ vmask) {
+// (bid of nblocks: the kernel's own grid, or a range of blocks inside a fused launch)
+__device__ __forceinline__ void costs_body(int bid, int nblocks, int32_t V, int32_t E, const int2* __restrict__ eij,
+                                           const float4* __restrict__ ew, const float4* __restrict__ A,
+                                           const float4* __restrict__ B, float lambda, double* __restrict__ partials,
+                                           const uint8_t* __restrict__ emask, const uint8_t* __restrict__ vmask) {
   __shared__ double red[2][4];
   double s = 0.0, d = 0.0;
-  for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
+  for (int32_t e = bid * 256 + threadIdx.x; e < E; e += nblocks * 256) {
     if (emask && !emask[e]) continue;  // multi-GPU subdomain: only the edges this rank owns
     const int2 ij = eij[e];
     const float4 w = ew[e];
@@ -504,7 +502,7 @@ __global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2*
     const float t3 = w.y * fabsf(ai.z - aj.z);
     s += (double)t1 + (double)t2 + (double)t3;
   }
-  for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+  for (int32_t v = bid * 256 + threadIdx.x; v < V; v += nblocks * 256) {
     if (vmask && !vmask[v]) continue;
     const float4 a = A[v];
     const float c = (lambda * B[v].w) * fabsf(a.x - a.w);
@@ -516,9 +514,19 @@ __global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2*
   if ((threadIdx.x & 63) == 0) { red[0][wid] = s; red[1][wid] = d; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partials[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    partials[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    partials[2 * bid] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[2 * bid + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
+}
+
+__global__ __launch_bounds__(256) void k_costs(int32_t V, int32_t E, const int2* __restrict__ eij,
+                                               const float4* __restrict__ ew,
+                                               const float4* __restrict__ A,
+                                               const float4* __restrict__ B, float lambda,
+                                               double* __restrict__ partials,
+                                               const uint8_t* __restrict__ emask,
+                                               const uint8_t* __restrict__ vmask) {
+  costs_body((int)blockIdx.x, (int)gridDim.x, V, E, eij, ew, A, B, lambda, partials, emask, vmask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,12 +545,10 @@ __device__ __forceinline__ void backproject(const float* K, float2 uv, float x, 
   Z = fmaf(K[6], uv.x, fmaf(K[7], uv.y, K[8])) * depth;
 }
 
-__global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict__ pos,
-                                             const float4* __restrict__ A,
-                                             const int32_t* __restrict__ tris, TriParamsDev tp,
-                                             float4* __restrict__ tri_normals,
-                                             uint8_t* __restrict__ tri_valid, uint8_t* __restrict__ valid_out) {
-  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void tri_body(int32_t t, int32_t T, const float2* __restrict__ pos,
+                                         const float4* __restrict__ A, const int32_t* __restrict__ tris,
+                                         const TriParamsDev& tp, float4* __restrict__ tri_normals,
+                                         uint8_t* __restrict__ tri_valid, uint8_t* __restrict__ valid_out) {
   if (t >= T) return;
   const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
   const float xa = A[a].x, xb = A[b].x, xc = A[c].x;
@@ -592,13 +598,39 @@ __global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict
   if (valid_out) valid_out[t] = valid;
 }
 
-__global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* __restrict__ trow,
-                                                     const int32_t* __restrict__ tinc,
-                                                     const float4* __restrict__ tri_normals,
-                                                     float4* __restrict__ vtx_normals,
-                                                     const int32_t* __restrict__ i2o, const float4* __restrict__ A,
-                                                     float* __restrict__ out_x, float* __restrict__ out_n) {
-  const int32_t v = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_tri(int32_t T, const float2* __restrict__ pos,
+                                             const float4* __restrict__ A,
+                                             const int32_t* __restrict__ tris, TriParamsDev tp,
+                                             float4* __restrict__ tri_normals,
+                                             uint8_t* __restrict__ tri_valid, uint8_t* __restrict__ valid_out) {
+  tri_body(blockIdx.x * 256 + threadIdx.x, T, pos, A, tris, tp, tri_normals, tri_valid, valid_out);
+}
+
+// The first launch of a frame's results stage (flame_hip_frame_results): blocks [0, nbt) run the
+// triangle stage, the next ncb blocks the cost reduction (state not yet un-scaled: the caller fuses
+// only when no scaling is pending), and every thread clears its share of the raster's owner map --
+// three dependent launches of a small frame (~7 us of chain time each) in one.
+__global__ __launch_bounds__(256) void k_frame_a(int32_t T, int nbt, const float2* __restrict__ pos,
+                                                 const float4* __restrict__ A,
+                                                 const int32_t* __restrict__ tris, TriParamsDev tp,
+                                                 float4* __restrict__ tri_normals,
+                                                 uint8_t* __restrict__ tri_valid, uint8_t* __restrict__ valid_out,
+                                                 int ncb, int32_t V, int32_t E, const int2* __restrict__ eij,
+                                                 const float4* __restrict__ ew, const float4* __restrict__ B,
+                                                 float lambda, double* __restrict__ partials,
+                                                 uint32_t* __restrict__ owner, int64_t npix) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) owner[i] = 0xffffffffu;
+  const int b = (int)blockIdx.x;
+  if (b < nbt) tri_body(b * 256 + threadIdx.x, T, pos, A, tris, tp, tri_normals, tri_valid, valid_out);
+  else costs_body(b - nbt, ncb, V, E, eij, ew, A, B, lambda, partials, nullptr, nullptr);
+}
+
+__device__ __forceinline__ void vtx_normals_body(int32_t v, int32_t V, const int32_t* __restrict__ trow,
+                                                 const int32_t* __restrict__ tinc,
+                                                 const float4* __restrict__ tri_normals,
+                                                 float4* __restrict__ vtx_normals,
+                                                 const int32_t* __restrict__ i2o, const float4* __restrict__ A,
+                                                 float* __restrict__ out_x, float* __restrict__ out_n) {
   if (v >= V) return;
   float nx = 0.f, ny = 0.f, nz = 0.f;
   for (int32_t s = trow[v]; s < trow[v + 1]; ++s) {
@@ -615,6 +647,15 @@ __global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* _
     if (out_x) out_x[o] = A[v].x;
     if (out_n) { out_n[3 * (size_t)o] = nx; out_n[3 * (size_t)o + 1] = ny; out_n[3 * (size_t)o + 2] = nz; }
   }
+}
+
+__global__ __launch_bounds__(256) void k_vtx_normals(int32_t V, const int32_t* __restrict__ trow,
+                                                     const int32_t* __restrict__ tinc,
+                                                     const float4* __restrict__ tri_normals,
+                                                     float4* __restrict__ vtx_normals,
+                                                     const int32_t* __restrict__ i2o, const float4* __restrict__ A,
+                                                     float* __restrict__ out_x, float* __restrict__ out_n) {
+  vtx_normals_body(blockIdx.x * 256 + threadIdx.x, V, trow, tinc, tri_normals, vtx_normals, i2o, A, out_x, out_n);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -785,13 +826,12 @@ __device__ __forceinline__ void raster_cover(float2 A, float2 B, float2 Cc, int 
 }
 
 template <int LPT>
-__global__ __launch_bounds__(256) void k_raster_owner(int32_t T, int32_t width, int32_t height,
-                                                      const float2* __restrict__ pos,
-                                                      const int32_t* __restrict__ tris,
-                                                      const uint8_t* __restrict__ tri_valid,
-                                                      int32_t filtered, uint32_t* __restrict__ owner) {
+__device__ __forceinline__ void raster_owner_body(int bid, int32_t T, int32_t width, int32_t height,
+                                                  const float2* __restrict__ pos, const int32_t* __restrict__ tris,
+                                                  const uint8_t* __restrict__ tri_valid, int32_t filtered,
+                                                  uint32_t* __restrict__ owner) {
   const int lane = threadIdx.x & 63, sub = lane % LPT;
-  const int32_t t = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPT) + lane / LPT;
+  const int32_t t = (bid * 4 + (threadIdx.x >> 6)) * (64 / LPT) + lane / LPT;
   bool live = t < T && !(filtered && !tri_valid[t]);
   float2 A = make_float2(0.f, 0.f), B = A, Cc = A;
   int x0 = 0, y0 = 0, bw = 0, bh = 0;
@@ -818,6 +858,34 @@ __global__ __launch_bounds__(256) void k_raster_owner(int32_t T, int32_t width, 
     raster_cover(a, b, c, __shfl(x0, l, 64), __shfl(y0, l, 64), __shfl(bw, l, 64), __shfl(n, l, 64), lane, 64, width,
                  (uint32_t)__shfl(t, l, 64), owner);
   }
+}
+
+template <int LPT>
+__global__ __launch_bounds__(256) void k_raster_owner(int32_t T, int32_t width, int32_t height,
+                                                      const float2* __restrict__ pos,
+                                                      const int32_t* __restrict__ tris,
+                                                      const uint8_t* __restrict__ tri_valid,
+                                                      int32_t filtered, uint32_t* __restrict__ owner) {
+  raster_owner_body<LPT>((int)blockIdx.x, T, width, height, pos, tris, tri_valid, filtered, owner);
+}
+
+// The second launch of a frame's results stage: both halves only need the triangle stage's outputs --
+// blocks [0, nbv) make the vertex normals (and the frame's per-vertex outputs), the rest rasterise the
+// owner map.
+template <int LPT>
+__global__ __launch_bounds__(256) void k_frame_b(int32_t V, int nbv, const int32_t* __restrict__ trow,
+                                                 const int32_t* __restrict__ tinc,
+                                                 const float4* __restrict__ tri_normals,
+                                                 float4* __restrict__ vtx_normals,
+                                                 const int32_t* __restrict__ i2o, const float4* __restrict__ A,
+                                                 float* __restrict__ out_x, float* __restrict__ out_n, int32_t T,
+                                                 int32_t width, int32_t height, const float2* __restrict__ pos,
+                                                 const int32_t* __restrict__ tris,
+                                                 const uint8_t* __restrict__ tri_valid, int32_t filtered,
+                                                 uint32_t* __restrict__ owner) {
+  const int b = (int)blockIdx.x;
+  if (b < nbv) vtx_normals_body(b * 256 + threadIdx.x, V, trow, tinc, tri_normals, vtx_normals, i2o, A, out_x, out_n);
+  else raster_owner_body<LPT>(b - nbv, T, width, height, pos, tris, tri_valid, filtered, owner);
 }
 
 __global__ __launch_bounds__(256) void k_raster_fill(int32_t width, int32_t height,
@@ -1112,6 +1180,31 @@ hipError_t launch_raster(hipStream_t s, int32_t T, int32_t width, int32_t height
   }
   hipLaunchKernelGGL(k_raster_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, width, height,
                      pos, A, tris, owner, tp, min_depth, max_depth, idm, dm, cloud, covered);
+  return hipGetLastError();
+}
+
+// triangle stage + costs + dense raster of one frame in three launches (k_frame_a, k_frame_b, k_raster_fill)
+hipError_t launch_frame_stage(hipStream_t s, int32_t V, int32_t E, int32_t T, int32_t width, int32_t height,
+                              const float2* pos, const float4* A, const float4* B, const int2* eij, const float4* ew,
+                              const int32_t* tris, const int32_t* trow, const int32_t* tinc, TriParamsDev tp,
+                              float4* tri_normals, uint8_t* tri_valid, float4* vtx_normals, const FrameOut* fo,
+                              float lambda, double* partials, int32_t filtered, float min_depth, float max_depth,
+                              uint32_t* owner, float* idm, float* dm, float* cloud, uint32_t* covered) {
+  const int64_t npix = (int64_t)width * height;
+  const int nbt = (T + 255) / 256, ncb = partials ? kCostBlocks : 0, nbv = (V + 255) / 256;
+  if (T <= 0 || V <= 0 || npix <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_frame_a, dim3(nbt + ncb), dim3(256), 0, s, T, nbt, pos, A, tris, tp, tri_normals, tri_valid,
+                     fo ? fo->tri_valid : nullptr, ncb, V, E, eij, ew, B, lambda, partials, owner, npix);
+  if (npix / T >= 64)  // mean triangle area in pixels
+    hipLaunchKernelGGL(k_frame_b<64>, dim3(nbv + (T + 3) / 4), dim3(256), 0, s, V, nbv, trow, tinc, tri_normals, vtx_normals,
+                       fo ? fo->v_i2o : nullptr, A, fo ? fo->x : nullptr, fo ? fo->normals : nullptr, T, width, height, pos,
+                       tris, tri_valid, filtered, owner);
+  else
+    hipLaunchKernelGGL(k_frame_b<8>, dim3(nbv + (T + 31) / 32), dim3(256), 0, s, V, nbv, trow, tinc, tri_normals, vtx_normals,
+                       fo ? fo->v_i2o : nullptr, A, fo ? fo->x : nullptr, fo ? fo->normals : nullptr, T, width, height, pos,
+                       tris, tri_valid, filtered, owner);
+  hipLaunchKernelGGL(k_raster_fill, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, width, height, pos, A, tris, owner,
+                     tp, min_depth, max_depth, idm, dm, cloud, covered);
   return hipGetLastError();
 }
 
