@@ -639,11 +639,8 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     STG(hipEventRecord(g->ev_in, g->stream_in));
     STG(hipStreamWaitEvent(s, g->ev_in, 0));
     // non-finite inputs are found on the device (the flag is read with the builder's first sync)
-    STG(launch_check_finite(s, V, g->in_z, g->dflags));
-    STG(launch_check_finite(s, V, g->in_wgt, g->dflags));
-    STG(launch_check_finite(s, E, g->in_alpha, g->dflags));
-    STG(launch_check_finite(s, E, g->in_beta, g->dflags));
-    if (x0) STG(launch_check_finite(s, V, g->in_x0, g->dflags));
+    STG(DevPlanner::check_finite(s, g->dflags, g->in_z, V, g->in_wgt, V, g->in_alpha, E, g->in_beta, E,
+                                 x0 ? g->in_x0 : nullptr, V));
 #undef STG
     return hipSuccess;
   };

@@ -98,6 +98,10 @@ class DevPlanner {
   // written to nan_flag[1]; expect_edges(E) makes the NEXT build() check it at its first synchronisation
   // (user_flags_host[1] then holds the true count; a mismatch ends the build with ok = false)
   void expect_edges(int32_t E) { expect_E_ = E; }
+  // flags[0] |= 1 when any value of the (up to five) arrays is not finite; null arrays are skipped
+  static hipError_t check_finite(hipStream_t s, int32_t* flags, const float* a, int64_t na, const float* b = nullptr,
+                                 int64_t nb = 0, const float* c = nullptr, int64_t nc = 0, const float* d = nullptr,
+                                 int64_t nd = 0, const float* e = nullptr, int64_t ne = 0);
   // z = mu / scale, wgt = 1 or 1 / var, x0 = prediction / scale where finite (else z)
   hipError_t sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
                        float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0,

@@ -2449,6 +2449,27 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   return hipSuccess;
 }
 
+// flags[0] |= 1 when any value of up to five arrays is not finite (the upload path's input check: one
+// launch instead of one per array)
+struct FiniteJob { const float* p[5]; int64_t n[5]; };
+__global__ __launch_bounds__(256) void k_check_finite5(FiniteJob j, int32_t* flags) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  bool bad = false;
+  for (int a = 0; a < 5; ++a)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.n[a]; i += stride) bad |= !isfinite(j.p[a][i]);
+  if (bad) atomicOr(flags, 1);
+}
+
+hipError_t DevPlanner::check_finite(hipStream_t s, int32_t* flags, const float* a, int64_t na, const float* b, int64_t nb,
+                                    const float* c, int64_t nc, const float* d, int64_t nd, const float* e, int64_t ne) {
+  FiniteJob j = {{a, b, c, d, e}, {a ? na : 0, b ? nb : 0, c ? nc : 0, d ? nd : 0, e ? ne : 0}};
+  int64_t m = 0;
+  for (int k = 0; k < 5; ++k) m = std::max(m, j.n[k]);
+  if (m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_check_finite5, dim3((unsigned)std::min<int64_t>(2048, (m + 255) / 256)), dim3(256), 0, s, j, flags);
+  return hipGetLastError();
+}
+
 hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, const float* var, const float* pred,
                                  float scale, int adaptive, int init_pred, float* z, float* wgt, float* x0,
                                  int32_t* nan_flag) {
