@@ -250,6 +250,8 @@ struct flame_hip_graph {
   // device plan builder (row f3) and the staged inputs it reads (caller's order)
   int plan_device = 1;
   int plan_reuse = 1;          // frame streams: partition from the previous frame's tile map
+  int plan_mini = 1;           // option "plan_mini": small frames of a graph sync planned by one launch (k_mini_plan)
+  bool plan_mini_used = false; // ... the current plan was
   int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
                                // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
                                // that is solved once pays for its plan, and that is cheapest at depth 4-5
@@ -463,6 +465,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->plan_device = value != 0;
   } else if (k == "plan_reuse") {
     g->plan_reuse = value != 0;
+  } else if (k == "plan_mini") {
+    g->plan_mini = value != 0;
   } else if (k == "stream_depth") {
     if (value < 0 || value > kMaxDepth) return FLAME_HIP_ERR_ARG;
     g->stream_depth = value;
@@ -497,6 +501,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "plan_on_device") *value = P.on_device ? 1 : 0;
   else if (k == "plan_reused") *value = (P.on_device && g->plan_reused) ? 1 : 0;
   else if (k == "single_cap") *value = g->single_cap;
+  else if (k == "plan_mini") *value = (P.on_device && g->plan_mini_used) ? 1 : 0;
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
@@ -1062,6 +1067,66 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     if (g->euler_skip > 0) --g->euler_skip;
     else if ((int64_t)V + T + g->euler_off > 0 && (int64_t)V + T + g->euler_off <= 3ll * T) expected_E = V + T + g->euler_off;
     const bool use_pred = sp->init_with_prediction && prediction;
+    // ---- small frames: one launch for everything in front of the tile pass (plan_dev.hip k_mini_plan) ----
+    g->plan_mini_used = false;
+    if (g->plan_mini && expected_E >= 0 && DevPlanner::mini_eligible(V, T, expected_E) && g->plan_reuse && g->opt.balance &&
+        g->reuse_skip == 0 && g->opt.tile_own == g->reuse_tile_own_opt &&
+        g->planner.map_usable(V, plan_sizing(g->opt, V, expected_E).depth)) {
+      if ((vrc = validate())) return vrc;  // (a few microseconds at this size)
+      if (sp->rescale_data) {  // mean in the oracle's order (sequential, float64)
+        double acc = 0.0;
+        for (int32_t v = 0; v < V; ++v) acc += (double)idepth_mu[v];
+        sc = (float)(acc / (double)V);
+        if (!(sc > 0.0f)) sc = 1.0f;
+      }
+      HIPCHK(stage(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T));
+      HIPCHK(stage(g->in_pos, pos, sizeof(float2) * (size_t)V));
+      HIPCHK(stage(g->in_mu, idepth_mu, sizeof(float) * (size_t)V));
+      HIPCHK(stage(g->in_var, idepth_var, sizeof(float) * (size_t)V));
+      if (prediction) HIPCHK(stage(g->in_pred, prediction, sizeof(float) * (size_t)V));
+      HIPCHK(staged_for());
+      lap("H2D all");
+      DevPlanner::MiniSync ms;
+      ms.mu = g->in_mu; ms.var = g->in_var; ms.pred = use_pred ? g->in_pred : nullptr; ms.scale = sc;
+      ms.adaptive = sp->adaptive_data_weights; ms.init_pred = sp->init_with_prediction;
+      ms.z = g->in_z; ms.wgt = g->in_wgt; ms.x0 = g->in_x0; ms.edges = g->in_edges; ms.alpha = g->in_alpha;
+      ms.dflags = g->dflags;
+      g->planner.offer_mini(ms);
+      const int32_t V0 = g->V, E0 = g->E, T0 = g->T;
+      g->V = V; g->E = expected_E; g->T = T;
+      g->uploaded = false;
+      g->n_send_v = g->n_send_e = g->n_recv_v = g->n_recv_e = 0;
+      g->drop_execs();
+      g->solves_since_upload = 0;
+      g->lanes_applied = false;
+      g->beta_is_alpha = true;
+      g->spec_edges = true;
+      rc = upload_device_plan(g, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, true);
+      g->spec_edges = false;
+      g->planner.withdraw_mini();
+      if (g->planner.mini_used() && rc == 1) {
+        g->plan_mini_used = true;
+        g->euler_backoff = 0;
+        g->euler_off = (int32_t)((int64_t)g->E - V - T);
+        if ((rc = finish_upload(g))) return rc;
+        g->synced = true;
+        g->sync_on_device = true;
+        g->sync.scale = sc;
+        if (scale) *scale = sc;
+        return 0;
+      }
+      if (rc < 0) return rc;
+      // not taken (the build did not reuse the partition after all), a wrong edge-count prediction or a
+      // plan that does not fit: the usual way from the start (the inputs are staged again in its order)
+      (void)hipStreamSynchronize(s);
+      if (rc == 2) {
+        g->euler_backoff = std::min(16, std::max(1, 2 * g->euler_backoff));
+        g->euler_skip = g->euler_backoff;
+        expected_E = -1;
+      }
+      g->V = V0; g->E = E0; g->T = T0;
+      HIPCHK(hipMemsetAsync(g->dflags, 0, 8 * sizeof(int32_t), s));
+    }
     // The copies from the caller's (pageable) arrays block the host, so they are issued in the order the
     // kernels need them, each batch of kernels enqueued before the next copy starts: triangles ->
     // half-edge count / scan / fill; positions -> unique edges + alpha; idepths -> data terms.

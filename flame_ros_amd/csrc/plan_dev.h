@@ -98,6 +98,19 @@ class DevPlanner {
   // written to nan_flag[1]; expect_edges(E) makes the NEXT build() check it at its first synchronisation
   // (user_flags_host[1] then holds the true count; a mismatch ends the build with ok = false)
   void expect_edges(int32_t E) { expect_E_ = E; }
+  // Small frames of a graph sync (mini_eligible(), a reused partition, an expected edge count): the NEXT
+  // build() derives the edges and data terms itself and does everything in front of its tile pass in
+  // one launch of one workgroup (k_mini_plan) -- the caller stages the inputs and does NOT call
+  // edges_from_tris / sync_data.  mini_used() tells whether that build took the offer; if not (no
+  // reuse after all), nothing was derived and the caller goes the usual way.
+  struct MiniSync {
+    const float* mu; const float* var; const float* pred; float scale; int adaptive, init_pred;
+    float* z; float* wgt; float* x0; int2* edges; float* alpha; int32_t* dflags;
+  };
+  static bool mini_eligible(int32_t V, int32_t T, int32_t E) { return V >= 2 && V <= 2048 && T >= 1 && T <= 4096 && E >= 1 && E <= 6144; }
+  void offer_mini(const MiniSync& m) { mini_ = m; mini_set_ = true; mini_used_ = false; }
+  void withdraw_mini() { mini_set_ = false; }
+  bool mini_used() const { return mini_used_; }
   // flags[0] |= 1 when any value of the (up to five) arrays is not finite; null arrays are skipped
   static hipError_t check_finite(hipStream_t s, int32_t* flags, const float* a, int64_t na, const float* b = nullptr,
                                  int64_t nb = 0, const float* c = nullptr, int64_t nc = 0, const float* d = nullptr,
@@ -197,6 +210,8 @@ class DevPlanner {
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_grid_ = nullptr;
   bool grid_pending_ = false;    // update_grid()'s kernels may still run on s2_
+  MiniSync mini_{};
+  bool mini_set_ = false, mini_used_ = false;
   int64_t capV2_ = 0;
   size_t tcub_bytes_ = 0;
   void* tcub_tmp_ = nullptr;     // scan scratch of the triangle stage

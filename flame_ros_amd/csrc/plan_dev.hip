@@ -1859,6 +1859,413 @@ __global__ __launch_bounds__(256) void k_sync_data(int32_t V, const float* __res
   if (nan_flag && !(isfinite(zi) && isfinite(wi) && isfinite(xi))) atomicOr(nan_flag, 1);
 }
 
+// ------------------------------------------------------------------------------------------
+// SMALL frames (<= kMiniV vertices, reused partition, predicted edge count): everything in front of
+// the tile pass -- edges of the triangulation, data terms, partition from the previous frame's tile
+// map, vertex order, triangle CSR, edge order, incidence CSR -- in ONE launch of ONE workgroup.
+// At 1.2 k vertices those stages were 24 dependent launches whose kernels run 2-5 us each: ~0.15 ms
+// of a 0.55 ms frame was the dependency latency between them.  Same rules, same arrays as the
+// stages above (k_he_*, k_sync_data, k_reuse_*, k_tile_order, k_tri_*, k_edge_*, k_csr_*): the phases
+// below are those kernels' bodies as loops over one workgroup, counters and offsets in LDS,
+// __syncthreads() between them.  tests/test_gpu_plan_device.py compares the two paths array for array.
+// ------------------------------------------------------------------------------------------
+constexpr int kMiniV = 2048;          // vertices
+constexpr int kMiniT = 4096;          // triangles (3T half edges <= 12288)
+constexpr int kMiniE = 6144;          // edges
+constexpr int kMiniThreads = 1024;
+constexpr int kMiniTileCap = 128;     // own vertices of one tile (two keys per lane of the wave that orders it)
+constexpr int kMiniRows = 2 * kMiniE; // entries of the largest counting pass (3T = 2E = 12288)
+constexpr size_t kMiniLds = sizeof(uint32_t) * kMiniRows + sizeof(int32_t) * (2 * kMiniV + kMiniE) + sizeof(float2) * kMiniV;
+static_assert(3 * kMiniT <= kMiniRows, "half-edge and triangle rows fit the row buffer");
+static_assert(kMiniV == 2048 && kMiniT == 4096 && kMiniE == 6144, "DevPlanner::mini_eligible (plan_dev.h) states these limits");
+
+struct MiniArgs {
+  int32_t V, T, E_expect, ntiles, cap;
+  // inputs (device copies of the caller's arrays)
+  const int32_t* tris; const float2* pos; const float* mu; const float* var; const float* pred;
+  float scale; int32_t adaptive, init_pred; float dsign;
+  // graph sync outputs
+  int2* edges; float* alpha; float* z; float* wgt; float* x0;
+  int32_t* dflags;               // caller's words: [0] non-finite, [1] derived edge count, [2] bit 2 bad index
+  // scratch in global memory (L1 / L2 resident at these sizes)
+  int32_t* rank;                 // max(3T, 2E): ranks of the counting passes
+  int32_t* vt;                   // V
+  // partition
+  const float* gbbox; const int32_t* pyr; SegTab tab; int32_t* nseg; int32_t* flags;
+  int32_t* seg_pos;
+  // plan arrays
+  int32_t* v_i2o; int32_t* v_o2i; int32_t* tile_of_int;
+  int32_t* tris_int; int32_t* trow; uint32_t* tinc;
+  int32_t* e_i2o; int32_t* e_o2i; int2* eij; float4* ew; int32_t* estart;
+  int32_t* grow; uint32_t* ginc;
+  long long* prof;               // dev aid (FLAME_HIP_PLAN_TIMING=4): 20 phase stamps, or null
+};
+
+// exclusive scan of a[0 .. n) in place (LDS), 1024 threads, n <= 5 * 1024; returns the total.  Every
+// thread owns `per` consecutive entries: one block scan (three barriers) whatever n is.
+__device__ __forceinline__ int32_t mini_scan(int32_t* a, int n, int32_t* sh /* >= 17 */) {
+  const int tid = threadIdx.x;
+  const int per = (n + kMiniThreads - 1) / kMiniThreads;
+  const int i0 = tid * per;
+  int32_t v[5], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    v[k] = (k < per && i0 + k < n) ? a[i0 + k] : 0;
+    sum += v[k];
+  }
+  int32_t run = block_exclusive<int32_t>(sum, sh);
+  if (tid == kMiniThreads - 1) sh[16] = run + sum;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (k < per && i0 + k < n) a[i0 + k] = run;
+    run += v[k];
+  }
+  __syncthreads();
+  return sh[16];
+}
+
+// A row of <= N entries sorted through registers: every entry's place is the number of entries in front
+// of it (ties by position), N^2 register compares and no dependent LDS round trips (the insertion
+// sort of sort_row() on an LDS row is ~200 cycles per move: 25 k ticks for the half-edge rows of a
+// 1.2 k-vertex frame, this: 4 k).  *dups (optional) = entries that repeat an earlier one.
+template <int N>
+__device__ __forceinline__ void sort_row_reg(uint32_t* row, int d, int* dups) {
+  uint32_t r[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = i < d ? row[i] : 0xffffffffu;
+  int nd = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    int rank = 0, dup = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (j == i) continue;
+      const bool eq_before = r[j] == r[i] && j < i;
+      rank += (r[j] < r[i] || eq_before) ? 1 : 0;
+      dup |= eq_before ? 1 : 0;
+    }
+    if (i < d) { row[rank] = r[i]; nd += dup; }
+  }
+  if (dups) *dups = nd;
+}
+
+// sorts row[0 .. d) ascending; returns the number of distinct entries
+__device__ __forceinline__ int mini_sort_row(uint32_t* row, int d) {
+  int nd = 0;
+  if (d <= 8) { sort_row_reg<8>(row, d, &nd); return d - nd; }
+  if (d <= 16) { sort_row_reg<16>(row, d, &nd); return d - nd; }
+  sort_row(row, d);
+  int uq = 0;
+  for (int k = 0; k < d; ++k) uq += (k == 0 || row[k] != row[k - 1]) ? 1 : 0;
+  return uq;
+}
+
+// dev aid: phase boundaries of the launch (shader-clock ticks) into a.prof when it is set
+#define MINI_STAMP(n) do { if (a.prof && tid == 0) a.prof[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+__global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
+  __shared__ int32_t s_a[2 * kMiniV + 4];         // he offsets | triangle rows | edge buckets (2V + 1) | degrees
+  __shared__ int32_t s_b[kMiniV + 4];             // distinct entries per half-edge row -> first edge id of the row
+  __shared__ int32_t s_tl[kSegCap + 1];           // tile counts -> tile starts
+  __shared__ uint64_t s_key[16][kMiniTileCap];    // one tile's (Morton code, id) keys per wave
+  __shared__ int32_t s_sc[20];
+  // rows of the counting passes (half edges, triangle rows, edge buckets, incidence rows) are filled and
+  // sorted HERE and written out once, coalesced: a thread that sorts its row in global memory pays a
+  // round trip per element (the first version of this kernel: 125 us at 1.2 k vertices, 80 of them there)
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_buf[];  // kMiniRows entries, then:
+  // what the later phases gather from, on chip (a dependent gather from global memory is a 1-2 us round
+  // trip for the one workgroup; the phases chain three or four of them)
+  int32_t* s_vo2i = reinterpret_cast<int32_t*>(s_buf + kMiniRows);    // V: original -> internal vertex id
+  int32_t* s_tile = s_vo2i + kMiniV;                                  // V: tile of an internal vertex id
+  int32_t* s_eo2i = s_tile + kMiniV;                                  // E: original -> internal edge id
+  float2* s_pos = reinterpret_cast<float2*>(s_eo2i + kMiniE);          // V
+  const int tid = threadIdx.x, NT = kMiniThreads;
+  const int32_t V = a.V, ntiles = a.ntiles;
+  for (int v = tid; v < V; v += NT) s_pos[v] = a.pos[v];
+  MINI_STAMP(1);
+  // ---- flags of the build, counters ----
+  if (tid < 8) a.flags[tid] = 0;
+  for (int i = tid; i <= V; i += NT) { s_a[i] = 0; s_b[i] = 0; }
+  for (int i = tid; i <= ntiles; i += NT) s_tl[i] = 0;
+  __syncthreads();
+  MINI_STAMP(2);
+  // ---- edges of the triangulation (k_he_count / fill / unique) ----
+  // (a thread keeps its <= 4 triangles -- corner ids and the ranks its counting atomics returned -- in
+  // registers from here to the triangle CSR: fixed trip counts, so that the loads of a phase leave
+  // back to back instead of one round trip per loop iteration)
+  constexpr int kTri = kMiniT / kMiniThreads;  // 4
+  int32_t tv[kTri][3], tr[kTri][3];
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) {
+    const int32_t t = tid + i * NT;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tv[i][c] = t < a.T ? a.tris[3 * t + c] : -1;
+  }
+  if (a.prof) { __syncthreads(); asm volatile("" :: "v"(tv[0][0])); MINI_STAMP(3); }
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int32_t u = tv[i][c], w = tv[i][c == 2 ? 0 : c + 1];
+      tr[i][c] = -1;
+      if (tid + i * NT >= a.T) continue;
+      if (u < 0 || w < 0 || u >= V || w >= V || u == w) { atomicOr(&a.dflags[2], 2); continue; }  // = half_edge()
+      tr[i][c] = atomicAdd(&s_a[min(u, w)], 1);
+    }
+  }
+  __syncthreads();
+  MINI_STAMP(4);
+  mini_scan(s_a, V + 1, s_sc);
+  MINI_STAMP(5);
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int32_t u = tv[i][c], w = tv[i][c == 2 ? 0 : c + 1];
+      if (tr[i][c] >= 0) s_buf[s_a[min(u, w)] + tr[i][c]] = (uint32_t)max(u, w);
+    }
+  }
+  __syncthreads();
+  MINI_STAMP(6);
+  for (int v = tid; v < V; v += NT) {
+    uint32_t* row = s_buf + s_a[v];
+    const int d = s_a[v + 1] - s_a[v];
+    s_b[v] = mini_sort_row(row, d);
+  }
+  __syncthreads();
+  MINI_STAMP(7);
+  const int32_t E = mini_scan(s_b, V + 1, s_sc);
+  MINI_STAMP(8);
+  if (tid == 0) a.dflags[1] = E;
+  if (E != a.E_expect || E > kMiniE) return;  // (uniform) the host's prediction was wrong: it builds again
+  for (int v = tid; v < V; v += NT) {
+    const uint32_t* row = s_buf + s_a[v];
+    const int d = s_a[v + 1] - s_a[v];
+    int32_t idx = s_b[v];
+    const float2 pi = s_pos[v];
+    for (int k = 0; k < d; ++k) {
+      if (k > 0 && row[k] == row[k - 1]) continue;
+      const int32_t j = (int32_t)row[k];
+      const float2 pj = s_pos[j];
+      const float dx = pi.x - pj.x, dy = pi.y - pj.y;
+      a.edges[idx] = make_int2(v, j);
+      const float al = 1.0f / sqrtf(dx * dx + dy * dy);  // -ffp-contract=off: two roundings, as the oracle
+      a.alpha[idx] = al;
+      if (!isfinite(al)) atomicOr(&a.dflags[0], 1);
+      ++idx;
+    }
+  }
+  MINI_STAMP(9);
+  // ---- data terms (k_sync_data) ----
+  for (int v = tid; v < V; v += NT) {
+    const float zi = a.mu[v] / a.scale;
+    const float wi = a.adaptive ? 1.0f / a.var[v] : 1.0f;
+    const float xi = (a.init_pred && a.pred && isfinite(a.pred[v])) ? a.pred[v] / a.scale : zi;
+    a.z[v] = zi; a.wgt[v] = wi; a.x0[v] = xi;
+    if (!(isfinite(zi) && isfinite(wi) && isfinite(xi))) atomicOr(&a.dflags[0], 1);
+  }
+  MINI_STAMP(10);
+  // ---- partition from the previous frame's tile map (k_reuse_assign / scatter) ----
+  for (int v = tid; v < V; v += NT) {
+    const float2 q = s_pos[v];
+    int32_t t = 0;
+    for (int l = 0; l < kPyrLevels; ++l) {
+      const int32_t c = a.pyr[pyr_cell(a.gbbox, q, l)];
+      if (c > 0) { t = c - 1; break; }
+    }
+    t = max(0, min(t, ntiles - 1));
+    a.vt[v] = t;
+    a.rank[v] = atomicAdd(&s_tl[t], 1);  // (the half-edge ranks are spent)
+  }
+  __syncthreads();
+  {
+    const int32_t c0 = tid < ntiles ? s_tl[tid] : 0;  // (ntiles <= kSegCap = 1024 = NT)
+    __syncthreads();
+    const int32_t total = mini_scan(s_tl, ntiles + 1, s_sc);
+    if (tid < ntiles) {
+      const int32_t lo = s_tl[tid];
+      a.tab.lo[tid] = lo; a.tab.hi[tid] = lo + c0; a.tab.leaves[tid] = 1; a.tab.first[tid] = tid;
+      if (c0 < 1 || c0 > a.cap || c0 > kMiniTileCap) atomicOr(&a.flags[0], 64);
+    }
+    if (tid == 0) { a.nseg[0] = ntiles; if (total != V) atomicOr(&a.flags[0], 64); }
+  }
+  for (int v = tid; v < V; v += NT) {
+    const int32_t t = a.vt[v];
+    const int32_t p = s_tl[t] + a.rank[v];
+    a.v_i2o[p] = v;  // (= perm; ordered inside the tile below)
+    a.seg_pos[p] = t;
+  }
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(a.flags[0]) & 64) return;  // (uniform after the barrier) rejected: bisection next
+  MINI_STAMP(11);
+  // ---- order inside tiles: (Morton code, id), one wave per tile, rank by counting (k_tile_order) ----
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    const float mnx = a.gbbox[0], mny = a.gbbox[1], mxx = a.gbbox[2], mxy = a.gbbox[3];
+    uint64_t* keys = s_key[wave];
+    for (int t = wave; t < ntiles; t += NT / 64) {
+      const int32_t lo = s_tl[t], n = s_tl[t + 1] - lo;
+      uint64_t mine[2];
+      for (int h = 0; h < 2; ++h) {
+        const int p = lane + 64 * h;
+        uint64_t k = ~0ull;
+        if (p < n) {
+          const int32_t v = a.v_i2o[lo + p];
+          const float2 q = s_pos[v];
+          const uint32_t qx = (uint32_t)(65535.0f * (fminf(fmaxf(q.x, mnx), mxx) - mnx) / fmaxf(mxx - mnx, 1e-20f));
+          const uint32_t qy = (uint32_t)(65535.0f * (fminf(fmaxf(q.y, mny), mxy) - mny) / fmaxf(mxy - mny, 1e-20f));
+          k = ((uint64_t)(spread16(qx) | (spread16(qy) << 1)) << 32) | (uint32_t)v;
+        }
+        mine[h] = k;
+        keys[p] = k;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's keys are in LDS
+      int r[2] = {0, 0};
+      for (int j = 0; j < n; ++j) {
+        const uint64_t kj = keys[j];
+        r[0] += kj < mine[0] ? 1 : 0;
+        r[1] += kj < mine[1] ? 1 : 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int h = 0; h < 2; ++h) {
+        const int p = lane + 64 * h;
+        if (p < n) {
+          const int32_t v = (int32_t)(uint32_t)mine[h];
+          a.v_o2i[v] = lo + r[h]; s_vo2i[v] = lo + r[h];
+          a.tile_of_int[lo + r[h]] = t; s_tile[lo + r[h]] = t;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int v = tid; v < V; v += NT) a.v_i2o[s_vo2i[v]] = v;  // (the inverse, once every vertex has its place)
+  for (int i = tid; i <= V; i += NT) s_a[i] = 0;
+  __syncthreads();
+  MINI_STAMP(12);
+  // ---- triangle CSR (k_tri_count / fill / rows) ----
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) {
+    const int32_t t = tid + i * NT;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int32_t vo = tv[i][c];
+      tr[i][c] = -1;
+      if (t >= a.T) continue;
+      if (vo < 0 || vo >= V) { atomicOr(&a.flags[0], 2); a.tris_int[3 * t + c] = 0; continue; }
+      const int32_t v = s_vo2i[vo];
+      tv[i][c] = v;  // (internal id from here on)
+      a.tris_int[3 * t + c] = v;
+      tr[i][c] = atomicAdd(&s_a[v], 1);
+    }
+  }
+  __syncthreads();
+  mini_scan(s_a, V + 1, s_sc);
+  for (int i = tid; i <= V; i += NT) a.trow[i] = s_a[i];
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (tr[i][c] >= 0) s_buf[s_a[tv[i][c]] + tr[i][c]] = (uint32_t)(tid + i * NT);
+  }
+  __syncthreads();
+  for (int v = tid; v < V; v += NT) (void)mini_sort_row(s_buf + s_a[v], s_a[v + 1] - s_a[v]);
+  __syncthreads();
+  for (int i = tid; i < s_a[V]; i += NT) a.tinc[i] = s_buf[i];
+  __syncthreads();
+  MINI_STAMP(13);
+  // ---- edge order (k_edge_count / fill / rows / gather) ----
+  for (int i = tid; i <= 2 * V; i += NT) s_a[i] = 0;
+  for (int i = tid; i <= V; i += NT) s_b[i] = 0;  // degrees of the incidence CSR
+  __syncthreads();
+  constexpr int kEdg = kMiniE / kMiniThreads;  // 6 edges per thread, in registers from the count to the CSR fill
+  int2 eij_o[kEdg];
+  int32_t eb[kEdg], er[kEdg];
+#pragma unroll
+  for (int i = 0; i < kEdg; ++i) {
+    const int32_t e = tid + i * NT;
+    eij_o[i] = e < E ? a.edges[e] : make_int2(0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < kEdg; ++i) {  // (derived edges: both ends valid and distinct)
+    if (tid + i * NT >= E) continue;
+    const int32_t si = s_vo2i[eij_o[i].x], sj = s_vo2i[eij_o[i].y];
+    const int32_t ti = s_tile[si], tj = s_tile[sj];
+    const int32_t lo = s_tl[ti], n = s_tl[ti + 1] - lo;
+    eb[i] = 2 * lo + (ti == tj ? 0 : n) + (si - lo);  // = edge_bucket()
+    er[i] = atomicAdd(&s_a[eb[i]], 1);
+    eij_o[i] = make_int2(si, sj);                      // (internal ids from here on)
+  }
+  __syncthreads();
+  mini_scan(s_a, 2 * V + 1, s_sc);
+#pragma unroll
+  for (int i = 0; i < kEdg; ++i)
+    if (tid + i * NT < E) s_buf[s_a[eb[i]] + er[i]] = (uint32_t)(tid + i * NT);
+  __syncthreads();
+  for (int b = tid; b < 2 * V; b += NT) {
+    const int d = s_a[b + 1] - s_a[b];
+    if (d > 1) (void)mini_sort_row(s_buf + s_a[b], d);
+  }
+  for (int t = tid; t <= ntiles; t += NT) a.estart[t] = t < ntiles ? s_a[2 * max(0, min(s_tl[t], V))] : E;
+  __syncthreads();
+  int2* rank2 = reinterpret_cast<int2*>(a.rank);  // (2E ints; the edge ranks are spent)
+  {
+    int32_t ge[kEdg];
+    int2 gij[kEdg];
+    float gal[kEdg];
+#pragma unroll
+    for (int i = 0; i < kEdg; ++i) ge[i] = tid + i * NT < E ? (int32_t)s_buf[tid + i * NT] : 0;
+#pragma unroll
+    for (int i = 0; i < kEdg; ++i) { gij[i] = a.edges[ge[i]]; gal[i] = a.alpha[ge[i]]; }  // (E >= 1: index 0 is valid)
+#pragma unroll
+    for (int i = 0; i < kEdg; ++i) {
+      const int32_t kk = tid + i * NT;
+      if (kk >= E) continue;
+      const int32_t e = ge[i];
+      a.e_i2o[kk] = e;
+      a.e_o2i[e] = kk; s_eo2i[e] = kk;
+      const int32_t si = s_vo2i[gij[i].x], sj = s_vo2i[gij[i].y];
+      const float2 pi = s_pos[gij[i].x], pj = s_pos[gij[i].y];
+      a.eij[kk] = make_int2(si, sj);
+      a.ew[kk] = make_float4(gal[i], gal[i], a.dsign * (pi.x - pj.x), a.dsign * (pi.y - pj.y));
+      int2 r;
+      r.x = atomicAdd(&s_b[si], 1);
+      r.y = atomicAdd(&s_b[sj], 1);
+      rank2[e] = r;
+    }
+  }
+  __syncthreads();
+  MINI_STAMP(14);
+  // ---- incidence CSR (k_csr_fill / rows) ----
+  mini_scan(s_b, V + 1, s_sc);
+  for (int i = tid; i <= V; i += NT) a.grow[i] = s_b[i];
+  {
+    int2 fr[kEdg];
+#pragma unroll
+    for (int i = 0; i < kEdg; ++i) fr[i] = tid + i * NT < E ? rank2[tid + i * NT] : make_int2(0, 0);
+#pragma unroll
+    for (int i = 0; i < kEdg; ++i) {
+      const int32_t e = tid + i * NT;
+      if (e >= E) continue;
+      s_buf[s_b[eij_o[i].x] + fr[i].x] = (uint32_t)e << 1;
+      s_buf[s_b[eij_o[i].y] + fr[i].y] = ((uint32_t)e << 1) | 1u;
+    }
+  }
+  __syncthreads();
+  for (int v = tid; v < V; v += NT) {
+    uint32_t* row = s_buf + s_b[v];
+    const int d = s_b[v + 1] - s_b[v];
+    (void)mini_sort_row(row, d);
+    for (int i = 0; i < d; ++i) {
+      const uint32_t x = row[i];
+      row[i] = (uint32_t)s_eo2i[x >> 1] | ((x & 1u) << 31);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * E; i += NT) a.ginc[i] = s_buf[i];
+  MINI_STAMP(15);
+}
+
 template <class T>
 hipError_t dalloc(T** p, size_t n) {
   if (*p) (void)hipFree(*p);
@@ -2073,6 +2480,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mini_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMiniLds));
     attr_set_ = true;
   }
   // segment tables
@@ -2090,10 +2498,15 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // flags; the vertex order outputs (every entry is an index for the later stages, whatever the
   // partition); the triangle stage's counts and cursors
   const bool reuse = reuse_next_;  // the caller asked for the previous frame's partition (map_usable())
+  // small frame of a graph sync: stages A-E (and the edge derivation + data terms in front of them)
+  // in one launch of one workgroup (k_mini_plan)
+  const bool mini = mini_set_ && reuse && mini_eligible(V, T, E) && ntiles <= kSegCap && expect_E_ == E;
+  mini_used_ = mini_used_ || mini;  // (sticky until the next offer: a retry after a rejected partition keeps
+  mini_set_ = false;                //  what the mini launch derived -- edges and data terms come first in it)
   // (the reuse path's tile counters and stage C's bucket counts ride along: their scratch is free from
   // the start there, while the bisection stages still use it)
   int32_t* ecnt0 = reinterpret_cast<int32_t*>(keys_b_);
-  zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, reuse ? reuse_cnt_ : nullptr, (int64_t)kCntStride * ntiles,
+  if (!mini) zero4(s, flags_, 8, A->v_o2i, V, tile_of_int_, V, reuse ? reuse_cnt_ : nullptr, (int64_t)kCntStride * ntiles,
         (reuse && E > 0) ? ecnt0 : nullptr, 2 * (int64_t)V + 1);
   reuse_next_ = false;
   last_reused_ = false;
@@ -2102,7 +2515,37 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
 
   // ---- stage A ----
   int cur = 0;
-  if (reuse) {
+  if (mini) {
+    MiniArgs a;
+    a.V = V; a.T = T; a.E_expect = E; a.ntiles = ntiles;
+    a.cap = (int32_t)std::min<int64_t>(kOrderCap, ((int64_t)V * 3) / ntiles + 16);
+    a.tris = in.tris; a.pos = in.pos; a.mu = mini_.mu; a.var = mini_.var; a.pred = mini_.pred;
+    a.scale = mini_.scale; a.adaptive = mini_.adaptive; a.init_pred = mini_.init_pred;
+    a.dsign = opt.d_sign < 0 ? -1.0f : 1.0f;
+    a.edges = mini_.edges; a.alpha = mini_.alpha; a.z = mini_.z; a.wgt = mini_.wgt; a.x0 = mini_.x0;
+    a.dflags = mini_.dflags;
+    a.rank = rank_;
+    a.vt = w_int_;
+    a.gbbox = gbbox_; a.pyr = cell_pyr_; a.tab = tab[0]; a.nseg = nseg; a.flags = flags_;
+    a.seg_pos = seg_pos_;
+    a.v_i2o = A->v_i2o; a.v_o2i = A->v_o2i; a.tile_of_int = tile_of_int_;
+    a.tris_int = A->tris; a.trow = A->trow; a.tinc = reinterpret_cast<uint32_t*>(A->tinc);
+    a.e_i2o = A->e_i2o; a.e_o2i = A->e_o2i; a.eij = A->eij; a.ew = A->ew; a.estart = estart_;
+    a.grow = A->grow; a.ginc = reinterpret_cast<uint32_t*>(A->ginc);
+    static const bool mini_prof = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '4';
+    a.prof = mini_prof ? reinterpret_cast<long long*>(wscan_) : nullptr;  // (free in this path)
+    hipLaunchKernelGGL(k_mini_plan, dim3(1), dim3(kMiniThreads), kMiniLds, s, a);
+    if (mini_prof) {
+      long long h[20] = {0};
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h, wscan_, sizeof(h), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[mini] ticks per phase:");
+      int last = 1;
+      for (int q = 2; q < 20 && h[q]; ++q) { std::fprintf(stderr, " %lld", h[q] - h[q - 1]); last = q; }
+      std::fprintf(stderr, "  total %lld\n", h[last] - h[1]);
+    }
+    last_reused_ = true;
+  } else if (reuse) {
     // partition from the previous frame's tile map: lookup + counts, ranges, counting scatter
     int32_t* tile_cnt = reuse_cnt_;          // one counter per cache line
     int32_t* vt = w_int_;                    // (no weights in this path)
@@ -2212,14 +2655,15 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   lap("A rcb");
 
   // ---- stage B ----
-  hipLaunchKernelGGL(k_tile_order, dim3((unsigned)ntiles), dim3(256), 0, s, V, ntiles, leaf.lo, leaf.hi, in.pos, gbbox_, perm,
-                     A->v_o2i, tile_of_int_, flags_);
+  if (!mini)
+    hipLaunchKernelGGL(k_tile_order, dim3((unsigned)ntiles), dim3(256), 0, s, V, ntiles, leaf.lo, leaf.hi, in.pos, gbbox_, perm,
+                       A->v_o2i, tile_of_int_, flags_);
 
   lap("B morton");
   if (after_partition) HIPRET(after_partition());  // the caller's edge / data arrays arrive now
   // ---- stage E: vertex -> triangle CSR; needs only the vertex order, so it runs beside the edge
   // stages (C, D, tile pass 1) on a second stream and joins before the flags are read ----
-  const bool tri_stage = T > 0 && in.tris;
+  const bool tri_stage = T > 0 && in.tris && !mini;
   if (tri_stage) {
     HIPRET(hipEventRecord(ev_fork_, s));
     HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
@@ -2234,7 +2678,9 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     HIPRET(hipEventRecord(ev_join_, s2_));
   }
   // ---- stage C ----
-  if (E > 0) {
+  if (mini) {
+    // (stages C and D are part of k_mini_plan)
+  } else if (E > 0) {
     int32_t* ecnt = reinterpret_cast<int32_t*>(keys_b_);     // 2V + 1 bucket counts
     int32_t* eoff = reinterpret_cast<int32_t*>(vals_b_);     // (the lists of stage A are dead)
     uint32_t* esorted = reinterpret_cast<uint32_t*>(keys_a_);
@@ -2256,7 +2702,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   }
   lap("C edges");
   // ---- stage D ----
-  if (E > 0) {
+  if (mini) {
+  } else if (E > 0) {
     int2* rank2 = reinterpret_cast<int2*>(rank_);  // (degree counts and ranks: k_edge_rows_gather)
     HIPRET(scan_i32(s, 0, counts_, A->grow, (int64_t)V + 1, false, cub_tmp_, cub_bytes_));
     hipLaunchKernelGGL(k_csr_fill, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, A->grow, rank2,

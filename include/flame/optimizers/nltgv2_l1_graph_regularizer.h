@@ -89,12 +89,12 @@ class Graph {
     const int rc = flame_hip_graph_create(&g_, device, 0, 0, 0);
     if (rc) { g_ = nullptr; return rc; }
     // A Graph is re-built every frame, so the plan is paid by ONE solve.  Measured per frame (graph
-    // sync + 200 iterations + results, tools/exp/small_frame_sweep.py): up to ~1 000 vertices ONE
-    // isolated tile wins (trivial host plan: 0.45 ms at 770, 0.51 ms at 910 vertices against 0.57 on
-    // halo tiles); above, a few dozen halo tiles planned on the GPU do (1 200 vertices: 0.57 vs
-    // 0.66 ms), and with halo depth 5 rather than the 8 a resident graph of <= 64 tiles gets
-    // (1.2-2 k vertices: 0.56-0.62 vs 0.60-0.70 ms).
-    (void)flame_hip_set_option(g_, "tile_single_max", 1024);
+    // sync + 200 iterations + results, tools/exp/small_frame_sweep.py): up to ~900 vertices ONE
+    // isolated tile wins (trivial host plan: 0.44 ms at 770 vertices against 0.49 on halo tiles, a tie
+    // at 910); above, a few dozen halo tiles planned on the GPU do (1 200 vertices: 0.51 vs 0.64 ms),
+    // and with halo depth 5 rather than the 8 a resident graph of <= 64 tiles gets (1.2-2 k vertices:
+    // 0.51-0.58 vs 0.56-0.66 ms).
+    (void)flame_hip_set_option(g_, "tile_single_max", 896);
     (void)flame_hip_set_option(g_, "stream_depth", 5);
     device_ = device;
     return 0;

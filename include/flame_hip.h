@@ -84,6 +84,10 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * "plan_reuse" (1 = default: on a frame stream the device builder takes the PARTITION of a frame from
  * the previous frame's tile map while the frames hold about as many vertices, instead of sorting and
  * bisecting again; results do not depend on the partition; flame_hip_get_info "plan_reused"),
+ * "plan_mini" (1 = default: a graph sync of a small frame -- up to 2048 vertices / 4096 triangles, a
+ * reused partition, a predicted edge count -- derives the edges and builds everything in front of the
+ * tile pass in ONE launch of one workgroup instead of two dozen dependent ones; flame_hip_get_info
+ * "plan_mini" tells whether the current plan was made that way),
  * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
  * 512, up to 2048; a graph whose tile does not fit after all is partitioned, and the handle stops
  * trying at that size: flame_hip_get_info "single_cap"), "stream_depth" (0 = off, default; > 0: halo

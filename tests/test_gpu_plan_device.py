@@ -280,6 +280,51 @@ def test_isolated_tile_that_does_not_fit_goes_to_the_device_builder(gpu):
     dev.close()
 
 
+def test_small_frames_planned_by_one_launch(gpu):
+    """Graph sync of small frames on a stream (the facade's options): from the second frame on the edges,
+    the data terms and everything in front of the tile pass come from ONE launch (plan_mini).  The plan is
+    the one the two dozen separate launches build -- array for array, on a second handle fed the same
+    stream with plan_mini = 0 -- and the solve is the oracle's bits.  A frame that the previous partition
+    does not suit (all features in one corner) falls back by itself."""
+    from flame_ros_amd.regularizer import default_sync_params
+    from oracle import COracle
+    sp, p = default_sync_params(), default_params()
+    names = ("v_o2i", "v_i2o", "e_o2i", "e_i2o", "grow", "ginc", "tris", "trow", "tinc", "t_vmap", "t_emap", "t_srow")
+    a = GraphRegularizer.empty(device=0, tile_single_max=1, stream_depth=5)
+    b = GraphRegularizer.empty(device=0, tile_single_max=1, stream_depth=5, plan_mini=0)
+    rng = np.random.default_rng(11)
+    used = []
+    for k in range(9):
+        g = graphgen.named("tum" if k < 6 else "v2000", seed=20 + k)[0]
+        if k == 4:  # scene change: every feature inside the top-left eighth of the image
+            pos = (rng.random((1200, 2)) * np.array([80.0, 60.0])).astype(np.float32)
+            g = graphgen.from_points(pos, 640, 480, np.random.Generator(np.random.PCG64(5)))
+        var = np.full(g.V, 1e-4, np.float32)
+        pred = (g.z * 1.01).astype(np.float32) if k & 1 else None
+        for r in (a, b):
+            r.sync_features(g.pos, g.z, var, g.tris, sp, prediction=pred)
+        used.append((a.info("plan_mini"), a.info("plan_reused")))
+        assert b.info("plan_mini") == 0 and a.info("plan_on_device") == 1 and b.info("plan_on_device") == 1
+        assert a.info("plan_reused") == b.info("plan_reused"), k
+        for nm in names:
+            assert np.array_equal(a.plan_array(nm, np.int32), b.plan_array(nm, np.int32)), (k, nm)
+        for nm in ("eij", "ew", "t_eij", "t_ew"):
+            assert np.array_equal(a.plan_array(nm, np.uint32), b.plan_array(nm, np.uint32)), (k, nm)
+        e = a.edges()
+        assert np.array_equal(e, g.edges), k
+        o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, x0=pred)
+        o.solve(oracle_params(), 25)
+        a.step(p, 25)
+        x, w1, w2, q = a.download()
+        assert_bit_equal(x, o.x, "frame %d x" % k)
+        assert_bit_equal(q, o.q, "frame %d q" % k)
+    # (plan_mini, plan_reused): first frame; three from the one launch; the corner frame -- edges and data
+    # terms from the one launch, its partition rejected and bisected; one frame of back-off; a new size;
+    # and the one launch again
+    assert used == [(0, 0), (1, 1), (1, 1), (1, 1), (1, 0), (0, 0), (0, 0), (1, 1), (1, 1)], used
+    a.close(); b.close()
+
+
 def test_stream_depth_option(gpu):
     """stream_depth replaces the automatic depth 8 of small graphs (<= 2048 vertices) and nothing else."""
     p = default_params()
