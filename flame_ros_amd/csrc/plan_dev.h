@@ -105,6 +105,8 @@ class DevPlanner {
   // reuse after all), nothing was derived and the caller goes the usual way.
   struct MiniSync {
     const float* mu; const float* var; const float* pred; float scale; int adaptive, init_pred;
+    const int32_t* tris; const float2* pos;  // where the launch reads triangles / positions (null: the build's inputs;
+                                             // the positions are copied to the build's input array either way)
     float* z; float* wgt; float* x0; int2* edges; float* alpha; int32_t* dflags;
   };
   static bool mini_eligible(int32_t V, int32_t T, int32_t E) { return V >= 2 && V <= 2048 && T >= 1 && T <= 4096 && E >= 1 && E <= 6144; }

@@ -1883,6 +1883,8 @@ struct MiniArgs {
   int32_t V, T, E_expect, ntiles, cap;
   // inputs (device copies of the caller's arrays)
   const int32_t* tris; const float2* pos; const float* mu; const float* var; const float* pred;
+  float2* pos_out;               // the builder's own input arrays (the launch's inputs may sit in a staging arena;
+  int32_t* tris_out;             //  a retry that bisects reads these)
   float scale; int32_t adaptive, init_pred; float dsign;
   // graph sync outputs
   int2* edges; float* alpha; float* z; float* wgt; float* x0;
@@ -1980,7 +1982,11 @@ __global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
   float2* s_pos = reinterpret_cast<float2*>(s_eo2i + kMiniE);          // V
   const int tid = threadIdx.x, NT = kMiniThreads;
   const int32_t V = a.V, ntiles = a.ntiles;
-  for (int v = tid; v < V; v += NT) s_pos[v] = a.pos[v];
+  for (int v = tid; v < V; v += NT) {
+    const float2 q = a.pos[v];
+    s_pos[v] = q;
+    if (a.pos_out != a.pos) a.pos_out[v] = q;
+  }
   MINI_STAMP(1);
   // ---- flags of the build, counters ----
   if (tid < 8) a.flags[tid] = 0;
@@ -1998,7 +2004,10 @@ __global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
   for (int i = 0; i < kTri; ++i) {
     const int32_t t = tid + i * NT;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) tv[i][c] = t < a.T ? a.tris[3 * t + c] : -1;
+    for (int c = 0; c < 3; ++c) {
+      tv[i][c] = t < a.T ? a.tris[3 * t + c] : -1;
+      if (t < a.T && a.tris_out != a.tris) a.tris_out[3 * t + c] = tv[i][c];
+    }
   }
   if (a.prof) { __syncthreads(); asm volatile("" :: "v"(tv[0][0])); MINI_STAMP(3); }
 #pragma unroll
@@ -2519,7 +2528,9 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     MiniArgs a;
     a.V = V; a.T = T; a.E_expect = E; a.ntiles = ntiles;
     a.cap = (int32_t)std::min<int64_t>(kOrderCap, ((int64_t)V * 3) / ntiles + 16);
-    a.tris = in.tris; a.pos = in.pos; a.mu = mini_.mu; a.var = mini_.var; a.pred = mini_.pred;
+    a.tris = mini_.tris ? mini_.tris : in.tris; a.pos = mini_.pos ? mini_.pos : in.pos; a.pos_out = const_cast<float2*>(in.pos);
+    a.tris_out = const_cast<int32_t*>(in.tris);
+    a.mu = mini_.mu; a.var = mini_.var; a.pred = mini_.pred;
     a.scale = mini_.scale; a.adaptive = mini_.adaptive; a.init_pred = mini_.init_pred;
     a.dsign = opt.d_sign < 0 ? -1.0f : 1.0f;
     a.edges = mini_.edges; a.alpha = mini_.alpha; a.z = mini_.z; a.wgt = mini_.wgt; a.x0 = mini_.x0;
