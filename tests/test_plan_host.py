@@ -279,6 +279,36 @@ def test_global_path_and_fallbacks():
     assert r.info("V") == 0
 
 
+def test_isolated_tile_sizing_prices_the_slot_rows():
+    """One isolated tile holds 16 B per vertex + 16 B per incidence SLOT; the slot rows of a 64-vertex group
+    share the group's largest degree (odd) as pitch.  The sizing rule prices that from (V, E): a 1 344-
+    vertex feature grid is not offered as one tile any more (it used to be, failed in the builder and was
+    rebuilt as a halo plan on the host: 4.6 ms per frame), 1 200 vertices still are one tile on request;
+    a degree-4 lattice passes the rule and fails in the builder (one pad slot in five): the plan-only
+    builder falls back to halo tiles by itself, with a valid plan."""
+    g = graphgen.named("g15")[0]  # 1 344 vertices
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, tile_single_max=2048)
+    assert r.info("num_tiles") > 1
+    g = graphgen.named("tum")[0]  # 1 200 vertices
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, tile_single_max=2048)
+    assert r.info("num_tiles") == 1 and r.info("tile_depth") == 0
+    # 30 x 58 lattice, horizontal + vertical edges
+    nx, ny = 30, 58
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    pos = np.stack([ix.ravel() * 10.0 + 5.0, iy.ravel() * 8.0 + 4.0], 1).astype(np.float32)
+    vid = iy * nx + ix
+    edges = np.concatenate([np.stack([vid[:, :-1].ravel(), vid[:, 1:].ravel()], 1),
+                            np.stack([vid[:-1, :].ravel(), vid[1:, :].ravel()], 1)]).astype(np.int32)
+    V, E = len(pos), len(edges)
+    assert V * 16 + E * 38 + 1024 <= 160 * 1024  # the rule says "fits"
+    alpha = np.ones(E, np.float32)
+    r = GraphRegularizer(pos, edges, alpha, alpha, np.ones(V, np.float32), np.ones(V, np.float32), device=-1,
+                         tile_single_max=2048)
+    assert r.info("path") == lib.PATH_TILE and r.info("num_tiles") > 1
+    v_o2i = r.plan_array("v_o2i", np.int32)
+    assert np.array_equal(np.sort(v_o2i), np.arange(V))
+
+
 def test_batch_plan():
     gs = [graphgen.dataset_shaped(640, 480, 16, seed=s) for s in range(3)] + [graphgen.synthetic(200, seed=1)]
     r = GraphRegularizer.from_batch(gs, device=-1)
