@@ -16,6 +16,11 @@
 //                    of the vertices, rings sorted by internal id, local edge count
 //   G  tiles, pass 2 local edge keys (level, owned, source, edge id) sorted in LDS, gather lists,
 //                    incidence slots (odd pitch per 64-vertex group), local edge records
+// Frame streams take shortcuts through these stages that leave the same kind of plan behind: the
+// partition of a frame from the previous frame's tile map (k_reuse_*, "Partition REUSE"), the counting
+// passes' atomics doubling as ranks, fused launches (k_he_unique, k_edge_rows_gather, k_tile_fused,
+// k_publish) and, for frames of up to 2 k vertices, everything in front of the tile pass in one
+// launch of one workgroup (k_mini_plan).
 // Library code: hipcub's device sort (the two entry sorts), device scan, block radix sort.  rocprim
 // sorts fewer than ~1 M keys by block sort + log2 merge passes (7 launches for 50 k keys, 19 for
 // 300 k), which is why every sort that could be a counting pass is one.
@@ -942,8 +947,8 @@ __global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __re
 
 
 // Stage C's last two launches and stage D's first in one: a block sorts its 256 buckets in LDS
-// (k_csr_rows), then gathers the edge records of exactly those entries (k_edge_gather) and counts the
-// degrees of their endpoints for the incidence CSR (k_csr_count; the count is the rank again).
+// (as k_csr_rows does), then writes the edge records of exactly those entries and counts the degrees of
+// their endpoints for the incidence CSR (the count is the rank again).
 __global__ __launch_bounds__(256) void k_edge_rows_gather(int32_t nrows, const int32_t* __restrict__ off, uint32_t* sorted_e,
                                                           const int2* __restrict__ edges,
                                                           const float* __restrict__ alpha,

@@ -1,5 +1,5 @@
 # dev helper (gpurun): facade frame latency with / without one frame-path feature (env toggle), alternating in one call
-# usage: ab_env.sh FLAME_HIP_NO_ARENA   (any env toggle of the library)
+# usage: ab_env.sh FLAME_HIP_SCAN_CUB   (any env toggle of the library)
 show() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
