@@ -42,6 +42,7 @@
 #include "params.h"
 #include "types.h"
 #include "utils/assert.h"
+#include "utils/delaunay.h"
 #include "utils/image_utils.h"
 #include "utils/stats_tracker.h"
 #include "utils/visualization.h"
@@ -69,7 +70,8 @@ struct FeatureSet {
 struct FrontEnd {
   // detection + tracking + epipolar idepth filtering: all features tracked in this frame
   std::function<bool(const FrameInput&, FeatureSet*)> track;
-  // Delaunay triangulation of the features that passed the variance gate
+  // Delaunay triangulation of the features that passed the variance gate (optional: without it the
+  // built-in exact divide-and-conquer triangulator of flame/utils/delaunay.h is used)
   std::function<bool(const std::vector<Point2f>&, std::vector<Triangle>*)> triangulate;
   // pose-frame bookkeeping (optional)
   std::function<void(const std::vector<uint32_t>&, const std::vector<SE3f>&)> updatePoseFramePoses;
@@ -238,7 +240,7 @@ class Flame {
     stats_.tock("update_locking");
     stats_.tick("update");
     bool ok = false;
-    if (!frontend_.track || !frontend_.triangulate) {
+    if (!frontend_.track) {
       stats_.set("hip_error", FLAME_HIP_ERR_STATE);  // no feature pipeline registered
     } else {
       FeatureSet fs;
@@ -265,7 +267,7 @@ class Flame {
         std::vector<Triangle> tris;
         if (ok) {
           stats_.tick("triangulate");
-          ok = frontend_.triangulate(g.vtx, &tris);
+          ok = frontend_.triangulate ? frontend_.triangulate(g.vtx, &tris) : delaunay_.triangulate(g.vtx, &tris);
           stats_.tock("triangulate");
         }
         if (ok)
@@ -477,6 +479,7 @@ class Flame {
   mutable std::mutex mtx_;
   utils::StatsTracker stats_;
   FrontEnd frontend_;
+  utils::DelaunayTriangulator delaunay_;  // FrontEnd::triangulate's default (scratch kept across frames)
   optimizers::nltgv2_l1_graph_regularizer::Graph graph_;
   bool device_frame_valid_ = false;  // the device state belongs to the committed frame
   std::vector<Point2f> vtx_, raw_vtx_;

@@ -8,7 +8,8 @@
 // through flame::FrontEnd.  The stand-in used here is deliberately simple and says so: one feature
 // per detection_win_size cell (cfg/flame_offline_tum.yaml:78) where the dataset's DEPTH image is
 // valid, idepth = 1 / depth at that pixel (what analysis/pass_in_truth feeds, src/flame_offline_tum.cc:
-// 577-595), grid triangulation of the kept features.  Everything behind the FrontEnd is the product path.
+// 577-595).  The kept features are triangulated by the facade's built-in Delaunay triangulator
+// (flame/utils/delaunay.h); everything behind the FrontEnd is the product path.
 //
 //   flame_offline_lite <index.txt> <frame RDF|FLU|...> fx fy cx cy [iters] -> one line per frame:
 //   frame <id> time <t> ok <0|1> feats <n> vtx <n> tris <n> edges <n> coverage <c> cost_smooth <s> cost_data <d> rms_vs_truth <r> update_ms <ms>
@@ -41,12 +42,10 @@ int main(int argc, char** argv) {
   std::shared_ptr<flame::Flame> sensor;
   std::vector<float> depth;  // the current frame's depth image in metres (shared with the front end)
   int W = 0, H = 0, cols = 0, rows = 0;
-  std::vector<int> cell_of_feature;
 
   flame::FrontEnd fe;
   fe.track = [&](const flame::FrameInput&, flame::FeatureSet* fs) {
     cols = W / win; rows = H / win;
-    cell_of_feature.clear();
     for (int r = 0; r < rows; ++r)
       for (int c = 0; c < cols; ++c) {
         const int u = c * win + win / 2, v = r * win + win / 2;
@@ -55,24 +54,10 @@ int main(int argc, char** argv) {
         fs->vtx.push_back(flame::Point2f(static_cast<float>(u), static_cast<float>(v)));
         fs->idepth_mu.push_back(1.0f / d);
         fs->idepth_var.push_back(1e-4f);
-        cell_of_feature.push_back(r * cols + c);
       }
     return !fs->vtx.empty();
   };
-  fe.triangulate = [&](const std::vector<flame::Point2f>& vtx, std::vector<flame::Triangle>* tris) {
-    // two triangles per grid cell whose four corners all carry a feature (all features pass the
-    // variance gate here, so vtx is the track() list)
-    std::vector<int> at(static_cast<size_t>(cols) * rows, -1);
-    for (size_t f = 0; f < cell_of_feature.size() && f < vtx.size(); ++f) at[cell_of_feature[f]] = static_cast<int>(f);
-    tris->clear();
-    for (int r = 0; r + 1 < rows; ++r)
-      for (int c = 0; c + 1 < cols; ++c) {
-        const int a = at[r * cols + c], b = at[r * cols + c + 1], d = at[(r + 1) * cols + c], e = at[(r + 1) * cols + c + 1];
-        if (a >= 0 && b >= 0 && d >= 0) tris->push_back(flame::Triangle(a, b, d));
-        if (b >= 0 && e >= 0 && d >= 0) tris->push_back(flame::Triangle(b, e, d));
-      }
-    return !tris->empty();
-  };
+  // (no fe.triangulate: the facade's built-in Delaunay triangulator, flame/utils/delaunay.h)
 
   uint32_t id = 0;
   ds::TumFrame fr;
