@@ -190,6 +190,8 @@ class DevPlanner {
   int32_t* rank_ = nullptr;      // 2E + 3T places inside the counting CSRs' rows (what the counting atomics returned)
   int32_t* rank_tri_ = nullptr;  // = rank_ + 2 capE_
   int32_t* reuse_cnt_ = nullptr; // tile counters of the partition-reuse pass, one per 128-byte line
+  int32_t* gadj_ = nullptr;      // 2E: the vertex at the other end of every incidence (ring search of the tile passes)
+  int32_t* ipos_ = nullptr;      // 2E: place of (internal edge, role) in its vertex's incidence row (slots)
   int32_t* seg_tab_ = nullptr;   // segment tables + bbox + mids (see plan_dev.hip)
   int32_t* estart_ = nullptr;    // ntiles + 1
   int32_t* tile_ext_ = nullptr;  // ntiles * kCapExt (pass-1 vertex lists)

@@ -913,9 +913,15 @@ __device__ __forceinline__ void sort_row(uint32_t* a, int d) {
 }
 
 constexpr int kRowsLds = 6144;  // entries of 256 consecutive rows staged in LDS (else sorted in place)
+// CONVERT also leaves, for the tile passes: gadj[s] = the vertex at the other end of incidence s (the
+// ring search then needs two dependent loads per step, not three) and ipos[2k + role] = the place of
+// internal edge k in the row of its source (role 0) / target (role 1) (the slot of an incidence
+// without a search).
 template <bool CONVERT>
 __global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __restrict__ row,
-                                                  const int32_t* __restrict__ e_o2i, uint32_t* out) {
+                                                  const int32_t* __restrict__ e_o2i, uint32_t* out,
+                                                  const int2* __restrict__ eij = nullptr, int32_t* gadj = nullptr,
+                                                  int32_t* ipos = nullptr) {
   __shared__ uint32_t s_a[kRowsLds];
   const int32_t v0 = blockIdx.x * 256, v1 = min(v0 + 256, V);
   const int32_t r0 = row[v0], r1 = row[v1];
@@ -927,7 +933,17 @@ __global__ __launch_bounds__(256) void k_csr_rows(int32_t V, const int32_t* __re
   }
   if (v < V) {
     const int d = row[v + 1] - row[v];
-    sort_row(lds ? s_a + (row[v] - r0) : out + row[v], d);
+    uint32_t* a = lds ? s_a + (row[v] - r0) : out + row[v];
+    sort_row(a, d);
+    if (CONVERT && gadj) {
+      for (int i = 0; i < d; ++i) {
+        const uint32_t x = a[i];
+        const int32_t k = e_o2i[x >> 1];
+        const int2 ij = eij[k];
+        gadj[row[v] + i] = (x & 1u) ? ij.x : ij.y;
+        ipos[2 * k + (int32_t)(x & 1u)] = i;
+      }
+    }
   }
   if (lds) {
     __syncthreads();
@@ -1007,6 +1023,7 @@ struct TileGraph {
   int32_t V, depth;
   const int32_t* grow; const int32_t* ginc; const int2* eij;
   const int32_t* e_i2o; const int32_t* e_o2i;
+  const int32_t* gadj; const int32_t* ipos;  // k_csr_rows<true>
 };
 
 struct TileLds {
@@ -1056,9 +1073,7 @@ __device__ void tile_rings(const TileGraph& G, const TileLds& L, int32_t vstart,
       for (int it = tid; it < (prev_hi - prev_lo) * kRowLanes; it += NTB) {
         const int32_t v = L.ext[prev_lo + it / kRowLanes];
         for (int32_t s = G.grow[v] + it % kRowLanes; s < G.grow[v + 1]; s += kRowLanes) {
-          const int32_t ent = G.ginc[s];
-          const int2 ij = G.eij[ent & 0x7fffffff];
-          const int32_t u = ent < 0 ? ij.x : ij.y;
+          const int32_t u = G.gadj[s];
           const uint32_t bit = 1u << (u & 31);
           const uint32_t old = atomicOr(&L.bitmap[u >> 5], bit);
           if (!(old & bit)) {
@@ -1071,13 +1086,18 @@ __device__ void tile_rings(const TileGraph& G, const TileLds& L, int32_t vstart,
       int n = *s_n;
       if (n > kCapExt) { if (tid == 0) { *s_fail = 1; *s_n = kCapExt; } n = kCapExt; }
       const int cnt = n - prev_hi;
-      if (cnt > 1) {  // ring vertices in ascending internal id (any append order -> same list)
-        const int m = next_pow2(cnt);
+      if (cnt > 1) {  // ring vertices in ascending internal id (any append order -> same list): every vertex
+        // counts the smaller ones -- cnt broadcast reads and two barriers, where a bitonic sort of a few
+        // hundred ids is ~45 barrier-separated stages (half of this function's time, measured)
         int32_t* win = L.hkey;  // 2 * kHash ints contiguous (hkey, hval)
-        for (int i = tid; i < m; i += NTB) win[i] = i < cnt ? L.ext[prev_hi + i] : INT_MAX;
+        for (int i = tid; i < cnt; i += NTB) win[i] = L.ext[prev_hi + i];
         __syncthreads();
-        bitonic_sort<NTB, int32_t>(win, m);
-        for (int i = tid; i < cnt; i += NTB) L.ext[prev_hi + i] = win[i];
+        for (int i = tid; i < cnt; i += NTB) {
+          const int32_t v = win[i];
+          int r = 0;
+          for (int j = 0; j < cnt; ++j) r += win[j] < v ? 1 : 0;
+          L.ext[prev_hi + r] = v;
+        }
       }
       __syncthreads();
       prev_lo = prev_hi; prev_hi = n;
@@ -1299,7 +1319,9 @@ __device__ __forceinline__ void tile_collect_keys(const TileGraph& G, const Tile
 struct TileOut {
   const float4* ew; TileDesc* tiles; int32_t* t_vmap; int32_t* t_emap; uint2* t_eij; float4* t_ew; uint32_t* t_srow;
   int32_t* flags; int lane_order;
+  long long* prof;  // dev aid (FLAME_HIP_PLAN_TIMING=5): phase stamps of tile 0, or null
 };
+#define TILE_STAMP(O, n) do { if ((O).prof && blockIdx.x == 0 && threadIdx.x == 0) (O).prof[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 template <int NTB>
 __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, TileShared& S, uint64_t* ekeys, int t,
@@ -1312,6 +1334,7 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
   for (int i = e_loc + tid; i < msort; i += NTB) ekeys[i] = ~0ull;
   __syncthreads();
   bitonic_sort<NTB, uint64_t>(ekeys, msort);
+  TILE_STAMP(O, 6);
   // ---- gather lists, local records, level ends, owned prefix check ----
   if (e_own > e_loc && tid == 0) S.fail = 1;
   for (int le = tid; le < e_loc; le += NTB) {
@@ -1327,6 +1350,7 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
     O.t_eij[eoff + le] = make_uint2(li | (lj << 16), 0xffffffffu);
     O.t_ew[eoff + le] = O.ew[k];
   }
+  TILE_STAMP(O, 7);
   // ---- incidence slots: one row per updated vertex, odd pitch per 64-vertex group ----
   for (int lv = tid; lv < n_upd; lv += NTB) {
     const int32_t v = L.ext[lv];
@@ -1390,6 +1414,7 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
     }
   }
   __syncthreads();
+  TILE_STAMP(O, 8);
   // ---- lane order at build time (lane_order = 2): plan.cpp assign_lanes(), the identical greedy ----
   if (O.lane_order && !S.fail) {
     const int32_t nslots = S.gbase[kCapExt / 64];
@@ -1493,10 +1518,14 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const in
   __syncthreads();
   const int32_t vstart = vstart_tab[t], n_own = vend_tab[t] - vstart;
   const int32_t es = estart[t], e_own = estart[t + 1] - es;
+  TILE_STAMP(O, 1);
   tile_rings<kP2Threads>(G, L, vstart, n_own, &S.n, S.ring_end, &S.fail);
   const int n_ext = S.n;
+  TILE_STAMP(O, 2);
   tile_hash_build<kP2Threads>(L, n_ext);
+  TILE_STAMP(O, 3);
   tile_collect_keys<kP2Threads>(G, L, S, ekeys, n_ext);
+  TILE_STAMP(O, 4);
   const int e_cnt = S.ecnt;
   const int n_upd = G.depth == 0 ? n_ext : S.ring_end[G.depth - 1];
   const bool bad = S.fail || e_cnt > kCapEdge;
@@ -1504,6 +1533,7 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const in
   const int e_loc = min(e_cnt, kSortPad);
   const unsigned long long mine = (unsigned long long)n_ext | ((unsigned long long)e_loc << 22) | ((unsigned long long)n_upd << 44);
   const unsigned long long before = scan_lookback<unsigned long long>(mine, st, sh_lb);
+  TILE_STAMP(O, 5);
   const int32_t voff = (int32_t)(before & 0x3fffffu), eoff = (int32_t)((before >> 22) & 0x3fffffu),
                 soff = (int32_t)(before >> 44);
   int32_t* m = meta + (size_t)t * kMetaWords;
@@ -1904,7 +1934,7 @@ struct MiniArgs {
   int32_t* v_i2o; int32_t* v_o2i; int32_t* tile_of_int;
   int32_t* tris_int; int32_t* trow; uint32_t* tinc;
   int32_t* e_i2o; int32_t* e_o2i; int2* eij; float4* ew; int32_t* estart;
-  int32_t* grow; uint32_t* ginc;
+  int32_t* grow; uint32_t* ginc; int32_t* gadj; int32_t* ipos;
   long long* prof;               // dev aid (FLAME_HIP_PLAN_TIMING=4): 20 phase stamps, or null
 };
 
@@ -2272,7 +2302,11 @@ __global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
     (void)mini_sort_row(row, d);
     for (int i = 0; i < d; ++i) {
       const uint32_t x = row[i];
-      row[i] = (uint32_t)s_eo2i[x >> 1] | ((x & 1u) << 31);
+      const int32_t kk = s_eo2i[x >> 1];
+      const int2 oe = a.edges[x >> 1];
+      row[i] = (uint32_t)kk | ((x & 1u) << 31);
+      a.gadj[s_b[v] + i] = s_vo2i[(x & 1u) ? oe.x : oe.y];  // (what k_csr_rows<true> leaves for the tile passes)
+      a.ipos[2 * kk + (int32_t)(x & 1u)] = i;
     }
   }
   __syncthreads();
@@ -2302,12 +2336,12 @@ void DevPlanner::release() {
   void* ptrs[] = {cub_tmp_, keys_a_, keys_b_, vals_a_, vals_b_, seg_pos_, tile_of_int_, w_int_, wsort_, wscan_,
                   counts_, seg_tab_, estart_, tile_ext_, tile_meta_, flags_, grid_sum_, grid_cnt_, grid_w_,
                   grid_bounds_, gbbox_, tcub_tmp_, tcnt_, scan_agg_[0], scan_agg_[1], scan_flag_[0], scan_flag_[1],
-                  cell_pyr_, rank_, reuse_cnt_};
+                  cell_pyr_, rank_, reuse_cnt_, gadj_, ipos_};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   scan_agg_[0] = scan_agg_[1] = nullptr; scan_flag_[0] = scan_flag_[1] = nullptr;
   cell_pyr_ = nullptr; map_tiles_ = 0; map_V_ = 0;
-  rank_ = rank_tri_ = nullptr; reuse_cnt_ = nullptr;
+  rank_ = rank_tri_ = nullptr; reuse_cnt_ = nullptr; gadj_ = ipos_ = nullptr;
   if (hpin_) (void)hipHostFree(hpin_);
   hpin_ = nullptr; hpin_bytes_ = 0;
   if (s2_) (void)hipStreamDestroy(s2_);
@@ -2393,6 +2427,8 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     // places inside the counting CSRs' rows: [0, 2e) the edge stages (C: one per edge, D: one per edge
     // end), [2e, 2e + 3t) the triangle stages (half edges, then stage E on the second stream)
     HIPRET(dalloc(&rank_, (size_t)(2 * e + 3 * t) + 2));
+    HIPRET(dalloc(&gadj_, (size_t)(2 * e) + 2));
+    HIPRET(dalloc(&ipos_, (size_t)(2 * e) + 2));
     rank_tri_ = rank_ + 2 * e;
     capV_ = v; capE_ = e; capT_ = t;
     // temp storage of the library sorts / scans at the largest sizes
@@ -2547,7 +2583,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     a.v_i2o = A->v_i2o; a.v_o2i = A->v_o2i; a.tile_of_int = tile_of_int_;
     a.tris_int = A->tris; a.trow = A->trow; a.tinc = reinterpret_cast<uint32_t*>(A->tinc);
     a.e_i2o = A->e_i2o; a.e_o2i = A->e_o2i; a.eij = A->eij; a.ew = A->ew; a.estart = estart_;
-    a.grow = A->grow; a.ginc = reinterpret_cast<uint32_t*>(A->ginc);
+    a.grow = A->grow; a.ginc = reinterpret_cast<uint32_t*>(A->ginc); a.gadj = gadj_; a.ipos = ipos_;
     static const bool mini_prof = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '4';
     a.prof = mini_prof ? reinterpret_cast<long long*>(wscan_) : nullptr;  // (free in this path)
     hipLaunchKernelGGL(k_mini_plan, dim3(1), dim3(kMiniThreads), kMiniLds, s, a);
@@ -2725,7 +2761,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_csr_fill, grid1(E), dim3(256), 0, s, E, A->eij, A->e_o2i, A->grow, rank2,
                        reinterpret_cast<uint32_t*>(A->ginc));
     hipLaunchKernelGGL(k_csr_rows<true>, grid1(V), dim3(256), 0, s, V, A->grow, A->e_o2i,
-                       reinterpret_cast<uint32_t*>(A->ginc));
+                       reinterpret_cast<uint32_t*>(A->ginc), A->eij, gadj_, ipos_);
   } else {
     HIPRET(hipMemsetAsync(A->grow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
   }
@@ -2733,6 +2769,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   // ---- stage F ----
   TileGraph G;
   G.V = V; G.depth = depth; G.grow = A->grow; G.ginc = A->ginc; G.eij = A->eij; G.e_i2o = A->e_i2o; G.e_o2i = A->e_o2i;
+  G.gadj = gadj_; G.ipos = ipos_;
   // The tile arrays are sized from the totals pass 1 counts.  A frame stream does not wait for them:
   // the arrays are allocated for 9/8 of the PREVIOUS build's totals, pass 2 is launched right behind
   // pass 1 and the one synchronisation at the end tells whether the guess held (flags bit 128: the
@@ -2750,6 +2787,8 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     TileOut O;
     O.ew = A->ew; O.tiles = A->tiles; O.t_vmap = A->t_vmap; O.t_emap = A->t_emap; O.t_eij = A->t_eij; O.t_ew = A->t_ew;
     O.t_srow = A->t_srow; O.flags = flags_; O.lane_order = opt.lane_order == 2 ? 1 : 0;
+    static const bool tile_prof = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '5';
+    O.prof = tile_prof ? reinterpret_cast<long long*>(wscan_) : nullptr;  // (free by now)
     return O;
   };
   auto launch_pass2 = [&]() -> hipError_t {
@@ -2776,6 +2815,13 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_tile_fused, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
                        tile_meta_, tile_out(), st, spec_nv_, spec_ne_, spec_ns_);
     tiles_built = true;
+    if (timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '5') {
+      long long h[10] = {0};
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h, wscan_, sizeof(h), hipMemcpyDeviceToHost);
+      std::fprintf(stderr, "[tile0] ticks: rings %lld hash %lld keys %lld lookback %lld sort %lld records %lld slots %lld  total %lld\n",
+                   h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[1]);
+    }
   } else {
     hipLaunchKernelGGL(k_tile_pass1, dim3(ntiles), dim3(kP1Threads), lds1, s, G, leaf.lo, leaf.hi, tile_ext_, tile_meta_);
     hipLaunchKernelGGL(k_tile_offsets, dim3(1), dim3(kSegCap), 0, s, ntiles, tile_meta_, flags_, spec ? spec_nv_ : 0,

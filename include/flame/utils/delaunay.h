@@ -10,8 +10,8 @@
 // 2^-16 pixel lattice (float pixel coordinates >= 128 are on it already) and the determinants are
 // evaluated in 128-bit integers (|x|, |y| < 2^13 pixels: differences < 2^30, the in-circle sum
 // < 2^124).  Collinear and cocircular inputs are therefore handled like any other: the result is always a
-// triangulation of the convex hull in which no vertex lies strictly inside a circumcircle.  Points that coincide after snapping are triangulated once; the
-// later copies are not referenced by any triangle.
+// triangulation of the convex hull in which no vertex lies strictly inside a circumcircle.  Points that
+// coincide after snapping are triangulated once; the later copies are not referenced by any triangle.
 //
 // Output: counter-clockwise triangles in the (u right, v down) image frame's coordinates, i.e.
 // orient(a, b, c) > 0 with orient = (b - a) x (c - a); sorted by (min vertex, ...) for a stable order.
