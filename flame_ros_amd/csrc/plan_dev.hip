@@ -1332,29 +1332,16 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
   for (int l = tid; l < n_ext; l += NTB) O.t_vmap[voff + l] = L.ext[l];
   const int msort = next_pow2(max(e_loc, 1));
   for (int i = e_loc + tid; i < msort; i += NTB) ekeys[i] = ~0ull;
+  if (tid == 0) S.n = 0;  // (spent as the ring counter: now the balance of the halo closure check below)
   __syncthreads();
   bitonic_sort<NTB, uint64_t>(ekeys, msort);
   TILE_STAMP(O, 6);
-  // ---- gather lists, local records, level ends, owned prefix check ----
-  if (e_own > e_loc && tid == 0) S.fail = 1;
-  for (int le = tid; le < e_loc; le += NTB) {
-    const uint64_t key = ekeys[le];
-    const int32_t k = G.e_o2i[(int32_t)(key & 0xffffffffu)];
-    const int lvl = (int)(key >> 49);
-    const int nxt = le + 1 < e_loc ? (int)(ekeys[le + 1] >> 49) : kMaxDepth + 1;
-    for (int l = lvl; l < nxt && l <= kMaxDepth; ++l) S.level_end[l] = le + 1;
-    if (le < e_own && k != es + le) S.fail = 1;  // owned edges = the prefix, in internal order
-    const uint32_t li = (uint32_t)((key >> 32) & 0xffffu);
-    const uint32_t lj = (uint32_t)hash_lookup(L, G.eij[k].y);
-    O.t_emap[eoff + le] = k;
-    O.t_eij[eoff + le] = make_uint2(li | (lj << 16), 0xffffffffu);
-    O.t_ew[eoff + le] = O.ew[k];
-  }
-  TILE_STAMP(O, 7);
   // ---- incidence slots: one row per updated vertex, odd pitch per 64-vertex group ----
   for (int lv = tid; lv < n_upd; lv += NTB) {
     const int32_t v = L.ext[lv];
-    atomicMax(&S.gw[lv >> 6], G.grow[v + 1] - G.grow[v]);
+    const int32_t deg = G.grow[v + 1] - G.grow[v];
+    atomicMax(&S.gw[lv >> 6], deg);
+    atomicAdd(&S.n, -deg);  // (back at 0 when every incidence of an updated vertex finds its slot below)
   }
   __syncthreads();
   if (tid == 0) {
@@ -1370,49 +1357,37 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
     S.gbase[kCapExt / 64] = base;
   }
   __syncthreads();
-  for (int it = tid; it < n_upd * kRowLanes; it += NTB) {
-    const int lv = it / kRowLanes, sub = it % kRowLanes;
+  for (int lv = tid; lv < n_upd; lv += NTB) {
     const int32_t v = L.ext[lv];
-    const int32_t deg = G.grow[v + 1] - G.grow[v];
     const int g = lv >> 6;
-    const int32_t s0 = S.gbase[g] + (lv - (g << 6)) * S.gw[g];
-    if (sub == 0) O.t_srow[soff + lv] = (uint32_t)s0 | ((uint32_t)deg << 16);
-    const int rv = ring_of(S.ring_end, lv);
-    int j = sub;
-    for (int32_t s = G.grow[v] + sub; s < G.grow[v + 1]; s += kRowLanes, j += kRowLanes) {
-      const int32_t ent = G.ginc[s];
-      const int32_t k = ent & 0x7fffffff;
-      const int role = ent < 0 ? 1 : 0;  // 1: v is the target
-      const int2 ij = G.eij[k];
-      uint64_t key = 0;
-      bool ok;
-      if (!role) {
-        ok = local_edge_key(G, L, S.ring_end, k, lv, rv, ij.y, &key);
-      } else {
-        ok = ((L.bitmap[ij.x >> 5] >> (ij.x & 31)) & 1u) != 0;
-        if (ok) {
-          const int ls = hash_lookup(L, ij.x);
-          const int rs = ring_of(S.ring_end, ls);
-          ok = !(G.depth > 0 && min(rs, rv) >= G.depth);
-          const uint64_t lvl = (uint64_t)max(rs, rv);
-          const uint64_t notown = (lvl <= 1 && rs != 0) ? 1 : 0;
-          key = (lvl << 49) | (notown << 48) | ((uint64_t)(uint32_t)ls << 32) | (uint64_t)(uint32_t)G.e_i2o[k];
-        }
-      }
-      int le = -1;
-      if (ok) {  // position of the edge in the tile's sorted key list
-        int lo = 0, hi = e_loc - 1;
-        while (lo <= hi) {
-          const int mid = (lo + hi) >> 1;
-          const uint64_t km = ekeys[mid];
-          if (km == key) { le = mid; break; }
-          if (km < key) lo = mid + 1; else hi = mid - 1;
-        }
-      }
-      if (le < 0) { S.fail = 1; continue; }  // halo closure invariant
-      reinterpret_cast<unsigned short*>(&O.t_eij[eoff + le].y)[role] = (unsigned short)(s0 + j);
-    }
+    O.t_srow[soff + lv] = (uint32_t)(S.gbase[g] + (lv - (g << 6)) * S.gw[g]) | ((uint32_t)(G.grow[v + 1] - G.grow[v]) << 16);
   }
+  TILE_STAMP(O, 7);
+  // ---- gather lists, local records with their two slots, level ends, owned prefix check ----
+  // (the slot of an incidence = its vertex's row start + its place in the vertex's incidence row, which
+  // k_csr_rows<true> left in ipos: no search through the key list, no second walk over the rows)
+  if (e_own > e_loc && tid == 0) S.fail = 1;
+  int found = 0;
+  for (int le = tid; le < e_loc; le += NTB) {
+    const uint64_t key = ekeys[le];
+    const int32_t k = G.e_o2i[(int32_t)(key & 0xffffffffu)];
+    const int lvl = (int)(key >> 49);
+    const int nxt = le + 1 < e_loc ? (int)(ekeys[le + 1] >> 49) : kMaxDepth + 1;
+    for (int l = lvl; l < nxt && l <= kMaxDepth; ++l) S.level_end[l] = le + 1;
+    if (le < e_own && k != es + le) S.fail = 1;  // owned edges = the prefix, in internal order
+    const uint32_t li = (uint32_t)((key >> 32) & 0xffffu);
+    const uint32_t lj = (uint32_t)hash_lookup(L, G.eij[k].y);
+    uint32_t ss = 0xffffu, sd = 0xffffu;
+    if ((int)li < n_upd) { const int g = li >> 6; ss = (uint32_t)(S.gbase[g] + ((int)li - (g << 6)) * S.gw[g] + G.ipos[2 * k]); ++found; }
+    if ((int)lj < n_upd) { const int g = lj >> 6; sd = (uint32_t)(S.gbase[g] + ((int)lj - (g << 6)) * S.gw[g] + G.ipos[2 * k + 1]); ++found; }
+    O.t_emap[eoff + le] = k;
+    O.t_eij[eoff + le] = make_uint2(li | (lj << 16), (ss & 0xffffu) | (sd << 16));
+    O.t_ew[eoff + le] = O.ew[k];
+  }
+  if (found) atomicAdd(&S.n, found);
+  __syncthreads();
+  // halo closure invariant: every incidence of an updated vertex is a local edge
+  if (tid == 0 && S.n != 0) S.fail = 1;
   __syncthreads();
   TILE_STAMP(O, 8);
   // ---- lane order at build time (lane_order = 2): plan.cpp assign_lanes(), the identical greedy ----
@@ -2819,7 +2794,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
       long long h[10] = {0};
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h, wscan_, sizeof(h), hipMemcpyDeviceToHost);
-      std::fprintf(stderr, "[tile0] ticks: rings %lld hash %lld keys %lld lookback %lld sort %lld records %lld slots %lld  total %lld\n",
+      std::fprintf(stderr, "[tile0] ticks: rings %lld hash %lld keys %lld lookback %lld sort %lld slot rows %lld records %lld  total %lld\n",
                    h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7], h[8] - h[1]);
     }
   } else {
