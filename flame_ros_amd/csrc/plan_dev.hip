@@ -1292,30 +1292,6 @@ struct TileShared {
   int32_t gw[kCapExt / 64], gbase[kCapExt / 64 + 1];
 };
 
-// local edges: every local vertex contributes its outgoing incidences (keys into ekeys, count in S.ecnt)
-template <int NTB>
-__device__ __forceinline__ void tile_collect_keys(const TileGraph& G, const TileLds& L, TileShared& S, uint64_t* ekeys,
-                                                  int n_ext) {
-  const int tid = threadIdx.x;
-  for (int it = tid; it < n_ext * kRowLanes; it += NTB) {
-    const int lv = it / kRowLanes;
-    const int32_t v = L.ext[lv];
-    const int rv = ring_of(S.ring_end, lv);
-    for (int32_t s = G.grow[v] + it % kRowLanes; s < G.grow[v + 1]; s += kRowLanes) {
-      const int32_t ent = G.ginc[s];
-      if (ent < 0) continue;  // v is the target; the source adds the edge
-      uint64_t key;
-      if (local_edge_key(G, L, S.ring_end, ent, lv, rv, G.eij[ent].y, &key)) {
-        const int pos = atomicAdd(&S.ecnt, 1);
-        if (pos < kSortPad) ekeys[pos] = key;
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// everything behind the key list: sorted local edges, gather records, incidence slots, descriptor.
-// Expects L (ext, bitmap, hash), S.ring_end, S.fail, the keys and S.gw[] = 1, S.level_end[] = 0.
 struct TileOut {
   const float4* ew; TileDesc* tiles; int32_t* t_vmap; int32_t* t_emap; uint2* t_eij; float4* t_ew; uint32_t* t_srow;
   int32_t* flags; int lane_order;
@@ -1323,18 +1299,125 @@ struct TileOut {
 };
 #define TILE_STAMP(O, n) do { if ((O).prof && blockIdx.x == 0 && threadIdx.x == 0) (O).prof[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
+// ---- the local edge list of a tile without a sort ----
+// The order of the list (plan.cpp: level, owned before not owned, source, original edge id) is, with the
+// local vertices numbered ring by ring: for every ring r, first the edges of its vertices that stay
+// inside the rings 0..r ("same": level r), then those that lead to ring r + 1 ("next": level r + 1), each
+// block by source vertex, then by original id.  (Level 1's owned edges are ring 0's "next" block, its
+// not-owned ones ring 1's "same" block.)  That is a bucket order: bucket (source, kind) at
+// 2 * ring_start + (kind ? ring_size : 0) + (source - ring_start), and inside a bucket the order of the
+// source's incidence row, which is ascending original id already.  So: one walk over the rows counts the
+// buckets, a scan makes offsets, a second walk writes every edge's records straight to its place --
+// the 64-bit keys and their bitonic sort (~45 of ~180 k ticks per tile at 50 k vertices) are gone.
+constexpr int kBucketInts = 2 * kCapExt + 8;
+
+__device__ __forceinline__ int tile_bucket(const int32_t* ring_end, int lv, int rv, int kind) {
+  const int rs = rv == 0 ? 0 : ring_end[rv - 1];
+  return 2 * rs + (kind ? ring_end[rv] - rs : 0) + (lv - rs);
+}
+
 template <int NTB>
-__device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, TileShared& S, uint64_t* ekeys, int t,
+struct TileEmit {  // what the second walk needs beside the graph
+  int32_t es, e_own, n_upd, eoff;
+  const TileOut* O;
+};
+
+// kRowLanes (4) lanes walk one local vertex's incidence row together, four entries per step; what a
+// lane needs of its neighbours -- how many qualifying entries of its kind sit in front of it -- comes by
+// shuffles inside the group, so the place of every edge inside its bucket is known without atomics.
+// EMIT = false: bucket sizes into cnt[]; EMIT = true: cnt[] holds the offsets, the records are written.
+template <int NTB, bool EMIT>
+__device__ __forceinline__ int tile_walk(const TileGraph& G, const TileLds& L, TileShared& S, int32_t* cnt, int n_ext,
+                                         const TileEmit<NTB>* E) {
+  static_assert(kRowLanes == 4 && NTB % 4 == 0, "groups of four lanes");
+  const int tid = threadIdx.x, sub = tid & 3, lane0 = (tid & 63) & ~3;
+  int found = 0;
+  for (int it = tid; it < n_ext * 4; it += NTB) {
+    const int lv = it >> 2;
+    const int32_t v = L.ext[lv];
+    const int rv = ring_of(S.ring_end, lv);
+    const int32_t g0 = G.grow[v], g1 = G.grow[v + 1];
+    const int b_same = tile_bucket(S.ring_end, lv, rv, 0), b_next = tile_bucket(S.ring_end, lv, rv, 1);
+    int run_same = 0, run_next = 0;
+    for (int32_t base = g0; base < g1; base += 4) {
+      const int32_t s = base + sub;
+      int f = 0;  // 1: same, 2: next
+      int32_t ent = 0, ldst = 0;
+      if (s < g1) {
+        ent = G.ginc[s];
+        if (ent >= 0) {  // v is the source (the target's row does not add the edge)
+          const int32_t u = G.gadj[s];
+          if ((L.bitmap[u >> 5] >> (u & 31)) & 1u) {
+            ldst = hash_lookup(L, u);
+            const int rd = ring_of(S.ring_end, ldst);
+            if (!(G.depth > 0 && min(rv, rd) >= G.depth)) f = rd > rv ? 2 : 1;  // (else: feeds no updated vertex)
+          }
+        }
+      }
+      int before = 0, tot_same = 0, tot_next = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int fj = __shfl(f, lane0 + j, 64);
+        tot_same += fj == 1; tot_next += fj == 2;
+        before += (j < sub && fj == f) ? 1 : 0;
+      }
+      if (EMIT && f) {
+        const int32_t le = cnt[f == 2 ? b_next : b_same] + (f == 2 ? run_next : run_same) + before;
+        const int32_t k = ent;
+        uint32_t ss = 0xffffu, sd = 0xffffu;
+        if (lv < E->n_upd) { const int g = lv >> 6; ss = (uint32_t)(S.gbase[g] + (lv - (g << 6)) * S.gw[g] + G.ipos[2 * k]); ++found; }
+        if (ldst < E->n_upd) { const int g = ldst >> 6; sd = (uint32_t)(S.gbase[g] + (ldst - (g << 6)) * S.gw[g] + G.ipos[2 * k + 1]); ++found; }
+        if (le < E->e_own && k != E->es + le) S.fail = 1;  // owned edges = the prefix, in internal order
+        E->O->t_emap[E->eoff + le] = k;
+        E->O->t_eij[E->eoff + le] = make_uint2((uint32_t)lv | ((uint32_t)ldst << 16), (ss & 0xffffu) | (sd << 16));
+        E->O->t_ew[E->eoff + le] = E->O->ew[k];
+      }
+      run_same += tot_same; run_next += tot_next;
+    }
+    if (!EMIT && sub == 0) { cnt[b_same] = run_same; cnt[b_next] = run_next; }
+  }
+  return found;
+}
+
+// exclusive scan of a[0 .. n) in place (LDS), n <= 2 * kCapExt + 1; returns the total.  (Ends with a barrier.)
+template <int NTB>
+__device__ __forceinline__ int32_t tile_scan(int32_t* a, int n, int32_t* sh /* >= 17 */) {
+  const int tid = threadIdx.x;
+  const int per = (n + NTB - 1) / NTB;
+  const int i0 = tid * per, i1 = min(i0 + per, n);
+  int32_t sum = 0;
+  for (int i = i0; i < i1; ++i) sum += a[i];
+  int32_t run = block_exclusive<int32_t>(sum, sh);
+  if (tid == NTB - 1) sh[16] = run + sum;
+  for (int i = i0; i < i1; ++i) { const int32_t v = a[i]; a[i] = run; run += v; }
+  __syncthreads();
+  return sh[16];
+}
+
+// bucket counts -> offsets; returns the number of local edges
+template <int NTB>
+__device__ __forceinline__ int tile_count_edges(const TileGraph& G, const TileLds& L, TileShared& S, int32_t* cnt, int n_ext,
+                                                int32_t* sh) {
+  if (threadIdx.x == 0) cnt[2 * n_ext] = 0;
+  (void)tile_walk<NTB, false>(G, L, S, cnt, n_ext, nullptr);
+  __syncthreads();
+  return tile_scan<NTB>(cnt, 2 * n_ext + 1, sh);
+}
+
+// everything behind the bucket offsets: vertex map, incidence slot rows, the local edge records with
+// their slots, level ends, descriptor.  Expects L (ext, bitmap, hash), S.ring_end, S.fail, S.gw[] = 1.
+template <int NTB>
+__device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, TileShared& S, int32_t* off, int t,
                                           int32_t vstart, int32_t n_own, int32_t es, int32_t e_own, int n_ext,
                                           int e_loc, int n_upd, int32_t voff, int32_t eoff, int32_t soff,
                                           const TileOut& O) {
   const int tid = threadIdx.x;
   for (int l = tid; l < n_ext; l += NTB) O.t_vmap[voff + l] = L.ext[l];
-  const int msort = next_pow2(max(e_loc, 1));
-  for (int i = e_loc + tid; i < msort; i += NTB) ekeys[i] = ~0ull;
   if (tid == 0) S.n = 0;  // (spent as the ring counter: now the balance of the halo closure check below)
+  // level l ends where ring l's "next" block begins
+  if (tid <= kMaxDepth) S.level_end[tid] = off[(tid == 0 ? 0 : S.ring_end[tid - 1]) + S.ring_end[tid]];
+  if (e_own > e_loc && tid == 0) S.fail = 1;
   __syncthreads();
-  bitonic_sort<NTB, uint64_t>(ekeys, msort);
   TILE_STAMP(O, 6);
   // ---- incidence slots: one row per updated vertex, odd pitch per 64-vertex group ----
   for (int lv = tid; lv < n_upd; lv += NTB) {
@@ -1363,27 +1446,11 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
     O.t_srow[soff + lv] = (uint32_t)(S.gbase[g] + (lv - (g << 6)) * S.gw[g]) | ((uint32_t)(G.grow[v + 1] - G.grow[v]) << 16);
   }
   TILE_STAMP(O, 7);
-  // ---- gather lists, local records with their two slots, level ends, owned prefix check ----
-  // (the slot of an incidence = its vertex's row start + its place in the vertex's incidence row, which
-  // k_csr_rows<true> left in ipos: no search through the key list, no second walk over the rows)
-  if (e_own > e_loc && tid == 0) S.fail = 1;
-  int found = 0;
-  for (int le = tid; le < e_loc; le += NTB) {
-    const uint64_t key = ekeys[le];
-    const int32_t k = G.e_o2i[(int32_t)(key & 0xffffffffu)];
-    const int lvl = (int)(key >> 49);
-    const int nxt = le + 1 < e_loc ? (int)(ekeys[le + 1] >> 49) : kMaxDepth + 1;
-    for (int l = lvl; l < nxt && l <= kMaxDepth; ++l) S.level_end[l] = le + 1;
-    if (le < e_own && k != es + le) S.fail = 1;  // owned edges = the prefix, in internal order
-    const uint32_t li = (uint32_t)((key >> 32) & 0xffffu);
-    const uint32_t lj = (uint32_t)hash_lookup(L, G.eij[k].y);
-    uint32_t ss = 0xffffu, sd = 0xffffu;
-    if ((int)li < n_upd) { const int g = li >> 6; ss = (uint32_t)(S.gbase[g] + ((int)li - (g << 6)) * S.gw[g] + G.ipos[2 * k]); ++found; }
-    if ((int)lj < n_upd) { const int g = lj >> 6; sd = (uint32_t)(S.gbase[g] + ((int)lj - (g << 6)) * S.gw[g] + G.ipos[2 * k + 1]); ++found; }
-    O.t_emap[eoff + le] = k;
-    O.t_eij[eoff + le] = make_uint2(li | (lj << 16), (ss & 0xffffu) | (sd << 16));
-    O.t_ew[eoff + le] = O.ew[k];
-  }
+  // ---- local edge records with their two slots (the slot of an incidence = its vertex's row start + its
+  // place in the vertex's incidence row, which k_csr_rows<true> left in ipos) ----
+  TileEmit<NTB> E;
+  E.es = es; E.e_own = e_own; E.n_upd = n_upd; E.eoff = eoff; E.O = &O;
+  const int found = tile_walk<NTB, true>(G, L, S, off, n_ext, &E);
   if (found) atomicAdd(&S.n, found);
   __syncthreads();
   // halo closure invariant: every incidence of an updated vertex is a local edge
@@ -1416,14 +1483,15 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
                                                            const int32_t* __restrict__ meta, TileOut O) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ TileShared S;
+  __shared__ int32_t s_sc[20];
   const int t = blockIdx.x, tid = threadIdx.x;
   // a build that has already failed (bad indices, a tile that does not fit, a rejected partition, tile
   // arrays too small for a speculative launch: every bit but pass 2's own 8) must not be continued:
   // the host used to stop before this launch; without the round trip the kernel stops itself
   if (__builtin_amdgcn_readfirstlane(O.flags[0]) & ~8) return;
   TileLds L;
-  uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
-  L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
+  int32_t* cnt = reinterpret_cast<int32_t*>(smem);               // kBucketInts
+  L.bitmap = reinterpret_cast<uint32_t*>(cnt + kBucketInts);
   L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
   L.hkey = L.ext + kCapExt;
   L.hval = L.hkey + kHash;
@@ -1449,17 +1517,17 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_pass2(TileGraph G, const in
   }
   __syncthreads();
   tile_hash_build<kP2Threads>(L, n_ext);
-  tile_collect_keys<kP2Threads>(G, L, S, ekeys, n_ext);
-  if (S.ecnt != e_loc) { if (tid == 0) S.fail = 1; }
-  tile_emit<kP2Threads>(G, L, S, ekeys, t, vstart, n_own, es, e_own, n_ext, e_loc, n_upd, voff, eoff, soff, O);
+  const int e_cnt = tile_count_edges<kP2Threads>(G, L, S, cnt, n_ext, s_sc);
+  if (e_cnt != e_loc) { if (tid == 0) S.fail = 1; }
+  tile_emit<kP2Threads>(G, L, S, cnt, t, vstart, n_own, es, e_own, n_ext, e_loc, n_upd, voff, eoff, soff, O);
 }
 
 // Pass 1 + offsets + pass 2 in ONE launch (a frame stream with speculative tile arrays, tiles <=
-// kScanMaxBlocks): the rings, the hash and the key list are built once instead of twice, the three
-// running totals (local vertices, local edges, slot rows) come by look-back over the tiles before
-// this one, packed 22 | 22 | 20 bits.  Tiles are dispatched in index order and a tile only waits for
-// lower indices, so the grid may exceed the resident set.  tile_ext / meta are written all the same:
-// when the speculative arrays turn out too small (bit 128) the host re-runs plain pass 2 from them.
+// kScanMaxBlocks): the rings and the hash are built once instead of twice, the three running totals
+// (local vertices, local edges, slot rows) come by look-back over the tiles before this one, packed
+// 22 | 22 | 20 bits.  Tiles are dispatched in index order and a tile only waits for lower indices, so
+// the grid may exceed the resident set.  tile_ext / meta are written all the same: when the speculative
+// arrays turn out too small (bit 128) the host re-runs plain pass 2 from them.
 __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const int32_t* __restrict__ vstart_tab,
                                                            const int32_t* __restrict__ vend_tab,
                                                            const int32_t* __restrict__ estart, int32_t* tile_ext,
@@ -1468,6 +1536,7 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const in
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ TileShared S;
   __shared__ unsigned long long sh_lb[2];
+  __shared__ int32_t s_sc[20];
   const int t = blockIdx.x, tid = threadIdx.x, ntiles = gridDim.x;
   // failed before this launch (bits 4, 8, 128 are the launch's own: a tile must not leave on them,
   // the tiles behind it wait for its totals)
@@ -1482,8 +1551,8 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const in
     return;
   }
   TileLds L;
-  uint64_t* ekeys = reinterpret_cast<uint64_t*>(smem);          // kSortPad
-  L.bitmap = reinterpret_cast<uint32_t*>(ekeys + kSortPad);
+  int32_t* cnt = reinterpret_cast<int32_t*>(smem);               // kBucketInts
+  L.bitmap = reinterpret_cast<uint32_t*>(cnt + kBucketInts);
   L.ext = reinterpret_cast<int32_t*>(L.bitmap + ((G.V + 31) >> 5));
   L.hkey = L.ext + kCapExt;
   L.hval = L.hkey + kHash;
@@ -1499,9 +1568,8 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const in
   TILE_STAMP(O, 2);
   tile_hash_build<kP2Threads>(L, n_ext);
   TILE_STAMP(O, 3);
-  tile_collect_keys<kP2Threads>(G, L, S, ekeys, n_ext);
+  const int e_cnt = tile_count_edges<kP2Threads>(G, L, S, cnt, n_ext, s_sc);
   TILE_STAMP(O, 4);
-  const int e_cnt = S.ecnt;
   const int n_upd = G.depth == 0 ? n_ext : S.ring_end[G.depth - 1];
   const bool bad = S.fail || e_cnt > kCapEdge;
   __syncthreads();
@@ -1526,7 +1594,7 @@ __global__ __launch_bounds__(kP2Threads) void k_tile_fused(TileGraph G, const in
     if (tid == 0 && bad && !over) { TileDesc D = {}; D.n_ext = -1; O.tiles[t] = D; }
     return;
   }
-  tile_emit<kP2Threads>(G, L, S, ekeys, t, vstart, n_own, es, e_own, n_ext, e_loc, n_upd, voff, eoff, soff, O);
+  tile_emit<kP2Threads>(G, L, S, cnt, t, vstart, n_own, es, e_own, n_ext, e_loc, n_upd, voff, eoff, soff, O);
 }
 
 // What the host reads after a build -- the flags word, the caller's check word, the tile descriptors --
@@ -2500,7 +2568,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     (void)hipEventRecord(tev[0], s);
   }
   const size_t lds1 = ((size_t)(V + 31) / 32) * 4 + kCapExt * 4 + kHash * 8;
-  const size_t lds2 = lds1 + (size_t)kSortPad * 8;
+  const size_t lds2 = lds1 + (size_t)kBucketInts * 4;  // + the bucket counts / offsets of the local edge list
   if (!attr_set_) {  // per planner (= per handle = per device), not per process
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     HIPRET(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_pass2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
