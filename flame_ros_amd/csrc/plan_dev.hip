@@ -14,8 +14,9 @@
 //   E  triangle CSR  the same over the 3T corners, on a second stream
 //   F  tiles, pass 1 one workgroup per tile: breadth-first halo rings over the CSR with an LDS bitmap
 //                    of the vertices, rings sorted by internal id, local edge count
-//   G  tiles, pass 2 local edge keys (level, owned, source, edge id) sorted in LDS, gather lists,
-//                    incidence slots (odd pitch per 64-vertex group), local edge records
+//   G  tiles, pass 2 the local edge list in the order (level, owned, source, edge id) by bucket counting
+//                    (no keys, no sort), gather lists, incidence slots (odd pitch per 64-vertex group),
+//                    local edge records
 // Frame streams take shortcuts through these stages that leave the same kind of plan behind: the
 // partition of a frame from the previous frame's tile map (k_reuse_*, "Partition REUSE"), the counting
 // passes' atomics doubling as ranks, fused launches (k_he_unique, k_edge_rows_gather, k_tile_fused,
@@ -43,7 +44,7 @@ constexpr int kIdBits = 22;       // vertex ids in sort keys
 constexpr int kEdgeBits = 24;     // edge / triangle ids in sort keys
 constexpr int kCapExt = 2048;     // local vertices per tile (largest kernel configuration)
 constexpr int kCapEdge = 6144;    // local edges per tile (largest kernel configuration)
-constexpr int kSortPad = 8192;    // LDS sort window (keys)
+constexpr int kSortPad = 8192;    // bound of a tile's local edge count in the packed look-back totals
 constexpr int kHash = 4096;       // LDS hash slots (global -> local vertex id)
 constexpr int kMetaWords = 32;    // per tile: 0 n_ext, 1 e_loc, 2 n_upd, 3 fail, 4..20 ring_end, 21..23 offsets
 constexpr int kP1Threads = 512, kP2Threads = 1024;
@@ -2410,7 +2411,7 @@ bool DevPlanner::eligible(const PlanOptions& opt, int32_t V, int32_t E, int32_t 
     return false;
   const int ntiles = (V + tile_own - 1) / std::max(tile_own, 1);
   if (ntiles < 2 || ntiles > kSegCap) return false;
-  const int64_t lds2 = (int64_t)kSortPad * 8 + ((V + 31) / 32) * 4ll + kCapExt * 4 + kHash * 8;
+  const int64_t lds2 = (int64_t)kBucketInts * 4 + ((V + 31) / 32) * 4ll + kCapExt * 4 + kHash * 8;
   // the tile passes and the subtree kernel opt in to (almost) all of gfx950's 160 KiB of LDS: a
   // device / option set with less is the host builder's
   if ((int64_t)kSubLdsBytes > lds_bytes || 160 * 1024 - 512 > lds_bytes) return false;
