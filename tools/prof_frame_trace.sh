@@ -13,7 +13,7 @@ if m:
         rows.append(dict(kind='C', name='copy %s %s B' % (r.get('Direction', ''), r.get('Size', '?')), s=int(r['Start_Timestamp']), e=int(r['End_Timestamp'])))
 rows.sort(key=lambda r: r['s'])
 # the last frame starts at the last k_he_count (device sync) or after the previous frame's last copy
-idx = [i for i, r in enumerate(rows) if 'k_he_count' in r['name']]
+idx = [i for i, r in enumerate(rows) if 'k_he_count' in r['name'] or 'k_mini_plan' in r['name']]
 i0 = idx[-1] if idx else 0
 if not idx:  # host sync path (single tile): start after the last k_tile burst before the final one
     kt = [i for i, r in enumerate(rows) if 'k_tile<' in r['name']]
