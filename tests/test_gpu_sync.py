@@ -138,3 +138,24 @@ def test_edge_count_is_predicted_and_verified(gpu):
         assert_bit_equal(x, o.x, "frame %d (%s) x" % (k, kind))
         assert_bit_equal(q, o.q, "frame %d (%s) q" % (k, kind))
     r.close()
+
+
+def test_large_frames_take_the_unfused_chains(gpu):
+    """Two frames of 120 k vertices through the graph sync: beyond 114 k vertices the edge derivation is the
+    unfused rows / mark / scan / compact chain, and 512 tiles exceed the fused tile pass's look-back grid
+    (plain pass 1 / offsets / pass 2) -- the same edges and the oracle's bits all the same."""
+    sp, p = default_sync_params(), default_params()
+    r = GraphRegularizer.empty(device=0)
+    for k in range(2):
+        g = graphgen.synthetic(120000, 1280, 1024, seed=90 + k)
+        var = np.full(g.V, 1e-4, np.float32)
+        r.sync_features(g.pos, g.z, var, g.tris, sp)
+        assert r.info("plan_on_device") == 1 and r.info("num_tiles") > 448
+        assert np.array_equal(r.edges(), g.edges)
+        o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+        o.solve(oracle_params(), 6)
+        r.step(p, 6)
+        x, w1, w2, q = r.download()
+        assert_bit_equal(x, o.x, "frame %d x" % k)
+        assert_bit_equal(q, o.q, "frame %d q" % k)
+    r.close()
