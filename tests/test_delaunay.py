@@ -115,3 +115,26 @@ def test_degenerate_inputs(exe):
     assert run(exe, np.array([[0, 0], [1, 1], [2, 2], [5, 5]], np.float32)) is None
     assert run(exe, np.array([[0, 0], [1, 0], [np.inf, 3]], np.float32)) is None
     assert run(exe, np.zeros((0, 2), np.float32)) is None
+
+
+def test_small_integer_sets_stress(exe):
+    """Many tiny point sets on a coarse integer grid: ties in both cut directions, collinear subsets,
+    cocircular quadruples and duplicates at every level of the recursion."""
+    rng = np.random.default_rng(7)
+    for trial in range(150):
+        n = int(rng.integers(3, 40))
+        pts = rng.integers(0, 7, (n, 2)).astype(np.float32) * np.float32(8.0) + np.float32(128.0)
+        tris = run(exe, pts)
+        P = set(map(tuple, pts.tolist()))
+        xs, ys = {p[0] for p in P}, {p[1] for p in P}
+        collinear = len(P) < 3 or all(orient(*(snapped([a, b, c]))) == 0
+                                      for a in list(P)[:1] for b in list(P)[1:2] for c in P)
+        if collinear:
+            assert tris is None, trial
+            continue
+        assert tris is not None, trial
+        check_properties(pts, tris)
+    # a circle through 12 lattice points, a vertical and a horizontal line through its centre
+    circle = [(5, 0), (4, 3), (3, 4), (0, 5), (-3, 4), (-4, 3), (-5, 0), (-4, -3), (-3, -4), (0, -5), (3, -4), (4, -3)]
+    pts = np.array(circle + [(0, k) for k in range(-4, 5)] + [(k, 0) for k in range(-4, 5) if k], np.float32) * 4 + 200
+    check_properties(pts, run(exe, pts))
