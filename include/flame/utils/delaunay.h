@@ -85,7 +85,7 @@ class DelaunayTriangulator {
   }
 
  private:
-  typedef __int128 i128;
+  __extension__ typedef __int128 i128;
   // quad-edge: edge q occupies slots 4q .. 4q + 3 (rotations); next_ = Onext, org_ on the even slots
   std::vector<int32_t> next_, org_;
   std::vector<uint8_t> dead_;
