@@ -267,7 +267,9 @@ class Flame {
         std::vector<Triangle> tris;
         if (ok) {
           stats_.tick("triangulate");
-          ok = frontend_.triangulate ? frontend_.triangulate(g.vtx, &tris) : delaunay_.triangulate(g.vtx, &tris);
+          // (the reference's `omp_num_threads`, cfg/flame_offline_tum.yaml:70, is what its CPU stages run on)
+          ok = frontend_.triangulate ? frontend_.triangulate(g.vtx, &tris)
+                                     : delaunay_.triangulate(g.vtx, &tris, params_.omp_num_threads);
           stats_.tock("triangulate");
         }
         if (ok)

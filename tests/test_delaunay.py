@@ -14,15 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("dt") / "delaunay_test")
-    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "delaunay_test.cc"), "-o", out])
     return out
 
 
-def run(exe, pts):
+def run(exe, pts, threads=1):
     pts = np.asarray(pts, np.float32)
     txt = "%d\n" % len(pts) + "".join("%.9g %.9g\n" % (x, y) for x, y in pts)
-    out = subprocess.run([exe], input=txt.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
+    out = subprocess.run([exe, str(threads)], input=txt.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().split("\n")
     if out[0] == "FAIL":
         return None
     return np.array([[int(v) for v in l.split()] for l in out if l.strip()], np.int64).reshape(-1, 3)
@@ -138,3 +138,17 @@ def test_small_integer_sets_stress(exe):
     circle = [(5, 0), (4, 3), (3, 4), (0, 5), (-3, 4), (-4, 3), (-5, 0), (-4, -3), (-3, -4), (0, -5), (3, -4), (4, -3)]
     pts = np.array(circle + [(0, k) for k in range(-4, 5)] + [(k, 0) for k in range(-4, 5) if k], np.float32) * 4 + 200
     check_properties(pts, run(exe, pts))
+
+
+def test_threads_give_the_same_triangulation(exe):
+    """threads = 2 / 4: the top levels of the recursion on threads of their own, parts joined afterwards --
+    the same triangles (the predicates are exact, the result is unique for generic points), also when the
+    input is a lattice (any valid choice inside cocircular cells: checked by the properties)."""
+    rng = np.random.default_rng(9)
+    pts = (rng.random((6000, 2)) * np.array([640.0, 480.0]) + 128.0).astype(np.float32)
+    ref = canon(run(exe, pts, 1))
+    for th in (2, 4):
+        assert np.array_equal(canon(run(exe, pts, th)), ref), th
+    ix, iy = np.meshgrid(np.arange(80), np.arange(60))
+    lattice = np.stack([ix.ravel() * 8.0 + 130.0, iy.ravel() * 8.0 + 130.0], 1)
+    check_properties(lattice, run(exe, lattice, 4))
