@@ -247,9 +247,16 @@ class DelaunayTriangulator {
         part.next_.resize(static_cast<size_t>(32) * (mid - lo)); part.org_.resize(part.next_.size()); part.dead_.resize(part.next_.size() / 4);
       }
       int32_t pl = 0, pr = 0;
-      std::thread worker([&]() { part.build(0, mid - lo, 1 - axis, &pl, &pr, par - 1); });
-      build(mid, hi, 1 - axis, &cl, &cr, par - 1);
-      worker.join();
+      std::thread worker;
+#if defined(__cpp_exceptions)
+      try { worker = std::thread([&]() { part.build(0, mid - lo, 1 - axis, &pl, &pr, par - 1); }); } catch (...) {}
+#else
+      worker = std::thread([&]() { part.build(0, mid - lo, 1 - axis, &pl, &pr, par - 1); });
+#endif
+      const bool spawned = worker.joinable();
+      build(mid, hi, 1 - axis, &cl, &cr, spawned ? par - 1 : 0);
+      if (spawned) worker.join();
+      else part.build(0, mid - lo, 1 - axis, &pl, &pr, 0);  // (no thread to be had: this one does both parts)
       handles(cl, axis, &rdi, &rdo);
       const int32_t base = 4 * n_edges_, cnt = 4 * part.n_edges_;
       if (static_cast<size_t>(base) + cnt > next_.size()) { next_.resize(2 * (static_cast<size_t>(base) + cnt) + 64); org_.resize(next_.size()); dead_.resize(next_.size() / 4); }
