@@ -78,7 +78,25 @@ int main(int argc, char** argv) {
   Kinv(2, 0) = 0.f; Kinv(2, 1) = 0.f; Kinv(2, 2) = 1.f;
   std::shared_ptr<flame::Flame> sensor = std::make_shared<flame::Flame>(W, H, K, Kinv, params);
 
-  std::vector<double> upd, sync, solve, wall, get;
+  // FLAME_BENCH_FRONTEND=1: the frames go through update() with a FrontEnd whose track() hands over the
+  // frame's features and NO triangulate(): the built-in host triangulator (flame/utils/delaunay.h) runs
+  // inside update(), as it does for a caller that only brings features
+  const char* fe_env = std::getenv("FLAME_BENCH_FRONTEND");
+  const bool with_frontend = fe_env && fe_env[0] == '1';
+  const Frame* cur = nullptr;
+  if (with_frontend) {
+    flame::FrontEnd fe;
+    fe.track = [&](const flame::FrameInput&, flame::FeatureSet* fs) {
+      fs->vtx = cur->vtx; fs->idepth_mu = cur->mu; fs->idepth_var = cur->var;
+      return true;
+    };
+    sensor->setFrontEnd(fe);
+  }
+  flame::Image1b gray(H, W);
+  flame::SE3f pose;
+  pose.q[0] = pose.q[1] = pose.q[2] = 0.f; pose.q[3] = 1.f;
+  pose.t[0] = pose.t[1] = pose.t[2] = 0.f;
+  std::vector<double> upd, sync, solve, wall, get, tri;
   std::vector<flame::Point2f> ovtx;
   std::vector<float> oid;
   std::vector<flame::Vector3f> normals;
@@ -92,7 +110,9 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < frames.size(); ++k, ++n) {
       const Frame& f = frames[k];
       const auto t0 = std::chrono::steady_clock::now();
-      const bool ok = sensor->updateGraph(0.033 * n, static_cast<uint32_t>(n), f.vtx, f.mu, f.var, f.tris);
+      cur = &f;
+      const bool ok = with_frontend ? sensor->update(0.033 * n, static_cast<uint32_t>(n), pose, gray, false)
+                                    : sensor->updateGraph(0.033 * n, static_cast<uint32_t>(n), f.vtx, f.mu, f.var, f.tris);
       const auto t1 = std::chrono::steady_clock::now();
       if (!ok) {
         std::printf("{\"error\": \"update failed\", \"hip_error\": %d}\n", static_cast<int>(sensor->stats().stats("hip_error")));
@@ -110,6 +130,7 @@ int main(int argc, char** argv) {
       upd.push_back(sensor->stats().timings("update"));
       sync.push_back(sensor->stats().timings("sync_graph"));
       solve.push_back(sensor->stats().timings("nltgv2"));
+      tri.push_back(with_frontend ? sensor->stats().timings("triangulate") : 0.0);
       wall.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
       get.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
     }
@@ -117,10 +138,11 @@ int main(int argc, char** argv) {
       "{\"V\": %d, \"T\": %d, \"E\": %d, \"iters\": %d, \"frames\": %d, \"getters\": %d, "
       "\"update_ms\": {\"p50\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"max\": %.4f}, "
       "\"update_wall_ms_p50\": %.4f, \"sync_graph_ms_p50\": %.4f, \"nltgv2_ms_p50\": %.4f, "
-      "\"nltgv2_device_ms\": %.4f, \"getters_ms_p50\": %.4f, \"coverage\": %.6f, \"checksum\": %lu}\n",
+      "\"nltgv2_device_ms\": %.4f, \"getters_ms_p50\": %.4f, \"coverage\": %.6f, \"checksum\": %lu, "
+      "\"triangulate_ms_p50\": %.4f}\n",
       static_cast<int>(frames[0].vtx.size()), static_cast<int>(frames[0].tris.size()),
       static_cast<int>(sensor->stats().stats("num_edges")), iters, static_cast<int>(upd.size()), getters,
       pct(upd, 0.5), pct(upd, 0.1), pct(upd, 0.9), pct(upd, 1.0), pct(wall, 0.5), pct(sync, 0.5), pct(solve, 0.5),
-      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum);
+      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum, pct(tri, 0.5));
   return 0;
 }
