@@ -152,3 +152,21 @@ def test_threads_give_the_same_triangulation(exe):
     ix, iy = np.meshgrid(np.arange(80), np.arange(60))
     lattice = np.stack([ix.ravel() * 8.0 + 130.0, iy.ravel() * 8.0 + 130.0], 1)
     check_properties(lattice, run(exe, lattice, 4))
+
+
+def test_sanitizers_clean(tmp_path):
+    """The triangulator under AddressSanitizer + UBSan (serial and threaded, generic and degenerate input)."""
+    out = str(tmp_path / "delaunay_asan")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "delaunay_test.cc"), "-o", out])
+    rng = np.random.default_rng(3)
+    ix, iy = np.meshgrid(np.arange(70), np.arange(60))
+    cases = [((rng.random((3000, 2)) * np.array([640.0, 480.0])).astype(np.float32), 1),
+             ((rng.random((6000, 2)) * np.array([640.0, 480.0])).astype(np.float32), 4),
+             (np.stack([ix.ravel() * 8.0 + 130.0, iy.ravel() * 8.0 + 130.0], 1).astype(np.float32), 4)]
+    cases += [(rng.integers(0, 6, (int(rng.integers(3, 50)), 2)).astype(np.float32) * 4 + 130, 1) for _ in range(10)]
+    for pts, th in cases:
+        txt = "%d\n" % len(pts) + "".join("%.9g %.9g\n" % (x, y) for x, y in pts)
+        p = subprocess.run([out, str(th)], input=txt.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
