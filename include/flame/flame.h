@@ -16,8 +16,9 @@
 // (OpenCV/Sophus code upstream of the hot path, SURVEY.md 2 "OUT OF SCOPE") followed by the part
 // this class runs on the GPU: graph sync (row a7), N x nltgv2 step (a2-a5), costs (a6), the
 // per-triangle stage (a8), dense maps / mesh (f1, f2).  The feature pipeline plugs in through
-// FrontEnd (two callbacks: tracked features of the frame; triangulation of the gated features);
-// update() returns false when none is registered, exactly like any other failed update (the
+// FrontEnd (tracked features of the frame; optionally the triangulation of the gated features, whose
+// default is the exact host triangulator of utils/delaunay.h);
+// update() returns false when no `track` is registered, exactly like any other failed update (the
 // frontends warn and skip the frame, src/flame_offline_tum.cc:597-601).  updateGraph() is the GPU
 // tail on its own, for callers that already hold features + triangulation.
 //
