@@ -38,7 +38,8 @@ class DelaunayTriangulator {
  public:
   // false: fewer than 3 distinct points, all points collinear, or a coordinate that is not finite /
   // beyond 2^13 pixels
-  // threads > 1: the top one or two levels of the recursion run on 2 / 4 threads (sets of >= 4096 points;
+  // threads > 1: the top one to three levels of the recursion run on 2 / 4 / 8 threads (sets of >= 4096 points,
+  // 8 threads from 16384;
   // every thread triangulates its part in arrays of its own, the parts are then joined); the result does
   // not depend on the thread count.
   bool triangulate(const std::vector<Point2f>& pts, std::vector<Triangle>* out, int threads = 1) {
@@ -78,7 +79,7 @@ class DelaunayTriangulator {
     std::iota(idx_.begin(), idx_.end(), 0);
     xyp_ = xy_.data();
     int32_t le, re;
-    build(0, n, 0, &le, &re, (threads >= 2 && n >= 4096) ? (threads >= 4 ? 2 : 1) : 0);
+    build(0, n, 0, &le, &re, (threads >= 2 && n >= 4096) ? (threads >= 8 && n >= 16384 ? 3 : (threads >= 4 ? 2 : 1)) : 0);
     // ---- faces: every counter-clockwise 3-cycle of Lnext, once ----
     const int32_t ne = 4 * n_edges_;
     for (int32_t e = 0; e < ne; e += 2) {  // directed edges are the even slots
@@ -103,7 +104,7 @@ class DelaunayTriangulator {
   std::vector<int32_t> order_;
   std::vector<double> xy_;  // (x, y) of the distinct points by rank
   const double* xyp_ = nullptr;  // = xy_.data(), or the parent's when this object triangulates a part for it
-  std::unique_ptr<DelaunayTriangulator> part_[2];  // the triangulators of the left parts (threads > 1), by level
+  std::unique_ptr<DelaunayTriangulator> part_[3];  // the triangulators of the left parts (threads > 1), by level
   std::vector<int32_t> idx_;  // the vertices (ranks) in the order of the recursion's cuts
 
   static int32_t rot(int32_t e) { return (e & ~3) | ((e + 1) & 3); }

@@ -11,7 +11,7 @@ int main() {
     for (auto& q : p) q = flame::Point2f(ux(rng), uy(rng));
     flame::utils::DelaunayTriangulator dt;
     std::vector<flame::Triangle> t, t1;
-    for (int th : {1, 2, 4}) {
+    for (int th : {1, 2, 4, 8}) {
       double best = 1e9;
       for (int r = 0; r < 5; ++r) {
         auto t0 = std::chrono::steady_clock::now();
