@@ -255,6 +255,7 @@ struct flame_hip_graph {
   int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
                                // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
                                // that is solved once pays for its plan, and that is cheapest at depth 4-5
+  int tile_imbalance_pct = 100; // info "tile_imbalance_pct": 100 x max / mean of the tiles' cost (e_loc + 2 n_ext)
   int single_cap = 1 << 30;    // an isolated tile did not fit a graph of this many vertices + 1 on this handle
   bool plan_reused = false;    // the current plan's partition came from the map
   int reuse_tile_own_opt = 0;  // the "tile_own" option the map was made with
@@ -504,6 +505,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "plan_on_device") *value = P.on_device ? 1 : 0;
   else if (k == "plan_reused") *value = (P.on_device && g->plan_reused) ? 1 : 0;
   else if (k == "single_cap") *value = g->single_cap;
+  else if (k == "tile_imbalance_pct") *value = P.on_device ? g->tile_imbalance_pct : 0;
   else if (k == "plan_mini") *value = (P.on_device && g->plan_mini_used) ? 1 : 0;
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
@@ -745,6 +747,14 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   }
   if (!built) return 0;
   lap("plan build");
+  {  // how even the tiles are (a launch lasts as long as its slowest tile): max / mean of the cost model
+    long long sum = 0, mx = 0;
+    for (const TileDesc& D : tiles) {
+      const long long c = (long long)D.e_loc + 2 * (long long)D.n_ext;
+      sum += c; mx = std::max(mx, c);
+    }
+    g->tile_imbalance_pct = sum > 0 ? (int)(100 * mx * (long long)tiles.size() / sum) : 100;
+  }
   if (g->opt.balance && ntiles >= 16) {
     HIPCHK(g->planner.update_grid(s, V, ntiles, in, A));  // cost-density grid + the tile map of this frame
     g->planner.set_map_depth(depth);

@@ -88,6 +88,9 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * reused partition, a predicted edge count -- derives the edges and builds everything in front of the
  * tile pass in ONE launch of one workgroup instead of two dozen dependent ones; flame_hip_get_info
  * "plan_mini" tells whether the current plan was made that way),
+ * (flame_hip_get_info "tile_imbalance_pct": 100 x max / mean of the tiles' modelled cost, local edges + 2 x
+ * local vertices -- a launch lasts as long as its slowest tile; 125-155 on 50 k-vertex frames, the border
+ * tiles' long hull edges)
  * "tile_single_max" (auto: graphs up to this many vertices become ONE LDS-resident tile, default
  * 512, up to 2048; a graph whose tile does not fit after all is partitioned, and the handle stops
  * trying at that size: flame_hip_get_info "single_cap"), "stream_depth" (0 = off, default; > 0: halo
