@@ -325,6 +325,71 @@ def test_small_frames_planned_by_one_launch(gpu):
     a.close(); b.close()
 
 
+def test_small_odd_meshes_through_one_launch(gpu):
+    """Small frames that are not triangulated disks, every frame three times in a row (the third time its edge
+    count is predicted from the offset seen before, which is what admits it to plan_mini): a hub of degree
+    72 (rows longer than the register sorts), holes, vertices no triangle references, a triangle listed
+    twice, two components.  Edges, plan arrays (against a handle with plan_mini = 0) and the solve
+    (against the oracle's sync + iterations) are the same bits."""
+    from flame_ros_amd.regularizer import default_sync_params
+    from oracle import COracle
+    from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
+    sp, p = default_sync_params(), default_params()
+    names = ("v_o2i", "v_i2o", "e_o2i", "e_i2o", "grow", "ginc", "tris", "trow", "tinc", "t_vmap", "t_emap", "t_srow")
+    a = GraphRegularizer.empty(device=0, tile_single_max=1, stream_depth=5)
+    b = GraphRegularizer.empty(device=0, tile_single_max=1, stream_depth=5, plan_mini=0)
+    rng = np.random.default_rng(23)
+    took = {}
+    order = ["disk", "hub", "holes", "isolated", "twice", "two_parts"]
+    # the same frame three times: a wrong edge-count guess, one frame of back-off, then the offset predicts it
+    kinds = ["disk"] + [kk for kk in order[1:] for _ in range(3)] + ["disk"]
+    for k, kind in enumerate(kinds):
+        rng = np.random.default_rng(23 + order.index(kind))
+        pos = (rng.random((1300, 2)) * np.array([640.0, 480.0])).astype(np.float32)
+        if kind == "hub":  # 72 points on a circle, nothing but the centre inside
+            c = np.array([320.0, 240.0])
+            keep = np.linalg.norm(pos - c, axis=1) > 81.0
+            ang = np.arange(72) * (2 * np.pi / 72)
+            ring = c + 80.0 * np.column_stack([np.cos(ang), np.sin(ang)])
+            pos = np.concatenate([pos[keep], ring, c[None]]).astype(np.float32)
+        g = graphgen.from_points(pos, 640, 480, np.random.Generator(np.random.PCG64(40 + order.index(kind))))
+        tris = g.tris
+        if kind == "hub":
+            deg = np.bincount(g.edges.ravel(), minlength=g.V)
+            assert deg[-1] == 72
+        elif kind == "holes":
+            tris = tris[rng.random(len(tris)) > 0.15]
+        elif kind == "isolated":  # every triangle of 40 vertices goes: they stay in the frame without edges
+            gone = rng.choice(g.V, 40, replace=False)
+            tris = tris[~np.isin(tris, gone).any(1)]
+        elif kind == "twice":
+            tris = np.concatenate([tris, tris[100:103]])
+        elif kind == "two_parts":
+            cx = g.pos[tris].mean(1)[:, 0]
+            tris = tris[(cx < 300) | (cx > 330)]
+        tris = np.ascontiguousarray(tris, np.int32)
+        var = np.full(g.V, 1e-4, np.float32)
+        s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, tris, None)
+        for r in (a, b):
+            r.sync_features(g.pos, g.z, var, tris, sp)
+        took.setdefault(kind, []).append(a.info("plan_mini"))
+        assert b.info("plan_mini") == 0 and a.E == len(s["edges"]) == b.E, (k, kind)
+        assert np.array_equal(a.edges(), s["edges"]), (k, kind)
+        if a.info("plan_reused") == b.info("plan_reused"):
+            for nm in names:
+                assert np.array_equal(a.plan_array(nm, np.int32), b.plan_array(nm, np.int32)), (k, kind, nm)
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+        o.solve(oracle_params(), 20)
+        for r in (a, b):
+            r.step(p, 20)
+            x, w1, w2, q = r.download()
+            assert_bit_equal(x, o.x, "frame %d (%s) x" % (k, kind))
+            assert_bit_equal(q, o.q, "frame %d (%s) q" % (k, kind))
+    print("plan_mini per kind:", took)
+    assert all(v[-1] == 1 for kk, v in took.items() if kk != "disk"), took
+    a.close(); b.close()
+
+
 def test_stream_depth_option(gpu):
     """stream_depth replaces the automatic depth 8 of small graphs (<= 2048 vertices) and nothing else."""
     p = default_params()
