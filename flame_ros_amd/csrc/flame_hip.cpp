@@ -654,6 +654,20 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
 #undef STG
     return hipSuccess;
   };
+  // ---- state: written INSIDE the build, right behind the vertex order (stage B) -- the launch is then off
+  // the path between the builder's round trip and the first iteration (a retry writes it again) ----
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dev_alloc(g->caps, &g->A[b], V)) || (rc = dev_alloc(g->caps, &g->B[b], V)) ||
+        (rc = dev_alloc(g->caps, &g->q[b], E)))
+      return rc;
+  }
+  if ((rc = dev_alloc(g->caps, &g->pos, V))) return rc;
+  auto after_order = [&]() -> hipError_t {
+    hipError_t e = stage_rest();
+    if (e != hipSuccess) return e;
+    return launch_init_state(s, V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, have_x0 ? g->in_x0 : nullptr, g->A[0],
+                             g->B[0], g->pos, E > 0 ? E : 1, g->q[0], g->q[1]);
+  };
   int tile_own = sz.tile_own;
   const int depth = sz.depth;
   bool balanced = false, built = false;
@@ -691,7 +705,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
                                        // derivation beside the build) ride on the builder's first sync
     g->planner.expect_edges(g->spec_edges ? E : -1);
     HIPCHK(g->planner.build(s, g->opt, V, E, T, ntiles, depth, in, &A, alloc_tile_arrays, &ctx, &tiles, &ok,
-                            &index_error, g->dflags, uflags, stage_rest));
+                            &index_error, g->dflags, uflags, after_order));
     g->planner.expect_edges(-1);
     if (g->spec_edges && uflags[1] != E) { g->true_edges = uflags[1]; return 2; }  // the predicted edge count was wrong
     if (uflags[0] & 1) return FLAME_HIP_ERR_NAN;
@@ -777,16 +791,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   g->path = FLAME_HIP_PATH_TILE;
   if (!tile_config_exists(cfg_nt, cfg_ept, cfg_vpt)) return FLAME_HIP_ERR_STATE;
   HIPCHK(prepare_tile(cfg_nt, cfg_ept, cfg_vpt, (size_t)lds_max));
-  // ---- state ----
-  for (int b = 0; b < 2; ++b) {
-    if ((rc = dev_alloc(g->caps, &g->A[b], V)) || (rc = dev_alloc(g->caps, &g->B[b], V)) ||
-        (rc = dev_alloc(g->caps, &g->q[b], E)))
-      return rc;
-  }
-  g->cur = 0;
-  if ((rc = dev_alloc(g->caps, &g->pos, V))) return rc;
-  HIPCHK(launch_init_state(s, V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, have_x0 ? g->in_x0 : nullptr, g->A[0],
-                           g->B[0], g->pos, E > 0 ? E : 1, g->q[0], g->q[1]));
+  g->cur = 0;  // (the state was written inside the build: after_order)
   if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)T)))
     return rc;
   if (T == 0) HIPCHK(hipMemsetAsync(g->trow, 0, sizeof(int32_t) * ((size_t)V + 1), s));
@@ -1420,6 +1425,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
   g->timed = true;
+  HIPCHK(g->planner.flush_grid());  // the maps of the NEXT frame's builder: enqueued behind this frame's iterations
   return 0;
 }
 

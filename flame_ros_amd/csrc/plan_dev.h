@@ -136,6 +136,7 @@ class DevPlanner {
   // update_grid() works on the builder's second stream, beside the caller's iterations: host-side wait
   // before anything it reads (positions, tile descriptors, vertex order) or writes is touched again
   hipError_t wait_maps();
+  hipError_t flush_grid();  // enqueue update_grid()'s launches now (no-op when they are out already)
   int grid_tiles() const { return grid_tiles_; }
   void drop_grid() { grid_tiles_ = 0; }
 
@@ -214,6 +215,9 @@ class DevPlanner {
   hipStream_t s2_ = nullptr;
   hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_grid_ = nullptr;
   bool grid_pending_ = false;    // update_grid()'s kernels may still run on s2_
+  bool grid_deferred_ = false;   // ... or have not been enqueued yet (flush_grid())
+  struct GridJob { hipStream_t stream = nullptr; int32_t V = 0; const float2* pos = nullptr; const int32_t* v_i2o = nullptr;
+                   const TileDesc* tiles = nullptr; } grid_job_;
   MiniSync mini_{};
   bool mini_set_ = false, mini_used_ = false;
   int64_t capV2_ = 0;

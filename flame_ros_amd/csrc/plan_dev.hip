@@ -2376,6 +2376,7 @@ static_assert(Plan::kGrid * Plan::kGrid == 1024, "k_grid_final assumes a 32 x 32
 DevPlanner::~DevPlanner() { release(); }
 
 void DevPlanner::release() {
+  grid_deferred_ = false;  // (maps nobody will read)
   (void)wait_maps();
   void* ptrs[] = {cub_tmp_, keys_a_, keys_b_, vals_a_, vals_b_, seg_pos_, tile_of_int_, w_int_, wsort_, wscan_,
                   counts_, seg_tab_, estart_, tile_ext_, tile_meta_, flags_, grid_sum_, grid_cnt_, grid_w_,
@@ -2451,6 +2452,7 @@ hipError_t DevPlanner::scan_i32(hipStream_t s, int lane, const int32_t* in, int3
 }
 
 hipError_t DevPlanner::wait_maps() {
+  HIPRET(flush_grid());
   if (!grid_pending_) return hipSuccess;
   grid_pending_ = false;
   return hipEventSynchronize(ev_grid_);
@@ -3034,26 +3036,39 @@ hipError_t DevPlanner::sync_data(hipStream_t s, int32_t V, const float* mu, cons
 
 hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const DevPlanInputs& in,
                                    const DevPlanArrays& A) {
-  const int n = Plan::kGrid * Plan::kGrid;
   // Only the NEXT build reads these maps: they are made on the second stream, beside the iterations
-  // of this frame instead of in front of them.  Every entry point that touches what they read or
-  // write (the next build, the next edge derivation, the caller's next upload) waits for ev_grid_.
-  hipStream_t g2 = s2_ ? s2_ : s;
+  // of this frame instead of in front of them -- and their launches are ENQUEUED behind the first
+  // iterations too (flush_grid(), called by the solve once its own launches are out; the host's
+  // enqueue time of three launches was in front of the first iteration otherwise).  Every entry point
+  // that touches what they read or write (the next build, the next edge derivation, the caller's next
+  // upload) goes through wait_maps(), which enqueues them if nobody has and waits for ev_grid_.
   if (s2_) {
     HIPRET(hipEventRecord(ev_fork_, s));
     HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
   }
-  zero4(g2, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
-  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, g2, V, in.pos, A.v_i2o, tile_of_int_, A.tiles, gbbox_,
-                     reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_);
+  grid_job_.stream = s2_ ? s2_ : s;
+  grid_job_.V = V; grid_job_.pos = in.pos; grid_job_.v_i2o = A.v_i2o; grid_job_.tiles = A.tiles;
+  grid_deferred_ = true;
   map_tiles_ = ntiles; map_V_ = V;
+  grid_tiles_ = ntiles;
+  return hipSuccess;
+}
+
+hipError_t DevPlanner::flush_grid() {
+  if (!grid_deferred_) return hipSuccess;
+  grid_deferred_ = false;
+  const int n = Plan::kGrid * Plan::kGrid;
+  hipStream_t g2 = grid_job_.stream;
+  const int32_t V = grid_job_.V;
+  zero4(g2, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
+  hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, g2, V, grid_job_.pos, grid_job_.v_i2o, tile_of_int_,
+                     grid_job_.tiles, gbbox_, reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_);
   hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, g2, V, reinterpret_cast<unsigned long long*>(grid_sum_),
                      grid_cnt_, grid_w_, gbbox_, grid_bounds_, cell_pyr_);
   if (s2_) {
     HIPRET(hipEventRecord(ev_grid_, s2_));
     grid_pending_ = true;
   }
-  grid_tiles_ = ntiles;
   return hipGetLastError();
 }
 

@@ -31,9 +31,10 @@ def short(n):
 prev = t0; tot = 0; ntile = 0; tile_t = 0
 for r in rows[i0:]:
     if 'k_tile<' in r['name']:
+        if not ntile: first = (r['s'] - t0) / 1e3, (r['s'] - prev) / 1e3
         ntile += 1; tile_t += r['e'] - r['s']; prev = r['e']; continue
     if ntile:
-        print('   ... %d x k_tile, kernel time %.1f us' % (ntile, tile_t / 1e3)); ntile = 0; tile_t = 0
+        print('%8.1f us  gap %5.1f  ... %d x k_tile, kernel time %.1f us' % (first[0], first[1], ntile, tile_t / 1e3)); ntile = 0; tile_t = 0
     print('%8.1f us  dur %6.1f  gap %5.1f  %s %s' % ((r['s'] - t0) / 1e3, (r['e'] - r['s']) / 1e3, (r['s'] - prev) / 1e3, r['kind'], short(r['name'])))
     prev = r['e']; tot += r['e'] - r['s']
 print('non-tile busy %.1f us, span %.1f us' % (tot / 1e3, (prev - t0) / 1e3))
