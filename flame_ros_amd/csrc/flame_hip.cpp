@@ -256,6 +256,12 @@ struct flame_hip_graph {
   int plan_reuse = 1;          // frame streams: partition from the previous frame's tile map
   int plan_mini = 1;           // option "plan_mini": small frames of a graph sync planned by one launch (k_mini_plan)
   bool plan_mini_used = false; // ... the current plan was
+  // option "persist": graphs of <= kPersistMaxTiles tiles are solved by ONE launch of resident tiles on one XCD
+  // (kernels.hip k_tile_persist); experimental, off by default
+  bool persist = false, persist_used = false;
+  int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [32 + t] XCC ids
+  int32_t* persist_err = nullptr;   // page-locked: raised by the launch (timeout / tiles not on one XCD)
+  int32_t persist_base = 0;         // value of the flags before the next launch
   int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
                                // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
                                // that is solved once pays for its plan, and that is cheapest at depth 4-5
@@ -389,6 +395,8 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     (void)g->planner.wait_maps();
     g->free_device();
+    if (g->persist_sync) (void)hipFree(g->persist_sync);
+    if (g->persist_err) (void)hipHostFree(g->persist_err);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->ev_in) (void)hipEventDestroy(g->ev_in);
@@ -478,6 +486,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "stream_depth") {
     if (value < 0 || value > kMaxDepth) return FLAME_HIP_ERR_ARG;
     g->stream_depth = value;
+  } else if (k == "persist") {
+    static const char* force = std::getenv("FLAME_HIP_PERSIST");  // dev A/B: overrides the caller's choice
+    g->persist = force ? std::atoi(force) != 0 : value != 0;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -512,6 +523,8 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "tile_imbalance_pct") *value = P.on_device ? g->tile_imbalance_pct : 0;
   else if (k == "plan_mini") *value = (P.on_device && g->plan_mini_used) ? 1 : 0;
   else if (k == "stream_depth") *value = g->stream_depth;
+  else if (k == "persist") *value = g->persist ? 1 : 0;
+  else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
     int khz = 0;
@@ -1334,15 +1347,59 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
 
 // Enqueue the launches of `num_iters` PD iterations on stream s, starting from buffer `cur`.
 // Returns the buffer index holding the result through *cur_out.
+// one launch of resident tiles instead of ceil(num_iters / depth) launches?
+static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
+  const Plan& P = g->plan;
+  if (!g->persist || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 || num_iters <= P.tile_depth) return false;
+  const size_t nt = P.tiles.size();
+  if (nt < 2 || nt > (size_t)kPersistMaxTiles || !tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return false;
+  for (const TileDesc& D : P.tiles)
+    if (D.n_ext <= 0) return false;  // (an empty tile would have to take part in the barriers)
+  return true;
+}
+
+static int persist_check(flame_hip_graph* g) {  // after a synchronisation: did a persistent launch give up?
+  if (!g->persist_err || *g->persist_err == 0) return 0;
+  *g->persist_err = 0;
+  g->persist = false;  // (not on this device / not now: the launches per round from here on)
+  g->uploaded = false; // the state is that of an unfinished solve
+  return FLAME_HIP_ERR_STATE;
+}
+
 static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t num_iters,
                               hipStream_t s, int cur, int* cur_out, int* launches) {
   const Plan& P = g->plan;
   *launches = 0;
+  g->persist_used = false;
   if (g->path == FLAME_HIP_PATH_TILE) {
     TileArgs a;
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
+    if (persist_applies(g, num_iters)) {
+      if (!g->persist_sync) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g->persist_sync), sizeof(int32_t) * 2 * kPersistMaxTiles));
+        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * 2 * kPersistMaxTiles, s));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
+        *g->persist_err = 0;
+        g->persist_base = 0;
+      }
+      const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
+      if (g->persist_base > (1 << 30)) {  // (the counter only grows)
+        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * kPersistMaxTiles, s));
+        g->persist_base = 0;
+      }
+      a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];
+      a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
+      a.iters = num_iters;
+      HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, g->persist_sync,
+                                 g->persist_err, g->persist_base));
+      g->persist_base += rounds - 1;
+      g->persist_used = true;
+      *launches = 1;
+      *cur_out = cur ^ (rounds & 1);
+      return 0;
+    }
     const int per = P.tile_depth > 0 ? P.tile_depth : num_iters;
     for (int32_t done = 0; done < num_iters;) {
       const int32_t n = std::min<int32_t>(per, num_iters - done);
@@ -1395,7 +1452,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   HIPCHK(hipEventRecord(g->ev0, s));
   int launches = 0, cur_out = g->cur;
   if (num_iters > 0 && g->V > 0) {
-    if (g->use_graph && g->solves_since_upload > 0) {  // a frame stream that re-uploads before
+    if (g->use_graph && g->solves_since_upload > 0 && !persist_applies(g, num_iters)) {  // a frame stream that re-uploads before
       // every solve never pays capture + instantiate; the captured launches replay on any stream
       // (the subdomain solver of the multi-GPU path passes its own)
       GraphExecEntry* hit = nullptr;
@@ -1444,7 +1501,7 @@ int flame_hip_sync(flame_hip_graph* g) {
   HIPCHK(hipSetDevice(g->device));
   if (g->timed) HIPCHK(hipEventSynchronize(g->ev1));
   HIPCHK(hipStreamSynchronize(g->stream));
-  return 0;
+  return persist_check(g);
 }
 
 int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches) {
@@ -1692,6 +1749,7 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     }
   }
   HIPCHK(hipStreamSynchronize(s));
+  if ((rc = persist_check(g))) return rc;
   if (smooth || data) {
     const double* h = reinterpret_cast<const double*>(host + off_part);
     double sm = 0.0, da = 0.0;

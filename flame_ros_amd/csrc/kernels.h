@@ -37,6 +37,14 @@ hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes
 bool tile_config_exists(int nt, int ept, int vpt);
 // one-time per configuration: opt in to > 48 KiB of dynamic LDS (not capturable in a hipGraph)
 hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes);
+// persistent tiles (one launch for the whole solve; graphs of <= kPersistMaxTiles tiles, all on one XCD):
+// a.iters = the TOTAL iteration count, rounds of `depth` iterations inside; sync: 64 ints of device memory,
+// 128-byte aligned ([t] = round flag of tile t, only grows: base = its value before the launch), err_host:
+// page-locked word
+constexpr int kPersistMaxTiles = 32;
+bool tile_persist_exists(int nt, int ept, int vpt);
+hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, int32_t* sync,
+                               int32_t* err_host, int32_t base);
 
 // ---- costs: per-block float64 partial sums (partials[2*b] smooth, [2*b+1] data) ----
 int costs_num_blocks(int32_t V, int32_t E);

@@ -258,28 +258,37 @@ struct SlotTail<0> {
 // Explicit parameters, hottest first: the first 16 dwords of the kernel arguments are preloaded into
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16, flame_ros_amd/build.py), so the
 // tile descriptor's address is known at cycle 0 instead of two scalar round trips later.
-template <int NT, int EPT, int VPT>
-__global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_arg,
-                                             const int32_t* __restrict__ t_vmap,
-                                             const uint32_t* __restrict__ t_srow,
-                                             const uint2* __restrict__ t_eij,
-                                             const int32_t* __restrict__ t_emap,
-                                             const float4* __restrict__ t_ew,
-                                             const float4* __restrict__ B_src,
-                                             const float4* __restrict__ A_src,
-                                             const float4* __restrict__ q_src, float4* __restrict__ A_dst,
-                                             float4* __restrict__ B_dst, float4* __restrict__ q_dst,
-                                             unsigned long long* prof_arg, const SolveParams p_arg) {
-  TileArgs a;
-  a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
-  a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
-  a.p = p_arg; a.iters = iters_arg; a.ntiles = ntiles; a.prof = prof_arg;
+// PERSIST (k_tile_persist, graphs of <= 32 tiles): the tiles stay resident for the WHOLE solve.  Block b runs on
+// XCD b % 8, the grid has 8 x ntiles blocks and only b % 8 == 0 works: every tile sits on ONE XCD, whose L2 is
+// then the point of coherence -- a round (= what a launch is otherwise: `depth` iterations) ends with the own
+// results written through to L2, one counter barrier over the tiles and a re-read of the halo state with
+// agent-scope loads (L1 miss, L2 hit); no kernel boundary, no reload of the constants or the own state, no
+// fences (tools/exp/xcd_handoff_probe.hip: 0.8 us per hand-off of 4 KB on one XCD; over all XCDs it is not
+// coherent without L2 write-back / invalidate).  Same arithmetic in the same order as the launches it replaces.
+struct PersistArgs {
+  int32_t* sync;      // [t] round flag of tile t (one 128-byte line), [32 + t] XCC id of tile t (device memory)
+  int32_t* err_host;  // page-locked: set when a wait timed out or the tiles were spread over XCDs
+  int32_t base;       // the flags' value before this launch (they only grow)
+};
+
+__device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the CU's L1, served by the XCD's L2
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                     __uint_as_float((uint32_t)(hi >> 32)));
+}
+
+template <int NT, int EPT, int VPT, bool PERSIST>
+__device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware block -> tile map (speed only): block b runs on XCD b % 8, tiles are numbered in
   // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
   // makes tiles that share halo vertices / edges share one L2.  Bijective for any tile count.
   const int nt_all = a.ntiles, xq = nt_all >> 3, xr = nt_all & 7, xcd = blockIdx.x & 7;
-  const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  if (PERSIST && xcd != 0) return;
+  const int tile_id = PERSIST ? (int)(blockIdx.x >> 3)
+                              : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
   const TileDesc& D = a.tiles[tile_id];
   const int tid = threadIdx.x;
   // the whole descriptor header up front, before anything with side effects: the compiler then
@@ -396,7 +405,11 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
   const float sigma = a.p.sigma, ntau = -a.p.tau, theta = a.p.theta;
   const f2v nt2 = {ntau, ntau}, th2 = {theta, theta};
   const float x_min = a.p.x_min, x_max = a.p.x_max;
-  const int iters = a.iters;
+  __shared__ int s_abort;
+  if (PERSIST && tid == 0) s_abort = 0;
+  int done = 0, round = 0;
+  for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
+  const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
   for (int it = 1; it <= iters; ++it) {
     const int rem = iters - it;
     // Active sets are prefixes (vertices by ring, edges by level).  Lanes past the cutoff inside
@@ -441,8 +454,13 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
-      store_result(&a.A_dst[vstart + lv], vx[k], vw[k].x, vw[k].y, vz[k]);
-      store_result(&a.B_dst[vstart + lv], vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
+      if (PERSIST) {  // (plain stores: written through the L1 and acknowledged by the XCD's L2, which is all a round needs)
+        a.A_dst[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, vz[k]);
+        a.B_dst[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
+      } else {
+        store_result(&a.A_dst[vstart + lv], vx[k], vw[k].x, vw[k].y, vz[k]);
+        store_result(&a.B_dst[vstart + lv], vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
+      }
     }
   }
 #pragma unroll
@@ -450,10 +468,117 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
     const int le = k * NT + tid;
     // owned <=> the edge's internal id lies in the tile's range (lanes inside a 64-edge block are
     // assigned by the plan's conflict-avoiding lane order, not by internal id)
-    if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own)
-      store_result(&a.q_dst[qi[k]], q1[k], q23[k].x, q23[k].y, 0.0f);
+    if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own) {
+      if (PERSIST) a.q_dst[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, 0.0f);
+      else store_result(&a.q_dst[qi[k]], q1[k], q23[k].x, q23[k].y, 0.0f);
+    }
   }
-  if (prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
+  if (!PERSIST) break;
+  done += iters;
+  ++round;
+  if (done >= a.iters) break;
+  // ---- end of a round: results in L2, barrier over the tiles, halo state of the next round ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // barrier over the tiles: every tile raises its own flag (all flags share one 128-byte line; no read-modify-
+  // write -- a counter that 32 tiles add to serialises at the L2's atomic unit), the lanes of the first wave
+  // watch one flag each
+  if (tid < 64) {
+    const int32_t target = pa.base + round;
+    if (tid == 0) {
+      if (round == 1) __hip_atomic_store(&pa.sync[32 + tile_id], (int32_t)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) + 1,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // HW_REG_XCC_ID
+      __hip_atomic_store(&pa.sync[tile_id], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long w0 = wall_clock64();
+    const int watch = min(tid, a.ntiles - 1);
+    for (;;) {
+      const bool there = __hip_atomic_load(&pa.sync[watch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0;
+      if (__all(there)) break;
+      if (wall_clock64() - w0 > 400000ull) {  // 4 ms: give up, never hang
+        if (tid == 0) { s_abort = 1; *pa.err_host = 1; }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (tid == 0 && round == 1 && !s_abort &&
+        __hip_atomic_load(&pa.sync[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+            __hip_atomic_load(&pa.sync[32 + tile_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      *pa.err_host = 2;  // not on one XCD: the reads below are not coherent -- the host discards this solve
+  }
+  __syncthreads();
+  if (s_abort) break;
+  {  // what this round wrote is what the next one reads
+    const float4* t;
+    t = a.A_src; a.A_src = a.A_dst; a.A_dst = const_cast<float4*>(t);
+    t = a.B_src; a.B_src = a.B_dst; a.B_dst = const_cast<float4*>(t);
+    t = a.q_src; a.q_src = a.q_dst; a.q_dst = const_cast<float4*>(t);
+  }
+  // (every load goes out before the first one is consumed; lanes that keep their own value read the tile's
+  // first own vertex / their own edge -- a select on the address, not a branch around the load)
+  float4 nb[VPT], na[VPT], nq[EPT];
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int lv = k * NT + tid;
+    const bool halo = lv >= n_own && lv < n_ext;
+    nb[k] = load_agent(&a.B_src[halo ? gi[k] : vstart]);
+    na[k] = load_agent(&a.A_src[(halo && lv < n_upd) ? gi[k] : vstart]);
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&a.q_src[e_loc > 0 ? qi[k] : 0]);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int lv = k * NT + tid;
+    if (lv >= n_own && lv < n_ext) {  // halo vertices: the owners' results of this round
+      vxb[k] = nb[k].x; vwb[k].x = nb[k].y; vwb[k].y = nb[k].z;
+      bar[lv] = make_float4(nb[k].y, nb[k].z, nb[k].x, 0.f);
+      if (lv < n_upd) { vx[k] = na[k].x; vw[k].x = na[k].y; vw[k].y = na[k].z; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int le = k * NT + tid;
+    if (le < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own)) {  // halo edges
+      q1[k] = nq[k].x; q23[k].x = nq[k].y; q23[k].y = nq[k].z;
+    }
+  }
+  __syncthreads();
+  }  // rounds
+  if (!PERSIST && prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
+}
+
+template <int NT, int EPT, int VPT>
+__global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_arg,
+                                             const int32_t* __restrict__ t_vmap,
+                                             const uint32_t* __restrict__ t_srow,
+                                             const uint2* __restrict__ t_eij,
+                                             const int32_t* __restrict__ t_emap,
+                                             const float4* __restrict__ t_ew,
+                                             const float4* __restrict__ B_src,
+                                             const float4* __restrict__ A_src,
+                                             const float4* __restrict__ q_src, float4* __restrict__ A_dst,
+                                             float4* __restrict__ B_dst, float4* __restrict__ q_dst,
+                                             unsigned long long* prof_arg, const SolveParams p_arg) {
+  TileArgs a;
+  a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
+  a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
+  a.p = p_arg; a.iters = iters_arg; a.ntiles = ntiles; a.prof = prof_arg;
+  tile_body<NT, EPT, VPT, false>(a, PersistArgs{nullptr, nullptr, 0});
+}
+
+// (no __restrict__ on the state arrays: a round reads what the previous one wrote)
+template <int NT, int EPT, int VPT>
+__global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_total,
+                                                     const int32_t* __restrict__ t_vmap, const uint32_t* __restrict__ t_srow,
+                                                     const uint2* __restrict__ t_eij, const int32_t* __restrict__ t_emap,
+                                                     const float4* __restrict__ t_ew, const float4* B_src, const float4* A_src,
+                                                     const float4* q_src, float4* A_dst, float4* B_dst, float4* q_dst,
+                                                     PersistArgs pa, const SolveParams p_arg) {
+  TileArgs a;
+  a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
+  a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
+  a.p = p_arg; a.iters = iters_total; a.ntiles = ntiles; a.prof = nullptr;
+  tile_body<NT, EPT, VPT, true>(a, pa);
 }
 
 template <int NT, int EPT, int VPT>
@@ -1279,6 +1404,38 @@ hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes
   if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_t<N, Ep, Vp>(s, lds_bytes, a);
   FLAME_TILE_CFGS(X)
+#undef X
+  return hipErrorInvalidConfiguration;
+}
+
+// persistent variant: the configurations small graphs get
+#define FLAME_PERSIST_CFGS(X) X(256, 2, 1) X(256, 3, 1) X(512, 2, 1) X(512, 3, 1) X(1024, 2, 1) X(1024, 3, 1)
+
+bool tile_persist_exists(int nt, int ept, int vpt) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return true;
+  FLAME_PERSIST_CFGS(X)
+#undef X
+  return false;
+}
+
+template <int NT, int EPT, int VPT>
+hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, int32_t* sync, int32_t* err_host, int32_t base) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  PersistArgs pa{sync, err_host, base};
+  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT>), dim3(8 * a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
+                     a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, pa, a.p);
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, int32_t* sync,
+                               int32_t* err_host, int32_t base) {
+  if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes, a, sync, err_host, base);
+  FLAME_PERSIST_CFGS(X)
 #undef X
   return hipErrorInvalidConfiguration;
 }
