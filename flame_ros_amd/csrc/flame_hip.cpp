@@ -525,6 +525,13 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "persist") *value = g->persist ? 1 : 0;
   else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
+  else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF): 10 ns ticks of tile 0, summed over rounds
+    const int i = std::atoi(k.c_str() + 13);
+    int32_t v = 0;
+    if (i < 0 || i > 4 || !g->persist_sync) return FLAME_HIP_ERR_ARG;
+    if (hipMemcpy(&v, g->persist_sync + 66 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
+    *value = v;
+  }
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
     int khz = 0;
@@ -1378,8 +1385,12 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.prof = g->prof;
     if (persist_applies(g, num_iters)) {
       if (!g->persist_sync) {
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g->persist_sync), sizeof(int32_t) * 2 * kPersistMaxTiles));
-        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * 2 * kPersistMaxTiles, s));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g->persist_sync), sizeof(int32_t) * 128));
+        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * 128, s));
+        if (std::getenv("FLAME_HIP_PERSIST_PROF")) {  // dev aid: tile 0 sums where its rounds' time goes ([66..70])
+          const int32_t one = 1;
+          HIPCHK(hipMemcpyAsync(g->persist_sync + 64, &one, sizeof(one), hipMemcpyHostToDevice, s));
+        }
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
         *g->persist_err = 0;
         g->persist_base = 0;

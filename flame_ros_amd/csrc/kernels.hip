@@ -407,6 +407,9 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   const float x_min = a.p.x_min, x_max = a.p.x_max;
   __shared__ int s_abort;
   if (PERSIST && tid == 0) s_abort = 0;
+  const bool pprof = PERSIST && tile_id == 0 && pa.sync[64] != 0;  // (dev aid, see the end of the round)
+  unsigned long long pround = pprof ? wall_clock64() : 0ull;
+  int32_t pacc[4] = {0, 0, 0, 0};
   int done = 0, round = 0;
   for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
   const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
@@ -478,8 +481,10 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   ++round;
   if (done >= a.iters) break;
   // ---- end of a round: results in L2, barrier over the tiles, halo state of the next round ----
+  const unsigned long long pt0 = pprof ? wall_clock64() : 0ull;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  const unsigned long long pt1 = pprof ? wall_clock64() : 0ull;
   // barrier over the tiles: every tile raises its own flag (all flags share one 128-byte line; no read-modify-
   // write -- a counter that 32 tiles add to serialises at the L2's atomic unit), the lanes of the first wave
   // watch one flag each
@@ -508,6 +513,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
   __syncthreads();
   if (s_abort) break;
+  const unsigned long long pt2 = pprof ? wall_clock64() : 0ull;
   {  // what this round wrote is what the next one reads
     const float4* t;
     t = a.A_src; a.A_src = a.A_dst; a.A_dst = const_cast<float4*>(t);
@@ -517,15 +523,37 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   // (every load goes out before the first one is consumed; lanes that keep their own value read the tile's
   // first own vertex / their own edge -- a select on the address, not a branch around the load)
   float4 nb[VPT], na[VPT], nq[EPT];
+  if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice the
+    const bool halo = tid >= n_own && tid < n_ext;  // requests, and the re-read is bound by their number)
+    const float4* pb = &a.B_src[halo ? gi[0] : vstart];
+    const float4* pv = &a.A_src[(halo && tid < n_upd) ? gi[0] : vstart];
+    const float4* p0 = &a.q_src[e_loc > 0 ? qi[0] : 0];
+    const float4* p1 = &a.q_src[e_loc > 0 ? qi[1] : 0];
+    const float4* p2 = &a.q_src[e_loc > 0 ? qi[EPT - 1] : 0];
+    f4v r0, r1, r2, r3, r4;
+    asm volatile(
+        "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
+        "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
+        "global_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+        : "v"(pb), "v"(pv), "v"(p0), "v"(p1), "v"(p2)
+        : "memory");
+    nb[0] = make_float4(r0.x, r0.y, r0.z, r0.w);
+    na[0] = make_float4(r1.x, r1.y, r1.z, r1.w);
+    nq[0] = make_float4(r2.x, r2.y, r2.z, r2.w);
+    nq[1] = make_float4(r3.x, r3.y, r3.z, r3.w);
+    nq[EPT - 1] = make_float4(r4.x, r4.y, r4.z, r4.w);
+  } else {
 #pragma unroll
-  for (int k = 0; k < VPT; ++k) {
-    const int lv = k * NT + tid;
-    const bool halo = lv >= n_own && lv < n_ext;
-    nb[k] = load_agent(&a.B_src[halo ? gi[k] : vstart]);
-    na[k] = load_agent(&a.A_src[(halo && lv < n_upd) ? gi[k] : vstart]);
+    for (int k = 0; k < VPT; ++k) {
+      const int lv = k * NT + tid;
+      const bool halo = lv >= n_own && lv < n_ext;
+      nb[k] = load_agent(&a.B_src[halo ? gi[k] : vstart]);
+      na[k] = load_agent(&a.A_src[(halo && lv < n_upd) ? gi[k] : vstart]);
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&a.q_src[e_loc > 0 ? qi[k] : 0]);
   }
-#pragma unroll
-  for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&a.q_src[e_loc > 0 ? qi[k] : 0]);
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
@@ -543,7 +571,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     }
   }
   __syncthreads();
+  if (pprof) {  // dev aid: where a round's time goes (10 ns ticks, summed over the rounds of tile 0)
+    const unsigned long long pt3 = wall_clock64();
+    pacc[0] += (int32_t)(pt0 - pround); pacc[1] += (int32_t)(pt1 - pt0); pacc[2] += (int32_t)(pt2 - pt1); pacc[3] += (int32_t)(pt3 - pt2);
+    pround = pt3;
+  }
   }  // rounds
+  if (PERSIST && pprof && tid == 0) {
+    pa.sync[66] = pacc[0]; pa.sync[67] = pacc[1]; pa.sync[68] = pacc[2]; pa.sync[69] = pacc[3]; pa.sync[70] = round;
+  }
   if (!PERSIST && prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
 
