@@ -101,7 +101,8 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * boundary; same bits; flame_hip_get_info "persist_used" tells whether the last solve ran that way; a
  * launch that could not keep its tiles on one XCD or waited longer than 4 ms makes the next
  * synchronising call return FLAME_HIP_ERR_STATE, switches the option off and leaves the graph to be
- * uploaded again; dev aid: with FLAME_HIP_PERSIST_PROF set in the environment flame_hip_get_info
+ * uploaded again -- two handles solving this way at the same time on one device can starve each
+ * other of the XCD's CUs and end in exactly that time-out; dev aid: with FLAME_HIP_PERSIST_PROF set in the environment flame_hip_get_info
  * "persist_prof_0".."persist_prof_4" return tile 0's time split of the last solve's rounds in 10 ns ticks:
  * iterations, store acknowledge, flags, halo re-read, and the number of rounds), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
