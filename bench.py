@@ -174,6 +174,29 @@ def frames_axis(device, batch=256, win=16, steps=5):
             "note": "one workgroup (one CU) per frame, all 200 iterations in one launch"}
 
 
+def small_graphs(device):
+    """Resident small graph (1 200 vertices, the TUM-shaped config 1): microseconds per PD iteration with the
+    default plan (launches of `depth` iterations) and with option persist (one launch of tiles resident on one
+    XCD; ~24 tiles, depth 5), device time of the best of 8 solves each.  r02 verdict item 2's target: <= 0.9."""
+    from flame_ros_amd import graphgen
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+    g, _ = graphgen.named("tum")
+    pr = default_params()
+    out = {"vertices": g.V, "iters": 200}
+    for key, kw in (("launches", {}), ("persist", dict(persist=1, tile_own=50, tile_depth=5))):
+        try:
+            with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=device, **kw) as r:
+                best = 1e9
+                for _ in range(8):
+                    r.step(pr, 200)
+                    best = min(best, r.last_solve_ms()[0])
+                out[key] = {"us_per_iteration": best * 1e3 / 200, "tiles": r.info("num_tiles"), "depth": r.info("tile_depth"),
+                            "persist_used": r.info("persist_used")}
+        except Exception as e:  # noqa: BLE001 -- a side measurement
+            out[key] = {"error": str(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -472,6 +495,7 @@ def main():
                                               "facade with reference-default params (debug draws enabled), "
                                               "tools/facade_bench.cc; targets 0.6 / 1.0 / 2.2 ms")
             out["frames_axis"] = frames_axis(local_rank)
+            out["small_graph_us_per_iteration"] = small_graphs(local_rank)
         if not args.no_cpu and world == 1:  # contract: rank 0 at N=1 only
             cb = cpu_baseline(args.workload, args.batch_win if args.batch else 0, iters, args.cpu_budget)
             out["cpu_baseline"] = cb

@@ -14,5 +14,6 @@ print('roofline', {k: rl.get(k) for k in ('bound','contract_bound','achieved','f
 print('phase', {k: rl['phase_split'][k] for k in ('load','iterate','store','boundary_us')})
 print('facade', {k: v.get('update_ms_p50') for k, v in d['facade_frame_ms'].items() if isinstance(v, dict)})
 print('frames_axis', d['frames_axis']['frame_iterations_per_s'], 'host_inclusive', d['host_inclusive']['ms_per_frame'])
+print('small', d.get('small_graph_us_per_iteration'))
 print('cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('cores'), 'parity', d['parity_vs_oracle']['bit_exact'])
 PY
