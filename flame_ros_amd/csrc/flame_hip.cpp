@@ -259,9 +259,15 @@ struct flame_hip_graph {
   // option "persist": graphs of <= kPersistMaxTiles tiles are solved by ONE launch of resident tiles on one XCD
   // (kernels.hip k_tile_persist); experimental, off by default
   bool persist = false, persist_used = false;
+  bool persist_sizing = false;  // option value 2: frames of 897..1280 vertices go on tiles of 50 own vertices (<= 26 tiles)
   int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [32 + t] XCC ids
   int32_t* persist_err = nullptr;   // page-locked: raised by the launch (timeout / tiles not on one XCD)
   int32_t persist_base = 0;         // value of the flags before the next launch
+  SolveParams last_sp{};            // the last solve (a persistent launch that gave up is repeated by launches)
+  int32_t last_iters = 0;
+  hipStream_t last_stream = nullptr;
+  bool init_have_x0 = false;        // the device-built plan's initial state came with an x0 array
+  int persist_recovered = 0;        // how many solves were repeated that way (flame_hip_get_info)
   int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
                                // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
                                // that is solved once pays for its plan, and that is cheapest at depth 4-5
@@ -488,7 +494,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     g->stream_depth = value;
   } else if (k == "persist") {
     static const char* force = std::getenv("FLAME_HIP_PERSIST");  // dev A/B: overrides the caller's choice
-    g->persist = force ? std::atoi(force) != 0 : value != 0;
+    const int v = force ? std::atoi(force) : value;
+    g->persist = v != 0;
+    g->persist_sizing = v == 2;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -525,6 +533,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "persist") *value = g->persist ? 1 : 0;
   else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
+  else if (k == "persist_recovered") *value = g->persist_recovered;
   else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF): 10 ns ticks of tile 0, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
     int32_t v = 0;
@@ -600,8 +609,14 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   // staged: the inputs are already in the in_* device buffers (graph sync on the device)
   const int32_t V = g->V, E = g->E, T = (tris || (staged && g->T > 0)) ? g->T : 0;
   if (!staged) have_x0 = x0 != nullptr;
+  g->init_have_x0 = have_x0;
   Plan& P = g->plan;
-  const PlanSizing sz = plan_sizing(g->opt, V, E);
+  PlanSizing sz = plan_sizing(g->opt, V, E);
+  // option persist = 2 (the facade's): where one launch of resident tiles wins on a frame stream -- 1.0-1.2 k vertices
+  // on 20-24 tiles of 50 own vertices (tools/exp/persist_frames.py: 0.446 -> 0.417 ms; 1.4 k: 0.476 -> 0.512) -- the
+  // graph is cut that way
+  if (g->persist && g->persist_sizing && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() && !sz.single && V <= 1280)
+    sz.tile_own = 50;
   if (!g->plan_device || g->opt.path == FLAME_HIP_PATH_GLOBAL ||
       !DevPlanner::eligible(g->opt, V, E, T, sz.tile_own, sz.depth, sz.single, g->opt.lds_bytes))
     return 0;
@@ -1365,12 +1380,39 @@ static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
   return true;
 }
 
-static int persist_check(flame_hip_graph* g) {  // after a synchronisation: did a persistent launch give up?
+static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t num_iters, hipStream_t s, int cur,
+                              int* cur_out, int* launches);
+
+// After a synchronisation: did a persistent launch give up (a wait timed out, tiles on several XCDs)?  Returns 0
+// when there was nothing, 1 when the solve was REPEATED by ordinary launches (enqueued, not yet waited for: the
+// caller synchronises again and redoes what it had queued behind the solve), an error code when it cannot be --
+// only the first solve of a device-built plan can: its initial state is re-derived from the staged inputs.
+static int persist_check(flame_hip_graph* g, bool scaled_ok = false) {  // (scaled_ok: the caller resets an un-scaling itself)
+  static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
+  if (force_fail && g->persist_used && g->persist_err) *g->persist_err = 3;
   if (!g->persist_err || *g->persist_err == 0) return 0;
   *g->persist_err = 0;
   g->persist = false;  // (not on this device / not now: the launches per round from here on)
-  g->uploaded = false; // the state is that of an unfinished solve
-  return FLAME_HIP_ERR_STATE;
+  const bool can = g->persist_used && g->plan.on_device && g->solves_since_upload == 1 && (scaled_ok || g->state_scale == 1.0f) &&
+                   g->last_iters > 0 && g->in_pos && g->in_z && g->in_wgt && (!g->init_have_x0 || g->in_x0);
+  g->persist_used = false;
+  if (!can) {
+    g->uploaded = false;  // the state is that of an unfinished solve
+    return FLAME_HIP_ERR_STATE;
+  }
+  hipStream_t s = g->last_stream ? g->last_stream : g->stream;
+  HIPCHK(launch_init_state(s, g->V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, g->init_have_x0 ? g->in_x0 : nullptr,
+                           g->A[0], g->B[0], g->pos, g->E > 0 ? g->E : 1, g->q[0], g->q[1]));
+  int cur_out = 0, launches = 0;
+  HIPCHK(hipEventRecord(g->ev0, s));
+  int rc = enqueue_iterations(g, g->last_sp, g->last_iters, s, 0, &cur_out, &launches);
+  if (rc) return rc;
+  g->cur = cur_out;
+  g->state_serial++;
+  g->last_launches = launches;
+  HIPCHK(hipEventRecord(g->ev1, s));
+  ++g->persist_recovered;
+  return 1;
 }
 
 static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t num_iters,
@@ -1461,6 +1503,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
     g->lanes_applied = true;
   }
   HIPCHK(hipEventRecord(g->ev0, s));
+  g->last_sp = sp; g->last_iters = num_iters; g->last_stream = s;
   int launches = 0, cur_out = g->cur;
   if (num_iters > 0 && g->V > 0) {
     if (g->use_graph && g->solves_since_upload > 0 && !persist_applies(g, num_iters)) {  // a frame stream that re-uploads before
@@ -1512,7 +1555,13 @@ int flame_hip_sync(flame_hip_graph* g) {
   HIPCHK(hipSetDevice(g->device));
   if (g->timed) HIPCHK(hipEventSynchronize(g->ev1));
   HIPCHK(hipStreamSynchronize(g->stream));
-  return persist_check(g);
+  rc = persist_check(g);
+  if (rc == 1) {  // the solve was repeated by launches: wait for those
+    HIPCHK(hipEventSynchronize(g->ev1));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    rc = 0;
+  }
+  return rc;
 }
 
 int flame_hip_last_solve_ms(flame_hip_graph* g, float* ms, int32_t* launches) {
@@ -1675,6 +1724,7 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
                             const float Kinv[9], const flame_hip_tri_params* tp, double* smooth, double* data,
                             float* x, float* vtx_normals, uint8_t* tri_valid, int32_t* edges, float* coverage) {
   RoctxRange roctx_("flame_hip_frame_results");
+  const float scale_back_arg = scale_back;
   int rc = require_device(g);
   if (rc) return rc;
   if (((smooth || data) && !p) || ((vtx_normals || tri_valid || coverage) && (!Kinv || !tp)) || !std::isfinite(scale_back))
@@ -1760,7 +1810,13 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     }
   }
   HIPCHK(hipStreamSynchronize(s));
-  if ((rc = persist_check(g))) return rc;
+  if ((rc = persist_check(g, true)) != 0) {
+    if (rc != 1) return rc;
+    // the solve was repeated by launches (its state is the initial one again, un-scaled): the whole call once more
+    g->state_scale = 1.0f;
+    g->raster_serial = 0;
+    return flame_hip_frame_results(g, p, scale_back_arg, Kinv, tp, smooth, data, x, vtx_normals, tri_valid, edges, coverage);
+  }
   if (smooth || data) {
     const double* h = reinterpret_cast<const double*>(host + off_part);
     double sm = 0.0, da = 0.0;

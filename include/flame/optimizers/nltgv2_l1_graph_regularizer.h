@@ -96,6 +96,9 @@ class Graph {
     // 0.51-0.58 vs 0.56-0.66 ms).
     (void)flame_hip_set_option(g_, "tile_single_max", 896);
     (void)flame_hip_set_option(g_, "stream_depth", 5);
+    // frames of 0.9-1.28 k vertices: ~24 tiles resident on one XCD for the whole solve (one launch; a launch that
+    // gives up is repeated the ordinary way) -- 0.446 -> 0.417 ms per 1.2 k frame (tools/exp/persist_frames.py)
+    (void)flame_hip_set_option(g_, "persist", 2);
     device_ = device;
     return 0;
   }

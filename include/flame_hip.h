@@ -96,15 +96,18 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * trying at that size: flame_hip_get_info "single_cap"), "stream_depth" (0 = off, default; > 0: halo
  * depth of graphs of up to 2048 vertices in place of the automatic 8 -- for handles that solve every
  * graph ONCE, where the plan of shallow tiles is cheaper than the launches deep tiles save), "persist"
- * (experimental, default 0: a graph of 2..32 tiles is solved by ONE launch of tiles resident on one XCD
- * -- a flag barrier and a re-read of the halo through L2 per `depth` iterations instead of a kernel
- * boundary; same bits; flame_hip_get_info "persist_used" tells whether the last solve ran that way; a
- * launch that could not keep its tiles on one XCD or waited longer than 4 ms makes the next
- * synchronising call return FLAME_HIP_ERR_STATE, switches the option off and leaves the graph to be
- * uploaded again -- two handles solving this way at the same time on one device can starve each
- * other of the XCD's CUs and end in exactly that time-out; dev aid: with FLAME_HIP_PERSIST_PROF set in the environment flame_hip_get_info
- * "persist_prof_0".."persist_prof_4" return tile 0's time split of the last solve's rounds in 10 ns ticks:
- * iterations, store acknowledge, flags, halo re-read, and the number of rounds), "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
+ * (default 0; 1: a graph of 2..32 tiles is solved by ONE launch of tiles resident on one XCD -- a flag
+ * barrier and a re-read of the halo through L2 per `depth` iterations instead of a kernel boundary, same
+ * bits; 2 (what flame::Flame sets): also cuts frames of up to 1280 vertices into tiles of 50 own vertices,
+ * the shape it pays for on a frame stream; flame_hip_get_info "persist_used" tells whether the last solve
+ * ran that way.  A launch that could not keep its tiles on one XCD or waited longer than 4 ms -- e.g. two
+ * handles solving this way at once on one device starving each other of the XCD's CUs -- is noticed at the
+ * next synchronising call, which switches the option off and REPEATS the solve by ordinary launches when it
+ * was the first solve of a device-built plan ("persist_recovered" counts those), else returns
+ * FLAME_HIP_ERR_STATE and leaves the graph to be uploaded again; dev aid: with FLAME_HIP_PERSIST_PROF set
+ * in the environment "persist_prof_0".."persist_prof_4" return tile 0's time split of the last solve's
+ * rounds in 10 ns ticks: iterations, store acknowledge, flags, halo re-read, and the number of rounds),
+ * "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
  * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile",
  * "d_sign" ([UPSTREAM-RECALL] switch: +1 (default) the edge vector entering K1 is d = pos_i - pos_j,

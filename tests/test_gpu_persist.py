@@ -45,3 +45,43 @@ def test_persist_not_taken_on_larger_graphs(gpu):
     o = make_oracle(g); o.solve(oracle_params(), 50)
     assert_bit_equal(r.download()[0], o.x, "x")
     r.close()
+
+
+def test_a_persistent_solve_that_gives_up_is_repeated_by_launches(gpu):
+    """FLAME_HIP_PERSIST_FAIL makes the library treat every persistent launch as failed (what a time-out or
+    tiles on several XCDs raise): the first solve of a device-built plan is repeated by ordinary launches from
+    the staged inputs -- through flame_hip_sync (download) and through frame_results -- with the oracle's bits;
+    the handle stops using the option."""
+    import os, subprocess, sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from flame_ros_amd import graphgen
+from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_sync_params, default_tri_params
+from oracle import COracle
+from oracle.cbind import default_params as oparams, SyncParams as OSync, graph_sync as oracle_sync
+g, _ = graphgen.named("tum")
+p, sp = default_params(), default_sync_params()
+sp.rescale_data = 0
+var = np.full(g.V, 1e-4, np.float32)
+s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
+o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"]); o.solve(oparams(), 60)
+Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
+for via in ("sync", "frame_results"):
+    r = GraphRegularizer.empty(device=0, tile_own=50, tile_depth=5, persist=1)
+    scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
+    r.step(p, 60, sync=False)
+    assert r.info("persist_used") == 1
+    if via == "sync":
+        x = r.download()[0]
+    else:
+        out = r.frame_results(p, Kinv, default_tri_params(g.width, g.height), scale_back=scale, with_edges=True, with_coverage=True)
+        x = out["x"] if isinstance(out, dict) else out[2]
+    assert r.info("persist_recovered") == 1 and r.info("persist") == 0, via
+    assert np.array_equal(np.asarray(x).view(np.uint32), o.x.view(np.uint32)), via
+    r.close()
+print("recovered ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLAME_HIP_PERSIST_FAIL="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "recovered ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

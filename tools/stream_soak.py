@@ -11,7 +11,9 @@ from oracle import COracle
 from tests.util import oracle_params, bits
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(11)
-r = GraphRegularizer.empty(device=0, tile_single_max=2048)
+# (argv[2] = "facade": the options flame::Flame sets -- small frames on halo tiles, 0.9-1.28 k vertices on persistent tiles)
+opts = dict(tile_single_max=896, stream_depth=5, persist=2) if len(sys.argv) > 2 and sys.argv[2] == "facade" else dict(tile_single_max=2048)
+r = GraphRegularizer.empty(device=0, **opts)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
 p, sp = default_params(), default_sync_params()
 free0 = torch.cuda.mem_get_info()[0]
@@ -21,13 +23,14 @@ for k in range(n):
     if k % 7 in (3, 4, 5) and k > 0:
         V = max(200, int(V * rng.uniform(0.95, 1.05)))
     else:
-        V = int(rng.choice([300, 900, 1500, 2600, 5000, 12000, 30000], p=[.15, .25, .2, .15, .1, .1, .05]))
+        V = int(rng.choice([300, 900, 1100, 1500, 2600, 5000, 12000, 30000], p=[.15, .15, .15, .15, .15, .1, .1, .05]))
     g = graphgen.synthetic(V, seed=1000 + k)
     var = np.full(g.V, 1e-4, np.float32)
     scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
     r.step(p, 60, sync=False)
     out = r.frame_results(p, Kinv, default_tri_params(g.width, g.height), scale_back=scale, with_edges=True, with_coverage=True)
     reused = reused + r.info("plan_reused") if k else 0
+    persisted = (persisted if k else 0) + r.info("persist_used")
     if k % 25 == 0 or (k % 7 == 4 and k % 3 == 0):
         s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
         o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"]); o.solve(oracle_params(), 60)
@@ -35,5 +38,5 @@ for k in range(n):
         print("frame %4d V %6d  plan_on_device %d reused %d  bad words %d" % (k, V, r.info("plan_on_device"), r.info("plan_reused"), nb), flush=True)
 dt = time.perf_counter() - t0
 free1 = torch.cuda.mem_get_info()[0]
-print("frames %d in %.1f s (incl. graph generation); %d plans from a reused partition; device memory in use changed by %.1f MiB; bad words %d" % (n, dt, reused, (free0 - free1) / 2**20, bad))
+print("frames %d in %.1f s (incl. graph generation); %d plans from a reused partition; device memory in use changed by %.1f MiB; bad words %d; %d solves on persistent tiles, %d of them repeated" % (n, dt, reused, (free0 - free1) / 2**20, bad, persisted, r.info("persist_recovered")))
 r.close()
