@@ -97,6 +97,7 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
 // runtime, call by call -- ~10 us each, the larger part of a small frame's upload).
 // frame_results: outputs up to this size are written to host memory by the kernels themselves (measured on
 // the facade stream, direct vs one copy: 1.2 k -14 us, 5 k -10 us, 10 k (185 KB) -15 us, 50 k (925 KB) +65 us)
+constexpr int kMapMinTiles = 6;  // partitions of at least this many tiles leave a tile map for the next frame (partition reuse)
 constexpr size_t kDirectOutBytes = 256 * 1024;
 
 struct PinnedArena {
@@ -808,7 +809,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     }
     g->tile_imbalance_pct = sum > 0 ? (int)(100 * mx * (long long)tiles.size() / sum) : 100;
   }
-  if (g->opt.balance && ntiles >= 16) {
+  if (g->opt.balance && ntiles >= kMapMinTiles) {  // (the cost grid only serves >= 16 tiles, the tile map any count)
     HIPCHK(g->planner.update_grid(s, V, ntiles, in, A));  // cost-density grid + the tile map of this frame
     g->planner.set_map_depth(depth);
     g->reuse_tile_own_opt = g->opt.tile_own;

@@ -94,7 +94,9 @@ class Graph {
     // at 910); above, a few dozen halo tiles planned on the GPU do (1 200 vertices: 0.51 vs 0.64 ms),
     // and with halo depth 5 rather than the 8 a resident graph of <= 64 tiles gets (1.2-2 k vertices:
     // 0.51-0.58 vs 0.56-0.66 ms).
-    (void)flame_hip_set_option(g_, "tile_single_max", 896);
+    // (r03, persistent tiles: the crossover moved down again -- 700 vertices 0.428 ms on one tile vs 0.412 on 14
+    // persistent tiles, 850: 0.479 vs 0.400, 500: 0.354 vs 0.370, tools/exp/persist_small.py)
+    (void)flame_hip_set_option(g_, "tile_single_max", 640);
     (void)flame_hip_set_option(g_, "stream_depth", 5);
     // frames of 0.9-1.28 k vertices: ~24 tiles resident on one XCD for the whole solve (one launch; a launch that
     // gives up is repeated the ordinary way) -- 0.446 -> 0.417 ms per 1.2 k frame (tools/exp/persist_frames.py)

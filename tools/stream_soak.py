@@ -12,7 +12,7 @@ from tests.util import oracle_params, bits
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(11)
 # (argv[2] = "facade": the options flame::Flame sets -- small frames on halo tiles, 0.9-1.28 k vertices on persistent tiles)
-opts = dict(tile_single_max=896, stream_depth=5, persist=2) if len(sys.argv) > 2 and sys.argv[2] == "facade" else dict(tile_single_max=2048)
+opts = dict(tile_single_max=640, stream_depth=5, persist=2) if len(sys.argv) > 2 and sys.argv[2] == "facade" else dict(tile_single_max=2048)
 r = GraphRegularizer.empty(device=0, **opts)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
 p, sp = default_params(), default_sync_params()
