@@ -65,7 +65,24 @@ __global__ __launch_bounds__(512) void probe(int* flags, float4* pay, unsigned l
   if (acc == -1.f) out[tile] = 0;
 }
 
+// block b -> XCC id (HW_REG_XCC_ID, hwreg 20, bits 3:0): the rule the single-XCD placement relies on
+__global__ void xcc_of_block(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15);
+}
+
 int main() {
+  {
+    int* d; int h[64];
+    hipMalloc(&d, sizeof(h));
+    hipLaunchKernelGGL(xcc_of_block, dim3(64), dim3(64), 0, 0, d);
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    std::printf("XCC id of blocks 0..23:");
+    for (int b = 0; b < 24; ++b) std::printf(" %d", h[b]);
+    bool rr = true;
+    for (int b = 8; b < 64; ++b) rr = rr && h[b] == h[b - 8];
+    std::printf("   (block b and b + 8 on the same XCC for all 64 blocks: %s)\n", rr ? "yes" : "NO");
+    hipFree(d);
+  }
   const int rounds = 200, work = 300;  // 3 us of "iterations" per round
   int* flags; float4* pay; unsigned long long* out;
   const int max_tiles = 256;
