@@ -1394,6 +1394,8 @@ static int persist_check(flame_hip_graph* g, bool scaled_ok = false) {  // (scal
   if (!g->persist_err || *g->persist_err == 0) return 0;
   *g->persist_err = 0;
   g->persist = false;  // (not on this device / not now: the launches per round from here on)
+  (void)hipFree(g->persist_sync);  // (the flags of an unfinished launch: a handle that gets the option again starts from zeroed ones)
+  g->persist_sync = nullptr;
   const bool can = g->persist_used && g->plan.on_device && g->solves_since_upload == 1 && (scaled_ok || g->state_scale == 1.0f) &&
                    g->last_iters > 0 && g->in_pos && g->in_z && g->in_wgt && (!g->init_have_x0 || g->in_x0);
   g->persist_used = false;
@@ -1434,7 +1436,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
           const int32_t one = 1;
           HIPCHK(hipMemcpyAsync(g->persist_sync + 64, &one, sizeof(one), hipMemcpyHostToDevice, s));
         }
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
+        if (!g->persist_err) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
         *g->persist_err = 0;
         g->persist_base = 0;
       }
