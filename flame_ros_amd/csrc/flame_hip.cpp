@@ -258,7 +258,7 @@ struct flame_hip_graph {
   int plan_mini = 1;           // option "plan_mini": small frames of a graph sync planned by one launch (k_mini_plan)
   bool plan_mini_used = false; // ... the current plan was
   // option "persist": graphs of <= kPersistMaxTiles tiles are solved by ONE launch of resident tiles on one XCD
-  // (kernels.hip k_tile_persist); experimental, off by default
+  // (kernels.hip k_tile_persist); off by default (flame::Flame sets 2)
   bool persist = false, persist_used = false;
   bool persist_sizing = false;  // option value 2: frames of 897..1280 vertices go on tiles of 50 own vertices (<= 26 tiles)
   int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [32 + t] XCC ids
