@@ -260,7 +260,7 @@ struct flame_hip_graph {
   // option "persist": graphs of <= kPersistMaxTiles tiles are solved by ONE launch of resident tiles on one XCD
   // (kernels.hip k_tile_persist); off by default (flame::Flame sets 2)
   bool persist = false, persist_used = false;
-  bool persist_sizing = false;  // option value 2: frames of 897..1280 vertices go on tiles of 50 own vertices (<= 26 tiles)
+  bool persist_sizing = false;  // option value 2: frames of up to 1280 vertices (above tile_single_max) go on tiles of 50 own vertices (<= 26 tiles)
   int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [32 + t] XCC ids
   int32_t* persist_err = nullptr;   // page-locked: raised by the launch (timeout / tiles not on one XCD)
   int32_t persist_base = 0;         // value of the flags before the next launch
