@@ -84,17 +84,28 @@ int main() {
     hipFree(d);
   }
   const int rounds = 200, work = 300;  // 3 us of "iterations" per round
-  int* flags; float4* pay; unsigned long long* out;
   const int max_tiles = 256;
-  hipMalloc(&flags, sizeof(int) * 32 * (max_tiles + 2));
-  hipMalloc(&pay, sizeof(float4) * 2 * max_tiles * kPay);
+  // memory kinds: ordinary device memory (cached in every XCD's L2), and the two kinds the runtime offers for
+  // data shared while kernels run -- what tiles spread over ALL XCDs would need
+  for (int kind = 0; kind < 3; ++kind) {
+  int* flags; float4* pay; unsigned long long* out;
+  const unsigned mflag = kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+  const size_t fb = sizeof(int) * 32 * (max_tiles + 2), pb = sizeof(float4) * 2 * max_tiles * kPay;
+  if (kind == 0) { hipMalloc(&flags, fb); hipMalloc(&pay, pb); }
+  else if (hipExtMallocWithFlags((void**)&flags, fb, mflag) != hipSuccess || hipExtMallocWithFlags((void**)&pay, pb, mflag) != hipSuccess) {
+    std::printf("memory kind %d not available\n", kind);
+    continue;
+  }
+  std::printf("---- flags and payload in %s ----\n", kind == 0 ? "ordinary device memory" : kind == 1 ? "uncached device memory" : "fine-grained device memory");
   hipMalloc(&out, sizeof(unsigned long long) * max_tiles);
   std::vector<unsigned long long> h(max_tiles);
   struct Cfg { const char* name; int single, ntiles, exchange; };
   const Cfg cfgs[] = {{"no exchange, 38 tiles on XCD 0", 1, 38, 0},       {"exchange, 38 tiles on XCD 0", 1, 38, 1},
                       {"exchange, 32 tiles on XCD 0", 1, 32, 1},          {"exchange, 16 tiles on XCD 0", 1, 16, 1},
-                      {"exchange, 38 tiles over all XCDs", 0, 38, 1},     {"exchange, 256 tiles over all XCDs", 0, 256, 1}};
+                      {"exchange, 38 tiles over all XCDs", 0, 38, 1},     {"exchange, 128 tiles over all XCDs", 0, 128, 1},
+                      {"exchange, 256 tiles over all XCDs", 0, 256, 1}};
   for (const Cfg& c : cfgs) {
+    if (kind != 0 && c.single && c.ntiles != 38) continue;
     for (int rep = 0; rep < 2; ++rep) {
       hipMemset(flags, 0, sizeof(int) * 32 * (max_tiles + 2));
       hipMemset(out, 0, sizeof(unsigned long long) * max_tiles);
@@ -110,6 +121,8 @@ int main() {
     std::sort(per.begin(), per.end());
     std::printf("%-36s per round beyond the %.1f us of work: median %.2f us, max %.2f us; stale payload words %d, timeouts %d\n", c.name,
                 work * 0.01, per[c.ntiles / 2], per[c.ntiles - 1], herr[0], herr[1]);
+  }
+  hipFree(flags); hipFree(pay); hipFree(out);
   }
   return 0;
 }
