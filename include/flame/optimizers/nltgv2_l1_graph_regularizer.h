@@ -98,7 +98,7 @@ class Graph {
     // persistent tiles, 850: 0.479 vs 0.400, 500: 0.354 vs 0.370, tools/exp/persist_small.py)
     (void)flame_hip_set_option(g_, "tile_single_max", 640);
     (void)flame_hip_set_option(g_, "stream_depth", 5);
-    // frames of 0.9-1.28 k vertices: ~24 tiles resident on one XCD for the whole solve (one launch; a launch that
+    // frames of 0.64-1.28 k vertices: 13-26 tiles resident on one XCD for the whole solve (one launch; a launch that
     // gives up is repeated the ordinary way) -- 0.446 -> 0.417 ms per 1.2 k frame (tools/exp/persist_frames.py)
     (void)flame_hip_set_option(g_, "persist", 2);
     device_ = device;
