@@ -11,9 +11,11 @@ import csv, sys, json
 w, f = sys.argv[1], sys.argv[2]
 rows = list(csv.DictReader(open(f)))
 frames = 4 * (25 + 3)
-line = open('gpurun_out/pf_%s.log' % w).read().strip().splitlines()[-1]
-try: upd = json.loads(line)[w]['update_ms']['p50']
-except Exception: upd = None
+upd = None
+for line in open('gpurun_out/pf_%s.log' % w).read().splitlines():  # (rocprofv3 logs behind the bench's JSON line)
+    if line.startswith('{"'):
+        try: upd = json.loads(line)[w]['update_ms']['p50']
+        except Exception: pass
 with open('gpurun_out/r03_frames_%s_summary.md' % w, 'w') as o:
     o.write('## rocprofv3 --kernel-trace --stats (python tools/facade_bench.py --workloads %s --repeats 25): %d frames of flame::Flame::update, p50 %s ms under the profiler\n\n' % (w, frames, upd))
     o.write('| kernel | calls | calls per frame | avg us | total ms |\n|---|---|---|---|---|\n')
