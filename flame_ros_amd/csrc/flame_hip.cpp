@@ -721,6 +721,8 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   bool try_reuse = g->plan_reuse && g->opt.balance && g->planner.map_usable(V, depth) &&
                    g->opt.tile_own == g->reuse_tile_own_opt;
   if (try_reuse && g->reuse_skip > 0) { --g->reuse_skip; try_reuse = false; }  // back-off after rejections
+  // (a frame that is to go on persistent tiles does not inherit a partition of more tiles than one XCD takes)
+  if (try_reuse && g->persist && g->persist_sizing && sz.tile_own == 50 && g->planner.map_tiles() > kPersistMaxTiles) try_reuse = false;
   g->plan_reused = false;
   for (int attempt = 0; attempt < 8 + kBalanceRefinePasses && !built; ++attempt) {
     const bool reusing = try_reuse;

@@ -85,3 +85,31 @@ print("recovered ok")
     env = dict(os.environ, FLAME_HIP_PERSIST_FAIL="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "recovered ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_facade_sized_frames_on_persistent_tiles(gpu):
+    """The options flame::Flame sets (tile_single_max 640, stream_depth 5, persist 2) on a stream of frames
+    around the thresholds: 600 vertices -> one isolated tile, 650..1280 -> tiles of 50 own vertices solved by
+    ONE launch, 1300 -> halo tiles and launches; every frame the oracle's bits."""
+    from flame_ros_amd.regularizer import default_sync_params
+    from oracle import COracle
+    from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
+    r = GraphRegularizer.empty(device=0, tile_single_max=640, stream_depth=5, persist=2)
+    p, sp = default_params(), default_sync_params()
+    seen = []
+    for k, V in enumerate((600, 1300, 650, 900, 900, 1280, 1280, 1000, 1000)):
+        g = graphgen.synthetic(V, seed=300 + k)
+        var = np.full(g.V, 1e-4, np.float32)
+        s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+        o.solve(oracle_params(), 47)
+        r.sync_features(g.pos, g.z, var, g.tris, sp)
+        r.step(p, 47)
+        seen.append((V, r.info("num_tiles"), r.info("persist_used")))
+        x, w1, w2, q = r.download()
+        assert_bit_equal(x, o.x, "V %d x" % V); assert_bit_equal(q, o.q, "V %d q" % V)
+    assert seen[0][1] == 1 and seen[0][2] == 0, seen          # one isolated tile
+    assert seen[1][2] == 0 and seen[1][1] > 32, seen           # 1300 vertices: halo tiles, launches
+    assert all(u == 1 and 13 <= t <= 26 for V, t, u in seen[2:]), seen  # (the 41-tile partition is not inherited)
+    assert r.info("persist_recovered") == 0
+    r.close()
