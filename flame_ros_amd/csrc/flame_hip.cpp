@@ -269,6 +269,7 @@ struct flame_hip_graph {
   hipStream_t last_stream = nullptr;
   bool init_have_x0 = false;        // the device-built plan's initial state came with an x0 array
   int persist_recovered = 0;        // how many solves were repeated that way (flame_hip_get_info)
+  uint64_t solve_serial = 0;        // state_serial right behind the last solve: later state-writing calls move on from it
   int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
                                // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
                                // that is solved once pays for its plan, and that is cheapest at depth 4-5
@@ -1390,7 +1391,9 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
 // when there was nothing, 1 when the solve was REPEATED by ordinary launches (enqueued, not yet waited for: the
 // caller synchronises again and redoes what it had queued behind the solve), an error code when it cannot be --
 // only the first solve of a device-built plan can: its initial state is re-derived from the staged inputs.
-static int persist_check(flame_hip_graph* g, bool scaled_ok = false) {  // (scaled_ok: the caller resets an un-scaling itself)
+// own_marks: state-writing steps the CALLER itself queued behind the solve and will redo (frame_results' un-scaling);
+// anything else that wrote the state since (a graph filter, new data terms) cannot be replayed here
+static int persist_check(flame_hip_graph* g, int own_marks = 0, bool scaled_ok = false) {
   static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
   if (force_fail && g->persist_used && g->persist_err) *g->persist_err = 3;
   if (!g->persist_err || *g->persist_err == 0) return 0;
@@ -1399,6 +1402,7 @@ static int persist_check(flame_hip_graph* g, bool scaled_ok = false) {  // (scal
   (void)hipFree(g->persist_sync);  // (the flags of an unfinished launch: a handle that gets the option again starts from zeroed ones)
   g->persist_sync = nullptr;
   const bool can = g->persist_used && g->plan.on_device && g->solves_since_upload == 1 && (scaled_ok || g->state_scale == 1.0f) &&
+                   g->state_serial == g->solve_serial + (uint64_t)own_marks &&
                    g->last_iters > 0 && g->in_pos && g->in_z && g->in_wgt && (!g->init_have_x0 || g->in_x0);
   g->persist_used = false;
   if (!can) {
@@ -1546,6 +1550,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   }
   g->cur = cur_out;
   g->state_serial++;
+  g->solve_serial = g->state_serial;
   g->last_launches = launches;
   g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
@@ -1815,7 +1820,7 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     }
   }
   HIPCHK(hipStreamSynchronize(s));
-  if ((rc = persist_check(g, true)) != 0) {
+  if ((rc = persist_check(g, scale_back != 1.0f ? 1 : 0, true)) != 0) {
     if (rc != 1) return rc;
     // the solve was repeated by launches (its state is the initial one again, un-scaled): the whole call once more
     g->state_scale = 1.0f;

@@ -61,13 +61,14 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_
 from oracle import COracle
 from oracle.cbind import default_params as oparams, SyncParams as OSync, graph_sync as oracle_sync
 g, _ = graphgen.named("tum")
-p, sp = default_params(), default_sync_params()
-sp.rescale_data = 0
+p = default_params()
 var = np.full(g.V, 1e-4, np.float32)
-s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
-o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"]); o.solve(oparams(), 60)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
-for via in ("sync", "frame_results"):
+for via, rescale in (("sync", 0), ("frame_results", 0), ("frame_results", 1)):  # (rescale: frame_results un-scales behind the solve)
+    sp = default_sync_params(0, rescale, 1, 0.01)
+    s = oracle_sync(OSync(0, rescale, 1, 0.01), g.pos, g.z, var, g.tris, None)
+    o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"]); o.solve(oparams(), 60)
+    if via == "frame_results": o.scale_state(s["scale"])
     r = GraphRegularizer.empty(device=0, tile_own=50, tile_depth=5, persist=1)
     scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
     r.step(p, 60, sync=False)
