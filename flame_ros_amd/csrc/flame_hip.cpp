@@ -72,6 +72,24 @@ int dev_alloc(CapMap& caps, T** p, size_t n) {
   return 0;
 }
 
+// ... in UNCACHED device memory (hipDeviceMallocUncached: no L2 holds it, so stores and loads of different XCDs meet in
+// memory while a kernel runs -- the mirrors and flags of the resident tiles over all XCDs, kernels.hip PersistArgs)
+template <class T>
+int dev_alloc_uncached(CapMap& caps, T** p, size_t n) {
+  n += 1;
+  const size_t bytes = n * sizeof(T);
+  auto it = caps.find((void*)p);
+  if (*p && it != caps.end() && it->second >= bytes) return 0;
+  if (*p && it != caps.end()) (void)hipFree(*p);
+  *p = nullptr;
+  const size_t want = bytes + bytes / 4;
+  hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(p), want, hipDeviceMallocUncached);
+  if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
+  if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
+  caps[(void*)p] = want;
+  return 0;
+}
+
 // All copies go through the handle's own non-blocking stream (hipMemcpyAsync + stream sync),
 // never the legacy stream: a legacy-stream copy in one host thread collides with a stream capture
 // running in another thread (hipErrorStreamCaptureImplicit), and distinct handles must be usable
@@ -185,6 +203,7 @@ struct flame_hip_graph {
   int32_t V = 0, E = 0, T = 0;
   bool uploaded = false;
   PlanOptions opt;
+  int num_cus = 0;
   int use_graph = 1;
   Plan plan;
   SyncOut sync;          // inputs derived by flame_hip_graph_sync (kept for flame_hip_graph_edges)
@@ -261,7 +280,12 @@ struct flame_hip_graph {
   // (kernels.hip k_tile_persist); off by default (flame::Flame sets 2)
   bool persist = false, persist_used = false;
   bool persist_sizing = false;  // option value 2: frames of up to 1280 vertices (above tile_single_max) go on tiles of 50 own vertices (<= 26 tiles)
-  int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [32 + t] XCC ids
+  // option value 3: also graphs of 33 .. 256 tiles, resident over ALL XCDs (k_tile_persist mode 2: L2 hand-offs inside an
+  // XCD's eighth of the tiles, uncached mirrors across; kernels.h XPersist)
+  bool persist_all = false;
+  XPersist xp;                      // buffers of that mode (registered in caps)
+  int persist_mode_used = 0;        // 1 / 2: what the last solve ran as
+  int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [256 + t] XCC ids, [512..] dev aid
   int32_t* persist_err = nullptr;   // page-locked: raised by the launch (timeout / tiles not on one XCD)
   int32_t persist_base = 0;         // value of the flags before the next launch
   SolveParams last_sp{};            // the last solve (a persistent launch that gave up is repeated by launches)
@@ -383,6 +407,7 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
       return FLAME_HIP_ERR_NODEVICE;
     }
     g->opt.lds_bytes = (int64_t)prop.sharedMemPerBlock > 0 ? (int64_t)prop.sharedMemPerBlock : 64 * 1024;
+    g->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
@@ -498,7 +523,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     static const char* force = std::getenv("FLAME_HIP_PERSIST");  // dev A/B: overrides the caller's choice
     const int v = force ? std::atoi(force) : value;
     g->persist = v != 0;
-    g->persist_sizing = v == 2;
+    g->persist_sizing = v >= 2;
+    g->persist_all = v >= 3;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -534,13 +560,13 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "plan_mini") *value = (P.on_device && g->plan_mini_used) ? 1 : 0;
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "persist") *value = g->persist ? 1 : 0;
-  else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
+  else if (k == "persist_used") *value = g->persist_used ? g->persist_mode_used : 0;
   else if (k == "persist_recovered") *value = g->persist_recovered;
   else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF): 10 ns ticks of tile 0, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
     int32_t v = 0;
     if (i < 0 || i > 4 || !g->persist_sync) return FLAME_HIP_ERR_ARG;
-    if (hipMemcpy(&v, g->persist_sync + 66 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
+    if (hipMemcpy(&v, g->persist_sync + 514 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
     *value = v;
   }
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
@@ -1374,14 +1400,20 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
 // Enqueue the launches of `num_iters` PD iterations on stream s, starting from buffer `cur`.
 // Returns the buffer index holding the result through *cur_out.
 // one launch of resident tiles instead of ceil(num_iters / depth) launches?
-static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
+// 0: no; 1: all tiles on one XCD (<= kPersistMaxTiles); 2: over all XCDs (option value 3, <= kXPersistMaxTiles and <= one per CU)
+static int persist_applies(const flame_hip_graph* g, int32_t num_iters) {
   const Plan& P = g->plan;
-  if (!g->persist || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 || num_iters <= P.tile_depth) return false;
+  if (!g->persist || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 || num_iters <= P.tile_depth) return 0;
   const size_t nt = P.tiles.size();
-  if (nt < 2 || nt > (size_t)kPersistMaxTiles || !tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return false;
+  if (nt < 2 || !tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return 0;
+  int mode = 1;
+  if (nt > (size_t)kPersistMaxTiles) {
+    if (!g->persist_all || nt > (size_t)kXPersistMaxTiles || (int)nt > g->num_cus) return 0;
+    mode = 2;
+  }
   for (const TileDesc& D : P.tiles)
-    if (D.n_ext <= 0) return false;  // (an empty tile would have to take part in the barriers)
-  return true;
+    if (D.n_ext <= 0) return 0;  // (an empty tile would have to take part in the hand-offs)
+  return mode;
 }
 
 static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t num_iters, hipStream_t s, int cur,
@@ -1434,30 +1466,53 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
-    if (persist_applies(g, num_iters)) {
+    if (const int pmode = persist_applies(g, num_iters)) {
       if (!g->persist_sync) {
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g->persist_sync), sizeof(int32_t) * 128));
-        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * 128, s));
-        if (std::getenv("FLAME_HIP_PERSIST_PROF")) {  // dev aid: tile 0 sums where its rounds' time goes ([66..70])
-          const int32_t one = 1;
-          HIPCHK(hipMemcpyAsync(g->persist_sync + 64, &one, sizeof(one), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g->persist_sync), sizeof(int32_t) * kPersistSyncInts));
+        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * kPersistSyncInts, s));
+        if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) {  // dev aid: tile <value - 1> sums where its rounds' time goes ([514..518])
+          const int32_t w[2] = {1, std::max(0, std::atoi(pp) - 1)};
+          HIPCHK(hipMemcpyAsync(g->persist_sync + 512, w, sizeof(w), hipMemcpyHostToDevice, s));
         }
         if (!g->persist_err) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
         *g->persist_err = 0;
         g->persist_base = 0;
       }
       const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
-      if (g->persist_base > (1 << 30)) {  // (the counter only grows)
-        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * kPersistMaxTiles, s));
+      if (g->persist_base > (1 << 30)) {  // (the flags only grow)
+        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * 256, s));
+        for (int b = 0; b < 2; ++b) {  // (the hand-off tags restart with the flags)
+          float4** pp[3] = {&g->xp.hA[b], &g->xp.hB[b], &g->xp.hq[b]};
+          for (float4** q : pp)
+            if (*q) HIPCHK(hipMemsetAsync(*q, 0, g->caps[(void*)q], s));
+        }
         g->persist_base = 0;
       }
       a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];
       a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
       a.iters = num_iters;
-      HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, g->persist_sync,
-                                 g->persist_err, g->persist_base));
+      if (pmode == 2) {
+        XPersist& x = g->xp;
+        int rc;
+        for (int b = 0; b < 2; ++b) {  // (a buffer that had to grow comes back zeroed: tag 0 is never a round's)
+          float4** pp[3] = {&x.hA[b], &x.hB[b], &x.hq[b]};
+          const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
+          for (int k = 0; k < 3; ++k) {
+            float4* before = *pp[k];
+            if ((rc = dev_alloc_uncached(g->caps, pp[k], nn[k]))) return rc;
+            if (*pp[k] != before) HIPCHK(hipMemsetAsync(*pp[k], 0, g->caps[(void*)pp[k]], s));
+          }
+        }
+        x.sync = g->persist_sync;
+        HIPCHK(launch_tile_xpersist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
+                                    g->persist_base));
+      } else {
+        HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, g->persist_sync,
+                                   g->persist_err, g->persist_base));
+      }
       g->persist_base += rounds - 1;
       g->persist_used = true;
+      g->persist_mode_used = pmode;
       *launches = 1;
       *cur_out = cur ^ (rounds & 1);
       return 0;

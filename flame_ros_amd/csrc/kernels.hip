@@ -266,9 +266,22 @@ struct SlotTail<0> {
 // fences (tools/exp/xcd_handoff_probe.hip: 0.8 us per hand-off of 4 KB on one XCD; over all XCDs it is not
 // coherent without L2 write-back / invalidate).  Same arithmetic in the same order as the launches it replaces.
 struct PersistArgs {
-  int32_t* sync;      // [t] round flag of tile t (one 128-byte line), [32 + t] XCC id of tile t (device memory)
-  int32_t* err_host;  // page-locked: set when a wait timed out or the tiles were spread over XCDs
+  int32_t* sync;      // ordinary device memory: [t] round flag of tile t, [256 + t] XCC id + 1 of tile t, [512..] dev aid
+  int32_t* err_host;  // page-locked: set when a wait timed out or tiles that share an L2 hand-off were not on one XCD
   int32_t base;       // the flags' value before this launch (they only grow)
+  // ---- mode 2 (33..256 tiles over ALL XCDs, one resident workgroup each, any placement) ----
+  // The L2s of different XCDs are not coherent, so what a tile hands to its neighbours travels through UNCACHED
+  // hand-off copies of the state arrays (hipDeviceMallocUncached: no L2 holds them, stores and loads meet in memory).
+  // No flags, no drain, no barrier over the tiles: every 16-byte entry carries the round it belongs to in its 4th
+  // word (z, the data weight and the dual's padding are constants a reader already has), an owner simply stores
+  // {value, base + round} and a reader polls the entries of its halo until their tags are this round's.  Buffers
+  // alternate with the round's parity; an owner can only reach round r + 2 after every reader of its round-r
+  // entries has published round r + 1 (the halo relation is symmetric), so two buffers are enough.  A 16-byte
+  // aligned store / load is one request inside one 32-byte sector (observed untorn on gfx950, MI355X guide, "R2";
+  // the parity tests compare every bit of 10^8 hand-offs).  The state arrays proper are written by the last round only.
+  float4* hA[2];
+  float4* hB[2];
+  float4* hq[2];
 };
 
 __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the CU's L1, served by the XCD's L2
@@ -279,16 +292,17 @@ __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the C
                      __uint_as_float((uint32_t)(hi >> 32)));
 }
 
-template <int NT, int EPT, int VPT, bool PERSIST>
+// PERSIST 0: one launch = `depth` iterations; 1: resident tiles on ONE XCD; 2: resident tiles over all XCDs
+template <int NT, int EPT, int VPT, int PERSIST>
 __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware block -> tile map (speed only): block b runs on XCD b % 8, tiles are numbered in
   // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
   // makes tiles that share halo vertices / edges share one L2.  Bijective for any tile count.
   const int nt_all = a.ntiles, xq = nt_all >> 3, xr = nt_all & 7, xcd = blockIdx.x & 7;
-  if (PERSIST && xcd != 0) return;
-  const int tile_id = PERSIST ? (int)(blockIdx.x >> 3)
-                              : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  if (PERSIST == 1 && xcd != 0) return;
+  const int g_first = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;  // first tile of this XCD's eighth
+  const int tile_id = PERSIST == 1 ? (int)(blockIdx.x >> 3) : g_first + (int)(blockIdx.x >> 3);
   const TileDesc& D = a.tiles[tile_id];
   const int tid = threadIdx.x;
   // the whole descriptor header up front, before anything with side effects: the compiler then
@@ -303,6 +317,8 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   asm volatile("" ::"s"(vstart), "s"(estart), "s"(nslots), "s"(vmap_off), "s"(emap_off), "s"(erec_off),
                "s"(srow_off), "s"(n_own), "s"(n_upd), "s"(e_own), "s"(e_loc), "s"(depth));
   if (n_ext == 0) return;  // empty tile (more tiles than vertices)
+  const int32_t my_xcc = PERSIST == 1 ? (int32_t)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) + 1 : 0;  // HW_REG_XCC_ID
+  if (PERSIST == 1 && threadIdx.x == 0) __hip_atomic_store(&pa.sync[256 + tile_id], my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float4* bar = reinterpret_cast<float4*>(smem);
   float4* cs = bar + n_ext;  // nslots + kDummySlots incidence slots
   const int lane = tid & 63;
@@ -407,7 +423,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   const float x_min = a.p.x_min, x_max = a.p.x_max;
   __shared__ int s_abort;
   if (PERSIST && tid == 0) s_abort = 0;
-  const bool pprof = PERSIST && tile_id == 0 && pa.sync[64] != 0;  // (dev aid, see the end of the round)
+  const bool pprof = PERSIST && pa.sync[512] != 0 && tile_id == pa.sync[513];  // (dev aid, see the end of the round)
   unsigned long long pround = pprof ? wall_clock64() : 0ull;
   int32_t pacc[4] = {0, 0, 0, 0};
   int done = 0, round = 0;
@@ -453,13 +469,20 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
 
   // ---- write back what this tile owns ----
+  // (mode 2, every round but the last: not the state arrays but the uncached hand-off copies, tagged with the round)
+  const bool last_round = !PERSIST || done + iters >= a.iters;
+  const bool handoff = PERSIST == 2 && !last_round;
+  const float tagf = __int_as_float(pa.base + round + 1);
+  float4* const oA = handoff ? pa.hA[(round + 1) & 1] : a.A_dst;
+  float4* const oB = handoff ? pa.hB[(round + 1) & 1] : a.B_dst;
+  float4* const oq = handoff ? pa.hq[(round + 1) & 1] : a.q_dst;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
-      if (PERSIST) {  // (plain stores: written through the L1 and acknowledged by the XCD's L2, which is all a round needs)
-        a.A_dst[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, vz[k]);
-        a.B_dst[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
+      if (PERSIST) {  // (plain stores: mode 1 -- through the L1, acknowledged by the XCD's L2, which is all a round needs)
+        oA[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, handoff ? tagf : vz[k]);
+        oB[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, handoff ? tagf : vwgt[k]);
       } else {
         store_result(&a.A_dst[vstart + lv], vx[k], vw[k].x, vw[k].y, vz[k]);
         store_result(&a.B_dst[vstart + lv], vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
@@ -472,7 +495,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     // owned <=> the edge's internal id lies in the tile's range (lanes inside a 64-edge block are
     // assigned by the plan's conflict-avoiding lane order, not by internal id)
     if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own) {
-      if (PERSIST) a.q_dst[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, 0.0f);
+      if (PERSIST) oq[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, handoff ? tagf : 0.0f);
       else store_result(&a.q_dst[qi[k]], q1[k], q23[k].x, q23[k].y, 0.0f);
     }
   }
@@ -480,21 +503,20 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   done += iters;
   ++round;
   if (done >= a.iters) break;
-  // ---- end of a round: results in L2, barrier over the tiles, halo state of the next round ----
   const unsigned long long pt0 = pprof ? wall_clock64() : 0ull;
+  unsigned long long pt1 = pt0, pt2 = pt0;
+  float4 nb[VPT], na[VPT], nq[EPT];
+  if (PERSIST == 1) {
+  // ---- end of a round: results in L2, barrier over the tiles, halo state of the next round ----
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const unsigned long long pt1 = pprof ? wall_clock64() : 0ull;
+  pt1 = pprof ? wall_clock64() : 0ull;
   // barrier over the tiles: every tile raises its own flag (all flags share one 128-byte line; no read-modify-
   // write -- a counter that 32 tiles add to serialises at the L2's atomic unit), the lanes of the first wave
   // watch one flag each
   if (tid < 64) {
     const int32_t target = pa.base + round;
-    if (tid == 0) {
-      if (round == 1) __hip_atomic_store(&pa.sync[32 + tile_id], (int32_t)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) + 1,
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // HW_REG_XCC_ID
-      __hip_atomic_store(&pa.sync[tile_id], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) __hip_atomic_store(&pa.sync[tile_id], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long w0 = wall_clock64();
     const int watch = min(tid, a.ntiles - 1);
     for (;;) {
@@ -506,23 +528,93 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
       }
       __builtin_amdgcn_s_sleep(1);
     }
-    if (tid == 0 && round == 1 && !s_abort &&
-        __hip_atomic_load(&pa.sync[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
-            __hip_atomic_load(&pa.sync[32 + tile_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (tid == 0 && round == 1 && !s_abort && __hip_atomic_load(&pa.sync[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc)
       *pa.err_host = 2;  // not on one XCD: the reads below are not coherent -- the host discards this solve
   }
   __syncthreads();
   if (s_abort) break;
-  const unsigned long long pt2 = pprof ? wall_clock64() : 0ull;
+  pt2 = pprof ? wall_clock64() : 0ull;
+  }
   {  // what this round wrote is what the next one reads
     const float4* t;
     t = a.A_src; a.A_src = a.A_dst; a.A_dst = const_cast<float4*>(t);
     t = a.B_src; a.B_src = a.B_dst; a.B_dst = const_cast<float4*>(t);
     t = a.q_src; a.q_src = a.q_dst; a.q_dst = const_cast<float4*>(t);
   }
+  if (PERSIST == 2) {
+    // ---- halo state of the next round: poll the owners' hand-off entries until they carry this round's tag ----
+    // (a lane re-issues its loads until all of ITS entries are there; every load of a pass goes out before the first
+    // one is looked at; entries a lane does not need point at the tile's first own vertex / the lane's own edge)
+    const int32_t target = pa.base + round;
+    const float4* const hA = pa.hA[round & 1];
+    const float4* const hB = pa.hB[round & 1];
+    const float4* const hq = pa.hq[round & 1];
+    bool needv[VPT], needa[VPT], neede[EPT], want = false;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+      const int lv = k * NT + tid;
+      needv[k] = lv >= n_own && lv < n_ext;
+      needa[k] = needv[k] && lv < n_upd;
+      want = want || needv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      neede[k] = (k * NT + tid) < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own);
+      want = want || neede[k];
+    }
+    const unsigned long long w0 = wall_clock64();
+    bool stale = want;
+    for (;;) {
+      if (stale) {
+        if (VPT == 1 && EPT <= 3) {
+          const float4* pb = &hB[needv[0] ? gi[0] : vstart];
+          const float4* pv = &hA[needa[0] ? gi[0] : vstart];
+          const float4* p0 = &hq[e_loc > 0 ? qi[0] : 0];
+          const float4* p1 = &hq[e_loc > 0 ? qi[1] : 0];
+          const float4* p2 = &hq[e_loc > 0 ? qi[EPT - 1] : 0];
+          f4v r0, r1, r2, r3, r4;
+          asm volatile(
+              "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
+              "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
+              "global_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+              : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+              : "v"(pb), "v"(pv), "v"(p0), "v"(p1), "v"(p2)
+              : "memory");
+          nb[0] = make_float4(r0.x, r0.y, r0.z, r0.w);
+          na[0] = make_float4(r1.x, r1.y, r1.z, r1.w);
+          nq[0] = make_float4(r2.x, r2.y, r2.z, r2.w);
+          nq[1] = make_float4(r3.x, r3.y, r3.z, r3.w);
+          nq[EPT - 1] = make_float4(r4.x, r4.y, r4.z, r4.w);
+        } else {
+#pragma unroll
+          for (int k = 0; k < VPT; ++k) {
+            nb[k] = load_agent(&hB[needv[k] ? gi[k] : vstart]);
+            na[k] = load_agent(&hA[needa[k] ? gi[k] : vstart]);
+          }
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&hq[e_loc > 0 ? qi[k] : 0]);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+          ok = ok && (!needv[k] || __float_as_int(nb[k].w) == target);
+          ok = ok && (!needa[k] || __float_as_int(na[k].w) == target);
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) ok = ok && (!neede[k] || __float_as_int(nq[k].w) == target);
+        stale = !ok;
+      }
+      if (!__any(stale)) break;
+      if (wall_clock64() - w0 > 400000ull) {  // 4 ms: give up, never hang
+        s_abort = 1;
+        *pa.err_host = 1;
+        break;
+      }
+    }
+    pt1 = pt2 = pprof ? wall_clock64() : 0ull;
+  } else {
   // (every load goes out before the first one is consumed; lanes that keep their own value read the tile's
   // first own vertex / their own edge -- a select on the address, not a branch around the load)
-  float4 nb[VPT], na[VPT], nq[EPT];
   if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice the
     const bool halo = tid >= n_own && tid < n_ext;  // requests, and the re-read is bound by their number)
     const float4* pb = &a.B_src[halo ? gi[0] : vstart];
@@ -554,6 +646,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&a.q_src[e_loc > 0 ? qi[k] : 0]);
   }
+  }
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
@@ -571,14 +664,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     }
   }
   __syncthreads();
-  if (pprof) {  // dev aid: where a round's time goes (10 ns ticks, summed over the rounds of tile 0)
+  if (PERSIST == 2 && s_abort) break;
+  if (pprof) {  // dev aid: where a round's time goes (10 ns ticks, summed over the rounds of one tile)
     const unsigned long long pt3 = wall_clock64();
     pacc[0] += (int32_t)(pt0 - pround); pacc[1] += (int32_t)(pt1 - pt0); pacc[2] += (int32_t)(pt2 - pt1); pacc[3] += (int32_t)(pt3 - pt2);
     pround = pt3;
   }
   }  // rounds
   if (PERSIST && pprof && tid == 0) {
-    pa.sync[66] = pacc[0]; pa.sync[67] = pacc[1]; pa.sync[68] = pacc[2]; pa.sync[69] = pacc[3]; pa.sync[70] = round;
+    pa.sync[514] = pacc[0]; pa.sync[515] = pacc[1]; pa.sync[516] = pacc[2]; pa.sync[517] = pacc[3]; pa.sync[518] = round;
   }
   if (!PERSIST && prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
@@ -599,11 +693,11 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_arg; a.ntiles = ntiles; a.prof = prof_arg;
-  tile_body<NT, EPT, VPT, false>(a, PersistArgs{nullptr, nullptr, 0});
+  tile_body<NT, EPT, VPT, 0>(a, PersistArgs{});
 }
 
 // (no __restrict__ on the state arrays: a round reads what the previous one wrote)
-template <int NT, int EPT, int VPT>
+template <int NT, int EPT, int VPT, int MODE>
 __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_total,
                                                      const int32_t* __restrict__ t_vmap, const uint32_t* __restrict__ t_srow,
                                                      const uint2* __restrict__ t_eij, const int32_t* __restrict__ t_emap,
@@ -614,7 +708,7 @@ __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict_
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_total; a.ntiles = ntiles; a.prof = nullptr;
-  tile_body<NT, EPT, VPT, true>(a, pa);
+  tile_body<NT, EPT, VPT, MODE>(a, pa);
 }
 
 template <int NT, int EPT, int VPT>
@@ -1454,23 +1548,39 @@ bool tile_persist_exists(int nt, int ept, int vpt) {
   return false;
 }
 
-template <int NT, int EPT, int VPT>
-hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, int32_t* sync, int32_t* err_host, int32_t base) {
+template <int NT, int EPT, int VPT, int MODE>
+hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, const PersistArgs& pa) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  PersistArgs pa{sync, err_host, base};
-  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT>), dim3(8 * a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
-                     a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, pa, a.p);
+  // mode 1: 8 x ntiles blocks of which every eighth works (all tiles on XCD 0); mode 2: the launches' grid (one
+  // workgroup per tile, all of them resident: the caller keeps ntiles <= the number of CUs)
+  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, MODE>), dim3(MODE == 1 ? 8 * a.ntiles : a.ntiles), dim3(NT), lds, s, a.tiles,
+                     a.ntiles, a.iters, a.t_vmap, a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst,
+                     a.q_dst, pa, a.p);
   return hipGetLastError();
 }
 
 hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, int32_t* sync,
                                int32_t* err_host, int32_t base) {
   if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
-#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes, a, sync, err_host, base);
+  PersistArgs pa{};
+  pa.sync = sync; pa.err_host = err_host; pa.base = base;
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, 1>(s, lds_bytes, a, pa);
+  FLAME_PERSIST_CFGS(X)
+#undef X
+  return hipErrorInvalidConfiguration;
+}
+
+hipError_t launch_tile_xpersist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const XPersist& x,
+                                int32_t* err_host, int32_t base) {
+  if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
+  PersistArgs pa{};
+  pa.sync = x.sync; pa.err_host = err_host; pa.base = base;
+  for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, 2>(s, lds_bytes, a, pa);
   FLAME_PERSIST_CFGS(X)
 #undef X
   return hipErrorInvalidConfiguration;

@@ -37,7 +37,7 @@ for name in (names or ["5k", "euroc", "50k"]):
         if persist and os.environ.get("FLAME_HIP_PERSIST_PROF"):
             t = [r.info("persist_prof_%d" % k) for k in range(5)]
             n = max(t[4] - 1, 1)
-            prof = "  tile %s rounds %d: iterate+store %.2f us, drain %.2f, flags %.2f, re-read %.2f per round" % (
+            prof = "  tile %s rounds %d: iterate+store %.2f us, drain|poll %.2f, flags %.2f, re-read|apply %.2f per round" % (
                 os.environ["FLAME_HIP_PERSIST_PROF"], t[4], t[0] / n / 100., t[1] / n / 100., t[2] / n / 100., t[3] / n / 100.)
         print("%-6s persist %d: %.3f us/it (%.3f ms per %d)  tiles %d depth %d threads %d used %d recovered %d  bit-exact: first solve vs oracle %s, 9th vs launches %s%s" % (
             name, persist, best * 1e3 / it, best, it, r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("persist_used"),
