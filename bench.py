@@ -183,7 +183,7 @@ def small_graphs(device):
     g, _ = graphgen.named("tum")
     pr = default_params()
     out = {"vertices": g.V, "iters": 200}
-    for key, kw in (("launches", {}), ("persist", dict(persist=1, tile_own=50, tile_depth=5))):
+    for key, kw in (("launches", dict(persist=0)), ("persist", dict(persist=1, tile_own=50, tile_depth=5))):
         try:
             with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=device, **kw) as r:
                 best = 1e9

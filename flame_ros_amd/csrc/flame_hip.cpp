@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "kernels.h"
@@ -276,18 +277,16 @@ struct flame_hip_graph {
   int plan_reuse = 1;          // frame streams: partition from the previous frame's tile map
   int plan_mini = 1;           // option "plan_mini": small frames of a graph sync planned by one launch (k_mini_plan)
   bool plan_mini_used = false; // ... the current plan was
-  // option "persist": graphs of <= kPersistMaxTiles tiles are solved by ONE launch of resident tiles on one XCD
-  // (kernels.hip k_tile_persist); off by default (flame::Flame sets 2)
-  bool persist = false, persist_used = false;
-  bool persist_sizing = false;  // option value 2: frames of up to 1280 vertices (above tile_single_max) go on tiles of 50 own vertices (<= 26 tiles)
-  // option value 3: also graphs of 33 .. 256 tiles, resident over ALL XCDs (k_tile_persist mode 2: L2 hand-offs inside an
-  // XCD's eighth of the tiles, uncached mirrors across; kernels.h XPersist)
-  bool persist_all = false;
-  XPersist xp;                      // buffers of that mode (registered in caps)
-  int persist_mode_used = 0;        // 1 / 2: what the last solve ran as
-  int32_t* persist_sync = nullptr;  // device: [t] round flag of tile t, [256 + t] XCC ids, [512..] dev aid
-  int32_t* persist_err = nullptr;   // page-locked: raised by the launch (timeout / tiles not on one XCD)
-  int32_t persist_base = 0;         // value of the flags before the next launch
+  // option "persist" (default 1): graphs of 2 .. min(kPersistMaxTiles, CUs) halo tiles are solved by ONE launch of
+  // RESIDENT tiles (kernels.hip k_tile_persist: round-tagged hand-offs through uncached memory instead of a kernel
+  // boundary per `depth` iterations); 0: launches; 2 (flame::Flame's): also sizes small frames for it
+  bool persist = true, persist_used = false;
+  bool persist_sizing = false;      // option value 2: frames of up to 1280 vertices (above tile_single_max) go on tiles of 50 own vertices
+  PersistBufs xp;                   // hand-off buffers (uncached) + dev-aid words, registered in caps
+  bool persist_skip_once = false;   // the next enqueue goes by launches (the repeat of a solve that gave up)
+  int last_src = 0;                 // the buffer the last solve started from
+  int32_t* persist_err = nullptr;   // page-locked: raised by a launch whose wait timed out
+  int32_t persist_base = 0;         // the hand-off tags used so far (they only grow)
   SolveParams last_sp{};            // the last solve (a persistent launch that gave up is repeated by launches)
   int32_t last_iters = 0;
   hipStream_t last_stream = nullptr;
@@ -421,14 +420,18 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
   return 0;
 }
 
+static void persist_lease_drop(flame_hip_graph* g, bool gave_up);
+static int persist_gave_up_count(int device);
+
 void flame_hip_graph_destroy(flame_hip_graph* g) {
   if (!g) return;
   if (g->device >= 0) {
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->timed) (void)hipEventSynchronize(g->ev1);
+    persist_lease_drop(g, false);
     (void)g->planner.wait_maps();
     g->free_device();
-    if (g->persist_sync) (void)hipFree(g->persist_sync);
     if (g->persist_err) (void)hipHostFree(g->persist_err);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -524,7 +527,6 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     const int v = force ? std::atoi(force) : value;
     g->persist = v != 0;
     g->persist_sizing = v >= 2;
-    g->persist_all = v >= 3;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -560,13 +562,14 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "plan_mini") *value = (P.on_device && g->plan_mini_used) ? 1 : 0;
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "persist") *value = g->persist ? 1 : 0;
-  else if (k == "persist_used") *value = g->persist_used ? g->persist_mode_used : 0;
+  else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
   else if (k == "persist_recovered") *value = g->persist_recovered;
-  else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF): 10 ns ticks of tile 0, summed over rounds
+  else if (k == "persist_gave_up") *value = persist_gave_up_count(g->device);  // (give-ups of any handle on this device)
+  else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF=<tile + 1>): 10 ns ticks of that tile, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
     int32_t v = 0;
-    if (i < 0 || i > 4 || !g->persist_sync) return FLAME_HIP_ERR_ARG;
-    if (hipMemcpy(&v, g->persist_sync + 514 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
+    if (i < 0 || i > 3 || !g->xp.prof) return FLAME_HIP_ERR_ARG;
+    if (hipMemcpy(&v, g->xp.prof + 2 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
     *value = v;
   }
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
@@ -748,8 +751,6 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   bool try_reuse = g->plan_reuse && g->opt.balance && g->planner.map_usable(V, depth) &&
                    g->opt.tile_own == g->reuse_tile_own_opt;
   if (try_reuse && g->reuse_skip > 0) { --g->reuse_skip; try_reuse = false; }  // back-off after rejections
-  // (a frame that is to go on persistent tiles does not inherit a partition of more tiles than one XCD takes)
-  if (try_reuse && g->persist && g->persist_sizing && sz.tile_own == 50 && g->planner.map_tiles() > kPersistMaxTiles) try_reuse = false;
   g->plan_reused = false;
   for (int attempt = 0; attempt < 8 + kBalanceRefinePasses && !built; ++attempt) {
     const bool reusing = try_reuse;
@@ -1400,53 +1401,89 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
 // Enqueue the launches of `num_iters` PD iterations on stream s, starting from buffer `cur`.
 // Returns the buffer index holding the result through *cur_out.
 // one launch of resident tiles instead of ceil(num_iters / depth) launches?
-// 0: no; 1: all tiles on one XCD (<= kPersistMaxTiles); 2: over all XCDs (option value 3, <= kXPersistMaxTiles and <= one per CU)
-static int persist_applies(const flame_hip_graph* g, int32_t num_iters) {
+// one launch of resident tiles instead of ceil(num_iters / depth) launches?
+static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
   const Plan& P = g->plan;
-  if (!g->persist || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 || num_iters <= P.tile_depth) return 0;
+  if (!g->persist || g->persist_skip_once || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 ||
+      num_iters <= P.tile_depth)
+    return false;
   const size_t nt = P.tiles.size();
-  if (nt < 2 || !tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return 0;
-  int mode = 1;
-  if (nt > (size_t)kPersistMaxTiles) {
-    if (!g->persist_all || nt > (size_t)kXPersistMaxTiles || (int)nt > g->num_cus) return 0;
-    mode = 2;
-  }
+  if (nt < 2 || nt > (size_t)kPersistMaxTiles || (int)nt > g->num_cus) return false;  // (one workgroup per CU is always resident)
+  if (!tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return false;
   for (const TileDesc& D : P.tiles)
-    if (D.n_ext <= 0) return 0;  // (an empty tile would have to take part in the hand-offs)
-  return mode;
+    if (D.n_ext <= 0) return false;  // (an empty tile has nothing to hand over, but its neighbours would not know)
+  return true;
+}
+
+// Resident tiles need every workgroup of their launch on the chip at once.  Two such launches from two handles of one
+// process can each get part of the CUs and starve each other until both time out, so a device has ONE lease: a handle
+// takes it for a solve and holds it until that solve's end event has fired; a handle that finds it taken solves by
+// ordinary launches.  After a launch gave up for any other reason (a foreign kernel holding CUs, another process) the
+// whole process stays off resident tiles for a while: 16 solves, doubling up to 4096 with every further give-up.
+struct PersistLease {
+  std::mutex m;
+  flame_hip_graph* holder = nullptr;
+  hipEvent_t holder_done = nullptr;  // (the holder's ev1)
+  int backoff = 0;                   // solves (of any handle) to sit out
+  int backoff_next = 16;
+  int gave_up = 0;                   // give-ups seen on this device (info "persist_gave_up")
+};
+static PersistLease& persist_lease(int device) {
+  static PersistLease leases[64];
+  return leases[(unsigned)device & 63];
+}
+static bool persist_lease_take(flame_hip_graph* g) {
+  PersistLease& L = persist_lease(g->device);
+  std::lock_guard<std::mutex> lk(L.m);
+  if (L.backoff > 0) { --L.backoff; return false; }
+  if (L.holder && L.holder != g && hipEventQuery(L.holder_done) != hipSuccess) return false;
+  L.holder = g;
+  L.holder_done = g->ev1;
+  return true;
+}
+static int persist_gave_up_count(int device) {
+  PersistLease& L = persist_lease(device);
+  std::lock_guard<std::mutex> lk(L.m);
+  return L.gave_up;
+}
+static void persist_lease_drop(flame_hip_graph* g, bool gave_up) {
+  PersistLease& L = persist_lease(g->device);
+  std::lock_guard<std::mutex> lk(L.m);
+  if (L.holder == g) { L.holder = nullptr; L.holder_done = nullptr; }
+  if (gave_up) {
+    ++L.gave_up;
+    L.backoff = L.backoff_next;
+    L.backoff_next = std::min(L.backoff_next * 2, 4096);
+  }
 }
 
 static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t num_iters, hipStream_t s, int cur,
                               int* cur_out, int* launches);
 
-// After a synchronisation: did a persistent launch give up (a wait timed out, tiles on several XCDs)?  Returns 0
-// when there was nothing, 1 when the solve was REPEATED by ordinary launches (enqueued, not yet waited for: the
-// caller synchronises again and redoes what it had queued behind the solve), an error code when it cannot be --
-// only the first solve of a device-built plan can: its initial state is re-derived from the staged inputs.
-// own_marks: state-writing steps the CALLER itself queued behind the solve and will redo (frame_results' un-scaling);
-// anything else that wrote the state since (a graph filter, new data terms) cannot be replayed here
-static int persist_check(flame_hip_graph* g, int own_marks = 0, bool scaled_ok = false) {
+// After a synchronisation: did a launch of resident tiles give up (a wait timed out: not all of its workgroups were
+// on the chip)?  Returns 0 when there was nothing, 1 when the solve was REPEATED by ordinary launches (enqueued, not
+// yet waited for: the caller synchronises again and redoes what it had queued behind the solve), an error code when it
+// cannot be.  The launch only reads its source buffers, so it can be repeated whenever nothing else wrote the state
+// since.  own_marks: state-writing steps the CALLER itself queued behind the solve and will redo (frame_results'
+// un-scaling); anything else that wrote the state since (a graph filter, new data terms) cannot be replayed here
+static int persist_check(flame_hip_graph* g, int own_marks = 0) {
   static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
   if (force_fail && g->persist_used && g->persist_err) *g->persist_err = 3;
   if (!g->persist_err || *g->persist_err == 0) return 0;
   *g->persist_err = 0;
-  g->persist = false;  // (not on this device / not now: the launches per round from here on)
-  (void)hipFree(g->persist_sync);  // (the flags of an unfinished launch: a handle that gets the option again starts from zeroed ones)
-  g->persist_sync = nullptr;
-  const bool can = g->persist_used && g->plan.on_device && g->solves_since_upload == 1 && (scaled_ok || g->state_scale == 1.0f) &&
-                   g->state_serial == g->solve_serial + (uint64_t)own_marks &&
-                   g->last_iters > 0 && g->in_pos && g->in_z && g->in_wgt && (!g->init_have_x0 || g->in_x0);
+  persist_lease_drop(g, true);
+  const bool can = g->persist_used && g->state_serial == g->solve_serial + (uint64_t)own_marks && g->last_iters > 0;
   g->persist_used = false;
   if (!can) {
     g->uploaded = false;  // the state is that of an unfinished solve
     return FLAME_HIP_ERR_STATE;
   }
   hipStream_t s = g->last_stream ? g->last_stream : g->stream;
-  HIPCHK(launch_init_state(s, g->V, g->v_i2o_dev, g->in_pos, g->in_z, g->in_wgt, g->init_have_x0 ? g->in_x0 : nullptr,
-                           g->A[0], g->B[0], g->pos, g->E > 0 ? g->E : 1, g->q[0], g->q[1]));
   int cur_out = 0, launches = 0;
   HIPCHK(hipEventRecord(g->ev0, s));
-  int rc = enqueue_iterations(g, g->last_sp, g->last_iters, s, 0, &cur_out, &launches);
+  g->persist_skip_once = true;
+  int rc = enqueue_iterations(g, g->last_sp, g->last_iters, s, g->last_src, &cur_out, &launches);
+  g->persist_skip_once = false;
   if (rc) return rc;
   g->cur = cur_out;
   g->state_serial++;
@@ -1466,55 +1503,41 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
-    if (const int pmode = persist_applies(g, num_iters)) {
-      if (!g->persist_sync) {
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g->persist_sync), sizeof(int32_t) * kPersistSyncInts));
-        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * kPersistSyncInts, s));
-        if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) {  // dev aid: tile <value - 1> sums where its rounds' time goes ([514..518])
-          const int32_t w[2] = {1, std::max(0, std::atoi(pp) - 1)};
-          HIPCHK(hipMemcpyAsync(g->persist_sync + 512, w, sizeof(w), hipMemcpyHostToDevice, s));
-        }
-        if (!g->persist_err) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
+    if (persist_applies(g, num_iters) && persist_lease_take(g)) {
+      PersistBufs& x = g->xp;
+      int rc;
+      if (!g->persist_err) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
         *g->persist_err = 0;
-        g->persist_base = 0;
+      }
+      if (!x.prof) {
+        if ((rc = dev_alloc(g->caps, &x.prof, 8))) return rc;
+        int32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) { w[0] = 1; w[1] = std::max(0, std::atoi(pp) - 1); }
+        HIPCHK(memcpy_sync(s, x.prof, w, sizeof(w), hipMemcpyHostToDevice));
       }
       const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
-      if (g->persist_base > (1 << 30)) {  // (the flags only grow)
-        HIPCHK(hipMemsetAsync(g->persist_sync, 0, sizeof(int32_t) * 256, s));
-        for (int b = 0; b < 2; ++b) {  // (the hand-off tags restart with the flags)
-          float4** pp[3] = {&g->xp.hA[b], &g->xp.hB[b], &g->xp.hq[b]};
-          for (float4** q : pp)
-            if (*q) HIPCHK(hipMemsetAsync(*q, 0, g->caps[(void*)q], s));
+      bool rezero = g->persist_base > (1 << 30);  // (the tags only grow)
+      if (rezero) g->persist_base = 0;
+      for (int b = 0; b < 2; ++b) {  // (a buffer that had to grow comes back zeroed: tag 0 is never a round's)
+        float4** pp[3] = {&x.hA[b], &x.hB[b], &x.hq[b]};
+        const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
+        for (int k = 0; k < 3; ++k) {
+          float4* before = *pp[k];
+          if ((rc = dev_alloc_uncached(g->caps, pp[k], nn[k]))) return rc;
+          if (*pp[k] != before || rezero) HIPCHK(hipMemsetAsync(*pp[k], 0, g->caps[(void*)pp[k]], s));
         }
-        g->persist_base = 0;
       }
       a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];
       a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
       a.iters = num_iters;
-      if (pmode == 2) {
-        XPersist& x = g->xp;
-        int rc;
-        for (int b = 0; b < 2; ++b) {  // (a buffer that had to grow comes back zeroed: tag 0 is never a round's)
-          float4** pp[3] = {&x.hA[b], &x.hB[b], &x.hq[b]};
-          const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
-          for (int k = 0; k < 3; ++k) {
-            float4* before = *pp[k];
-            if ((rc = dev_alloc_uncached(g->caps, pp[k], nn[k]))) return rc;
-            if (*pp[k] != before) HIPCHK(hipMemsetAsync(*pp[k], 0, g->caps[(void*)pp[k]], s));
-          }
-        }
-        x.sync = g->persist_sync;
-        HIPCHK(launch_tile_xpersist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
-                                    g->persist_base));
-      } else {
-        HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, g->persist_sync,
-                                   g->persist_err, g->persist_base));
-      }
+      HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
+                                 g->persist_base));
       g->persist_base += rounds - 1;
       g->persist_used = true;
-      g->persist_mode_used = pmode;
+      g->last_src = cur;
       *launches = 1;
-      *cur_out = cur ^ (rounds & 1);
+      *cur_out = cur ^ 1;  // (written once, by the last round; the source buffers are only read)
       return 0;
     }
     const int per = P.tile_depth > 0 ? P.tile_depth : num_iters;
@@ -1875,7 +1898,7 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
     }
   }
   HIPCHK(hipStreamSynchronize(s));
-  if ((rc = persist_check(g, scale_back != 1.0f ? 1 : 0, true)) != 0) {
+  if ((rc = persist_check(g, scale_back != 1.0f ? 1 : 0)) != 0) {
     if (rc != 1) return rc;
     // the solve was repeated by launches (its state is the initial one again, un-scaled): the whole call once more
     g->state_scale = 1.0f;

@@ -37,28 +37,23 @@ hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes
 bool tile_config_exists(int nt, int ept, int vpt);
 // one-time per configuration: opt in to > 48 KiB of dynamic LDS (not capturable in a hipGraph)
 hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes);
-// persistent tiles (one launch for the whole solve; graphs of <= kPersistMaxTiles tiles, all on one XCD):
-// a.iters = the TOTAL iteration count, rounds of `depth` iterations inside; sync: kPersistSyncInts ints of device
-// memory, 128-byte aligned ([t] = round flag of tile t, only grows: base = its value before the launch; [256 + t] XCC
-// ids; [512..] dev aid), err_host: page-locked word
-constexpr int kPersistMaxTiles = 32, kPersistSyncInts = 1024;
-bool tile_persist_exists(int nt, int ept, int vpt);
-hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, int32_t* sync,
-                               int32_t* err_host, int32_t base);
-// ... for graphs of kPersistMaxTiles + 1 .. kXPersistMaxTiles tiles (<= one per CU): resident tiles over ALL XCDs, any
-// placement.  Neighbours hand their results over through uncached, round-tagged copies of the state arrays
-// (kernels.hip PersistArgs).  The caller owns the buffers: sync as above (dev aid words only), hA / hB / hq [2]
-// (V / V / E float4, same indices as the state arrays) in hipDeviceMallocUncached memory, zeroed once; `base` grows by
-// rounds - 1 per launch exactly as for launch_tile_persist (tags base + 1 .. base + rounds - 1 never repeat).
-constexpr int kXPersistMaxTiles = 256;
-struct XPersist {
-  int32_t* sync = nullptr;
+// resident tiles (ONE launch for the whole solve; graphs of 2 .. kPersistMaxTiles tiles, at most one per CU: every
+// workgroup of the launch must be on the chip at once).  a.iters = the TOTAL iteration count, rounds of `depth`
+// iterations inside; neighbours hand their results over through uncached, round-tagged copies of the state arrays
+// (kernels.hip PersistArgs).  The caller owns the buffers: hA / hB / hq [2] (V / V / E float4, same indices as the
+// state arrays) in hipDeviceMallocUncached memory, zeroed once; prof: 8 ints of device memory (dev aid, zero = off);
+// err_host: a page-locked word.  `base` grows by rounds - 1 per launch (tags base + 1 .. base + rounds - 1 never repeat).
+// The result lands in a.A_dst / B_dst / q_dst whatever the number of rounds; the source buffers are only read.
+constexpr int kPersistMaxTiles = 256;
+struct PersistBufs {
   float4* hA[2] = {nullptr, nullptr};
   float4* hB[2] = {nullptr, nullptr};
   float4* hq[2] = {nullptr, nullptr};
+  int32_t* prof = nullptr;
 };
-hipError_t launch_tile_xpersist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const XPersist& x,
-                                int32_t* err_host, int32_t base);
+bool tile_persist_exists(int nt, int ept, int vpt);
+hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,
+                               int32_t* err_host, int32_t base);
 
 // ---- costs: per-block float64 partial sums (partials[2*b] smooth, [2*b+1] data) ----
 int costs_num_blocks(int32_t V, int32_t E);

@@ -258,30 +258,33 @@ struct SlotTail<0> {
 // Explicit parameters, hottest first: the first 16 dwords of the kernel arguments are preloaded into
 // SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16, flame_ros_amd/build.py), so the
 // tile descriptor's address is known at cycle 0 instead of two scalar round trips later.
-// PERSIST (k_tile_persist, graphs of <= 32 tiles): the tiles stay resident for the WHOLE solve.  Block b runs on
-// XCD b % 8, the grid has 8 x ntiles blocks and only b % 8 == 0 works: every tile sits on ONE XCD, whose L2 is
-// then the point of coherence -- a round (= what a launch is otherwise: `depth` iterations) ends with the own
-// results written through to L2, one counter barrier over the tiles and a re-read of the halo state with
-// agent-scope loads (L1 miss, L2 hit); no kernel boundary, no reload of the constants or the own state, no
-// fences (tools/exp/xcd_handoff_probe.hip: 0.8 us per hand-off of 4 KB on one XCD; over all XCDs it is not
-// coherent without L2 write-back / invalidate).  Same arithmetic in the same order as the launches it replaces.
+//
+// PERSIST (k_tile_persist, graphs of 2 .. one-tile-per-CU tiles): the tiles stay RESIDENT for the whole solve, one
+// workgroup each, on whatever CU / XCD the dispatcher gives them.  A round (= what a launch is otherwise: `depth`
+// iterations) ends with a hand-off between neighbouring tiles instead of a kernel boundary: no reload of the constants
+// or the own state, no end-of-kernel release.  The L2s of different XCDs are not coherent and a CU's L1 is never
+// refreshed, so what a tile hands over travels through UNCACHED copies of the state arrays (hipDeviceMallocUncached:
+// no cache holds them, stores and loads meet in memory).  There are no flags, no drain and no barrier over the tiles:
+// every 16-byte entry carries the round it belongs to in its 4th word (z, the data weight and the dual's padding
+// are constants a reader already has), an owner stores {value, base + round} and a reader polls the entries of its
+// halo until their tags are this round's.  The buffers alternate with the round's parity: an owner can only reach
+// round r + 2 after every reader of its round-r entries has published round r + 1 (the halo relation is symmetric),
+// so two buffers are enough.  A 16-byte aligned store / load is one request inside one 32-byte sector (observed
+// untorn on gfx950: MI355X guide, "R2"; the parity tests compare every bit of ~10^8 hand-offs per solve).  The state
+// arrays proper are read once and written once, by the last round, into the OTHER buffer: a launch that gave up
+// (a wait is bounded: 4 ms) leaves its source intact and is repeated by ordinary launches.  Same arithmetic in the
+// same order as the launches it replaces.  What it relies on: all workgroups of the launch being resident at once
+// (the host keeps ntiles <= the CU count and gives one such launch per device the chip at a time).
+// History: r03 kept the tiles of <= 32-tile graphs on ONE XCD (L2 hand-offs, a flag barrier; it relied on block b
+// running on XCD b % 8); r04's first attempt mixed L2 hand-offs inside an XCD with uncached mirrors across and
+// neighbour flags (tools/exp/xpersist_mixed_flags.patch: flag latency 3-5 us per round, slower than launches).
 struct PersistArgs {
-  int32_t* sync;      // ordinary device memory: [t] round flag of tile t, [256 + t] XCC id + 1 of tile t, [512..] dev aid
-  int32_t* err_host;  // page-locked: set when a wait timed out or tiles that share an L2 hand-off were not on one XCD
-  int32_t base;       // the flags' value before this launch (they only grow)
-  // ---- mode 2 (33..256 tiles over ALL XCDs, one resident workgroup each, any placement) ----
-  // The L2s of different XCDs are not coherent, so what a tile hands to its neighbours travels through UNCACHED
-  // hand-off copies of the state arrays (hipDeviceMallocUncached: no L2 holds them, stores and loads meet in memory).
-  // No flags, no drain, no barrier over the tiles: every 16-byte entry carries the round it belongs to in its 4th
-  // word (z, the data weight and the dual's padding are constants a reader already has), an owner simply stores
-  // {value, base + round} and a reader polls the entries of its halo until their tags are this round's.  Buffers
-  // alternate with the round's parity; an owner can only reach round r + 2 after every reader of its round-r
-  // entries has published round r + 1 (the halo relation is symmetric), so two buffers are enough.  A 16-byte
-  // aligned store / load is one request inside one 32-byte sector (observed untorn on gfx950, MI355X guide, "R2";
-  // the parity tests compare every bit of 10^8 hand-offs).  The state arrays proper are written by the last round only.
-  float4* hA[2];
+  float4* hA[2];      // uncached, zeroed once: hand-off copies of vtxA / vtxB / q (same indices), [round & 1]
   float4* hB[2];
   float4* hq[2];
+  int32_t* err_host;  // page-locked: set when a wait timed out
+  int32_t base;       // tags of this launch are base + 1 .. base + rounds - 1 (they only grow)
+  int32_t* prof;      // device memory, dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]
 };
 
 __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the CU's L1, served by the XCD's L2
@@ -292,17 +295,14 @@ __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the C
                      __uint_as_float((uint32_t)(hi >> 32)));
 }
 
-// PERSIST 0: one launch = `depth` iterations; 1: resident tiles on ONE XCD; 2: resident tiles over all XCDs
-template <int NT, int EPT, int VPT, int PERSIST>
+template <int NT, int EPT, int VPT, bool PERSIST>
 __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware block -> tile map (speed only): block b runs on XCD b % 8, tiles are numbered in
   // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
   // makes tiles that share halo vertices / edges share one L2.  Bijective for any tile count.
   const int nt_all = a.ntiles, xq = nt_all >> 3, xr = nt_all & 7, xcd = blockIdx.x & 7;
-  if (PERSIST == 1 && xcd != 0) return;
-  const int g_first = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;  // first tile of this XCD's eighth
-  const int tile_id = PERSIST == 1 ? (int)(blockIdx.x >> 3) : g_first + (int)(blockIdx.x >> 3);
+  const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
   const TileDesc& D = a.tiles[tile_id];
   const int tid = threadIdx.x;
   // the whole descriptor header up front, before anything with side effects: the compiler then
@@ -317,8 +317,6 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   asm volatile("" ::"s"(vstart), "s"(estart), "s"(nslots), "s"(vmap_off), "s"(emap_off), "s"(erec_off),
                "s"(srow_off), "s"(n_own), "s"(n_upd), "s"(e_own), "s"(e_loc), "s"(depth));
   if (n_ext == 0) return;  // empty tile (more tiles than vertices)
-  const int32_t my_xcc = PERSIST == 1 ? (int32_t)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) + 1 : 0;  // HW_REG_XCC_ID
-  if (PERSIST == 1 && threadIdx.x == 0) __hip_atomic_store(&pa.sync[256 + tile_id], my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float4* bar = reinterpret_cast<float4*>(smem);
   float4* cs = bar + n_ext;  // nslots + kDummySlots incidence slots
   const int lane = tid & 63;
@@ -423,9 +421,9 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   const float x_min = a.p.x_min, x_max = a.p.x_max;
   __shared__ int s_abort;
   if (PERSIST && tid == 0) s_abort = 0;
-  const bool pprof = PERSIST && pa.sync[512] != 0 && tile_id == pa.sync[513];  // (dev aid, see the end of the round)
+  const bool pprof = PERSIST && pa.prof[0] != 0 && tile_id == pa.prof[1];  // (dev aid, see the end of the round)
   unsigned long long pround = pprof ? wall_clock64() : 0ull;
-  int32_t pacc[4] = {0, 0, 0, 0};
+  int32_t pacc[3] = {0, 0, 0};
   int done = 0, round = 0;
   for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
   const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
@@ -469,9 +467,8 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
 
   // ---- write back what this tile owns ----
-  // (mode 2, every round but the last: not the state arrays but the uncached hand-off copies, tagged with the round)
-  const bool last_round = !PERSIST || done + iters >= a.iters;
-  const bool handoff = PERSIST == 2 && !last_round;
+  // (resident tiles, every round but the last: not the state arrays but the uncached hand-off copies, tagged with the round)
+  const bool handoff = PERSIST && done + iters < a.iters;
   const float tagf = __int_as_float(pa.base + round + 1);
   float4* const oA = handoff ? pa.hA[(round + 1) & 1] : a.A_dst;
   float4* const oB = handoff ? pa.hB[(round + 1) & 1] : a.B_dst;
@@ -480,7 +477,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
-      if (PERSIST) {  // (plain stores: mode 1 -- through the L1, acknowledged by the XCD's L2, which is all a round needs)
+      if (PERSIST) {
         oA[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, handoff ? tagf : vz[k]);
         oB[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, handoff ? tagf : vwgt[k]);
       } else {
@@ -503,48 +500,12 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   done += iters;
   ++round;
   if (done >= a.iters) break;
+  // ---- end of a round: the halo state of the next one = the owners' hand-off entries, polled until they carry this
+  // round's tag.  A lane re-issues its loads until all of ITS entries are there; every load of a pass goes out before
+  // the first one is looked at; entries a lane does not need point at one address per tile (one request per wave) ----
   const unsigned long long pt0 = pprof ? wall_clock64() : 0ull;
-  unsigned long long pt1 = pt0, pt2 = pt0;
   float4 nb[VPT], na[VPT], nq[EPT];
-  if (PERSIST == 1) {
-  // ---- end of a round: results in L2, barrier over the tiles, halo state of the next round ----
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  pt1 = pprof ? wall_clock64() : 0ull;
-  // barrier over the tiles: every tile raises its own flag (all flags share one 128-byte line; no read-modify-
-  // write -- a counter that 32 tiles add to serialises at the L2's atomic unit), the lanes of the first wave
-  // watch one flag each
-  if (tid < 64) {
-    const int32_t target = pa.base + round;
-    if (tid == 0) __hip_atomic_store(&pa.sync[tile_id], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w0 = wall_clock64();
-    const int watch = min(tid, a.ntiles - 1);
-    for (;;) {
-      const bool there = __hip_atomic_load(&pa.sync[watch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0;
-      if (__all(there)) break;
-      if (wall_clock64() - w0 > 400000ull) {  // 4 ms: give up, never hang
-        if (tid == 0) { s_abort = 1; *pa.err_host = 1; }
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (tid == 0 && round == 1 && !s_abort && __hip_atomic_load(&pa.sync[256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc)
-      *pa.err_host = 2;  // not on one XCD: the reads below are not coherent -- the host discards this solve
-  }
-  __syncthreads();
-  if (s_abort) break;
-  pt2 = pprof ? wall_clock64() : 0ull;
-  }
-  {  // what this round wrote is what the next one reads
-    const float4* t;
-    t = a.A_src; a.A_src = a.A_dst; a.A_dst = const_cast<float4*>(t);
-    t = a.B_src; a.B_src = a.B_dst; a.B_dst = const_cast<float4*>(t);
-    t = a.q_src; a.q_src = a.q_dst; a.q_dst = const_cast<float4*>(t);
-  }
-  if (PERSIST == 2) {
-    // ---- halo state of the next round: poll the owners' hand-off entries until they carry this round's tag ----
-    // (a lane re-issues its loads until all of ITS entries are there; every load of a pass goes out before the first
-    // one is looked at; entries a lane does not need point at the tile's first own vertex / the lane's own edge)
+  {
     const int32_t target = pa.base + round;
     const float4* const hA = pa.hA[round & 1];
     const float4* const hB = pa.hB[round & 1];
@@ -566,12 +527,12 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     bool stale = want;
     for (;;) {
       if (stale) {
-        if (VPT == 1 && EPT <= 3) {
-          const float4* pb = &hB[needv[0] ? gi[0] : vstart];
+        if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice
+          const float4* pb = &hB[needv[0] ? gi[0] : vstart];  // the requests, and the poll is bound by their number)
           const float4* pv = &hA[needa[0] ? gi[0] : vstart];
-          const float4* p0 = &hq[e_loc > 0 ? qi[0] : 0];
-          const float4* p1 = &hq[e_loc > 0 ? qi[1] : 0];
-          const float4* p2 = &hq[e_loc > 0 ? qi[EPT - 1] : 0];
+          const float4* p0 = &hq[neede[0] ? qi[0] : estart];
+          const float4* p1 = &hq[neede[1] ? qi[1] : estart];
+          const float4* p2 = &hq[neede[EPT - 1] ? qi[EPT - 1] : estart];
           f4v r0, r1, r2, r3, r4;
           asm volatile(
               "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
@@ -592,7 +553,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
             na[k] = load_agent(&hA[needa[k] ? gi[k] : vstart]);
           }
 #pragma unroll
-          for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&hq[e_loc > 0 ? qi[k] : 0]);
+          for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&hq[neede[k] ? qi[k] : estart]);
         }
         bool ok = true;
 #pragma unroll
@@ -605,48 +566,14 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         stale = !ok;
       }
       if (!__any(stale)) break;
-      if (wall_clock64() - w0 > 400000ull) {  // 4 ms: give up, never hang
+      if (wall_clock64() - w0 > 400000ull) {  // 4 ms: give up, never hang (the host repeats the solve by launches)
         s_abort = 1;
         *pa.err_host = 1;
         break;
       }
     }
-    pt1 = pt2 = pprof ? wall_clock64() : 0ull;
-  } else {
-  // (every load goes out before the first one is consumed; lanes that keep their own value read the tile's
-  // first own vertex / their own edge -- a select on the address, not a branch around the load)
-  if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice the
-    const bool halo = tid >= n_own && tid < n_ext;  // requests, and the re-read is bound by their number)
-    const float4* pb = &a.B_src[halo ? gi[0] : vstart];
-    const float4* pv = &a.A_src[(halo && tid < n_upd) ? gi[0] : vstart];
-    const float4* p0 = &a.q_src[e_loc > 0 ? qi[0] : 0];
-    const float4* p1 = &a.q_src[e_loc > 0 ? qi[1] : 0];
-    const float4* p2 = &a.q_src[e_loc > 0 ? qi[EPT - 1] : 0];
-    f4v r0, r1, r2, r3, r4;
-    asm volatile(
-        "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
-        "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
-        "global_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
-        : "v"(pb), "v"(pv), "v"(p0), "v"(p1), "v"(p2)
-        : "memory");
-    nb[0] = make_float4(r0.x, r0.y, r0.z, r0.w);
-    na[0] = make_float4(r1.x, r1.y, r1.z, r1.w);
-    nq[0] = make_float4(r2.x, r2.y, r2.z, r2.w);
-    nq[1] = make_float4(r3.x, r3.y, r3.z, r3.w);
-    nq[EPT - 1] = make_float4(r4.x, r4.y, r4.z, r4.w);
-  } else {
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      const int lv = k * NT + tid;
-      const bool halo = lv >= n_own && lv < n_ext;
-      nb[k] = load_agent(&a.B_src[halo ? gi[k] : vstart]);
-      na[k] = load_agent(&a.A_src[(halo && lv < n_upd) ? gi[k] : vstart]);
-    }
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&a.q_src[e_loc > 0 ? qi[k] : 0]);
   }
-  }
+  const unsigned long long pt1 = pprof ? wall_clock64() : 0ull;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
@@ -664,15 +591,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     }
   }
   __syncthreads();
-  if (PERSIST == 2 && s_abort) break;
+  if (s_abort) break;
   if (pprof) {  // dev aid: where a round's time goes (10 ns ticks, summed over the rounds of one tile)
-    const unsigned long long pt3 = wall_clock64();
-    pacc[0] += (int32_t)(pt0 - pround); pacc[1] += (int32_t)(pt1 - pt0); pacc[2] += (int32_t)(pt2 - pt1); pacc[3] += (int32_t)(pt3 - pt2);
-    pround = pt3;
+    const unsigned long long pt2 = wall_clock64();
+    pacc[0] += (int32_t)(pt0 - pround); pacc[1] += (int32_t)(pt1 - pt0); pacc[2] += (int32_t)(pt2 - pt1);
+    pround = pt2;
   }
   }  // rounds
   if (PERSIST && pprof && tid == 0) {
-    pa.sync[514] = pacc[0]; pa.sync[515] = pacc[1]; pa.sync[516] = pacc[2]; pa.sync[517] = pacc[3]; pa.sync[518] = round;
+    pa.prof[2] = pacc[0]; pa.prof[3] = pacc[1]; pa.prof[4] = pacc[2]; pa.prof[5] = round;
   }
   if (!PERSIST && prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
@@ -693,22 +620,22 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_arg; a.ntiles = ntiles; a.prof = prof_arg;
-  tile_body<NT, EPT, VPT, 0>(a, PersistArgs{});
+  tile_body<NT, EPT, VPT, false>(a, PersistArgs{});
 }
 
-// (no __restrict__ on the state arrays: a round reads what the previous one wrote)
-template <int NT, int EPT, int VPT, int MODE>
+template <int NT, int EPT, int VPT>
 __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_total,
                                                      const int32_t* __restrict__ t_vmap, const uint32_t* __restrict__ t_srow,
                                                      const uint2* __restrict__ t_eij, const int32_t* __restrict__ t_emap,
-                                                     const float4* __restrict__ t_ew, const float4* B_src, const float4* A_src,
-                                                     const float4* q_src, float4* A_dst, float4* B_dst, float4* q_dst,
-                                                     PersistArgs pa, const SolveParams p_arg) {
+                                                     const float4* __restrict__ t_ew, const float4* __restrict__ B_src,
+                                                     const float4* __restrict__ A_src, const float4* __restrict__ q_src,
+                                                     float4* __restrict__ A_dst, float4* __restrict__ B_dst,
+                                                     float4* __restrict__ q_dst, PersistArgs pa, const SolveParams p_arg) {
   TileArgs a;
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_total; a.ntiles = ntiles; a.prof = nullptr;
-  tile_body<NT, EPT, VPT, MODE>(a, pa);
+  tile_body<NT, EPT, VPT, true>(a, pa);
 }
 
 template <int NT, int EPT, int VPT>
@@ -1548,39 +1475,26 @@ bool tile_persist_exists(int nt, int ept, int vpt) {
   return false;
 }
 
-template <int NT, int EPT, int VPT, int MODE>
+template <int NT, int EPT, int VPT>
 hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, const PersistArgs& pa) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  // mode 1: 8 x ntiles blocks of which every eighth works (all tiles on XCD 0); mode 2: the launches' grid (one
-  // workgroup per tile, all of them resident: the caller keeps ntiles <= the number of CUs)
-  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, MODE>), dim3(MODE == 1 ? 8 * a.ntiles : a.ntiles), dim3(NT), lds, s, a.tiles,
-                     a.ntiles, a.iters, a.t_vmap, a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst,
-                     a.q_dst, pa, a.p);
+  // the launches' grid: one workgroup per tile, all of them resident (the caller keeps ntiles <= the number of CUs)
+  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
+                     a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, pa, a.p);
   return hipGetLastError();
 }
 
-hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, int32_t* sync,
+hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,
                                int32_t* err_host, int32_t base) {
   if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
   PersistArgs pa{};
-  pa.sync = sync; pa.err_host = err_host; pa.base = base;
-#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, 1>(s, lds_bytes, a, pa);
-  FLAME_PERSIST_CFGS(X)
-#undef X
-  return hipErrorInvalidConfiguration;
-}
-
-hipError_t launch_tile_xpersist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const XPersist& x,
-                                int32_t* err_host, int32_t base) {
-  if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
-  PersistArgs pa{};
-  pa.sync = x.sync; pa.err_host = err_host; pa.base = base;
+  pa.err_host = err_host; pa.base = base; pa.prof = x.prof;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
-#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, 2>(s, lds_bytes, a, pa);
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes, a, pa);
   FLAME_PERSIST_CFGS(X)
 #undef X
   return hipErrorInvalidConfiguration;

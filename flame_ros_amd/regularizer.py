@@ -113,6 +113,11 @@ class GraphRegularizer:
             _l.check(self._lib.flame_hip_set_option(self._h, k.encode(), int(v)), "flame_hip_set_option(%s)" % k)
         return self
 
+    def set_option(self, key, value):
+        """flame_hip_set_option on a live handle (plan options take effect with the next upload; "persist" and
+        "use_graph" with the next solve)."""
+        _l.check(self._lib.flame_hip_set_option(self._h, key.encode(), int(value)), "flame_hip_set_option(%s)" % key)
+
     def sync_features(self, pos, idepth_mu, idepth_var, tris, sync_params, prediction=None):
         """Row a7 (graph sync): tracked features + their Delaunay triangulation -> edges, weights,
         data terms, initial x; resizes this handle and uploads.  Returns the data scale."""

@@ -96,17 +96,21 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * trying at that size: flame_hip_get_info "single_cap"), "stream_depth" (0 = off, default; > 0: halo
  * depth of graphs of up to 2048 vertices in place of the automatic 8 -- for handles that solve every
  * graph ONCE, where the plan of shallow tiles is cheaper than the launches deep tiles save), "persist"
- * (default 0; 1: a graph of 2..32 tiles is solved by ONE launch of tiles resident on one XCD -- a flag
- * barrier and a re-read of the halo through L2 per `depth` iterations instead of a kernel boundary, same
- * bits; 2 (what flame::Flame sets): also cuts frames of up to 1280 vertices into tiles of 50 own vertices,
- * the shape it pays for on a frame stream; flame_hip_get_info "persist_used" tells whether the last solve
- * ran that way.  A launch that could not keep its tiles on one XCD or waited longer than 4 ms -- e.g. two
- * handles solving this way at once on one device starving each other of the XCD's CUs -- is noticed at the
- * next synchronising call, which switches the option off and REPEATS the solve by ordinary launches when it
- * was the first solve of a device-built plan ("persist_recovered" counts those), else returns
- * FLAME_HIP_ERR_STATE and leaves the graph to be uploaded again; dev aid: with FLAME_HIP_PERSIST_PROF set
- * in the environment "persist_prof_0".."persist_prof_4" return tile 0's time split of the last solve's
- * rounds in 10 ns ticks: iterations, store acknowledge, flags, halo re-read, and the number of rounds),
+ * (default 1: a graph of 2 .. 256 halo tiles -- at most one per CU -- is solved by ONE launch of RESIDENT tiles:
+ * neighbours hand their results over through uncached, round-tagged copies of the state arrays every `depth`
+ * iterations instead of meeting at a kernel boundary; same bits, any placement of the tiles on the chip; 0: one
+ * launch per `depth` iterations; 2 (what flame::Flame sets): also cuts frames of up to 1280 vertices into
+ * tiles of 50 own vertices; flame_hip_get_info "persist_used" tells whether the last solve ran that way.  The
+ * launch ASSUMES that all its workgroups are on the chip at once.  The library keeps the tile count within the
+ * CU count and lets one handle per device and process run such a launch at a time (another handle solving at the
+ * same moment uses ordinary launches), but a foreign kernel that holds CUs for long -- another process, another
+ * library -- can still keep tiles from starting: every wait inside the launch is bounded (4 ms), a launch that
+ * gave up is noticed at the next synchronising call and REPEATED by ordinary launches from its untouched source
+ * buffers ("persist_recovered" counts those; FLAME_HIP_ERR_STATE only when another call rewrote the state in
+ * between), and the whole process then stays off resident tiles for 16 solves, doubling with every further
+ * give-up ("persist_gave_up").  Dev aid: with FLAME_HIP_PERSIST_PROF=<tile + 1> in the environment
+ * "persist_prof_0".."persist_prof_3" return that tile's time split of the last solve's rounds in 10 ns ticks:
+ * iterations + stores, poll of the halo entries, halo applied + barrier, and the number of rounds),
  * "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
  * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile",

@@ -1,6 +1,7 @@
-"""-m gpu: option "persist" -- graphs of <= 32 tiles solved by ONE launch of resident tiles on one XCD
-(kernels.hip k_tile_persist: a counter barrier and a re-read of the halo state through L2 instead of a
-kernel boundary per `depth` iterations).  Same bits as the launches per round and as the oracle."""
+"""-m gpu: option "persist" (default on) -- graphs of 2 .. 256 halo tiles solved by ONE launch of resident tiles
+(kernels.hip k_tile_persist: neighbours hand their results over through uncached, round-tagged copies of the state
+arrays instead of meeting at a kernel boundary per `depth` iterations).  Same bits as the launches per round and as
+the oracle, whatever the placement of the tiles."""
 import numpy as np
 import pytest
 
@@ -10,14 +11,18 @@ from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,own,depth", [("tum", 40, 5), ("tum", 64, 4), ("v2000", 70, 5), ("v800", 30, 8), ("tum", 40, 2)])
-def test_persistent_tiles_match_oracle(gpu, name, own, depth):
+@pytest.mark.parametrize("name,own,depth", [("tum", 40, 5), ("tum", 64, 4), ("v2000", 70, 5), ("v800", 30, 8), ("tum", 40, 2),
+                                            ("tum", 16, 8), ("5k", 0, 0), ("5k", 24, 3), ("euroc", 0, 0), ("euroc", 0, 6)])
+def test_resident_tiles_match_oracle(gpu, name, own, depth):
     g, _ = graphgen.named(name)
     p = default_params()
-    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_own=own, tile_depth=depth,
-                         persist=1)
-    ref = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_own=own, tile_depth=depth)
-    assert 2 <= r.info("num_tiles") <= 32 and r.info("tile_depth") == depth
+    kw = {}
+    if own: kw["tile_own"] = own
+    if depth: kw["tile_depth"] = depth
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=1, **kw)
+    ref = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=0, **kw)
+    depth = r.info("tile_depth")
+    assert 2 <= r.info("num_tiles") <= 256 and depth > 0
     o = make_oracle(g)
     for iters in (depth + 1, 200, 23, depth, 1, 77):  # ragged last rounds; <= depth: the ordinary launch
         o.solve(oracle_params(), iters)
@@ -33,13 +38,30 @@ def test_persistent_tiles_match_oracle(gpu, name, own, depth):
     xbr = ref.download_bar()
     for a, b in zip(xb, xbr):
         assert_bit_equal(a, b, "x_bar")
+    assert r.info("persist_recovered") == 0
     r.close(); ref.close()
 
 
-def test_persist_not_taken_on_larger_graphs(gpu):
-    g, it = graphgen.named("5k")
-    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=1)
-    assert r.info("num_tiles") > 32
+def test_resident_tiles_at_the_headline_size(gpu):
+    """BASELINE config 4 (50 k vertices, 500 iterations): 256 tiles, one per CU, 125 rounds; every bit of x, w, q."""
+    g, it = graphgen.named("50k")
+    p = default_params()
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)  # (the default IS persist = 1)
+    o = make_oracle(g)
+    for _ in range(2):  # (the second solve runs with the conflict-avoiding lane order applied)
+        o.solve(oracle_params(), it)
+        r.step(p, it)
+        assert r.info("persist_used") == 1 and r.last_solve_ms()[1] == 1
+        x, w1, w2, q = r.download()
+        assert_bit_equal(x, o.x, "x"); assert_bit_equal(q, o.q, "q"); assert_bit_equal(w1, o.w1, "w1"); assert_bit_equal(w2, o.w2, "w2")
+    assert r.info("persist_recovered") == 0
+    r.close()
+
+
+def test_resident_tiles_not_taken_beyond_one_tile_per_cu(gpu):
+    g, _ = graphgen.named("v20000")
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_own=32, persist=1)
+    assert r.info("num_tiles") > 256
     r.step(default_params(), 50)
     assert r.info("persist_used") == 0
     o = make_oracle(g); o.solve(oracle_params(), 50)
@@ -47,11 +69,11 @@ def test_persist_not_taken_on_larger_graphs(gpu):
     r.close()
 
 
-def test_a_persistent_solve_that_gives_up_is_repeated_by_launches(gpu):
-    """FLAME_HIP_PERSIST_FAIL makes the library treat every persistent launch as failed (what a time-out or
-    tiles on several XCDs raise): the first solve of a device-built plan is repeated by ordinary launches from
-    the staged inputs -- through flame_hip_sync (download) and through frame_results -- with the oracle's bits;
-    the handle stops using the option."""
+def test_a_resident_solve_that_gives_up_is_repeated_by_launches(gpu):
+    """FLAME_HIP_PERSIST_FAIL makes the library treat every launch of resident tiles as failed (what a time-out
+    raises): the solve is repeated by ordinary launches from its untouched source buffers -- through flame_hip_sync
+    (download) and through frame_results, on the first solve of a frame and on a later solve of a resident graph -- with
+    the oracle's bits; the process then sits out 16 solves before it tries resident tiles again."""
     import os, subprocess, sys
     code = r'''
 import numpy as np, sys
@@ -64,21 +86,47 @@ g, _ = graphgen.named("tum")
 p = default_params()
 var = np.full(g.V, 1e-4, np.float32)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
-for via, rescale in (("sync", 0), ("frame_results", 0), ("frame_results", 1)):  # (rescale: frame_results un-scales behind the solve)
+# (i) a resident graph, third solve: nothing staged to restart from -- the source buffer of the solve is intact
+o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_own=50, tile_depth=5, persist=0)
+for n in (30, 41):
+    o.solve(oparams(), n); r.step(p, n)
+r.set_option("persist", 1)
+o.solve(oparams(), 60); r.step(p, 60, sync=False)
+assert r.info("persist_used") == 1
+x = r.download()[0]
+assert r.info("persist_recovered") == 1 and r.info("persist_gave_up") == 1
+assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)), "resident graph"
+for k in range(16):  # the back-off: launches, no further give-up
+    o.solve(oparams(), 12); r.step(p, 12, sync=False)
+    assert r.info("persist_used") == 0, k
+o.solve(oparams(), 12); r.step(p, 12, sync=False)
+assert r.info("persist_used") == 1  # (tried again; FLAME_HIP_PERSIST_FAIL fails it again)
+x = r.download()[0]
+assert r.info("persist_recovered") == 2 and r.info("persist_gave_up") == 2
+assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)), "resident graph, after the back-off"
+r.close()
+# (ii) frame streams: first solve of a device-built plan, via sync and via frame_results (with and without un-scaling)
+skip = 32
+for via, rescale in (("sync", 0), ("frame_results", 0), ("frame_results", 1)):
     sp = default_sync_params(0, rescale, 1, 0.01)
     s = oracle_sync(OSync(0, rescale, 1, 0.01), g.pos, g.z, var, g.tris, None)
     o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"]); o.solve(oparams(), 60)
     if via == "frame_results": o.scale_state(s["scale"])
     r = GraphRegularizer.empty(device=0, tile_own=50, tile_depth=5, persist=1)
     scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
+    for k in range(skip):  # (sit out the process-wide back-off of the give-ups above: 32, 64, 128 solves)
+        r.step(p, 6, sync=False)  # (> depth: each consumes one solve of the back-off)
+    skip *= 2
+    scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
     r.step(p, 60, sync=False)
-    assert r.info("persist_used") == 1
+    assert r.info("persist_used") == 1, via
     if via == "sync":
         x = r.download()[0]
     else:
         out = r.frame_results(p, Kinv, default_tri_params(g.width, g.height), scale_back=scale, with_edges=True, with_coverage=True)
         x = out["x"] if isinstance(out, dict) else out[2]
-    assert r.info("persist_recovered") == 1 and r.info("persist") == 0, via
+    assert r.info("persist_recovered") == 1 and r.info("persist") == 1, via
     assert np.array_equal(np.asarray(x).view(np.uint32), o.x.view(np.uint32)), via
     r.close()
 print("recovered ok")
@@ -88,10 +136,10 @@ print("recovered ok")
     assert out.returncode == 0 and "recovered ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_facade_sized_frames_on_persistent_tiles(gpu):
+def test_facade_sized_frames_on_resident_tiles(gpu):
     """The options flame::Flame sets (tile_single_max 640, stream_depth 5, persist 2) on a stream of frames
-    around the thresholds: 600 vertices -> one isolated tile, 650..1280 -> tiles of 50 own vertices solved by
-    ONE launch, 1300 -> halo tiles and launches; every frame the oracle's bits."""
+    around the thresholds: 600 vertices -> one isolated tile, 650..1280 -> tiles of 50 own vertices, 1300 -> the
+    automatic halo tiles, all solved by ONE launch of resident tiles; every frame the oracle's bits."""
     from flame_ros_amd.regularizer import default_sync_params
     from oracle import COracle
     from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
@@ -110,7 +158,7 @@ def test_facade_sized_frames_on_persistent_tiles(gpu):
         x, w1, w2, q = r.download()
         assert_bit_equal(x, o.x, "V %d x" % V); assert_bit_equal(q, o.q, "V %d q" % V)
     assert seen[0][1] == 1 and seen[0][2] == 0, seen          # one isolated tile
-    assert seen[1][2] == 0 and seen[1][1] > 32, seen           # 1300 vertices: halo tiles, launches
-    assert all(u == 1 and 13 <= t <= 26 for V, t, u in seen[2:]), seen  # (the 41-tile partition is not inherited)
+    assert seen[1][2] == 1 and seen[1][1] > 32, seen           # 1300 vertices: the automatic halo tiles, resident too
+    assert all(u == 1 and 13 <= t <= 26 for V, t, u in seen[2:]), seen  # (tiles of 50 own vertices)
     assert r.info("persist_recovered") == 0
     r.close()

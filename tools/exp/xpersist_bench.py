@@ -10,18 +10,20 @@ from tests.util import make_oracle, oracle_params
 args = sys.argv[1:]
 kw = {}
 names = []
+pv = 1
 i = 0
 while i < len(args):
     if args[i] == "--depth": kw["tile_depth"] = int(args[i + 1]); i += 2
     elif args[i] == "--own": kw["tile_own"] = int(args[i + 1]); i += 2
     elif args[i] == "--threads": kw["tile_threads"] = int(args[i + 1]); i += 2
+    elif args[i] == "--persist": pv = int(args[i + 1]); i += 2
     else: names.append(args[i]); i += 1
 p = default_params()
 for name in (names or ["5k", "euroc", "50k"]):
     g, it = graphgen.named(name)
     o = make_oracle(g); o.solve(oracle_params(), it)
     ref = None
-    for persist in (0, 3):
+    for persist in (0, pv):
         r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=persist, **kw)
         r.step(p, it)
         x, w1, w2, q = r.download()
@@ -35,10 +37,10 @@ for name in (names or ["5k", "euroc", "50k"]):
         else: ok2 = np.array_equal(x2.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(q2.view(np.uint32), ref[1].view(np.uint32))
         prof = ""
         if persist and os.environ.get("FLAME_HIP_PERSIST_PROF"):
-            t = [r.info("persist_prof_%d" % k) for k in range(5)]
-            n = max(t[4] - 1, 1)
-            prof = "  tile %s rounds %d: iterate+store %.2f us, drain|poll %.2f, flags %.2f, re-read|apply %.2f per round" % (
-                os.environ["FLAME_HIP_PERSIST_PROF"], t[4], t[0] / n / 100., t[1] / n / 100., t[2] / n / 100., t[3] / n / 100.)
+            t = [r.info("persist_prof_%d" % k) for k in range(4)]
+            n = max(t[3] - 1, 1)
+            prof = "  tile %s rounds %d: iterate+store %.2f us, poll %.2f, apply+barrier %.2f per round" % (
+                os.environ["FLAME_HIP_PERSIST_PROF"], t[3], t[0] / n / 100., t[1] / n / 100., t[2] / n / 100.)
         print("%-6s persist %d: %.3f us/it (%.3f ms per %d)  tiles %d depth %d threads %d used %d recovered %d  bit-exact: first solve vs oracle %s, 9th vs launches %s%s" % (
             name, persist, best * 1e3 / it, best, it, r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("persist_used"),
             r.info("persist_recovered"), ok, ok2, prof), flush=True)
