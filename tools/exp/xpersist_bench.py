@@ -17,6 +17,7 @@ while i < len(args):
     elif args[i] == "--own": kw["tile_own"] = int(args[i + 1]); i += 2
     elif args[i] == "--threads": kw["tile_threads"] = int(args[i + 1]); i += 2
     elif args[i] == "--persist": pv = int(args[i + 1]); i += 2
+    elif args[i] == "--percu": kw["persist_per_cu"] = int(args[i + 1]); i += 2
     else: names.append(args[i]); i += 1
 p = default_params()
 for name in (names or ["5k", "euroc", "50k"]):
