@@ -230,16 +230,40 @@ def main():
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
-    if local_rank >= torch.cuda.device_count():  # launcher restricted visibility to one GPU per rank
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
     # FLAME_BENCH_BACKEND=gloo: several ranks on ONE GPU (development check of the N>1 code paths;
     # timing tensors then live on the host); the product backend is nccl (= RCCL over xGMI)
     backend = os.environ.get("FLAME_BENCH_BACKEND", "nccl")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    ndev = torch.cuda.device_count()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, the same
+        # command line the driver uses) instead of quietly running one
+        if ndev < args.gpus and backend != "gloo":
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible (FLAME_BENCH_BACKEND=gloo runs the ranks on "
+                     "one GPU as a development check)" % (args.gpus, ndev))
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1:  # (an explicit --gpus must agree with the launcher)
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        args.gpus = world
+    shared_gpu = False
+    if local_rank >= ndev:  # fewer devices than ranks: only as the gloo development check, all ranks on the devices there are
+        if backend != "gloo":
+            sys.exit("bench.py: rank %d has no GPU of its own (%d visible); RCCL needs one device per rank" % (rank, ndev))
+        local_rank %= ndev
+        shared_gpu = True
+    shared_gpu = shared_gpu or (backend == "gloo" and world > ndev)
+    torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -270,6 +294,8 @@ def main():
     if args.no_balance: opts["balance"] = 0
     if args.host_plan: opts["plan_device"] = 0
     if args.order_mode >= 0: opts["order_mode"] = args.order_mode
+    if shared_gpu:  # resident tiles assume the whole chip; ranks sharing one GPU would starve each other
+        opts["persist"] = 0
     for kv in args.opt:
         k, v = kv.split("=")
         opts[k] = int(v)

@@ -121,56 +121,79 @@ class PartitionedSolver:
       halo_register(send_v, send_e, recv_v, recv_e); halo_pack() -> tensor; halo_unpack(tensor);
       step(params, n); download() -> (x, w1, w2, q)
     operating on the subdomain's LOCAL numbering.
+
+    parts_per_rank = k > 1 over-decomposes: the graph is cut into world * k subdomains and a rank holds k
+    consecutive ones (part p lives on rank p // k); halo records between two parts of one rank travel the
+    same way as all others -- a send / receive pair of the rank with ITSELF inside the one batch of P2P
+    operations (ncclGroupStart .. ncclSend / ncclRecv to the own rank .. ncclGroupEnd).  world 1, k 2 is
+    how the RCCL path is exercised on a single GPU (tests/test_gpu_nccl_self.py).
     """
 
-    def __init__(self, pos, edges, alpha, beta, z, wgt, make_solver, depth=8, x0=None):
+    def __init__(self, pos, edges, alpha, beta, z, wgt, make_solver, depth=8, x0=None, parts_per_rank=1):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        k = self.k = int(parts_per_rank)
+        nparts = self.nparts = self.world * k
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
         edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
         self.V, self.E, self.depth = len(pos), len(edges), depth
-        self.part = rcb_parts(pos, self.world)
-        sub = self.sub = build_subdomain(pos, edges, self.part, self.rank, depth)
+        self.part = rcb_parts(pos, nparts)
+        self.my_parts = list(range(self.rank * k, (self.rank + 1) * k))
         f = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
-        self.solver = make_solver(sub, pos[sub.vid], sub.edges, f(alpha)[sub.eid], f(beta)[sub.eid],
-                                  f(z)[sub.vid], f(wgt)[sub.vid],
-                                  None if x0 is None else f(x0)[sub.vid])
-        # tell every owner which of its vertices / edges (GLOBAL ids, int64 arrays) this rank needs;
-        # the owner maps them to its local numbering with a binary search (own vertices and the local
-        # edge list are ascending in global id): no per-element Python anywhere
+        self.subs, self.solvers = [], []
+        for p in self.my_parts:
+            sub = build_subdomain(pos, edges, self.part, p, depth)
+            self.subs.append(sub)
+            self.solvers.append(make_solver(sub, pos[sub.vid], sub.edges, f(alpha)[sub.eid], f(beta)[sub.eid],
+                                            f(z)[sub.vid], f(wgt)[sub.vid],
+                                            None if x0 is None else f(x0)[sub.vid]))
+        self.sub, self.solver = self.subs[0], self.solvers[0]  # (the one-part-per-rank names)
+        # tell every owner which of its vertices / edges (GLOBAL ids, int64 arrays) a part needs; the owner
+        # maps them to its local numbering with a binary search (own vertices and the local edge list are
+        # ascending in global id): no per-element Python anywhere
         none = np.zeros(0, np.int32)
-        want = {int(r): (sub.vid[sub.recv_v.get(r, none)], sub.eid[sub.recv_e.get(r, none)])
-                for r in set(sub.recv_v) | set(sub.recv_e)}
+        want = {}  # (owner part, wanting part) -> (global vertex ids, global edge ids)
+        for sub in self.subs:
+            for o in set(sub.recv_v) | set(sub.recv_e):
+                want[(int(o), sub.rank)] = (sub.vid[sub.recv_v.get(o, none)], sub.eid[sub.recv_e.get(o, none)])
         allwant = [None] * self.world
         dist.all_gather_object(allwant, want)
-        own_gid = sub.vid[:sub.n_own]
-        self.peers = sorted(set(want) | {r for r in range(self.world) if self.rank in allwant[r]})
-        send_v, send_e, recv_v, recv_e = [], [], [], []
-        self.send_cnt, self.recv_cnt = {}, {}
-        for r in self.peers:
-            wv, we = allwant[r].get(self.rank, (np.zeros(0, np.int64), np.zeros(0, np.int64)))
-            sv = np.searchsorted(own_gid, wv).astype(np.int32)
-            se = np.searchsorted(sub.eid, we).astype(np.int32)
-            assert np.array_equal(own_gid[sv], wv) and np.array_equal(sub.eid[se], we), "request for state this rank does not own"
-            rv, re_ = sub.recv_v.get(r, none), sub.recv_e.get(r, none)
-            self.send_cnt[r] = (len(sv), len(se))
-            self.recv_cnt[r] = (len(rv), len(re_))
-            send_v.append(sv); send_e.append(se); recv_v.append(rv); recv_e.append(re_)
-        cat = lambda a: np.concatenate(a).astype(np.int32) if a else none  # noqa: E731
-        send_v, send_e, recv_v, recv_e = cat(send_v), cat(send_e), cat(recv_v), cat(recv_e)
-        self.n_send = (len(send_v), len(send_e))
-        self.n_recv = (len(recv_v), len(recv_e))
-        self.solver.halo_register(send_v, send_e, recv_v, recv_e)
+        wants = {}
+        for w in allwant:
+            wants.update(w)
+        # per local part: its peer parts in ascending order, send / receive lists and counts per peer
+        self.peers_of, self.send_cnt, self.recv_cnt, self.n_send_of, self.n_recv_of = [], [], [], [], []
+        for sub, solver in zip(self.subs, self.solvers):
+            me = sub.rank
+            peers = sorted({w for (o, w) in wants if o == me} | {o for (o, w) in wants if w == me})
+            own_gid = sub.vid[:sub.n_own]
+            send_v, send_e, recv_v, recv_e, sc, rc = [], [], [], [], {}, {}
+            for r in peers:
+                wv, we = wants.get((me, r), (np.zeros(0, np.int64), np.zeros(0, np.int64)))
+                sv = np.searchsorted(own_gid, wv).astype(np.int32)
+                se = np.searchsorted(sub.eid, we).astype(np.int32)
+                assert np.array_equal(own_gid[sv], wv) and np.array_equal(sub.eid[se], we), "request for state this part does not own"
+                rv, re_ = sub.recv_v.get(r, none), sub.recv_e.get(r, none)
+                sc[r] = (len(sv), len(se))
+                rc[r] = (len(rv), len(re_))
+                send_v.append(sv); send_e.append(se); recv_v.append(rv); recv_e.append(re_)
+            cat = lambda a: np.concatenate(a).astype(np.int32) if a else none  # noqa: E731
+            send_v, send_e, recv_v, recv_e = cat(send_v), cat(send_e), cat(recv_v), cat(recv_e)
+            solver.halo_register(send_v, send_e, recv_v, recv_e)
+            self.peers_of.append(peers); self.send_cnt.append(sc); self.recv_cnt.append(rc)
+            self.n_send_of.append((len(send_v), len(send_e))); self.n_recv_of.append((len(recv_v), len(recv_e)))
+        self.peers, self.n_send, self.n_recv = self.peers_of[0], self.n_send_of[0], self.n_recv_of[0]
         self._rings_left = depth  # a fresh upload holds exact state on every ring
         self._sbuf = self._rbuf = None  # persistent exchange buffers, allocated on the first exchange
         self._ops_cache = None
 
-    # packed buffer layout: all vertex records (VREC floats each, peers in order) then all edge
-    # records (EREC floats each, peers in order) -> per-peer messages are two slices each
-    def _slices(self, cnt, n):
+    # packed buffer layout of one part: all vertex records (VREC floats each, peers in order) then all
+    # edge records (EREC floats each, peers in order) -> per-peer messages are two slices each
+    @staticmethod
+    def _slices(peers, cnt, n):
         out, ov, oe = {}, 0, VREC * n[0]
-        for r in self.peers:
+        for r in peers:
             nv, ne = cnt[r]
             out[r] = ((ov, ov + VREC * nv), (oe, oe + EREC * ne))
             ov += VREC * nv
@@ -178,7 +201,7 @@ class PartitionedSolver:
         return out
 
     def exchange(self):
-        if self.world == 1 or not self.peers:
+        if self.nparts == 1 or not any(self.peers_of):
             return
         ctx = getattr(self.solver, "stream_context", None)
         if ctx is None:
@@ -190,38 +213,54 @@ class PartitionedSolver:
         """pack -> P2P -> unpack.  The send and receive buffers are allocated ONCE (first exchange) and
         the P2POp list is built once; with the nccl backend everything is enqueued on the solver's
         stream (Work.wait() of an NCCL op orders the stream, it does not block the host), so a step()
-        returns without a host synchronisation -- only download() / costs() synchronise."""
+        returns without a host synchronisation -- only download() / costs() synchronise.
+        Messages between one pair of ranks match by ORDER (no tags in ncclSend / ncclRecv): both sides
+        issue them sorted by (sending part, receiving part, vertex records before edge records)."""
         dist = self.dist
         if self._sbuf is None:
-            first = self.solver.halo_pack()  # (a solver without persistent buffers returns a new one)
+            firsts = [sv.halo_pack() for sv in self.solvers]  # (a solver without persistent buffers returns a new one)
             # gloo has no device-to-device path: stage through the host (tests with several ranks on
             # ONE GPU; the product backend is nccl = RCCL, device buffers straight into ncclSend/Recv)
-            self._staged = first.is_cuda and dist.get_backend() == "gloo"
-            self._dev = first.device
-            self._sbuf = first.cpu() if self._staged else first
-            self._rbuf = self._sbuf.new_empty(VREC * self.n_recv[0] + EREC * self.n_recv[1])
-            self._rdev = self._rbuf.to(self._dev) if self._staged else self._rbuf
-            ops, ssl, rsl = [], self._slices(self.send_cnt, self.n_send), self._slices(self.recv_cnt, self.n_recv)
-            for r in self.peers:
-                for a, b in ssl[r]:
-                    if b > a:
-                        ops.append(dist.P2POp(dist.isend, self._sbuf[a:b], r))
-                for a, b in rsl[r]:
-                    if b > a:
-                        ops.append(dist.P2POp(dist.irecv, self._rbuf[a:b], r))
-            self._ops_cache = ops
-            self._pack_into = getattr(self.solver, "halo_pack_into", None)
-        elif self._pack_into is not None and not self._staged:
-            self._pack_into(self._sbuf)  # in place: no allocation
+            self._staged = firsts[0].is_cuda and dist.get_backend() == "gloo"
+            self._dev = firsts[0].device
+            self._sbuf = [f.cpu() if self._staged else f for f in firsts]
+            self._rbuf = [self._sbuf[i].new_empty(VREC * n[0] + EREC * n[1]) for i, n in enumerate(self.n_recv_of)]
+            self._rdev = [r.to(self._dev) if self._staged else r for r in self._rbuf]
+            sends, recvs = [], []
+            for i, me in enumerate(self.my_parts):
+                ssl = self._slices(self.peers_of[i], self.send_cnt[i], self.n_send_of[i])
+                rsl = self._slices(self.peers_of[i], self.recv_cnt[i], self.n_recv_of[i])
+                for r in self.peers_of[i]:
+                    for kind, (a, b) in enumerate(ssl[r]):
+                        if b > a:
+                            sends.append(((me, r, kind), dist.P2POp(dist.isend, self._sbuf[i][a:b], r // self.k)))
+                    for kind, (a, b) in enumerate(rsl[r]):
+                        if b > a:
+                            recvs.append(((r, me, kind), dist.P2POp(dist.irecv, self._rbuf[i][a:b], r // self.k)))
+            self._self_copies = []
+            if dist.get_backend() != "nccl":  # gloo has no pair of a rank with itself: those records are copied
+                rmap = {key: op for key, op in recvs if op.peer == self.rank}
+                self._self_copies = [(rmap[key].tensor, op.tensor) for key, op in sends if op.peer == self.rank]
+                sends = [t for t in sends if t[1].peer != self.rank]
+                recvs = [t for t in recvs if t[1].peer != self.rank]
+            self._ops_cache = [op for _, op in sorted(sends, key=lambda t: t[0])] + \
+                              [op for _, op in sorted(recvs, key=lambda t: t[0])]
+            self._pack_into = [getattr(sv, "halo_pack_into", None) for sv in self.solvers]
         else:
-            packed = self.solver.halo_pack()
-            self._sbuf.copy_(packed)  # (gloo test path / solvers without halo_pack_into)
+            for i, sv in enumerate(self.solvers):
+                if self._pack_into[i] is not None and not self._staged:
+                    self._pack_into[i](self._sbuf[i])  # in place: no allocation
+                else:
+                    self._sbuf[i].copy_(sv.halo_pack())  # (gloo test path / solvers without halo_pack_into)
         if self._ops_cache:
             for w in dist.batch_isend_irecv(self._ops_cache):
                 w.wait()
-        if self._staged:
-            self._rdev.copy_(self._rbuf)
-        self.solver.halo_unpack(self._rdev)
+        for dst, src in self._self_copies:
+            dst.copy_(src)
+        for i, sv in enumerate(self.solvers):
+            if self._staged:
+                self._rdev[i].copy_(self._rbuf[i])
+            sv.halo_unpack(self._rdev[i])
 
     def step(self, params, num_iters):
         """Every local iteration invalidates one halo ring: `_rings_left` counts how many more
@@ -233,42 +272,50 @@ class PartitionedSolver:
                 self.exchange()
                 self._rings_left = self.depth
             n = min(self._rings_left, num_iters - done)
-            self.solver.step(params, n)
+            for sv in self.solvers:
+                sv.step(params, n)
             self._rings_left -= n
             done += n
 
     def costs(self, params):
         """nltgv2_total_smoothness_cost / nltgv2_total_data_cost of the WHOLE graph (the stat keys read
-        at reference src/utils.cc:131-136): every rank sums the edges and vertices it owns, one
-        all-reduce of 2 doubles (SURVEY.md 8e "final cost reduction")."""
+        at reference src/utils.cc:131-136): every part sums the edges and vertices it owns, one
+        all-reduce of 2 doubles (SURVEY.md 8e "final cost reduction"; with nccl a device tensor, also at
+        world 1, so that the collective itself runs)."""
         import torch
-        s = self.sub
         if self._rings_left == 0 and self.depth > 0:  # an owned edge reads its target in ring 1
             self.exchange()
             self._rings_left = self.depth
-        vmask = np.zeros(len(s.vid), np.uint8)
-        vmask[:s.n_own] = 1
-        sm, da = self.solver.costs_owned(params, vmask, s.e_owned.astype(np.uint8))
+        sm = da = 0.0
+        for s, sv in zip(self.subs, self.solvers):
+            vmask = np.zeros(len(s.vid), np.uint8)
+            vmask[:s.n_own] = 1
+            a, b = sv.costs_owned(params, vmask, s.e_owned.astype(np.uint8))
+            sm += a
+            da += b
         t = torch.tensor([sm, da], dtype=torch.float64)
-        if self.world > 1:
-            if self.dist.get_backend() == "nccl":
+        nccl = self.dist.get_backend() == "nccl"
+        if self.world > 1 or nccl:
+            if nccl:
                 t = t.cuda()
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t[0]), float(t[1])
 
     def gather_solution(self):
         """x, w1, w2 (V) and q (E,3) of the whole graph on every rank (verification helper)."""
-        x, w1, w2, q = self.solver.download()
-        s = self.sub
-        own_e = np.flatnonzero(s.e_owned)
-        mine = (s.vid[:s.n_own], x[:s.n_own], w1[:s.n_own], w2[:s.n_own], s.eid[own_e], q[own_e])
+        mine = []
+        for s, sv in zip(self.subs, self.solvers):
+            x, w1, w2, q = sv.download()
+            own_e = np.flatnonzero(s.e_owned)
+            mine.append((s.vid[:s.n_own], x[:s.n_own], w1[:s.n_own], w2[:s.n_own], s.eid[own_e], q[own_e]))
         parts = [None] * self.world
         self.dist.all_gather_object(parts, mine)
         X, W1, W2 = (np.zeros(self.V, np.float32) for _ in range(3))
         Q = np.zeros((self.E, 3), np.float32)
-        for vid, px, p1, p2, eid, pq in parts:
-            X[vid], W1[vid], W2[vid] = px, p1, p2
-            Q[eid] = pq
+        for plist in parts:
+            for vid, px, p1, p2, eid, pq in plist:
+                X[vid], W1[vid], W2[vid] = px, p1, p2
+                Q[eid] = pq
         return X, W1, W2, Q
 
 
@@ -289,7 +336,15 @@ class HipSubdomainSolver:
         # pack/unpack, torch copies and the RCCL P2P ops issued under stream_context().  (A NULL
         # stream would mean "the handle's own stream" to the C ABI, unordered with torch.)
         self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
-        # the D-iteration local solve is captured once into a hipGraph and replayed on this stream
+        # resident tiles assume the whole chip: off when several ranks share one GPU (the gloo development
+        # check of the N>1 paths), where the ranks' launches would starve each other until they time out
+        try:
+            import torch.distributed as tdist
+            if tdist.is_initialized() and tdist.get_world_size() > torch.cuda.device_count():
+                options.setdefault("persist", 0)
+        except Exception:  # noqa: BLE001
+            pass
+        # the D-iteration local solve runs as one launch of resident tiles (or a replayed hipGraph) on this stream
         self.reg = GraphRegularizer(pos, edges, alpha, beta, z, wgt, x0=x0, device=device, **options)
         self.n_send = self.n_recv = (0, 0)
 
@@ -337,6 +392,13 @@ class HipSubdomainSolver:
 
 
 def make_hip_solver(device=0, **options):
+    """Factory for PartitionedSolver: every subdomain this rank holds (parts_per_rank of them) is solved on
+    ONE torch stream, which also orders the packs, the P2P operations and the unpacks between them."""
+    shared = {}
+
     def f(sub, pos, edges, alpha, beta, z, wgt, x0):
-        return HipSubdomainSolver(sub, pos, edges, alpha, beta, z, wgt, x0, device=device, **options)
+        if "stream" not in shared:
+            import torch
+            shared["stream"] = torch.cuda.Stream(torch.device("cuda", device))
+        return HipSubdomainSolver(sub, pos, edges, alpha, beta, z, wgt, x0, device=device, stream=shared["stream"], **options)
     return f

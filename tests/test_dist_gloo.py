@@ -70,14 +70,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, V, depth, iters, out):
+def _worker(rank, world, port, V, depth, iters, out, parts_per_rank=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = graphgen.synthetic(V, seed=11)
         p = default_params()
         ps = fdist.PartitionedSolver(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt,
-                                     lambda *a: OracleSubdomainSolver(*a), depth=depth)
+                                     lambda *a: OracleSubdomainSolver(*a), depth=depth, parts_per_rank=parts_per_rank)
+        assert len(ps.subs) == parts_per_rank and ps.nparts == world * parts_per_rank
         assert ps.sub.n_own > 0 and len(ps.peers) >= 1
         # two step() calls: the second continues on whatever halo rings the first left valid
         ps.step(p, iters // 2)
@@ -108,6 +109,23 @@ def test_partitioned_solve_matches_serial_oracle(tmp_path, world, depth, iters, 
     for k, want in (("x", o.x), ("w1", o.w1), ("w2", o.w2), ("q", o.q)):
         assert np.array_equal(r[k].view(np.uint32), want.view(np.uint32)), k
     so, do = o.costs(default_params())  # whole-graph costs = all-reduced owned sums
+    assert abs(r["costs"][0] - so) <= 1e-6 * so and abs(r["costs"][1] - do) <= 1e-6 * do, (r["costs"], so, do)
+
+
+@pytest.mark.parametrize("world,k,depth,iters", [(2, 2, 3, 14), (1, 3, 4, 17), (2, 3, 2, 9)])
+def test_over_decomposed_partition_matches_serial_oracle(tmp_path, world, k, depth, iters):
+    """parts_per_rank = k: world * k subdomains, k per rank; the records between two parts of one rank are a
+    send / receive of the rank with itself inside the same batch (the form the single-GPU RCCL test uses)."""
+    V = 1800
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(world, _free_port(), V, depth, iters, out, k), nprocs=world, join=True)
+    g = graphgen.synthetic(V, seed=11)
+    o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+    o.solve(default_params(), iters)
+    r = np.load(out)
+    for key, want in (("x", o.x), ("w1", o.w1), ("w2", o.w2), ("q", o.q)):
+        assert np.array_equal(r[key].view(np.uint32), want.view(np.uint32)), key
+    so, do = o.costs(default_params())
     assert abs(r["costs"][0] - so) <= 1e-6 * so and abs(r["costs"][1] - do) <= 1e-6 * do, (r["costs"], so, do)
 
 

@@ -83,3 +83,19 @@ def test_bench_runs_with_two_ranks(gpu, mode):
         assert d["config"]["parallelism"].startswith("partition2")
     else:
         assert d["config"]["parallelism"] == "replicas2"
+
+
+def test_bench_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no launcher in the command: bench.py starts the two ranks itself and the line
+    says n_gpus 2 (gloo development backend: both ranks on the one GPU of this box); with the product backend and
+    fewer GPUs than ranks it refuses loudly instead of quietly running one rank."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "5k"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(env, FLAME_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "replicas2" and d["value"] > 0
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode != 0 and "only 1 GPU(s) visible" in (p.stdout + p.stderr), p.stdout[-1000:] + p.stderr[-2000:]
