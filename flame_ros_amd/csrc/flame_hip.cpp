@@ -283,6 +283,7 @@ struct flame_hip_graph {
   bool persist = true, persist_used = false;
   bool persist_sizing = false;      // option value 2: frames of up to 1280 vertices (above tile_single_max) go on tiles of 50 own vertices
   PersistBufs xp;                   // hand-off buffers (uncached) + dev-aid words, registered in caps
+  int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
   bool persist_skip_once = false;   // the next enqueue goes by launches (the repeat of a solve that gave up)
   int last_src = 0;                 // the buffer the last solve started from
   int32_t* persist_err = nullptr;   // page-locked: raised by a launch whose wait timed out
@@ -527,6 +528,9 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     const int v = force ? std::atoi(force) : value;
     g->persist = v != 0;
     g->persist_sizing = v >= 2;
+  } else if (k == "persist_prof") {
+    if (value < 0) return FLAME_HIP_ERR_ARG;
+    g->persist_prof_want = value;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -1510,11 +1514,14 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
         *g->persist_err = 0;
       }
-      if (!x.prof) {
+      if (!x.prof || g->persist_prof_set != g->persist_prof_want) {  // dev aid: which tile (if any) splits its rounds' time
         if ((rc = dev_alloc(g->caps, &x.prof, 8))) return rc;
         int32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) { w[0] = 1; w[1] = std::max(0, std::atoi(pp) - 1); }
+        int want = g->persist_prof_want;
+        if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) want = std::atoi(pp);
+        if (want > 0) { w[0] = 1; w[1] = want - 1; }
         HIPCHK(memcpy_sync(s, x.prof, w, sizeof(w), hipMemcpyHostToDevice));
+        g->persist_prof_set = g->persist_prof_want;
       }
       const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
       bool rezero = g->persist_base > (1 << 30);  // (the tags only grow)
