@@ -116,6 +116,7 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
 // runtime, call by call -- ~10 us each, the larger part of a small frame's upload).
 // frame_results: outputs up to this size are written to host memory by the kernels themselves (measured on
 // the facade stream, direct vs one copy: 1.2 k -14 us, 5 k -10 us, 10 k (185 KB) -15 us, 50 k (925 KB) +65 us)
+constexpr int kPollDelayDefault = 2;  // x 256 clocks (tools/exp/poll_delay_sweep.sh: 50k 1.56 -> 1.52 us per iteration, 5k 1.08 -> 1.06; 6 and up lose); FLAME_HIP_POLL_DELAY overrides
 constexpr int kMapMinTiles = 6;  // partitions of at least this many tiles leave a tile map for the next frame (partition reuse)
 constexpr size_t kDirectOutBytes = 256 * 1024;
 
@@ -1538,6 +1539,10 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];
       a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
       a.iters = num_iters;
+      {
+        static const char* pd = std::getenv("FLAME_HIP_POLL_DELAY");  // dev A/B
+        x.poll_delay = pd ? std::atoi(pd) : kPollDelayDefault;
+      }
       HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
                                  g->persist_base));
       g->persist_base += rounds - 1;

@@ -50,6 +50,7 @@ struct PersistBufs {
   float4* hB[2] = {nullptr, nullptr};
   float4* hq[2] = {nullptr, nullptr};
   int32_t* prof = nullptr;
+  int32_t poll_delay = 0;  // x 256 clocks between a round's stores and the first poll pass
 };
 bool tile_persist_exists(int nt, int ept, int vpt);
 hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,

@@ -285,6 +285,7 @@ struct PersistArgs {
   int32_t* err_host;  // page-locked: set when a wait timed out
   int32_t base;       // tags of this launch are base + 1 .. base + rounds - 1 (they only grow)
   int32_t* prof;      // device memory, dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]
+  int32_t poll_delay; // units of 256 clocks between a round's stores and its first poll pass
 };
 
 __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the CU's L1, served by the XCD's L2
@@ -523,6 +524,9 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
       neede[k] = (k * NT + tid) < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own);
       want = want || neede[k];
     }
+    // (the neighbours finish their round at about the same time and their stores take ~0.7 us to land: a poll pass
+    // issued at once samples memory too early and costs a second round trip)
+    for (int w = 0; w < pa.poll_delay; ++w) __builtin_amdgcn_s_sleep(4);
     const unsigned long long w0 = wall_clock64();
     bool stale = want;
     for (;;) {
@@ -1492,7 +1496,7 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
                                int32_t* err_host, int32_t base) {
   if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
   PersistArgs pa{};
-  pa.err_host = err_host; pa.base = base; pa.prof = x.prof;
+  pa.err_host = err_host; pa.base = base; pa.prof = x.prof; pa.poll_delay = x.poll_delay;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes, a, pa);
   FLAME_PERSIST_CFGS(X)
