@@ -280,9 +280,8 @@ struct flame_hip_graph {
   bool plan_mini_used = false; // ... the current plan was
   // option "persist" (default 1): graphs of 2 .. min(kPersistMaxTiles, CUs) halo tiles are solved by ONE launch of
   // RESIDENT tiles (kernels.hip k_tile_persist: round-tagged hand-offs through uncached memory instead of a kernel
-  // boundary per `depth` iterations); 0: launches; 2 (flame::Flame's): also sizes small frames for it
+  // boundary per `depth` iterations); 0: launches
   bool persist = true, persist_used = false;
-  bool persist_sizing = false;      // option value 2: frames of up to 1280 vertices (above tile_single_max) go on tiles of 50 own vertices
   PersistBufs xp;                   // hand-off buffers (uncached) + dev-aid words, registered in caps
   int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
   bool persist_skip_once = false;   // the next enqueue goes by launches (the repeat of a solve that gave up)
@@ -527,8 +526,7 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "persist") {
     static const char* force = std::getenv("FLAME_HIP_PERSIST");  // dev A/B: overrides the caller's choice
     const int v = force ? std::atoi(force) : value;
-    g->persist = v != 0;
-    g->persist_sizing = v >= 2;
+    g->persist = v != 0;  // (2 was r03's "also size small frames for it": the automatic tiles do as well now)
   } else if (k == "persist_prof") {
     if (value < 0) return FLAME_HIP_ERR_ARG;
     g->persist_prof_want = value;
@@ -648,11 +646,6 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   g->init_have_x0 = have_x0;
   Plan& P = g->plan;
   PlanSizing sz = plan_sizing(g->opt, V, E);
-  // option persist = 2 (the facade's): where one launch of resident tiles wins on a frame stream -- 1.0-1.2 k vertices
-  // on 20-24 tiles of 50 own vertices (tools/exp/persist_frames.py: 0.446 -> 0.417 ms; 1.4 k: 0.476 -> 0.512) -- the
-  // graph is cut that way
-  if (g->persist && g->persist_sizing && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() && !sz.single && V <= 1280)
-    sz.tile_own = 50;
   if (!g->plan_device || g->opt.path == FLAME_HIP_PATH_GLOBAL ||
       !DevPlanner::eligible(g->opt, V, E, T, sz.tile_own, sz.depth, sz.single, g->opt.lds_bytes))
     return 0;

@@ -393,6 +393,11 @@ class Flame {
     int32_t launches = 0;
     if (params_.do_nltgv2 && flame_hip_last_solve_ms(graph_.handle(), &ms, &launches) == 0)
       stats_.setTiming("nltgv2_device", ms);
+    // resident tiles (include/flame_hip.h, option "persist"): did this frame's solve run as one launch, and how many
+    // solves of this object had to be repeated by launches because a launch gave up (contention for the chip)
+    int64_t iv = 0;
+    if (flame_hip_get_info(graph_.handle(), "persist_used", &iv) == 0) stats_.set("persist_used", static_cast<double>(iv));
+    if (flame_hip_get_info(graph_.handle(), "persist_recovered", &iv) == 0) stats_.set("persist_recovered", static_cast<double>(iv));
     return true;
   }
 

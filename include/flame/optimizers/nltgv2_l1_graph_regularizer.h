@@ -94,13 +94,12 @@ class Graph {
     // at 910); above, a few dozen halo tiles planned on the GPU do (1 200 vertices: 0.51 vs 0.64 ms),
     // and with halo depth 5 rather than the 8 a resident graph of <= 64 tiles gets (1.2-2 k vertices:
     // 0.51-0.58 vs 0.56-0.66 ms).
-    // (r03, persistent tiles: the crossover moved down again -- 700 vertices 0.428 ms on one tile vs 0.412 on 14
-    // persistent tiles, 850: 0.479 vs 0.400, 500: 0.354 vs 0.370, tools/exp/persist_small.py)
+    // (r03 / r04, resident tiles -- one launch per solve, the library's default -- moved the crossover down again:
+    // 700 vertices 0.428 ms on one tile vs 0.412 on 14 resident tiles, 850: 0.479 vs 0.400, 500: 0.354 vs 0.370,
+    // tools/exp/persist_small.py; r04: the automatic 32-vertex tiles do as well as any special tile size on frames of
+    // 0.8-3 k vertices, tools/exp/facade_small_sweep.py)
     (void)flame_hip_set_option(g_, "tile_single_max", 640);
     (void)flame_hip_set_option(g_, "stream_depth", 5);
-    // frames of 0.64-1.28 k vertices: 13-26 tiles resident on one XCD for the whole solve (one launch; a launch that
-    // gives up is repeated the ordinary way) -- 0.446 -> 0.417 ms per 1.2 k frame (tools/exp/persist_frames.py)
-    (void)flame_hip_set_option(g_, "persist", 2);
     device_ = device;
     return 0;
   }

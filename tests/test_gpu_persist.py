@@ -136,17 +136,17 @@ print("recovered ok")
     assert out.returncode == 0 and "recovered ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-def test_facade_sized_frames_on_resident_tiles(gpu):
-    """The options flame::Flame sets (tile_single_max 640, stream_depth 5, persist 2) on a stream of frames
-    around the thresholds: 600 vertices -> one isolated tile, 650..1280 -> tiles of 50 own vertices, 1300 -> the
-    automatic halo tiles, all solved by ONE launch of resident tiles; every frame the oracle's bits."""
+def test_facade_frames_on_resident_tiles(gpu):
+    """The options flame::Flame sets (tile_single_max 640, stream_depth 5; resident tiles are the library's default)
+    on a stream of frames around the thresholds: 600 vertices -> one isolated tile, above -> halo tiles solved by ONE
+    launch of resident tiles; every frame the oracle's bits."""
     from flame_ros_amd.regularizer import default_sync_params
     from oracle import COracle
     from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
-    r = GraphRegularizer.empty(device=0, tile_single_max=640, stream_depth=5, persist=2)
+    r = GraphRegularizer.empty(device=0, tile_single_max=640, stream_depth=5)
     p, sp = default_params(), default_sync_params()
     seen = []
-    for k, V in enumerate((600, 1300, 650, 900, 900, 1280, 1280, 1000, 1000)):
+    for k, V in enumerate((600, 1300, 650, 900, 900, 1280, 1280, 1000, 1000, 3000, 3000)):
         g = graphgen.synthetic(V, seed=300 + k)
         var = np.full(g.V, 1e-4, np.float32)
         s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
@@ -158,7 +158,96 @@ def test_facade_sized_frames_on_resident_tiles(gpu):
         x, w1, w2, q = r.download()
         assert_bit_equal(x, o.x, "V %d x" % V); assert_bit_equal(q, o.q, "V %d q" % V)
     assert seen[0][1] == 1 and seen[0][2] == 0, seen          # one isolated tile
-    assert seen[1][2] == 1 and seen[1][1] > 32, seen           # 1300 vertices: the automatic halo tiles, resident too
-    assert all(u == 1 and 13 <= t <= 26 for V, t, u in seen[2:]), seen  # (tiles of 50 own vertices)
+    assert all(u == 1 and 2 <= t <= 256 for V, t, u in seen[1:]), seen
     assert r.info("persist_recovered") == 0
     r.close()
+
+
+def _frame_set(sizes, iters, seed0):
+    """(graph, var, expected x) per size: the oracle's result of a graph sync + `iters` iterations."""
+    from oracle import COracle
+    from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
+    out = []
+    for k, V in enumerate(sizes):
+        g = graphgen.synthetic(V, seed=seed0 + k)
+        var = np.full(g.V, 1e-4, np.float32)
+        s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
+        o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+        o.solve(oracle_params(), iters)
+        out.append((g, var, o.x.copy()))
+    return out
+
+
+def _stream_frames(frames, nframes, iters, lat, bad, stats):
+    import time
+    from flame_ros_amd.regularizer import default_sync_params
+    r = GraphRegularizer.empty(device=0, tile_single_max=640, stream_depth=5)  # (what flame::Flame sets)
+    p, sp = default_params(), default_sync_params()
+    used = 0
+    for k in range(nframes):
+        g, var, want = frames[k % len(frames)]
+        t0 = time.perf_counter()
+        r.sync_features(g.pos, g.z, var, g.tris, sp)
+        r.step(p, iters, sync=False)
+        x = r.download(with_q=False)[0]
+        lat.append((time.perf_counter() - t0) * 1e3)
+        used += r.info("persist_used")
+        if not np.array_equal(x.view(np.uint32), want.view(np.uint32)):
+            bad.append(k)
+    stats.append({"resident": used, "recovered": r.info("persist_recovered"), "gave_up": r.info("persist_gave_up")})
+    r.close()
+
+
+def test_two_handles_stream_concurrently(gpu):
+    """Two frame streams (two handles, two host threads, the facade's options) for 200 frames each: resident tiles
+    need the whole chip, so the library gives ONE handle per device the lease for a solve and the other one solves by
+    launches meanwhile -- every frame the oracle's bits, nothing repeated, no give-up, bounded latency."""
+    import threading
+    sets = [_frame_set((1200, 3000, 1000, 5000), 60, 700), _frame_set((2000, 900, 4000, 1500), 60, 710)]
+    lat, bad, stats = [[], []], [[], []], [[], []]
+    th = [threading.Thread(target=_stream_frames, args=(sets[i], 200, 60, lat[i], bad[i], stats[i])) for i in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not bad[0] and not bad[1], (bad[0][:5], bad[1][:5])
+    for i in range(2):
+        l = np.sort(np.asarray(lat[i][5:]))
+        p50, p99 = l[len(l) // 2], l[int(0.99 * (len(l) - 1))]
+        print("stream %d: p50 %.3f ms, p99 %.3f ms, %s" % (i, p50, p99, stats[i][0]))
+        assert p99 < 25.0, (p50, p99)
+        assert stats[i][0]["recovered"] == 0 and stats[i][0]["gave_up"] == 0, stats[i]
+    assert stats[0][0]["resident"] + stats[1][0]["resident"] > 0
+
+
+def test_frame_stream_beside_a_foreign_kernel(gpu):
+    """A frame stream while ANOTHER library keeps the chip busy (torch matmuls back to back on a stream of its own:
+    thousands of short-lived workgroups that compete with the resident tiles for the CUs): every frame the
+    oracle's bits and bounded latency whatever happens -- resident tiles that started late just wait (bounded), a
+    launch that gave up is repeated by launches and the process backs off ("persist_recovered" / "persist_gave_up"
+    are reported, not asserted: they depend on how the dispatcher interleaves the two queues)."""
+    import threading
+    import torch
+    frames = _frame_set((1200, 3000, 5000, 2000), 60, 720)
+    stop = threading.Event()
+
+    def hog():
+        st = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device="cuda")
+        b = torch.randn(4096, 4096, device="cuda")
+        with torch.cuda.stream(st):
+            while not stop.is_set():
+                for _ in range(8):
+                    a @ b
+                st.synchronize()
+    t = threading.Thread(target=hog)
+    t.start()
+    lat, bad, stats = [], [], []
+    try:
+        _stream_frames(frames, 150, 60, lat, bad, stats)
+    finally:
+        stop.set()
+        t.join()
+    assert not bad, bad[:5]
+    l = np.sort(np.asarray(lat[5:]))
+    p50, p99 = l[len(l) // 2], l[int(0.99 * (len(l) - 1))]
+    print("beside matmuls: p50 %.3f ms, p99 %.3f ms, max %.3f ms, %s" % (p50, p99, l[-1], stats[0]))
+    assert p99 < 60.0, (p50, p99, stats)
