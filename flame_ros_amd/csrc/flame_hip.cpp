@@ -69,25 +69,63 @@ int dev_alloc(CapMap& caps, T** p, size_t n) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), want);
   if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
   if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
+  static const int fill = std::getenv("FLAME_HIP_FILL_ALLOC") ? std::atoi(std::getenv("FLAME_HIP_FILL_ALLOC")) : -1;  // dev: 0..255
+  if (fill >= 0) (void)hipMemset(*p, fill, want);
   caps[(void*)p] = want;
   return 0;
 }
 
 // ... in UNCACHED device memory (hipDeviceMallocUncached: no L2 holds it, so stores and loads of different XCDs meet in
-// memory while a kernel runs -- the mirrors and flags of the resident tiles over all XCDs, kernels.hip PersistArgs)
+// memory while a kernel runs -- the hand-off copies of the resident tiles, kernels.hip PersistArgs).  Uncached blocks
+// are never handed back to the runtime: on this stack (ROCm 7.2) a later ordinary hipMalloc that recycles such a
+// block misbehaves (tools/exp/fault_repro.py: the plan builder's kernels fault on it), so freed blocks wait in a
+// process-wide pool, per device, for the next uncached request (bounded by the largest graph the process has seen).
+struct UncachedPool {
+  std::mutex m;
+  struct Block { void* p; size_t bytes; int device; };
+  std::vector<Block> free_blocks;
+  void* take(int device, size_t bytes, size_t* got) {
+    std::lock_guard<std::mutex> lk(m);
+    size_t best = free_blocks.size();
+    for (size_t i = 0; i < free_blocks.size(); ++i)
+      if (free_blocks[i].device == device && free_blocks[i].bytes >= bytes &&
+          (best == free_blocks.size() || free_blocks[i].bytes < free_blocks[best].bytes))
+        best = i;
+    if (best == free_blocks.size()) return nullptr;
+    void* p = free_blocks[best].p;
+    *got = free_blocks[best].bytes;
+    free_blocks.erase(free_blocks.begin() + (long)best);
+    return p;
+  }
+  void give(int device, void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(m);
+    free_blocks.push_back({p, bytes, device});
+  }
+};
+static UncachedPool& uncached_pool() {
+  static UncachedPool* pool = new UncachedPool();  // (never destroyed: handles may outlive static destruction order)
+  return *pool;
+}
+// (the blocks are NOT registered in the handle's CapMap: free_device() must not hipFree them; *cap = bytes of *p)
 template <class T>
-int dev_alloc_uncached(CapMap& caps, T** p, size_t n) {
+int dev_alloc_uncached(int device, T** p, size_t* cap, size_t n, bool* fresh) {
   n += 1;
   const size_t bytes = n * sizeof(T);
-  auto it = caps.find((void*)p);
-  if (*p && it != caps.end() && it->second >= bytes) return 0;
-  if (*p && it != caps.end()) (void)hipFree(*p);
-  *p = nullptr;
+  *fresh = false;
+  if (*p && *cap >= bytes) return 0;
+  if (*p) uncached_pool().give(device, *p, *cap);
+  *p = nullptr; *cap = 0;
+  *fresh = true;  // (contents unknown: the caller zeroes it)
+  size_t got = 0;
+  if (void* q = uncached_pool().take(device, bytes, &got)) {
+    *p = static_cast<T*>(q); *cap = got;
+    return 0;
+  }
   const size_t want = bytes + bytes / 4;
   hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(p), want, hipDeviceMallocUncached);
   if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
   if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
-  caps[(void*)p] = want;
+  *cap = want;
   return 0;
 }
 
@@ -282,7 +320,8 @@ struct flame_hip_graph {
   // RESIDENT tiles (kernels.hip k_tile_persist: round-tagged hand-offs through uncached memory instead of a kernel
   // boundary per `depth` iterations); 0: launches
   bool persist = true, persist_used = false;
-  PersistBufs xp;                   // hand-off buffers (uncached) + dev-aid words, registered in caps
+  PersistBufs xp;                   // hand-off buffers (uncached, from the process-wide pool: NOT in caps) + dev-aid words
+  size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
   int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
   bool persist_skip_once = false;   // the next enqueue goes by launches (the repeat of a solve that gave up)
   int last_src = 0;                 // the buffer the last solve started from
@@ -363,6 +402,14 @@ struct flame_hip_graph {
       *pp = nullptr;
     }
     caps.clear();
+    for (int b = 0; b < 2; ++b) {  // (uncached blocks go back to the pool, never to the runtime)
+      float4** pp[3] = {&xp.hA[b], &xp.hB[b], &xp.hq[b]};
+      for (int k = 0; k < 3; ++k) {
+        if (*pp[k]) uncached_pool().give(device, *pp[k], xp_cap[3 * b + k]);
+        *pp[k] = nullptr; xp_cap[3 * b + k] = 0;
+      }
+    }
+    xp.prof = nullptr;  // (was in caps)
     pin.release();
     pin_in.release();
     pout.release();
@@ -1520,13 +1567,13 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
       bool rezero = g->persist_base > (1 << 30);  // (the tags only grow)
       if (rezero) g->persist_base = 0;
-      for (int b = 0; b < 2; ++b) {  // (a buffer that had to grow comes back zeroed: tag 0 is never a round's)
+      for (int b = 0; b < 2; ++b) {  // (a new or recycled buffer is zeroed: tag 0 is never a round's)
         float4** pp[3] = {&x.hA[b], &x.hB[b], &x.hq[b]};
         const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
         for (int k = 0; k < 3; ++k) {
-          float4* before = *pp[k];
-          if ((rc = dev_alloc_uncached(g->caps, pp[k], nn[k]))) return rc;
-          if (*pp[k] != before || rezero) HIPCHK(hipMemsetAsync(*pp[k], 0, g->caps[(void*)pp[k]], s));
+          bool fresh = false;
+          if ((rc = dev_alloc_uncached(g->device, pp[k], &g->xp_cap[3 * b + k], nn[k], &fresh))) return rc;
+          if (fresh || rezero) HIPCHK(hipMemsetAsync(*pp[k], 0, g->xp_cap[3 * b + k], s));
         }
       }
       a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];

@@ -2362,7 +2362,10 @@ template <class T>
 hipError_t dalloc(T** p, size_t n) {
   if (*p) (void)hipFree(*p);
   *p = nullptr;
-  return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
+  static const int fill = std::getenv("FLAME_HIP_FILL_ALLOC") ? std::atoi(std::getenv("FLAME_HIP_FILL_ALLOC")) : -1;  // dev: 0..255
+  if (e == hipSuccess && fill >= 0) { e = hipMemset(*p, fill, std::max<size_t>(n, 1) * sizeof(T)); }
+  return e;
 }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + 255) / 256)); }
