@@ -323,6 +323,7 @@ struct flame_hip_graph {
   PersistBufs xp;                   // hand-off buffers (uncached, from the process-wide pool: NOT in caps) + dev-aid words
   size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
   int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
+  bool persist_unchecked = false;   // a resident launch is in flight / finished and nobody has looked at persist_err yet
   bool persist_skip_once = false;   // the next enqueue goes by launches (the repeat of a solve that gave up)
   int last_src = 0;                 // the buffer the last solve started from
   int32_t* persist_err = nullptr;   // page-locked: raised by a launch whose wait timed out
@@ -1271,8 +1272,8 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
       // not taken (the build did not reuse the partition after all), a wrong edge-count prediction or a
       // plan that does not fit: the usual way from the start (the inputs are staged again in its order)
       (void)hipStreamSynchronize(s);
-      if (rc == 2) {
-        g->euler_backoff = std::min(16, std::max(1, 2 * g->euler_backoff));
+      if (rc == 2 && g->planner.mini_used()) {  // (only the one-launch path derives the edges: without it rc == 2 says
+        g->euler_backoff = std::min(16, std::max(1, 2 * g->euler_backoff));  // nothing about the prediction -- ADVICE r3)
         g->euler_skip = g->euler_backoff;
         expected_E = -1;
       }
@@ -1374,6 +1375,8 @@ int flame_hip_graph_edges(const flame_hip_graph* g, int32_t* edges) {
 
 // New data terms on an unchanged topology: resets the solver state (x = x0 or z, w = 0,
 // x_bar = x, q = 0) without rebuilding the host plan or touching the graph arrays.
+int flame_hip_sync(flame_hip_graph* g);  // (defined below)
+
 int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float* wgt, const float* x0) {
   int rc = require_device(g);
   if (rc) return rc;
@@ -1383,6 +1386,7 @@ int flame_hip_graph_update_data(flame_hip_graph* g, const float* z, const float*
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
+  if (g->persist_unchecked && (rc = flame_hip_sync(g))) return rc;  // (a resident launch that gave up is repeated first)
   if ((rc = dev_alloc(g->caps, &g->in_z, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) ||
       (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)))
     return rc;
@@ -1413,6 +1417,7 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
   HIPCHK(hipSetDevice(g->device));
   HIPCHK(wait_last_solve(g));
   HIPCHK(hipStreamSynchronize(g->stream));
+  if (g->persist_unchecked && (rc = flame_hip_sync(g))) return rc;  // (a resident launch that gave up is repeated first)
   if ((rc = ensure_host_perms(g))) return rc;
   g->state_serial++;
   if (x || w1 || w2 || xb || w1b || w2b) {
@@ -1514,6 +1519,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
 static int persist_check(flame_hip_graph* g, int own_marks = 0) {
   static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
   if (force_fail && g->persist_used && g->persist_err) *g->persist_err = 3;
+  g->persist_unchecked = false;  // (every caller has synchronised the solve's stream)
   if (!g->persist_err || *g->persist_err == 0) return 0;
   *g->persist_err = 0;
   persist_lease_drop(g, true);
@@ -1587,6 +1593,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
                                  g->persist_base));
       g->persist_base += rounds - 1;
       g->persist_used = true;
+      g->persist_unchecked = true;
       g->last_src = cur;
       *launches = 1;
       *cur_out = cur ^ 1;  // (written once, by the last round; the source buffers are only read)
@@ -1987,6 +1994,9 @@ int flame_hip_debug_image(flame_hip_graph* g, int32_t kind, const float Kinv[9],
     return FLAME_HIP_ERR_ARG;
   if (g->plan.T <= 0 && g->T > 0) return FLAME_HIP_ERR_STATE;
   HIPCHK(hipSetDevice(g->device));
+  // (a launch of resident tiles that gave up is noticed -- and repeated -- at a synchronising call: an image must not
+  // be drawn from an unfinished solve)
+  if (g->persist_unchecked && (rc = flame_hip_sync(g))) return rc;
   hipStream_t s = g->stream;
   if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));
   if ((rc = ensure_raster(g, Kinv, tp, 1, 0.f, 0.f, false, false))) return rc;
@@ -2054,6 +2064,7 @@ int flame_hip_graph_filter(flame_hip_graph* g, int32_t kind, int32_t passes) {
   if (rc) return rc;
   if ((kind != 0 && kind != 1) || passes < 0) return FLAME_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(g->device));
+  if (g->persist_unchecked && passes > 0 && (rc = flame_hip_sync(g))) return rc;  // (the filter rewrites what a repeat would need)
   if ((rc = dev_alloc(g->caps, &g->filter_tmp, (size_t)g->V))) return rc;
   if (g->timed) HIPCHK(hipStreamWaitEvent(g->stream, g->ev1, 0));
   for (int32_t k = 0; k < passes; ++k)
@@ -2068,6 +2079,7 @@ int flame_hip_scale_state(flame_hip_graph* g, float s) {
   if (rc) return rc;
   if (!std::isfinite(s)) return FLAME_HIP_ERR_NAN;
   HIPCHK(hipSetDevice(g->device));
+  if (g->persist_unchecked && (rc = flame_hip_sync(g))) return rc;
   if (g->timed) HIPCHK(hipStreamWaitEvent(g->stream, g->ev1, 0));
   HIPCHK(launch_scale_state(g->stream, g->V, g->A[g->cur], g->B[g->cur], s));
   g->state_scale *= s;

@@ -2043,6 +2043,31 @@ __device__ __forceinline__ int mini_sort_row(uint32_t* row, int d) {
 
 // dev aid: phase boundaries of the launch (shader-clock ticks) into a.prof when it is set
 #define MINI_STAMP(n) do { if (a.prof && tid == 0) a.prof[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+// k_mini_plan gives up early in two places (the predicted edge count was wrong; the reused partition does not suit the
+// frame).  The host only learns that at the builder's synchronisation, AFTER the stages behind this launch (initial
+// state, tile passes) have run on whatever the plan arrays hold -- the previous frame's tables, or, after the arrays
+// grew, nothing at all.  So an early exit leaves a VALID plan behind: every tile empty, no incidences, no
+// triangles, an identity vertex order (unless the partition phase already wrote a permutation).
+__device__ __forceinline__ void mini_leave_empty_plan(const MiniArgs& a, bool keep_perm) {
+  const int tid = threadIdx.x, V = a.V, ntiles = a.ntiles;
+  for (int v = tid; v < V; v += kMiniThreads) {
+    if (!keep_perm) a.v_i2o[v] = v;
+    a.v_o2i[v] = keep_perm ? 0 : v;  // (only ever an index into [0, V))
+    a.tile_of_int[v] = 0;
+    a.grow[v] = 0;
+    a.trow[v] = 0;
+  }
+  if (keep_perm) {
+    __syncthreads();
+    for (int p = tid; p < V; p += kMiniThreads) a.v_o2i[a.v_i2o[p]] = p;
+  }
+  for (int t = tid; t <= ntiles; t += kMiniThreads) {
+    a.estart[t] = 0;
+    if (t < ntiles) { a.tab.lo[t] = 0; a.tab.hi[t] = 0; a.tab.leaves[t] = 1; a.tab.first[t] = t; }
+  }
+  if (tid == 0) { a.grow[V] = 0; a.trow[V] = 0; a.nseg[0] = ntiles; }
+}
+
 __global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
   __shared__ int32_t s_a[2 * kMiniV + 4];         // he offsets | triangle rows | edge buckets (2V + 1) | degrees
   __shared__ int32_t s_b[kMiniV + 4];             // distinct entries per half-edge row -> first edge id of the row
@@ -2124,7 +2149,10 @@ __global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
   const int32_t E = mini_scan(s_b, V + 1, s_sc);
   MINI_STAMP(8);
   if (tid == 0) a.dflags[1] = E;
-  if (E != a.E_expect || E > kMiniE) return;  // (uniform) the host's prediction was wrong: it builds again
+  if (E != a.E_expect || E > kMiniE) {  // (uniform) the host's prediction was wrong: it builds again
+    mini_leave_empty_plan(a, false);
+    return;
+  }
   for (int v = tid; v < V; v += NT) {
     const uint32_t* row = s_buf + s_a[v];
     const int d = s_a[v + 1] - s_a[v];
@@ -2183,7 +2211,10 @@ __global__ __launch_bounds__(kMiniThreads) void k_mini_plan(MiniArgs a) {
     a.seg_pos[p] = t;
   }
   __syncthreads();
-  if (__builtin_amdgcn_readfirstlane(a.flags[0]) & 64) return;  // (uniform after the barrier) rejected: bisection next
+  if (__builtin_amdgcn_readfirstlane(a.flags[0]) & 64) {  // (uniform after the barrier) rejected: bisection next
+    mini_leave_empty_plan(a, true);
+    return;
+  }
   MINI_STAMP(11);
   // ---- order inside tiles: (Morton code, id), one wave per tile, rank by counting (k_tile_order) ----
   {

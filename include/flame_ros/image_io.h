@@ -27,6 +27,8 @@
 namespace flame_ros {
 namespace images {
 
+constexpr long kMaxImageDim = 1 << 15;  // per side: anything larger is refused before sizes are computed from it
+
 struct Image {
   int width = 0, height = 0, channels = 0, bit_depth = 0;  // 8: u8 holds the samples, 16: u16 (host order)
   std::vector<uint8_t> u8;
@@ -76,7 +78,7 @@ inline int decodeSymbol(BitReader* br, const Huffman& h) {
   }
   return -1;
 }
-inline bool inflateCodes(BitReader* br, std::vector<uint8_t>* out, const Huffman& lit, const Huffman& dist) {
+inline bool inflateCodes(BitReader* br, std::vector<uint8_t>* out, const Huffman& lit, const Huffman& dist, size_t max_out) {
   static const short lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
   static const short lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
   static const short dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -84,6 +86,7 @@ inline bool inflateCodes(BitReader* br, std::vector<uint8_t>* out, const Huffman
   for (;;) {
     int sym = decodeSymbol(br, lit);
     if (sym < 0) return false;
+    if (out->size() > max_out) return false;  // (a stream that inflates past what the caller can use: refused, not followed)
     if (sym < 256) { out->push_back(static_cast<uint8_t>(sym)); continue; }
     if (sym == 256) return true;
     sym -= 257;
@@ -99,7 +102,8 @@ inline bool inflateCodes(BitReader* br, std::vector<uint8_t>* out, const Huffman
 }
 }  // namespace detail
 
-inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out) {
+// max_out: the output is refused once it grows past this many bytes (no unbounded inflate)
+inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out, size_t max_out = static_cast<size_t>(-1)) {
   using namespace detail;
   if (n < 6 || (src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) return false;
   BitReader br(src + 2, n - 2);
@@ -115,6 +119,7 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out) {
       const unsigned len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
       br.pos += 4;
       if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
+      if (out->size() + len > max_out) return false;
       out->insert(out->end(), br.p + br.pos, br.p + br.pos + len);
       br.pos += len;
     } else if (type == 1) {
@@ -127,7 +132,7 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out) {
       buildHuffman(&lit, l, 288);
       for (int s = 0; s < 30; ++s) l[s] = 5;
       buildHuffman(&dist, l, 30);
-      if (!inflateCodes(&br, out, lit, dist)) return false;
+      if (!inflateCodes(&br, out, lit, dist, max_out)) return false;
     } else if (type == 2) {
       static const short order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
       const int nlen = br.bits(5) + 257, ndist = br.bits(5) + 1, ncode = br.bits(4) + 4;
@@ -153,7 +158,7 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>* out) {
       Huffman lit, dist;
       if (!buildHuffman(&lit, l, nlen)) return false;
       buildHuffman(&dist, l + nlen, ndist);  // (an incomplete distance code is legal)
-      if (!inflateCodes(&br, out, lit, dist)) return false;
+      if (!inflateCodes(&br, out, lit, dist, max_out)) return false;
     } else {
       return false;
     }
@@ -205,9 +210,12 @@ inline bool decodePNG(const uint8_t* d, size_t n, Image* img, std::string* err) 
   if (img->bit_depth != 8 && img->bit_depth != 16) return fail("only 8- and 16-bit samples are supported");
   img->channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
   if (!img->channels) return fail("palette PNGs are not supported");
-  std::vector<uint8_t> raw;
-  if (!inflate(z.data(), z.size(), &raw)) return fail("corrupt zlib stream");
+  // (IHDR is untrusted -- dimensions are bounded before any size is computed from them, and the inflate
+  // output is bounded by what these dimensions can hold, plus slack for the 258-byte match that crosses the bound)
+  if (img->width > kMaxImageDim || img->height > kMaxImageDim) return fail("image dimensions out of range");
   const size_t bpp = static_cast<size_t>(img->channels) * img->bit_depth / 8, stride = bpp * img->width;
+  std::vector<uint8_t> raw;
+  if (!inflate(z.data(), z.size(), &raw, (stride + 1) * img->height + 512)) return fail("corrupt zlib stream");
   if (raw.size() < (stride + 1) * img->height) return fail("short image data");
   std::vector<uint8_t> pix(stride * img->height);
   for (int y = 0; y < img->height; ++y) {  // undo the row filters (PNG spec 9.2)
@@ -251,11 +259,12 @@ inline bool decodePNM(const uint8_t* d, size_t n, Image* img, std::string* err) 
       break;
     }
     long x = 0; bool any = false;
-    while (off < n && d[off] >= '0' && d[off] <= '9') { x = x * 10 + (d[off++] - '0'); any = true; }
+    while (off < n && d[off] >= '0' && d[off] <= '9') { x = x * 10 + (d[off++] - '0'); any = true; if (x > (1l << 30)) return fail("bad PNM header"); }
     if (!any) return fail("bad PNM header");
     v[k] = x;
   }
   ++off;  // the single whitespace behind maxval
+  if (v[0] < 1 || v[1] < 1 || v[0] > kMaxImageDim || v[1] > kMaxImageDim || v[2] < 1 || v[2] > 65535) return fail("bad PNM header");
   img->width = static_cast<int>(v[0]); img->height = static_cast<int>(v[1]);
   img->channels = d[1] == '5' ? 1 : 3;
   img->bit_depth = v[2] < 256 ? 8 : 16;

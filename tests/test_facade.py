@@ -244,11 +244,12 @@ def test_callsites_run_on_gpu(gpu, callsite_exe):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,bound_ms", [("tum", 1.2), ("euroc", 2.0), ("50k", 4.4)])
+@pytest.mark.parametrize("workload,bound_ms", [("tum", 0.65), ("euroc", 1.0), ("50k", 2.4)])
 def test_facade_update_latency(gpu, workload, bound_ms):
     """Median flame::Flame::update latency of a 40-frame stream with the reference's default
-    parameters (debug draws enabled, cfg/flame_offline_tum.yaml:58-64) at the BASELINE sizes: at
-    most 2x the round-3 targets (0.6 / 1.0 / 2.2 ms).  The mesh getter and the
+    parameters (debug draws enabled, cfg/flame_offline_tum.yaml:58-64) at the BASELINE sizes: about
+    1.6x what the driver measured in round 4 (0.40 / 0.59 / 1.37 ms; the bounds are VERDICT r03 item 9's, the
+    slack is for the slower boxes of the pool).  The mesh getter and the
     three default debug images are fetched after every update, outside the timed update."""
     import sys
     sys.path.insert(0, ROOT)

@@ -168,6 +168,31 @@ def test_corrupt_files_are_rejected(exe, tmp_path):
         assert p.returncode == 3, name
 
 
+def test_crafted_headers_are_rejected(exe, tmp_path):
+    """IHDR / PNM dimensions are untrusted.  A PNG whose IHDR claims 2^31 - 1 x 2^31 - 1 (sizes that wrap
+    in size_t arithmetic), one whose IHDR claims a tiny image in front of a zlib stream that inflates to megabytes,
+    and PNM headers with absurd dimensions are all refused (exit 3), none is followed into an allocation or a copy."""
+    import struct, zlib
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+
+    def png(w, h, payload):
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(payload)) + chunk(b"IEND", b""))
+    cases = {"huge.png": png(0x7fffffff, 0x7fffffff, b"\0" * 64),
+             "wide.png": png(1 << 20, 4, b"\0" * 64),
+             "bomb.png": png(4, 4, b"\0" * (8 << 20)),
+             "huge.pgm": b"P5\n2147483647 2147483647\n255\n" + b"\0" * 16,
+             "wide.pgm": b"P5\n99999999999999999999 3\n255\n" + b"\0" * 16,
+             "zero.pgm": b"P5\n0 3\n255\n"}
+    for name, data in cases.items():
+        bad = str(tmp_path / name)
+        open(bad, "wb").write(data)
+        p = subprocess.run([exe, "decode", bad, str(tmp_path / "o.bin")], capture_output=True, timeout=60)
+        assert p.returncode == 3, (name, p.returncode)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_inflate_against_zlib_streams(exe, tmp_path, seed):
     """The header-only inflate against streams zlib produced with every strategy / level / window size
