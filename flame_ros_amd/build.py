@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflame_hip.so")
-SOURCES = ["kernels.hip", "plan_dev.hip", "flame_hip.cpp", "plan.cpp", "sync.cpp"]
+SOURCES = ["kernels.hip", "plan_dev.hip", "flame_hip.cpp", "plan.cpp", "sync.cpp", "part.cpp"]
 HEADERS = ["common.h", "kernels.h", "plan.h", "plan_dev.h", "sync.h", os.path.join("..", "..", "include", "flame_hip.h")]
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs at wave
 # launch (gfx950) instead of through a scalar load -- the tile kernel's argument order relies on it.
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lroctx64"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lroctx64", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

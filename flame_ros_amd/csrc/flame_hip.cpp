@@ -421,7 +421,7 @@ struct flame_hip_graph {
 
 extern "C" {
 
-int flame_hip_version(void) { return 300; }
+int flame_hip_version(void) { return 400; }
 
 const char* flame_hip_strerror(int code) {
   switch (code) {
@@ -431,8 +431,10 @@ const char* flame_hip_strerror(int code) {
     case FLAME_HIP_ERR_NAN: return "non-finite input";
     case FLAME_HIP_ERR_ALLOC: return "allocation failed";
     case FLAME_HIP_ERR_NODEVICE: return "no HIP device (plan-only handle or no GPU present)";
+    case FLAME_HIP_ERR_NORCCL: return "librccl.so could not be loaded";
     default: break;
   }
+  if (code <= FLAME_HIP_ERR_RCCL) return "RCCL error (code = -(3000 + ncclResult_t))";
   if (code <= FLAME_HIP_ERR_HIP) return hipGetErrorString((hipError_t)(FLAME_HIP_ERR_HIP - code));
   return "unknown error";
 }

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libflame_hip.so")
 
-ERR_ARG, ERR_STATE, ERR_NAN, ERR_ALLOC, ERR_NODEVICE, ERR_HIP = -1, -2, -3, -4, -5, -1000
+ERR_ARG, ERR_STATE, ERR_NAN, ERR_ALLOC, ERR_NODEVICE, ERR_NORCCL, ERR_HIP, ERR_RCCL = -1, -2, -3, -4, -5, -6, -1000, -3000
 PATH_AUTO, PATH_GLOBAL, PATH_TILE = 0, 1, 2
 IMG_WIREFRAME, IMG_FEATURES, IMG_NORMALS, IMG_IDEPTHMAP = 0, 1, 2, 3
 
@@ -80,6 +80,19 @@ SYMBOLS = {
     "flame_hip_halo_bytes": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "flame_hip_halo_pack": (C.c_int, [_VP, _VP, _VP]),
     "flame_hip_halo_unpack": (C.c_int, [_VP, _VP, _VP]),
+    "flame_hip_rccl_available": (C.c_int, []),
+    "flame_hip_comm_get_unique_id": (C.c_int, [_VP]),
+    "flame_hip_comm_create": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int, C.c_int, _VP]),
+    "flame_hip_comm_destroy": (None, [_VP]),
+    "flame_hip_comm_stream": (_VP, [_VP]),
+    "flame_hip_part_create": (C.c_int, [C.POINTER(_VP), _VP, _I32, _I32, _I32, _I32, _I32, _I32] + [_VP] * 7),
+    "flame_hip_part_destroy": (None, [_VP]),
+    "flame_hip_part_solve": (C.c_int, [_VP, C.POINTER(Params), _I32]),
+    "flame_hip_part_sync": (C.c_int, [_VP]),
+    "flame_hip_part_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "flame_hip_part_gather": (C.c_int, [_VP] + [_VP] * 4),
+    "flame_hip_part_info": (C.c_int, [_VP, C.c_char_p, _I32, C.POINTER(_I64)]),
+    "flame_hip_part_array": (_I64, [_VP, C.c_char_p, _I32, _VP, _I64]),
     "flame_hip_debug_plan_array": (_I64, [_VP, C.c_char_p, _VP, _I64]),
     "flame_hip_strerror": (C.c_char_p, [C.c_int]),
     "flame_hip_version": (C.c_int, []),

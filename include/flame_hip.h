@@ -57,7 +57,9 @@ enum {
   FLAME_HIP_ERR_NAN = -3,     /* non-finite input */
   FLAME_HIP_ERR_ALLOC = -4,   /* host or device allocation failed */
   FLAME_HIP_ERR_NODEVICE = -5,
-  FLAME_HIP_ERR_HIP = -1000   /* -(1000 + hipError_t) */
+  FLAME_HIP_ERR_NORCCL = -6,  /* librccl.so could not be loaded (flame_hip_comm_* / flame_hip_part_*) */
+  FLAME_HIP_ERR_HIP = -1000,  /* -(1000 + hipError_t) */
+  FLAME_HIP_ERR_RCCL = -3000  /* -(3000 + ncclResult_t) */
 };
 
 /* Solver paths (flame_hip_set_option key "path"). */
@@ -275,6 +277,47 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
 int flame_hip_halo_bytes(const flame_hip_graph* g, int64_t* send_bytes, int64_t* recv_bytes);
 int flame_hip_halo_pack(flame_hip_graph* g, void* send_buf_dev, void* stream);
 int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* stream);
+
+/* ---- partition mode without Python (BASELINE.json configs 4 / 5): ONE graph cut into world x
+ * parts_per_rank subdomains by recursive coordinate bisection (METIS is not in the image), every rank solves its parts
+ * with ordinary handles (resident tiles), and every halo_depth iterations the parts swap their halo records through
+ * RCCL on one stream: flame_hip_halo_pack -> ncclGroupStart / ncclSend + ncclRecv per neighbouring part (a part of the
+ * same rank is a send / receive of the rank with itself) / ncclGroupEnd -> flame_hip_halo_unpack.  Bit-identical to
+ * the single-GPU result.  The reference has no counterpart (one CPU process, reference src/flame_offline_tum.cc:
+ * 403-563).  One process per GPU; librccl.so is loaded at the first call (no link-time dependency).
+ *   rank 0: flame_hip_comm_get_unique_id(id); hand `id` to every rank (MPI, a file, a socket ...);
+ *   every rank: flame_hip_comm_create(&c, device, rank, world, id);
+ *               flame_hip_part_create(&p, c, 0, 0, parts_per_rank, halo_depth, V, E, ... the WHOLE graph ...);
+ *               flame_hip_part_solve(p, &params, iters);  flame_hip_part_costs(...);  flame_hip_part_gather(...).
+ * Every rank derives all subdomains from the whole graph, so no request lists travel.  comm == NULL makes a
+ * host-only plan of rank plan_rank of plan_world (tests: flame_hip_part_info / _array on it, no device, no RCCL). */
+typedef struct flame_hip_comm flame_hip_comm;
+typedef struct flame_hip_part flame_hip_part;
+#define FLAME_HIP_COMM_ID_BYTES 128
+int flame_hip_rccl_available(void); /* 1: librccl.so loads and exports every entry point this file needs */
+int flame_hip_comm_get_unique_id(char id[FLAME_HIP_COMM_ID_BYTES]);
+int flame_hip_comm_create(flame_hip_comm** out, int device, int rank, int world, const char id[FLAME_HIP_COMM_ID_BYTES]);
+void flame_hip_comm_destroy(flame_hip_comm* c);
+void* flame_hip_comm_stream(flame_hip_comm* c); /* the hipStream_t everything of this communicator is ordered on */
+int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t plan_rank, int32_t plan_world,
+                          int32_t parts_per_rank, int32_t halo_depth, int32_t V, int32_t E, const float* pos,
+                          const int32_t* edges, const float* alpha, const float* beta, const float* z,
+                          const float* wgt, const float* x0 /* or NULL */);
+void flame_hip_part_destroy(flame_hip_part* p);
+/* num_iters more PD iterations, an exchange whenever the halo rings are used up; asynchronous on the communicator's
+ * stream (no host synchronisation inside); successive calls continue on the rings the last one left */
+int flame_hip_part_solve(flame_hip_part* p, const flame_hip_params* params, int32_t num_iters);
+int flame_hip_part_sync(flame_hip_part* p);
+/* the whole graph's cost terms: owned sums of every part + one ncclAllReduce of 2 doubles.  Synchronises. */
+int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, double* smooth, double* data);
+/* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */
+int flame_hip_part_gather(flame_hip_part* p, float* x, float* w1, float* w2, float* q);
+/* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left"; per local part: "part_id", "n_own",
+ * "n_ext", "e_loc", "num_peers", "send_bytes", "recv_bytes", "persist_used" */
+int flame_hip_part_info(const flame_hip_part* p, const char* key, int32_t local_part, int64_t* value);
+/* int32 arrays: "part" (V: the part of every vertex), per local part "vid", "eid", "edges", "e_owned", "peers",
+ * "send_v", "send_e", "recv_v", "recv_e", "send_cnt", "recv_cnt"; returns the element count or a negative error */
+int64_t flame_hip_part_array(const flame_hip_part* p, const char* key, int32_t local_part, int32_t* out, int64_t cap);
 
 /* Debug/test hook (no device needed; works on a handle created with device = -1): copies the
  * named host-side plan array ("v_o2i", "e_o2i", "grow", "ginc", "eij", "tiles", "t_vmap",

@@ -1,0 +1,50 @@
+"""-m gpu: the library's own partition mode (csrc/part.cpp) on the ONE GPU of the test box: a communicator that owns
+an ncclComm_t of world size 1, the graph cut into parts_per_rank subdomains all held by rank 0, so every halo record
+travels through ncclGroupStart / ncclSend + ncclRecv to the own rank / ncclGroupEnd on the solve stream, between
+flame_hip_halo_pack and flame_hip_halo_unpack, with no host synchronisation inside a solve; costs through
+ncclAllReduce.  No torch.distributed, no Python in the data path.  Bit-exact against the oracle.  (A process of its own:
+the RCCL copy it loads is the library's, not one torch initialised.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CODE = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from flame_ros_amd import graphgen, partition
+from flame_ros_amd.regularizer import default_params
+from oracle import COracle
+from oracle.cbind import default_params as oparams
+assert partition.rccl_available()
+uid = partition.unique_id()
+with partition.Communicator(0, 0, 1, uid) as comm:
+    for V, k, depth, iters in ((6000, 2, 8, 50), (9000, 3, 4, 23), (50000, 2, 16, 100)):
+        g = graphgen.synthetic(V, seed=5)
+        with partition.Partition(comm, g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, parts_per_rank=k, halo_depth=depth) as ps:
+            p = default_params()
+            ps.step(p, iters // 2)
+            ps.step(p, iters - iters // 2)
+            assert ps.info("p2p_ops") >= 2 * k and ps.info("exchanges") == (iters - 1) // depth, (ps.info("p2p_ops"), ps.info("exchanges"))
+            x, w1, w2, q = ps.gather_solution()
+            sm, da = ps.costs(p)
+            o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+            o.solve(oparams(), iters)
+            for name, got, want in (("x", x, o.x), ("w1", w1, o.w1), ("w2", w2, o.w2), ("q", q, o.q)):
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (V, k, name)
+            so, do = o.costs(oparams())
+            assert abs(sm - so) <= 1e-9 * so and abs(da - do) <= 1e-9 * do, (sm, so, da, do)
+            print("V %%d, %%d parts on rank 0, depth %%d: %%d P2P ops per exchange, %%d exchanges, resident tiles on part 0: %%d, bit-exact" %% (
+                V, k, depth, ps.info("p2p_ops"), ps.info("exchanges"), ps.info("persist_used", 0)))
+print("native partition ok")
+''' % ROOT
+
+
+def test_native_rccl_partition_with_itself(gpu):
+    out = subprocess.run([sys.executable, "-c", CODE], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "native partition ok" in out.stdout, out.stdout[-3000:] + out.stderr[-5000:]
