@@ -6,8 +6,8 @@
 # by hand into profiles/.  Every rocprofv3 run uses --kernel-trace only (no sys/hip/hsa trace).
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-tag=${1:-r03}; shift
-out=gpurun_out/$tag; mkdir -p $out
+tag=${1:-r04}; shift
+out=gpurun_out/$tag; mkdir -p $out gpurun_out
 BENCH="python bench.py --no-cpu --no-facade --steps 10 --warmup 2 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- $BENCH > $out/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- $BENCH > $out/bench_fetch.log 2>&1
