@@ -134,6 +134,73 @@ inline float dataCost(const Params& params, const Graph& graph) {
   return static_cast<float>(d);
 }
 
+// ---- the same regulariser on ONE graph cut over several GPUs (one process per GPU; include/flame_hip.h
+// flame_hip_comm_* / flame_hip_part_*: RCB subdomains, halo records by ncclSend / ncclRecv inside the library).
+// Upstream has no counterpart (a single CPU process); the interface mirrors Graph / step() / the costs above.
+//   rank 0: Communicator::uniqueId(&id); hand the 128 bytes to every rank; every rank:
+//   Communicator comm; comm.init(device, rank, world, id);
+//   PartitionedGraph g; g.build(comm, 1, 16, V, E, pos, edges, alpha, beta, z, wgt, nullptr);   // the WHOLE graph
+//   step(params, &g, 500); g.gather(x.data(), nullptr, nullptr, nullptr);
+class Communicator {
+ public:
+  Communicator() = default;
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  ~Communicator() { reset(); }
+  static int uniqueId(char id[FLAME_HIP_COMM_ID_BYTES]) { return flame_hip_comm_get_unique_id(id); }
+  int init(int device, int rank, int world, const char id[FLAME_HIP_COMM_ID_BYTES]) {
+    reset();
+    return flame_hip_comm_create(&c_, device, rank, world, id);
+  }
+  void reset() { if (c_) flame_hip_comm_destroy(c_); c_ = nullptr; }
+  flame_hip_comm* handle() const { return c_; }
+
+ private:
+  flame_hip_comm* c_ = nullptr;
+};
+
+class PartitionedGraph {
+ public:
+  PartitionedGraph() = default;
+  PartitionedGraph(const PartitionedGraph&) = delete;
+  PartitionedGraph& operator=(const PartitionedGraph&) = delete;
+  ~PartitionedGraph() { reset(); }
+  void reset() { if (p_) flame_hip_part_destroy(p_); p_ = nullptr; V_ = E_ = 0; }
+  // every rank passes the WHOLE graph (caller's order); halo_depth iterations run between two exchanges
+  int build(const Communicator& comm, int parts_per_rank, int halo_depth, int32_t V, int32_t E, const float* pos,
+            const int32_t* edges, const float* alpha, const float* beta, const float* z, const float* wgt, const float* x0) {
+    reset();
+    const int rc = flame_hip_part_create(&p_, comm.handle(), 0, 0, parts_per_rank, halo_depth, V, E, pos, edges, alpha, beta, z,
+                                         wgt, x0);
+    if (!rc) { V_ = V; E_ = E; }
+    return rc;
+  }
+  bool valid() const { return p_ != nullptr; }
+  int32_t numVertices() const { return V_; }
+  int32_t numEdges() const { return E_; }
+  // the whole solution on every rank (any pointer may be null; q is 3E interleaved)
+  int gather(float* x, float* w1, float* w2, float* q) { return p_ ? flame_hip_part_gather(p_, x, w1, w2, q) : FLAME_HIP_ERR_STATE; }
+  flame_hip_part* handle() const { return p_; }
+
+ private:
+  flame_hip_part* p_ = nullptr;
+  int32_t V_ = 0, E_ = 0;
+};
+
+inline int step(const Params& params, PartitionedGraph* graph, int num_iters = 1, bool wait = true) {
+  if (!graph || !graph->valid()) return FLAME_HIP_ERR_STATE;
+  const flame_hip_params p = toC(params);
+  int rc = flame_hip_part_solve(graph->handle(), &p, num_iters);
+  return (rc || !wait) ? rc : flame_hip_part_sync(graph->handle());
+}
+
+// whole-graph costs (owned sums of every part + one ncclAllReduce); both through one call to save a reduction
+inline int costs(const Params& params, const PartitionedGraph& graph, double* smooth, double* data) {
+  if (!graph.valid()) return FLAME_HIP_ERR_STATE;
+  const flame_hip_params p = toC(params);
+  return flame_hip_part_costs(graph.handle(), &p, smooth, data);
+}
+
 }  // namespace nltgv2_l1_graph_regularizer
 }  // namespace optimizers
 }  // namespace flame

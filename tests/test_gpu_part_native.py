@@ -48,3 +48,16 @@ print("native partition ok")
 def test_native_rccl_partition_with_itself(gpu):
     out = subprocess.run([sys.executable, "-c", CODE], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "native partition ok" in out.stdout, out.stdout[-3000:] + out.stderr[-5000:]
+
+
+@pytest.mark.parametrize("parts,depth,iters,V", [(2, 8, 60, 8000), (3, 4, 25, 12000)])
+def test_partitioned_graph_from_cpp(gpu, tmp_path, parts, depth, iters, V):
+    """tests/cpp/part_native.cc: the C++ mirror (flame::optimizers::nltgv2_l1_graph_regularizer::Communicator /
+    PartitionedGraph / step / costs) against a single Graph handle on the same random Delaunay graph -- every bit."""
+    exe = str(tmp_path / "part_native")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "part_native.cc"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "flame_ros_amd"), "-lflame_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "flame_ros_amd"), "-pthread"])
+    p = subprocess.run([exe, "0", str(parts), str(depth), str(iters), str(V)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "bit_exact 1 costs_ok 1" in p.stdout, (p.returncode, p.stdout, p.stderr)
