@@ -154,7 +154,7 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
 // runtime, call by call -- ~10 us each, the larger part of a small frame's upload).
 // frame_results: outputs up to this size are written to host memory by the kernels themselves (measured on
 // the facade stream, direct vs one copy: 1.2 k -14 us, 5 k -10 us, 10 k (185 KB) -15 us, 50 k (925 KB) +65 us)
-constexpr int kPollDelayDefault = 2;  // x 256 clocks (tools/exp/poll_delay_sweep.sh: 50k 1.56 -> 1.52 us per iteration, 5k 1.08 -> 1.06; 6 and up lose); FLAME_HIP_POLL_DELAY overrides
+constexpr int kPollDelayDefault = 1;  // x 256 clocks (tools/exp/poll_delay_sweep.sh: 50k 1.56 -> 1.52 us per iteration before the hand-off stores moved into the last iteration, 0..2 alike since; 6 and up lose); FLAME_HIP_POLL_DELAY overrides
 constexpr int kMapMinTiles = 6;  // partitions of at least this many tiles leave a tile map for the next frame (partition reuse)
 constexpr size_t kDirectOutBytes = 256 * 1024;
 

@@ -128,6 +128,9 @@ __device__ __forceinline__ void lds_store3(float4* slot, float a, float b, float
 #endif
 }
 
+#ifndef FLAME_EARLY_Q
+#define FLAME_EARLY_Q 1
+#endif
 // Write-back of a tile's results.  FLAME_WT_STORE 1: write-through (sc0 sc1) so the lines drain
 // while slower tiles still compute instead of at the end-of-kernel release (guide, "boundary":
 // dirty bytes / 6 TB/s are added to the kernel boundary); 2: nontemporal.
@@ -439,6 +442,19 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
     // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
     PhaseD<EPT, EPT>::run(nk, bar, eij, es, ed, ew, q1, q23, sigma);
+#if FLAME_EARLY_Q
+    // resident tiles: the duals of a round are final after its last phase D -- their hand-off entries (58 % of what
+    // a tile hands over) leave now and travel while phase P still runs
+    if (PERSIST && it == iters && done + iters < a.iters) {
+      float4* const oq_ = pa.hq[(round + 1) & 1];
+      const float tagq = __int_as_float(pa.base + round + 1);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int le = k * NT + tid;
+        if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own) oq_[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, tagq);
+      }
+    }
+#endif
     __syncthreads();
     if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it] = __builtin_readcyclecounter();
     // ---- phase P: primal descent (slot order = ascending original edge id), prox, extra-grad ----
@@ -461,6 +477,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         vwb[k] = pk_fma(th2, w - wp, w);
         vx[k] = x; vw[k] = w;
         if (lv < n_upd) lds_store3(&bar[lv], vwb[k].x, vwb[k].y, vxb[k]);
+#if FLAME_EARLY_Q
+        // (resident tiles: the own vertices' hand-off entries leave as soon as the round's last phase P has them, in
+        // front of the workgroup barrier)
+        if (PERSIST && it == iters && done + iters < a.iters && lv < n_own) {
+          const float tagv = __int_as_float(pa.base + round + 1);
+          pa.hA[(round + 1) & 1][vstart + lv] = make_float4(x, w.x, w.y, tagv);
+          pa.hB[(round + 1) & 1][vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, tagv);
+        }
+#endif
       }
     }
     __syncthreads();
@@ -479,8 +504,10 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     const int lv = k * NT + tid;
     if (lv < n_own) {
       if (PERSIST) {
-        oA[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, handoff ? tagf : vz[k]);
-        oB[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, handoff ? tagf : vwgt[k]);
+        if (!(FLAME_EARLY_Q && handoff)) {  // (the hand-off entries left inside the last phase P)
+          oA[vstart + lv] = make_float4(vx[k], vw[k].x, vw[k].y, handoff ? tagf : vz[k]);
+          oB[vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, handoff ? tagf : vwgt[k]);
+        }
       } else {
         store_result(&a.A_dst[vstart + lv], vx[k], vw[k].x, vw[k].y, vz[k]);
         store_result(&a.B_dst[vstart + lv], vxb[k], vwb[k].x, vwb[k].y, vwgt[k]);
@@ -493,7 +520,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     // owned <=> the edge's internal id lies in the tile's range (lanes inside a 64-edge block are
     // assigned by the plan's conflict-avoiding lane order, not by internal id)
     if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own) {
-      if (PERSIST) oq[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, handoff ? tagf : 0.0f);
+      if (PERSIST) { if (!(FLAME_EARLY_Q && handoff)) oq[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, handoff ? tagf : 0.0f); }
       else store_result(&a.q_dst[qi[k]], q1[k], q23[k].x, q23[k].y, 0.0f);
     }
   }
