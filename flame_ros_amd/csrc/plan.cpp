@@ -226,7 +226,12 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // few tiles (a small lone graph): CUs are idle anyway, so redundant halo work is free and deeper
   // halos amortise the per-launch load (1.2 k vertices: depth 8 = 652 k it/s vs depth 4 = 573 k)
   const int auto_tiles = (V + auto_own - 1) / std::max(auto_own, 1);
-  const int auto_depth = !one_round ? 3 : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
+  // (resident tiles, r04: a round's hand-off costs ~2 us where a launch cost ~3.5: shallower halos win -- depth 5 up to
+  // ~100 tiles, 4 above; tools/exp/xpersist_bench.py: 1.2 k / 38 tiles depth 5 / 8 = 0.92 / 1.00 us per iteration, 5 k /
+  // 157 tiles depth 4 / 5 = 1.01 / 1.04, 4 k / 125 tiles 1.00 / 1.01)
+  const int auto_depth = !one_round ? 3
+                         : opt.resident ? (auto_tiles <= 100 ? 5 : 4)
+                                        : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
   int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
   int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;
   // Auto: a lone graph is one isolated tile only when it is small (<= single_max = 512 vertices):

@@ -27,6 +27,8 @@ struct PlanOptions {
   // SECOND time (a frame stream that solves every graph once never pays for it); 2 at build time
   int lane_order = 1;
   int d_sign = 1;        // [UPSTREAM-RECALL] switch: the edge vector is d_sign * (pos_i - pos_j)
+  bool resident = false; // the caller solves by ONE launch of resident tiles (flame_hip option "persist"): the automatic halo
+                         // depth is tuned for round hand-offs (~2 us per round) instead of kernel boundaries + reloads
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   bool single_only = false;  // build_plan(): return kPlanSingleNoFit instead of falling back to a
                              // halo'd partition when the isolated tile does not fit after all
