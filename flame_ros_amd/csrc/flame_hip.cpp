@@ -679,7 +679,7 @@ struct GraphOptScope {
   int saved_single_max, saved_depth;
   GraphOptScope(flame_hip_graph* g_, int32_t V) : g(g_), saved_single_max(g_->opt.single_max), saved_depth(g_->opt.tile_depth) {
     g->opt.single_max = std::min(g->opt.single_max, g->single_cap);
-    g->opt.resident = g->persist && g->device >= 0;
+    g->opt.resident = g->persist;  // (plan-only handles size their tiles the same way: they are the device plans' reference)
     if (g->stream_depth > 0 && g->opt.tile_depth == 0 && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() && V <= 64 * 32)
       g->opt.tile_depth = g->stream_depth;
   }

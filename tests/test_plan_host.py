@@ -271,7 +271,9 @@ def test_global_path_and_fallbacks():
     assert r.info("num_tiles") == 1 and r.info("tile_depth") == 0
     g = graphgen.dataset_shaped(640, 480, 16)  # 1200 vertices: tiles by default, one tile on request
     r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1)
-    assert r.info("num_tiles") > 1 and r.info("tile_depth") == 8
+    assert r.info("num_tiles") > 1 and r.info("tile_depth") == 5   # (resident tiles, the default: shallow halos)
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, persist=0)
+    assert r.info("num_tiles") > 1 and r.info("tile_depth") == 8   # (launches: deep halos amortise the kernel boundary)
     r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, tile_own=g.V)
     assert r.info("num_tiles") == 1 and r.info("tile_depth") == 0
     # empty graph
