@@ -391,12 +391,13 @@ def test_small_odd_meshes_through_one_launch(gpu):
 
 
 def test_stream_depth_option(gpu):
-    """stream_depth replaces the automatic depth 8 of small graphs (<= 2048 vertices) and nothing else."""
+    """stream_depth replaces the automatic depth 8 of small graphs (<= 2048 vertices) solved by launches (persist = 0;
+    resident tiles choose depth 5 there by themselves) and nothing else."""
     p = default_params()
     for name, want in (("v2000", 5), ("5k", None)):
         g = graphgen.named(name)[0]
-        a = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
-        b = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, stream_depth=5)
+        a = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=0)
+        b = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, stream_depth=5, persist=0)
         assert b.info("tile_depth") == (want if want else a.info("tile_depth"))
         if want:
             assert a.info("tile_depth") == 8
