@@ -270,7 +270,7 @@ class Flame {
           stats_.tick("triangulate");
           // (the reference's `omp_num_threads`, cfg/flame_offline_tum.yaml:70, is what its CPU stages run on)
           ok = frontend_.triangulate ? frontend_.triangulate(g.vtx, &tris)
-                                     : delaunay_.triangulate(g.vtx, &tris, params_.omp_num_threads);
+                                     : delaunay_.triangulate(g.vtx, &tris, params_.triangulate_threads > 0 ? params_.triangulate_threads : params_.omp_num_threads);
           stats_.tock("triangulate");
         }
         if (ok)

@@ -147,11 +147,17 @@ def test_threads_give_the_same_triangulation(exe):
     rng = np.random.default_rng(9)
     pts = (rng.random((6000, 2)) * np.array([640.0, 480.0]) + 128.0).astype(np.float32)
     ref = canon(run(exe, pts, 1))
-    for th in (2, 4):
+    for th in (2, 4, 8, 16, 23):
         assert np.array_equal(canon(run(exe, pts, th)), ref), th
     ix, iy = np.meshgrid(np.arange(80), np.arange(60))
     lattice = np.stack([ix.ravel() * 8.0 + 130.0, iy.ravel() * 8.0 + 130.0], 1)
     check_properties(lattice, run(exe, lattice, 4))
+    check_properties(lattice, run(exe, lattice, 16))
+    # duplicates, a collinear run and clusters on 16 threads (the bucket sort and the cuts see ties)
+    rng = np.random.default_rng(4)
+    clus = np.concatenate([rng.normal((300, 300), 3, (3000, 2)), np.stack([np.arange(1500) * 0.25 + 130, np.full(1500, 222.0)], 1),
+                           rng.integers(130, 400, (3000, 2)).astype(np.float64)]).astype(np.float32)
+    check_properties(clus, run(exe, clus, 16))
 
 
 def test_sanitizers_clean(tmp_path):
