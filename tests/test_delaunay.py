@@ -176,3 +176,23 @@ def test_sanitizers_clean(tmp_path):
         txt = "%d\n" % len(pts) + "".join("%.9g %.9g\n" % (x, y) for x, y in pts)
         p = subprocess.run([out, str(th)], input=txt.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
+
+
+def test_thread_sanitizer_clean(tmp_path):
+    """The pool, the shared quad-edge array with per-subtree ranges and the level-by-level cuts / merges under
+    ThreadSanitizer: no data race on 4, 8 and 16 threads (random points, a lattice)."""
+    out = str(tmp_path / "delaunay_tsan")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "delaunay_test.cc"), "-o", out], capture_output=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    rng = np.random.default_rng(5)
+    ix, iy = np.meshgrid(np.arange(70), np.arange(60))
+    cases = [((rng.random((1500, 2)) * np.array([640.0, 480.0])).astype(np.float32), 4),
+             ((rng.random((9000, 2)) * np.array([640.0, 480.0])).astype(np.float32), 8),
+             ((rng.random((9000, 2)) * np.array([640.0, 480.0])).astype(np.float32), 16),
+             (np.stack([ix.ravel() * 8.0 + 130.0, iy.ravel() * 8.0 + 130.0], 1).astype(np.float32), 8)]
+    for pts, th in cases:
+        txt = "%d\n" % len(pts) + "".join("%.9g %.9g\n" % (x, y) for x, y in pts)
+        p = subprocess.run([out, str(th)], input=txt.encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0 and b"ThreadSanitizer" not in p.stderr, p.stderr.decode()[-3000:]
