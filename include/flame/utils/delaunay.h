@@ -48,6 +48,9 @@
 namespace flame {
 namespace utils {
 
+#ifndef FLAME_DT_LEAF_FACTOR
+#define FLAME_DT_LEAF_FACTOR 2
+#endif
 #ifndef FLAME_DT_SPINS
 #define FLAME_DT_SPINS 20000  /* ~1 ms of `pause`: the workers outlast the GPU tail of a frame of a back-to-back stream; at camera rate they sleep */
 #endif
@@ -229,7 +232,7 @@ class DelaunayTriangulator {
     FLAME_DT_LAP(2)
     // levels of the recursion that are cut open: ~2 x threads subtrees of at least 256 points
     int levels = 0;
-    if (par) while ((1 << levels) < 2 * T && (n >> (levels + 1)) >= 256) ++levels;
+    if (par) while ((1 << levels) < FLAME_DT_LEAF_FACTOR * T && (n >> (levels + 1)) >= 256) ++levels;
     bool done = false;
     if (levels > 0) done = build_parallel(n, levels, out);
     if (!done) {  // serial (also the way out when a subtree outgrew its range of the edge array: never seen)
