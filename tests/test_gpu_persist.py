@@ -251,3 +251,48 @@ def test_frame_stream_beside_a_foreign_kernel(gpu):
     p50, p99 = l[len(l) // 2], l[int(0.99 * (len(l) - 1))]
     print("beside matmuls: p50 %.3f ms, p99 %.3f ms, max %.3f ms, %s" % (p50, p99, l[-1], stats[0]))
     assert p99 < 60.0, (p50, p99, stats)
+
+
+def test_hand_offs_under_uneven_load(gpu):
+    """The MI355X guide's advice for every hand-off protocol: test it under UNEVEN load, checking every word.  50 k
+    vertices on 256 resident tiles (125 rounds per solve, ~1 500 tagged 16-byte entries polled per tile and round) while
+    another stream floods the chip with matmul workgroups, so tiles start late, stall and drift apart by rounds; 40
+    solves in a row on one handle, each compared bit for bit (x, w, q) with a handle solved by launches.  A torn or
+    stale entry anywhere in ~10^9 hand-offs would show."""
+    import threading
+    import torch
+    g, it = graphgen.named("50k")
+    p = default_params()
+    res = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+    ref = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=0)
+    stop = threading.Event()
+
+    def hog():
+        st = torch.cuda.Stream()
+        a = torch.randn(2048, 2048, device="cuda")
+        b = torch.randn(2048, 2048, device="cuda")
+        with torch.cuda.stream(st):
+            while not stop.is_set():
+                for _ in range(16):
+                    a @ b
+                st.synchronize()
+    t = threading.Thread(target=hog)
+    t.start()
+    used = 0
+    try:
+        for k in range(40):
+            n = it if k % 4 else 37  # (ragged last rounds now and then)
+            res.step(p, n)
+            used += res.info("persist_used")
+            ref.step(p, n)
+            x, w1, w2, q = res.download()
+            xr, w1r, w2r, qr = ref.download()
+            assert_bit_equal(x, xr, "solve %d x" % k); assert_bit_equal(q, qr, "solve %d q" % k)
+            assert_bit_equal(w1, w1r, "solve %d w1" % k); assert_bit_equal(w2, w2r, "solve %d w2" % k)
+    finally:
+        stop.set()
+        t.join()
+    print("resident solves %d of 40, repeated by launches %d, give-ups on the device %d" % (
+        used, res.info("persist_recovered"), res.info("persist_gave_up")))
+    assert used > 0
+    res.close(); ref.close()
