@@ -29,9 +29,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
-#ifdef FLAME_DELAUNAY_TIMING
 #include <chrono>
-#endif
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -51,8 +49,9 @@ namespace utils {
 #ifndef FLAME_DT_LEAF_FACTOR
 #define FLAME_DT_LEAF_FACTOR 2
 #endif
-#ifndef FLAME_DT_SPINS
-#define FLAME_DT_SPINS 20000  /* ~1 ms of `pause`: the workers outlast the GPU tail of a frame of a back-to-back stream; at camera rate they sleep */
+#ifndef FLAME_DT_SPIN_US
+#define FLAME_DT_SPIN_US 2500  /* the workers spin this long between runs (they outlast the GPU tail and the getters of a frame of a
+                                  back-to-back stream: waking 15 sleepers costs 0.1-0.2 ms), then sleep; at camera rate they sleep */
 #endif
 #if defined(__x86_64__) || defined(__i386__)
 #define FLAME_DT_RELAX() __builtin_ia32_pause()
@@ -120,8 +119,12 @@ class SpinPool {
     unsigned seen = 0;  // (gen_ at construction: a worker that starts late must still see the first run's bump)
     for (;;) {
       int spins = 0;
+      std::chrono::steady_clock::time_point t0;
       while (gen_.load(std::memory_order_acquire) == seen) {
-        if (++spins < FLAME_DT_SPINS) { FLAME_DT_RELAX(); continue; }  // (the phases of one call are microseconds apart)
+        FLAME_DT_RELAX();  // (the phases of one call are microseconds apart)
+        if ((++spins & 255) != 0) continue;
+        if (spins == 256) { t0 = std::chrono::steady_clock::now(); continue; }
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(FLAME_DT_SPIN_US)) continue;
         std::unique_lock<std::mutex> lk(m_);
         sleepers_.fetch_add(1, std::memory_order_acq_rel);
         cv_.wait(lk, [&]() { return gen_.load(std::memory_order_acquire) != seen; });
