@@ -89,6 +89,7 @@ SYMBOLS = {
     "flame_hip_part_destroy": (None, [_VP]),
     "flame_hip_part_solve": (C.c_int, [_VP, C.POINTER(Params), _I32]),
     "flame_hip_part_sync": (C.c_int, [_VP]),
+    "flame_hip_part_update_data": (C.c_int, [_VP, _VP, _VP, _VP]),
     "flame_hip_part_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flame_hip_part_gather": (C.c_int, [_VP] + [_VP] * 4),
     "flame_hip_part_info": (C.c_int, [_VP, C.c_char_p, _I32, C.POINTER(_I64)]),

@@ -63,6 +63,12 @@ class Partition:
     def step(self, params, n):
         _l.check(self._lib.flame_hip_part_solve(self._h, C.byref(params), n), "flame_hip_part_solve")
 
+    def update_data(self, z, wgt, x0=None):
+        """New frame on the unchanged topology (whole-graph arrays, caller's order); the state is reset."""
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+        z, wgt, x0 = f(z), f(wgt), f(x0)
+        _l.check(self._lib.flame_hip_part_update_data(self._h, _p(z), _p(wgt), _p(x0)), "flame_hip_part_update_data")
+
     def sync(self):
         _l.check(self._lib.flame_hip_part_sync(self._h), "flame_hip_part_sync")
 

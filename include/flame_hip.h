@@ -308,6 +308,8 @@ void flame_hip_part_destroy(flame_hip_part* p);
  * stream (no host synchronisation inside); successive calls continue on the rings the last one left */
 int flame_hip_part_solve(flame_hip_part* p, const flame_hip_params* params, int32_t num_iters);
 int flame_hip_part_sync(flame_hip_part* p);
+/* new frame on the unchanged topology: data terms, weights, initial x of the WHOLE graph (x0 NULL = z); state reset */
+int flame_hip_part_update_data(flame_hip_part* p, const float* z, const float* wgt, const float* x0);
 /* the whole graph's cost terms: owned sums of every part + one ncclAllReduce of 2 doubles.  Synchronises. */
 int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, double* smooth, double* data);
 /* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */

@@ -39,6 +39,12 @@ with partition.Communicator(0, 0, 1, uid) as comm:
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (V, k, name)
             so, do = o.costs(oparams())
             assert abs(sm - so) <= 1e-9 * so and abs(da - do) <= 1e-9 * do, (sm, so, da, do)
+            if V == 6000:  # a second frame on the same topology: new data terms, state reset
+                z2 = (g.z * 1.07 + 0.01).astype(np.float32)
+                ps.update_data(z2, g.wgt)
+                ps.step(p, 33)
+                o2 = COracle(g.pos, g.edges, g.alpha, g.beta, z2, g.wgt); o2.solve(oparams(), 33)
+                assert np.array_equal(ps.gather_solution()[0].view(np.uint32), o2.x.view(np.uint32)), "update_data"
             print("V %%d, %%d parts on rank 0, depth %%d: %%d P2P ops per exchange, %%d exchanges, resident tiles on part 0: %%d, bit-exact" %% (
                 V, k, depth, ps.info("p2p_ops"), ps.info("exchanges"), ps.info("persist_used", 0)))
 print("native partition ok")
