@@ -1695,7 +1695,12 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
   g->timed = true;
-  HIPCHK(g->planner.flush_grid());  // the maps of the NEXT frame's builder: enqueued behind this frame's iterations
+  // the maps of the NEXT frame's builder: enqueued behind this frame's iterations -- and, when those run as ONE launch of
+  // resident tiles, ordered behind it too (they then overlap the results stage instead of fighting the tiles for CUs)
+  {
+    static const bool maps_beside = std::getenv("FLAME_HIP_MAPS_BESIDE") != nullptr;  // dev A/B
+    HIPCHK(g->planner.flush_grid((g->persist_used && !maps_beside) ? g->ev1 : nullptr));
+  }
   return 0;
 }
 

@@ -136,7 +136,9 @@ class DevPlanner {
   // update_grid() works on the builder's second stream, beside the caller's iterations: host-side wait
   // before anything it reads (positions, tile descriptors, vertex order) or writes is touched again
   hipError_t wait_maps();
-  hipError_t flush_grid();  // enqueue update_grid()'s launches now (no-op when they are out already)
+  // after (optional): the maps' launches wait for this event -- the end of a solve by RESIDENT tiles, which owns every CU:
+  // beside it the map kernels crawl (k_grid_accum 80 us instead of 9 at 50 k) and slow the tiles they share CUs with
+  hipError_t flush_grid(hipEvent_t after = nullptr);  // enqueue update_grid()'s launches now (no-op when they are out already)
   int grid_tiles() const { return grid_tiles_; }
   void drop_grid() { grid_tiles_ = 0; }
 

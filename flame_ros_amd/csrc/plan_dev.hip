@@ -3088,11 +3088,12 @@ hipError_t DevPlanner::update_grid(hipStream_t s, int32_t V, int ntiles, const D
   return hipSuccess;
 }
 
-hipError_t DevPlanner::flush_grid() {
+hipError_t DevPlanner::flush_grid(hipEvent_t after) {
   if (!grid_deferred_) return hipSuccess;
   grid_deferred_ = false;
   const int n = Plan::kGrid * Plan::kGrid;
   hipStream_t g2 = grid_job_.stream;
+  if (after && s2_ && g2 == s2_) HIPRET(hipStreamWaitEvent(g2, after, 0));
   const int32_t V = grid_job_.V;
   zero4(g2, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
   hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, g2, V, grid_job_.pos, grid_job_.v_i2o, tile_of_int_,
