@@ -324,6 +324,8 @@ struct flame_hip_graph {
   size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
   int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
   bool persist_unchecked = false;   // a resident launch is in flight / finished and nobody has looked at persist_err yet
+  int persist_unchecked_n = 0;      // ... how many of them (the error word does not say WHICH launch gave up: only when it
+                                    // can only have been the last solve is that solve repeated)
   bool persist_skip_once = false;   // the next enqueue goes by launches (the repeat of a solve that gave up)
   int last_src = 0;                 // the buffer the last solve started from
   int32_t* persist_err = nullptr;   // page-locked: raised by a launch whose wait timed out
@@ -502,6 +504,18 @@ static hipError_t wait_last_solve(flame_hip_graph* g) {
   return hipEventSynchronize(g->ev1);
 }
 
+// A new upload throws the state of the solves before it away: whether one of their resident launches gave up no longer
+// matters for the results -- only for the lease and the back-off.  (Called behind the upload's own wait for those solves.)
+static void persist_discard(flame_hip_graph* g) {
+  if (!g->persist_unchecked) return;
+  g->persist_unchecked = false;
+  g->persist_unchecked_n = 0;
+  if (g->persist_err && *g->persist_err != 0) {
+    *g->persist_err = 0;
+    persist_lease_drop(g, true);
+  }
+}
+
 // State-writing work enqueued on the handle's own stream (upload, un-scaling, filters) is marked
 // with an event; a solve / halo pack / unpack on a CALLER's stream orders itself behind it
 // (the device-plan upload returns with k_init_state still in flight).
@@ -521,6 +535,7 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T) 
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(wait_last_solve(g));
     HIPCHK(hipStreamSynchronize(g->stream));
+    persist_discard(g);
   }
   g->V = V; g->E = E; g->T = T;
   g->uploaded = false;
@@ -966,6 +981,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(wait_last_solve(g));
     HIPCHK(hipStreamSynchronize(g->stream));
+    persist_discard(g);
     HIPCHK(hipStreamSynchronize(g->stream_in));
     HIPCHK(g->planner.wait_maps());  // (the previous frame's maps read its positions / tiles on the builder's stream)
     g->drop_execs();  // captured launches hold the old grid / pointers
@@ -1158,6 +1174,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     HIPCHK(wait_last_solve(g));
     hipStream_t s = g->stream;
     HIPCHK(hipStreamSynchronize(s));
+    persist_discard(g);
     HIPCHK(g->planner.wait_maps());
     if ((rc = dev_alloc(g->caps, &g->in_pos, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_tris, 3 * (size_t)T)) ||
         (rc = dev_alloc(g->caps, &g->in_mu, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_var, (size_t)V)) ||
@@ -1523,10 +1540,14 @@ static int persist_check(flame_hip_graph* g, int own_marks = 0) {
   static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
   if (force_fail && g->persist_used && g->persist_err) *g->persist_err = 3;
   g->persist_unchecked = false;  // (every caller has synchronised the solve's stream)
+  const int unchecked = g->persist_unchecked_n;
+  g->persist_unchecked_n = 0;
   if (!g->persist_err || *g->persist_err == 0) return 0;
   *g->persist_err = 0;
   persist_lease_drop(g, true);
-  const bool can = g->persist_used && g->state_serial == g->solve_serial + (uint64_t)own_marks && g->last_iters > 0;
+  // (several solves queued without a synchronisation in between: an earlier one may have been the one that gave up, and
+  // the later ones started from its unfinished result -- nothing to repeat from)
+  const bool can = g->persist_used && unchecked <= 1 && g->state_serial == g->solve_serial + (uint64_t)own_marks && g->last_iters > 0;
   g->persist_used = false;
   if (!can) {
     g->uploaded = false;  // the state is that of an unfinished solve
@@ -1597,6 +1618,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       g->persist_base += rounds - 1;
       g->persist_used = true;
       g->persist_unchecked = true;
+      ++g->persist_unchecked_n;
       g->last_src = cur;
       *launches = 1;
       *cur_out = cur ^ 1;  // (written once, by the last round; the source buffers are only read)

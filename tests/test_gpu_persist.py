@@ -296,3 +296,47 @@ def test_hand_offs_under_uneven_load(gpu):
         used, res.info("persist_recovered"), res.info("persist_gave_up")))
     assert used > 0
     res.close(); ref.close()
+
+
+def test_give_up_with_several_solves_queued_is_an_error_not_a_guess(gpu):
+    """The error word does not say WHICH launch gave up.  With several resident solves queued behind each other and no
+    synchronisation in between, an earlier one may be the one that failed and the later ones started from its unfinished
+    result: the library must then refuse (FLAME_HIP_ERR_STATE) instead of repeating the last solve from a source it
+    cannot trust; a fresh upload afterwards works again, and a failure that a new upload makes irrelevant is forgotten."""
+    import os, subprocess, sys
+    code = r\'\'\'
+import numpy as np, sys
+sys.path.insert(0, %r)
+from flame_ros_amd import graphgen, lib
+from flame_ros_amd.regularizer import GraphRegularizer, default_params
+from oracle import COracle
+from oracle.cbind import default_params as oparams
+g, _ = graphgen.named("tum")
+p = default_params()
+r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+r.step(p, 20, sync=False); r.step(p, 20, sync=False)     # two resident solves, nobody looks in between
+try:
+    r.download()
+    raise SystemExit("expected FLAME_HIP_ERR_STATE")
+except lib.FlameHipError as e:
+    assert e.code == lib.ERR_STATE, e.code
+# a failure that a new upload discards is forgotten (only the back-off remembers it): upload, ONE solve, correct bits
+r.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+for k in range(16):                 # (the process-wide back-off of that give-up: 16 solves by launches)
+    r.step(p, 9, sync=False)
+    assert r.info("persist_used") == 0
+r.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
+o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt); o.solve(oparams(), 30)
+r.step(p, 30, sync=False)
+assert r.info("persist_used") == 1   # (ONE resident solve since the last look: it is repeated)
+x = r.download()[0]
+assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)) and r.info("persist_recovered") == 1
+r.step(p, 9, sync=False)            # (unchecked) ...
+r.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)   # ... and thrown away by the next upload
+r.step(p, 30, sync=False)
+x = r.download()[0]
+assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32))
+print("refused ok")
+\'\'\' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_PERSIST_FAIL="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "refused ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
