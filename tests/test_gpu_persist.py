@@ -304,7 +304,7 @@ def test_give_up_with_several_solves_queued_is_an_error_not_a_guess(gpu):
     result: the library must then refuse (FLAME_HIP_ERR_STATE) instead of repeating the last solve from a source it
     cannot trust; a fresh upload afterwards works again, and a failure that a new upload makes irrelevant is forgotten."""
     import os, subprocess, sys
-    code = r\'\'\'
+    code = r'''
 import numpy as np, sys
 sys.path.insert(0, %r)
 from flame_ros_amd import graphgen, lib
@@ -337,6 +337,6 @@ r.step(p, 30, sync=False)
 x = r.download()[0]
 assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32))
 print("refused ok")
-\'\'\' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_PERSIST_FAIL="1"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "refused ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
