@@ -1494,6 +1494,7 @@ struct PersistLease {
   std::mutex m;
   flame_hip_graph* holder = nullptr;
   hipEvent_t holder_done = nullptr;  // (the holder's ev1)
+  bool recorded = false;             // the holder's end event has been recorded behind its launch (until then: busy)
   int backoff = 0;                   // solves (of any handle) to sit out
   int backoff_next = 16;
   int gave_up = 0;                   // give-ups seen on this device (info "persist_gave_up")
@@ -1506,10 +1507,16 @@ static bool persist_lease_take(flame_hip_graph* g) {
   PersistLease& L = persist_lease(g->device);
   std::lock_guard<std::mutex> lk(L.m);
   if (L.backoff > 0) { --L.backoff; return false; }
-  if (L.holder && L.holder != g && hipEventQuery(L.holder_done) != hipSuccess) return false;
+  if (L.holder && L.holder != g && (!L.recorded || hipEventQuery(L.holder_done) != hipSuccess)) return false;
   L.holder = g;
   L.holder_done = g->ev1;
+  L.recorded = false;  // (flame_hip_solve records ev1 behind the launch, then persist_lease_recorded())
   return true;
+}
+static void persist_lease_recorded(flame_hip_graph* g) {
+  PersistLease& L = persist_lease(g->device);
+  std::lock_guard<std::mutex> lk(L.m);
+  if (L.holder == g) L.recorded = true;
 }
 static int persist_gave_up_count(int device) {
   PersistLease& L = persist_lease(device);
@@ -1716,6 +1723,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   g->last_launches = launches;
   g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
+  if (g->persist_used) persist_lease_recorded(g);
   g->timed = true;
   // the maps of the NEXT frame's builder: enqueued behind this frame's iterations -- and, when those run as ONE launch of
   // resident tiles, ordered behind it too (they then overlap the results stage instead of fighting the tiles for CUs)
