@@ -222,10 +222,14 @@ def facade_frames(workloads=("tum", "euroc", "50k")):
             out[w] = {"V": r["V"], "iters": r["iters"], "update_ms_p50": r["update_ms"]["p50"],
                       "update_ms_p90": r["update_ms"]["p90"], "sync_graph_ms_p50": r["sync_graph_ms_p50"],
                       "nltgv2_ms_p50": r["nltgv2_ms_p50"], "frames": r["frames"]}
-            if True:  # update() from features alone: the built-in HOST triangulator runs inside it (at 50 k it IS the frame)
-                f = facade_bench.run(w, repeats=5 if w != "50k" else 3, getters=1, env={"FLAME_BENCH_FRONTEND": "1"})
-                out[w]["from_features_update_ms_p50"] = f["update_ms"]["p50"]
-                out[w]["from_features_triangulate_ms_p50"] = f["triangulate_ms_p50"]
+            # update() from features alone: the built-in triangulation runs inside it -- on the GPU (flame_hip_delaunay, the
+            # default) and, beside it, on the host pool (Params::triangulate_on_gpu = false)
+            f = facade_bench.run(w, repeats=5 if w != "50k" else 3, getters=1, env={"FLAME_BENCH_FRONTEND": "1"})
+            out[w]["from_features_update_ms_p50"] = f["update_ms"]["p50"]
+            out[w]["from_features_triangulate_ms_p50"] = f["triangulate_ms_p50"]
+            f = facade_bench.run(w, repeats=5 if w != "50k" else 3, getters=1, env={"FLAME_BENCH_FRONTEND": "1", "FLAME_BENCH_TRI_GPU": "0"})
+            out[w]["from_features_host_triangulator_update_ms_p50"] = f["update_ms"]["p50"]
+            out[w]["from_features_host_triangulator_triangulate_ms_p50"] = f["triangulate_ms_p50"]
         except Exception as e:  # noqa: BLE001 -- the bench line must not die on the side measurement
             out[w] = {"error": str(e)[:200]}
     return out

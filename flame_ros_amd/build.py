@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflame_hip.so")
-SOURCES = ["kernels.hip", "plan_dev.hip", "flame_hip.cpp", "plan.cpp", "sync.cpp", "part.cpp"]
-HEADERS = ["common.h", "kernels.h", "plan.h", "plan_dev.h", "sync.h", os.path.join("..", "..", "include", "flame_hip.h")]
+SOURCES = ["kernels.hip", "plan_dev.hip", "delaunay_dev.hip", "flame_hip.cpp", "plan.cpp", "sync.cpp", "part.cpp"]
+HEADERS = ["common.h", "kernels.h", "plan.h", "plan_dev.h", "delaunay_dev.h", "sync.h", os.path.join("..", "..", "include", "flame_hip.h")]
 # -amdgpu-kernarg-preload-count: the first 16 dwords of a kernel's arguments arrive in SGPRs at wave
 # launch (gfx950) instead of through a scalar load -- the tile kernel's argument order relies on it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",

@@ -1,0 +1,27 @@
+// flame_ros_amd/csrc/delaunay_dev.h -- Delaunay triangulation of a frame's features on the GPU (SURVEY.md 8 row f3's
+// first leg: "Delaunay -> edge list"; reference evidence: stat key `triangulate`, msg/FlameStats.msg:44).  See
+// delaunay_dev.hip for the algorithm; include/flame_hip.h (flame_hip_delaunay) for the contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flamehip {
+
+struct DelaunayScratch {
+  char* dev = nullptr;       // one device arena, grown geometrically, reused frame after frame
+  size_t dev_cap = 0;
+  char* pin = nullptr;       // page-locked host arena: positions in, flags + triangles out
+  size_t pin_cap = 0;
+  float last_ms = 0.f;       // host time of the last call (copies included)
+  int32_t last_hull = 0;     // boundary vertices of the last triangulation
+  int32_t last_live = 0;     // points that are not later copies of another point
+  void release();
+};
+
+// Triangulates V points (host array of {u, v} floats) on stream s of the current device.  tris_out (host) receives
+// *T_out <= tri_cap counter-clockwise triangles (orient = (b - a) x (c - a) > 0 in the image frame's coordinates), each
+// starting at its smallest vertex, ordered by that vertex.  Returns 0, or a FLAME_HIP_ERR_* code.
+int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris_out,
+                    int32_t* T_out);
+
+}  // namespace flamehip

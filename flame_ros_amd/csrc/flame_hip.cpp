@@ -23,6 +23,7 @@
 #include <mutex>
 #include <vector>
 
+#include "delaunay_dev.h"
 #include "kernels.h"
 #include "plan.h"
 #include "plan_dev.h"
@@ -252,6 +253,7 @@ struct flame_hip_graph {
 
   hipStream_t stream = nullptr;
   hipStream_t stream_in = nullptr;  // input staging (H2D of a frame overlaps the partition kernels)
+  DelaunayScratch dt;               // flame_hip_delaunay: arenas kept between frames
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_in = nullptr;
   hipEvent_t ev_state = nullptr;  // last state-writing work on `stream` (upload, scale, filter, results)
   bool state_pending = false;     // ev_state was recorded since the last full synchronisation
@@ -485,6 +487,7 @@ void flame_hip_graph_destroy(flame_hip_graph* g) {
     persist_lease_drop(g, false);
     (void)g->planner.wait_maps();
     g->free_device();
+    g->dt.release();
     if (g->persist_err) (void)hipHostFree(g->persist_err);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
@@ -640,6 +643,9 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
     if (hipMemcpy(&v, g->xp.prof + 2 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
     *value = v;
   }
+  else if (k == "delaunay_hull") *value = g->dt.last_hull;  // flame_hip_delaunay: boundary vertices / live points / host microseconds of the last call
+  else if (k == "delaunay_live") *value = g->dt.last_live;
+  else if (k == "delaunay_us") *value = (int64_t)(g->dt.last_ms * 1000.0f);
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
     int khz = 0;
@@ -1377,6 +1383,15 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
   g->synced = true;
   if (scale) *scale = S.scale;
   return 0;
+}
+
+int flame_hip_delaunay(flame_hip_graph* g, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris, int32_t* T) {
+  RoctxRange roctx_("flame_hip_delaunay");
+  if (!g || V < 0 || tri_cap < 0 || !T || (V > 0 && !pos) || (tri_cap > 0 && !tris)) return FLAME_HIP_ERR_ARG;
+  if (g->device < 0) return FLAME_HIP_ERR_STATE;  // a plan-only handle has no GPU (the host triangulator is include/flame/utils/delaunay.h)
+  if (V > 0 && !all_finite(pos, 2 * (size_t)V)) return FLAME_HIP_ERR_NAN;
+  HIPCHK(hipSetDevice(g->device));
+  return delaunay_device(g->stream_in, &g->dt, V, pos, tri_cap, tris, T);
 }
 
 int flame_hip_graph_edges(const flame_hip_graph* g, int32_t* edges) {

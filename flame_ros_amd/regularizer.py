@@ -132,6 +132,16 @@ class GraphRegularizer:
         self.V, self.T, self.E = len(mu), len(tris), self.info("E")
         return scale.value
 
+    def delaunay(self, pos):
+        """Row f3's first leg on the GPU (flame_hip_delaunay): counter-clockwise triangles of the Delaunay triangulation
+        of pos (V x 2 pixel coordinates), each starting at its smallest vertex, ordered by that vertex."""
+        pos = _f32(pos).reshape(-1, 2)
+        tris = np.empty((max(2 * len(pos), 1), 3), np.int32)
+        T = C.c_int32()
+        _l.check(self._lib.flame_hip_delaunay(self._h, len(pos), _ptr(pos) if len(pos) else None, len(tris), _ptr(tris),
+                                              C.byref(T)), "flame_hip_delaunay")
+        return tris[:T.value].copy()
+
     def edges(self):
         """The edge list derived by sync_features ([E,2] int32, i < j, lexicographic)."""
         e = np.empty((self.E, 2), np.int32)

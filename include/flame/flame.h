@@ -269,8 +269,22 @@ class Flame {
         if (ok) {
           stats_.tick("triangulate");
           // (the reference's `omp_num_threads`, cfg/flame_offline_tum.yaml:70, is what its CPU stages run on)
-          ok = frontend_.triangulate ? frontend_.triangulate(g.vtx, &tris)
-                                     : delaunay_.triangulate(g.vtx, &tris, params_.triangulate_threads > 0 ? params_.triangulate_threads : params_.omp_num_threads);
+          if (frontend_.triangulate) {
+            ok = frontend_.triangulate(g.vtx, &tris);
+          } else if (params_.triangulate_on_gpu) {  // row f3's first leg in the library
+            static_assert(sizeof(Point2f) == 2 * sizeof(float) && sizeof(Triangle) == 3 * sizeof(int32_t), "boundary types are packed");
+            const int32_t nv = static_cast<int32_t>(g.vtx.size());
+            int32_t nt = 0;
+            tris.resize(2 * g.vtx.size() + 1);
+            const int rc = graph_.triangulate(params_.hip_device, nv, nv ? reinterpret_cast<const float*>(g.vtx.data()) : nullptr,
+                                              static_cast<int32_t>(tris.size()), reinterpret_cast<int32_t*>(tris.data()), &nt);
+            tris.resize(rc ? 0 : nt);
+            ok = rc == 0 && nt > 0;  // (nothing to triangulate -- fewer than three distinct points, or all on a line -- fails the
+                                     // frame, as the host triangulator's `false` does)
+            if (rc) stats_.set("hip_error", rc);
+          } else {
+            ok = delaunay_.triangulate(g.vtx, &tris, params_.triangulate_threads > 0 ? params_.triangulate_threads : params_.omp_num_threads);
+          }
           stats_.tock("triangulate");
         }
         if (ok)

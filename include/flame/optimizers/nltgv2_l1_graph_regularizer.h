@@ -75,6 +75,12 @@ class Graph {
     resident_ = true;
     return 0;
   }
+  // Row f3's first leg in the library (flame_hip_delaunay): the Delaunay triangulation of the features on the GPU of
+  // `device`.  tris (3 ints per triangle, e.g. a vector<cv::Vec3i>'s storage) needs room for 2V triangles.
+  int triangulate(int device, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris, int32_t* T) {
+    const int rc = acquire(device);
+    return rc ? rc : flame_hip_delaunay(g_, V, pos, tri_cap, tris, T);
+  }
   // a graph is resident (the last build / sync succeeded)
   bool valid() const { return g_ != nullptr && resident_; }
   int32_t numVertices() const { return V_; }

@@ -152,6 +152,18 @@ typedef struct {
 int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, int32_t V, int32_t T,
                          const float* pos, const float* idepth_mu, const float* idepth_var,
                          const int32_t* tris, const float* prediction, float* scale);
+/* Row f3's first leg -- the Delaunay triangulation of a frame's features, on the GPU (the reference budgets it as
+ * `triangulate` beside `sync_graph`, msg/FlameStats.msg:43-44; upstream calls Shewchuk's Triangle on the host; the
+ * host triangulator of the same contract is include/flame/utils/delaunay.h).  pos: V x {u, v} pixel coordinates
+ * (|u|, |v| < 2^13, snapped to a 2^-16 pixel lattice; exact predicates, so pixel lattices and collinear runs are
+ * ordinary inputs).  tris receives *T <= tri_cap (2V always suffices) counter-clockwise triangles -- (b - a) x (c - a)
+ * > 0 in these coordinates --, each starting at its smallest vertex, ordered by that vertex; cocircular points are cut
+ * as a fan from their smallest id, points that coincide after snapping are triangulated once (smallest id).  The
+ * list is a function of the input alone.  Independent of the graph held by g (own scratch, the handle's staging
+ * stream); returns when the list is in tris.  Errors: ARG (coordinate out of range, tri_cap too small), NAN, STATE
+ * (no device; or the result failed Euler's check T = 2 n - 2 - h: never seen, reported rather than handed out).
+ * flame_hip_get_info: "delaunay_hull" (h), "delaunay_live" (n), "delaunay_us" (host time of the call). */
+int flame_hip_delaunay(flame_hip_graph* g, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris, int32_t* T);
 /* keep[v] = var[v] < var_max; returns the number kept (or a negative error).  No device needed. */
 int32_t flame_hip_feature_gate(int32_t n, const float* idepth_var, float var_max, uint8_t* keep);
 /* The edge list flame_hip_graph_sync derived (2E ints; E from flame_hip_get_info "E"). */

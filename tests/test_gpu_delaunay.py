@@ -1,0 +1,126 @@
+"""-m gpu: flame_hip_delaunay (flame_ros_amd/csrc/delaunay_dev.hip) -- SURVEY.md 8 row f3's first leg, the Delaunay
+triangulation of a frame's features, on the GPU: against SciPy on generic points (the triangulation is unique there), and
+by the defining properties -- exact, in Python integers -- on degenerate ones (pixel lattices, cocircular rings, collinear
+runs, duplicates, clusters), exactly the cases tests/test_delaunay.py holds for the host triangulator of the same contract.
+(The reference has no test of its own for this step: upstream calls Shewchuk's Triangle; stat key `triangulate`,
+/root/reference/msg/FlameStats.msg:44.)"""
+import numpy as np
+import pytest
+
+from test_delaunay import canon, check_properties, orient, snapped
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def handle(gpu):
+    from flame_ros_amd.regularizer import GraphRegularizer
+    h = GraphRegularizer.empty()
+    yield h
+    h.close()
+
+
+def scipy_ccw(pts):
+    from scipy.spatial import Delaunay
+    P = pts.astype(np.float64)
+    ref = Delaunay(P).simplices
+    d = (P[ref[:, 1], 0] - P[ref[:, 0], 0]) * (P[ref[:, 2], 1] - P[ref[:, 0], 1]) - \
+        (P[ref[:, 1], 1] - P[ref[:, 0], 1]) * (P[ref[:, 2], 0] - P[ref[:, 0], 0])
+    return np.where(d[:, None] > 0, ref, ref[:, [0, 2, 1]])
+
+
+@pytest.mark.parametrize("n,seed", [(3, 0), (4, 1), (10, 2), (200, 3), (1200, 6), (5000, 4), (10000, 5), (50000, 7), (200000, 8)])
+def test_matches_scipy_on_generic_points(handle, n, seed):
+    rng = np.random.default_rng(seed)
+    pts = (rng.random((n, 2)) * np.array([640.0, 480.0]) + 128.0).astype(np.float32)  # (>= 128: on the lattice)
+    got = handle.delaunay(pts)
+    if n <= 200:
+        check_properties(pts, got)
+    assert np.array_equal(canon(got), canon(scipy_ccw(pts)))
+    # the list itself: every triangle starts at its smallest vertex, the list is ordered by it, and a second call
+    # returns the same list (not just the same set)
+    assert np.all(got[:, 0] < got[:, 1]) and np.all(got[:, 0] < got[:, 2]) and np.all(np.diff(got[:, 0]) >= 0)
+    assert np.array_equal(got, handle.delaunay(pts))
+    assert handle.info("delaunay_live") == n and 2 * n - 2 - handle.info("delaunay_hull") == len(got)
+
+
+def test_clustered_and_skewed_distributions(handle):
+    """Nothing about the grid assumes uniform features: clusters (cells with hundreds of points), a thin strip (one grid
+    row), points on a few image rows, a huge aspect ratio."""
+    rng = np.random.default_rng(11)
+    clus = np.concatenate([rng.normal((300, 300), 3, (3000, 2)), rng.normal((500, 200), 0.5, (2000, 2)),
+                           rng.random((500, 2)) * np.array([640.0, 480.0]) + 128.0]).astype(np.float32)
+    strip = np.stack([rng.random(4000) * 600 + 130, rng.random(4000) * 0.5 + 300], 1).astype(np.float32)
+    wide = np.stack([rng.random(3000) * 8000 - 4000, rng.random(3000) * 3 - 1], 1).astype(np.float32)
+    for pts in (clus, strip, wide):
+        pts = np.unique(pts, axis=0)
+        rng.shuffle(pts)
+        got = handle.delaunay(pts)
+        want = scipy_ccw((np.round(pts.astype(np.float64) * 65536.0)))  # (what is triangulated: the snapped points)
+        if np.array_equal(canon(got), canon(want)):
+            continue
+        check_properties(pts, got)  # (snapping may have made cocircular / collinear sets: any valid choice)
+
+
+def test_degenerate_inputs(handle):
+    # a pixel lattice: every cell is cocircular
+    ix, iy = np.meshgrid(np.arange(12), np.arange(9))
+    lattice = np.stack([ix.ravel() * 16.0 + 8.0, iy.ravel() * 16.0 + 8.0], 1)
+    check_properties(lattice, handle.delaunay(lattice))
+    # one feature per 16-pixel cell at integer pixels (what the detector produces)
+    rng = np.random.default_rng(5)
+    cells = np.stack([ix.ravel() * 16 + rng.integers(0, 16, ix.size), iy.ravel() * 16 + rng.integers(0, 16, ix.size)], 1)
+    check_properties(cells, handle.delaunay(cells))
+    # collinear runs inside the set, duplicates, tiny coordinates (off the lattice: snapped)
+    pts = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [0, 1], [3, 1], [1.5, 0.25], [1.5, 0.25], [0, 0], [2.5, 1e-3]], np.float32)
+    check_properties(pts, handle.delaunay(pts))
+    # nothing to triangulate: an empty list (the facade reports the frame as failed, like the host triangulator's `false`)
+    assert len(handle.delaunay(np.array([[0, 0], [1, 1]], np.float32))) == 0
+    assert len(handle.delaunay(np.array([[0, 0], [1, 1], [2, 2], [5, 5]], np.float32))) == 0
+    assert len(handle.delaunay(np.array([[3, 3], [3, 3], [3, 3], [3, 3]], np.float32))) == 0
+    assert len(handle.delaunay(np.zeros((0, 2), np.float32))) == 0
+    from flame_ros_amd.lib import FlameHipError
+    with pytest.raises(FlameHipError):
+        handle.delaunay(np.array([[0, 0], [1, 0], [np.inf, 3]], np.float32))
+    with pytest.raises(FlameHipError):
+        handle.delaunay(np.array([[0, 0], [1, 0], [9000.0, 3]], np.float32))  # outside |u| < 2^13
+
+
+def test_small_integer_sets_stress(handle):
+    """Many tiny point sets on a coarse integer grid: collinear subsets, cocircular quadruples and larger rings,
+    duplicates -- every star has to make the same choice inside every cocircular polygon."""
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        n = int(rng.integers(3, 60))
+        pts = rng.integers(0, 7, (n, 2)).astype(np.float32) * np.float32(8.0) + np.float32(128.0)
+        tris = handle.delaunay(pts)
+        P = list(set(map(tuple, pts.tolist())))
+        collinear = len(P) < 3 or all(orient(*(snapped([P[0], P[1], c]))) == 0 for c in P)
+        if collinear:
+            assert len(tris) == 0, trial
+            continue
+        check_properties(pts, tris)
+    # a circle through 12 lattice points, a vertical and a horizontal line through its centre
+    circle = [(5, 0), (4, 3), (3, 4), (0, 5), (-3, 4), (-4, 3), (-5, 0), (-4, -3), (-3, -4), (0, -5), (3, -4), (4, -3)]
+    pts = np.array(circle + [(0, k) for k in range(-4, 5)] + [(k, 0) for k in range(-4, 5) if k], np.float32) * 4 + 200
+    check_properties(pts, handle.delaunay(pts))
+    # the bare ring (one polygon of 12 cocircular points: a fan from vertex 0), in every rotation of the ids
+    ring = np.array(circle, np.float32) * 4 + 200
+    for k in range(12):
+        r = np.roll(ring, k, axis=0)
+        tris = handle.delaunay(r)
+        check_properties(r, tris)
+        assert len(tris) == 10 and np.all(tris[:, 0] == 0)
+
+
+def test_lattices_at_frame_size(handle):
+    """A full 80 x 60 lattice (4 800 cocircular cells) and integer-pixel features at the BASELINE sizes."""
+    ix, iy = np.meshgrid(np.arange(80), np.arange(60))
+    lattice = np.stack([ix.ravel() * 8.0 + 130.0, iy.ravel() * 8.0 + 130.0], 1)
+    check_properties(lattice, handle.delaunay(lattice))
+    rng = np.random.default_rng(4)
+    clus = np.concatenate([rng.normal((300, 300), 3, (3000, 2)), np.stack([np.arange(1500) * 0.25 + 130, np.full(1500, 222.0)], 1),
+                           rng.integers(130, 400, (3000, 2)).astype(np.float64)]).astype(np.float32)
+    check_properties(clus, handle.delaunay(clus))
+    pix = np.stack([rng.integers(0, 640, 10000), rng.integers(0, 480, 10000)], 1).astype(np.float32)  # duplicates, ties
+    check_properties(pix, handle.delaunay(pix))

@@ -70,6 +70,8 @@ int main(int argc, char** argv) {
   if (const char* e = std::getenv("FLAME_BENCH_NO_DEBUG")) {  // A/B: the debug draws off
     if (e[0] == '1') params.debug_draw_wireframe = params.debug_draw_features = params.debug_draw_idepthmap = false;
   }
+  if (const char* e = std::getenv("FLAME_BENCH_TRI_GPU")) params.triangulate_on_gpu = e[0] == '1';  // A/B: built-in triangulation on the GPU / on the host pool
+  if (const char* e = std::getenv("FLAME_BENCH_TRI_THREADS")) params.triangulate_threads = std::atoi(e);
   flame::Matrix3f K, Kinv;  // cfg/kinect.yaml: 525/525/319.5/239.5
   K(0, 0) = 525.f; K(0, 1) = 0.f; K(0, 2) = 319.5f; K(1, 0) = 0.f; K(1, 1) = 525.f; K(1, 2) = 239.5f;
   K(2, 0) = 0.f; K(2, 1) = 0.f; K(2, 2) = 1.f;
@@ -79,7 +81,7 @@ int main(int argc, char** argv) {
   std::shared_ptr<flame::Flame> sensor = std::make_shared<flame::Flame>(W, H, K, Kinv, params);
 
   // FLAME_BENCH_FRONTEND=1: the frames go through update() with a FrontEnd whose track() hands over the
-  // frame's features and NO triangulate(): the built-in host triangulator (flame/utils/delaunay.h) runs
+  // frame's features and NO triangulate(): the built-in triangulator (on the GPU, flame_hip_delaunay, or flame/utils/delaunay.h on the host) runs
   // inside update(), as it does for a caller that only brings features
   const char* fe_env = std::getenv("FLAME_BENCH_FRONTEND");
   const bool with_frontend = fe_env && fe_env[0] == '1';
