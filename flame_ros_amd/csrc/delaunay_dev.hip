@@ -3,26 +3,31 @@
 // calls Shewchuk's Triangle on the host).  include/flame/utils/delaunay.h is the host triangulator of the same contract
 // (exact predicates on a 2^-16 pixel lattice, |u|, |v| < 2^13); this file is the device one.
 //
-// One thread per point builds that point's STAR -- its Delaunay neighbours in angular order -- by gift wrapping, from
+// One WAVEFRONT per point builds that point's STAR -- its Delaunay neighbours in angular order -- by gift wrapping, from
 // exact predicates only:
 //   * the nearest neighbour q0 of p is a Delaunay neighbour of p in every Delaunay triangulation;
 //   * given a Delaunay edge p -> q, the third vertex of the triangle on its left is the point r strictly left of p -> q
-//     whose circle (p, q, r) holds no other point on that side: one pass over the candidates, "r' beats r when r' is
-//     strictly inside (p, q, r)";
+//     whose circle (p, q, r) holds no other point on that side ("r' beats r when r' is strictly inside (p, q, r)": a
+//     total preorder -- the angle under which p q is seen);
 //   * when nothing is strictly left of p -> q the edge is on the convex hull: the star is open, and is completed by
 //     wrapping the other way round from q0.
+// The 64 lanes test 64 candidates at a time (one coalesced 1 KB load of 16-byte records, the predicates in parallel, a
+// ballot; the star's own state -- current best, circle, ties -- is wave-uniform, so the control flow never diverges).
 // Cocircular points (pixel lattices are full of them) are resolved by ONE rule every star applies alike: the polygon of
 // the points on an empty circle is triangulated as a fan from its smallest vertex id.  A star sees the polygon either
 // whole (from one of its boundary edges) or as the part left of one of the fan's diagonals, in which the smallest id is
 // still a vertex: the rule restricted to the part is the same fan, so the stars agree and every triangle appears in the
 // stars of its three vertices.  It is written once, by the star of its smallest vertex.
 //
-// Candidates come from a uniform grid (about two points per cell).  Floating point is used for PRUNING only, always
-// conservatively: a cell row / cell is skipped when it cannot meet the current cap (the part of the current circle's
+// Candidates come from a uniform grid (about two points per cell, cells row-major: a run of cells in a grid row is ONE
+// run of records).  The 3 x 3 cells around p are loaded once per star, packed into the 64 lanes: they answer nearly
+// every step of an interior star.  Floating point is used for PRUNING only, always conservatively: a grid row, or the
+// part of it outside an x interval, is skipped when it cannot meet the current cap (the part of the current circle's
 // disk left of p -> q; every later cap is inside it), with the disk's centre and radius padded by their rounding
-// bounds.  Hull edges query a whole half-plane: per grid row the x extent of its points makes that one test per row.
-// Every accept / reject of a candidate is exact: orientation in 64-bit integers (differences < 2^30), in-circle by a
-// double-precision filter and 128-bit integers behind it (sum < 2^124), exactly as the host triangulator.
+// bounds; 64 rows are judged at a time, one per lane.  Hull edges query a whole half-plane: per grid row the x extent of
+// its points makes that one test per row.  Every accept / reject of a candidate is exact: orientation in 64-bit
+// integers (differences < 2^30), in-circle by a double-precision filter and 128-bit integers behind it (sum < 2^124),
+// exactly as the host triangulator.
 //
 // Output: counter-clockwise triangles (orient = (b - a) x (c - a) > 0), each starting at its smallest vertex, ordered by
 // that vertex, a star's triangles in wrapping order -- a function of the input alone (not of the order in which the
@@ -34,7 +39,10 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/flame_hip.h"
 
@@ -53,14 +61,20 @@ __extension__ typedef __int128 i128;
 // [4] min x, [5] min y, [6] max x, [7] max y (lattice)
 constexpr int kFlagWords = 8;
 constexpr int kErrRange = 1, kErrWrap = 2, kErrCap = 4, kErrCount = 8;
+constexpr int kStash = 12;  // triangles a star keeps beside its count in the first pass (more: the star is rebuilt in the second)
+
+struct DtRow {
+  double ylo, yhi;       // every point of the row has ylo <= y < yhi (lattice)
+  int32_t xlo, xhi;      // min / max x of its live points (xlo > xhi: none)
+};
 
 struct DtView {
-  const int2* sxy;       // lattice coordinates, cell by cell
-  const int32_t* sid;    // slot -> point id; ~id for a later copy of another point
+  const int4* rec;       // {x, y (lattice), id (~id: a later copy of another point), cell}, cell by cell
   const int32_t* start;  // G*G + 1 cell offsets (row-major: a grid row's cells are contiguous)
-  const int2* rowx;      // per grid row {min x, max x} of its live points ({1, 0}: none)
+  const DtRow* row;      // per grid row: its y extent and the x extent of its live points
   const int32_t* flags;
   int32_t G, V;
+  int32_t* dbg;          // dev aid (FLAME_HIP_DT_STATS): per point {own triangles, chunks, row batches, row scans}
 };
 
 struct DtBox {
@@ -94,9 +108,11 @@ __device__ inline int incircle_sign(int2 a, int2 b, int2 c, int2 d) {
     if (det > bound) return 1;
     if (det < -bound) return -1;
   }
-  const i128 ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
-  const i128 a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-  const i128 det = a2 * (bx * cy - by * cx) - b2 * (ax * cy - ay * cx) + c2 * (ax * by - ay * bx);
+  // differences < 2^30: squared norms and 2 x 2 minors < 2^61 fit 64 bits; three 64 x 64 -> 128-bit products, sum < 2^124
+  const int64_t ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+  const int64_t a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+  const int64_t mbc = bx * cy - by * cx, mac = ax * cy - ay * cx, mab = ax * by - ay * bx;
+  const i128 det = (i128)a2 * mbc - (i128)b2 * mac + (i128)c2 * mab;
   return det > 0 ? 1 : (det < 0 ? -1 : 0);
 }
 
@@ -123,23 +139,91 @@ __device__ inline int32_t clampi(double v, int32_t lo, int32_t hi) {
   return v <= (double)lo ? lo : (v >= (double)hi ? hi : (int32_t)v);
 }
 
+// the value lane `w` holds (w wave-uniform: it comes from a ballot)
+__device__ inline int32_t bcast(int32_t v, int w) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(w)); }
+__device__ inline double bcastd(double v, int w) {
+  const int32_t lo = bcast(__double2loint(v), w), hi = bcast(__double2hiint(v), w);
+  return __hiloint2double(hi, lo);
+}
+
+// One wavefront = one star.  Every member and every local below is wave-uniform except `lane` and what is loaded per lane.
 struct Star {
   const DtView& g;
   const DtBox bx;
-  const int32_t ps, ip, pcx, pcy;
+  const int32_t ps, ip, pcx, pcy, lane;
   const int2 p;
-  __device__ Star(const DtView& g_, DtBox b_, int32_t ps_, int32_t ip_, int2 p_)
-      : g(g_), bx(b_), ps(ps_), ip(ip_),
-        pcx((int32_t)(((int64_t)(p_.x - b_.minx) * g_.G) / b_.spanx)), pcy((int32_t)(((int64_t)(p_.y - b_.miny) * g_.G) / b_.spany)),
-        p(p_) {}
+  // the 3 x 3 cells around p, loaded ONCE per star (every step of the wrapping starts there, and an interior star
+  // rarely looks further): the three runs of records (one per grid row) packed into the 64 lanes, if they fit
+  int32_t sxa, sxb;        // the block's cell columns
+  int32_t cslot;           // this lane's slot
+  int4 crec;               // ... and record ({.., id = -1}: none)
+  bool cached;
+  mutable int32_t n_chunks = 0, n_rows = 0, n_scans = 0;
+  double ix0, ix1, iy0, iy1;  // a disk inside [ix0, ix1) x [iy0, iy1) holds points of the block only
+  __device__ Star(const DtView& g_, DtBox b_, int32_t ps_, int32_t ip_, int2 p_, int32_t cell_, int32_t lane_)
+      : g(g_), bx(b_), ps(ps_), ip(ip_), pcx(cell_ % g_.G), pcy(cell_ / g_.G), lane(lane_), p(p_) {
+    const int32_t G = g.G;
+    sxa = max(pcx - 1, 0); sxb = min(pcx + 1, G - 1);
+    const int32_t sya = max(pcy - 1, 0), syb = min(pcy + 1, G - 1);
+    int32_t cbase[3], cn[3], tot = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int32_t cy = pcy - 1 + k;
+      cbase[k] = 0; cn[k] = 0;
+      if (cy >= 0 && cy < G) {
+        cbase[k] = g.start[cy * G + sxa];
+        cn[k] = g.start[cy * G + sxb + 1] - cbase[k];
+      }
+      tot += cn[k];
+    }
+    cached = tot <= 64;
+    crec = make_int4(0, 0, -1, 0);
+    cslot = -1;
+    if (cached && lane < tot) {
+      cslot = lane < cn[0] ? cbase[0] + lane : (lane < cn[0] + cn[1] ? cbase[1] + lane - cn[0] : cbase[2] + lane - cn[0] - cn[1]);
+      crec = g.rec[cslot];
+    }
+    // a point left of column sxa has x < minx + ceil(sxa spanx / G); one right of column sxb has x >= minx + (sxb + 1) spanx / G
+    ix0 = sxa == 0 ? -INFINITY : (double)bx.minx + (double)(((int64_t)sxa * bx.spanx) / G) + 1.0;
+    ix1 = sxb == G - 1 ? INFINITY : (double)bx.minx + (double)(((int64_t)(sxb + 1) * bx.spanx) / G);
+    iy0 = sya == 0 ? -INFINITY : (double)bx.miny + (double)(((int64_t)sya * bx.spany) / G) + 1.0;
+    iy1 = syb == G - 1 ? INFINITY : (double)bx.miny + (double)(((int64_t)(syb + 1) * bx.spany) / G);
+  }
 
   // ---- the nearest live point (ties: smallest id): ring by ring around p's cell ----
   __device__ int32_t nearest() const {
     const int32_t G = g.G;
-    int64_t bd = INT64_MAX;
+    int64_t bd = INT64_MAX;   // per lane, reduced at the end of every ring
     int32_t bs = -1, bid = INT32_MAX;
     const double cmin = fmin((double)bx.spanx / G, (double)bx.spany / G);
-    for (int32_t k = 0; k < G; ++k) {
+    auto scan = [&](int32_t s0, int32_t s1) {
+      for (int32_t base = s0; base < s1; base += 64) {
+        const int32_t sl = base + lane;
+        if (sl < s1) {
+          const int4 r = g.rec[sl];
+          if (r.z >= 0 && sl != ps) {
+            const int64_t dx = r.x - p.x, dy = r.y - p.y, d2 = dx * dx + dy * dy;
+            if (d2 < bd || (d2 == bd && r.z < bid)) { bd = d2; bs = sl; bid = r.z; }
+          }
+        }
+      }
+    };
+    auto reduce = [&]() {  // the result so far, on every lane
+      for (int o = 32; o > 0; o >>= 1) {
+        const int64_t od = __shfl_xor(bd, o);
+        const int32_t os = __shfl_xor(bs, o), oi = __shfl_xor(bid, o);
+        if (od < bd || (od == bd && oi < bid)) { bd = od; bs = os; bid = oi; }
+      }
+    };
+    int32_t k0 = 0;
+    if (cached) {  // rings 0 and 1 are the cached block
+      if (crec.z >= 0 && cslot != ps) {
+        const int64_t dx = crec.x - p.x, dy = crec.y - p.y;
+        bd = dx * dx + dy * dy; bs = cslot; bid = crec.z;
+      }
+      reduce();
+      k0 = 2;
+    }
+    for (int32_t k = k0; k < G; ++k) {
       // after rings < k every unscanned point is at least (k - 1) cells away from p
       if (bs >= 0) {
         const double reach = (double)(k - 1) * cmin - 2.0;
@@ -147,21 +231,16 @@ struct Star {
       }
       const int32_t y0 = pcy - k, y1 = pcy + k, x0 = pcx - k, x1 = pcx + k;
       if (y0 < 0 && y1 >= G && x0 < 0 && x1 >= G) break;
+      const int32_t xa = max(x0, 0), xb = min(x1, G - 1);
       for (int32_t cy = max(y0, 0); cy <= min(y1, G - 1); ++cy) {
-        const bool edge_row = (cy == y0 || cy == y1);
-        const int32_t step = edge_row ? 1 : max(2 * k, 1);
-        for (int32_t cx = x0; cx <= x1; cx += step) {
-          if (cx < 0 || cx >= G) continue;
-          const int32_t c = cy * G + cx;
-          for (int32_t sl = g.start[c], se = g.start[c + 1]; sl < se; ++sl) {
-            const int32_t id = g.sid[sl];
-            if (id < 0 || sl == ps) continue;
-            const int2 r = g.sxy[sl];
-            const int64_t dx = r.x - p.x, dy = r.y - p.y, d2 = dx * dx + dy * dy;
-            if (d2 < bd || (d2 == bd && id < bid)) { bd = d2; bs = sl; bid = id; }
-          }
+        if (cy == y0 || cy == y1) {
+          scan(g.start[cy * G + xa], g.start[cy * G + xb + 1]);
+        } else {
+          if (x0 >= 0) scan(g.start[cy * G + x0], g.start[cy * G + x0 + 1]);
+          if (x1 < G) scan(g.start[cy * G + x1], g.start[cy * G + x1 + 1]);
         }
       }
+      reduce();
     }
     return bs;
   }
@@ -171,75 +250,134 @@ struct Star {
     const int32_t G = g.G;
     bool have = false;
     int2 b = p, f = p, l = p;
-    int32_t fs = -1, ls = -1, ms = -1, mid = INT32_MAX;
+    int32_t bsl = -1, fs = -1, ls = -1, ms = -1, mid = INT32_MAX;
     double ccx = 0.0, ccy = 0.0, rad = INFINITY;
-    auto consider = [&](int32_t sl) {
-      const int32_t id = g.sid[sl];
-      if (id < 0 || sl == ps || sl == qs) return;
-      const int2 r = g.sxy[sl];
-      const int64_t o = orient64(p, q, r);
-      if (s > 0 ? o <= 0 : o >= 0) return;
-      const int t = have ? s * incircle_sign(p, q, b, r) : 1;
-      if (t > 0) {
-        have = true; b = r; f = r; l = r; fs = ls = ms = sl; mid = id;
-        circle_of(p, q, r, &ccx, &ccy, &rad);
-      } else if (t == 0) {  // on the current circle: angular order as seen from p, turning towards side s
-        if (s * sgn64(orient64(p, r, f)) > 0) { f = r; fs = sl; }
-        if (s * sgn64(orient64(p, l, r)) > 0) { l = r; ls = sl; }
-        if (id < mid) { mid = id; ms = sl; }
+    auto chunk = [&](int32_t sl, int4 r) {  // 64 candidates: this lane's slot and record (r.z < 0: none)
+      ++n_chunks;
+      const int2 rp = make_int2(r.x, r.y);
+      bool ok = r.z >= 0 && sl != ps && sl != qs;
+      if (ok) {
+        const int64_t o = orient64(p, q, rp);
+        ok = s > 0 ? o > 0 : o < 0;
+      }
+      if (!__ballot(ok)) return;
+      int t;
+      bool moved = false;
+      for (;;) {  // candidates that beat the current best: one of them becomes the best, the others are asked again
+        t = !ok ? -1 : (!have ? 1 : (sl == bsl ? 0 : s * incircle_sign(p, q, b, rp)));  // (the best against itself: on the circle)
+        const unsigned long long m = __ballot(t > 0);
+        if (!m) break;
+        const int w = __ffsll(m) - 1;
+        b = make_int2(bcast(r.x, w), bcast(r.y, w));
+        have = true; moved = true; f = b; l = b; bsl = fs = ls = ms = bcast(sl, w); mid = bcast(r.z, w);
+      }
+      if (moved) circle_of(p, q, b, &ccx, &ccy, &rad);
+      // on the current circle: angular order as seen from p, turning towards side s (the best itself is among them already)
+      unsigned long long m0 = __ballot(t == 0);
+      m0 &= ~__ballot(sl == bsl);
+      while (m0) {
+        const int w = __ffsll(m0) - 1;
+        m0 &= m0 - 1;
+        const int2 rt = make_int2(bcast(r.x, w), bcast(r.y, w));
+        const int32_t it = bcast(r.z, w), st = bcast(sl, w);
+        if (s * sgn64(orient64(p, rt, f)) > 0) { f = rt; fs = st; }
+        if (s * sgn64(orient64(p, l, rt)) > 0) { l = rt; ls = st; }
+        if (it < mid) { mid = it; ms = st; }
       }
     };
-    auto scan_cell = [&](int32_t c) {
-      for (int32_t sl = g.start[c], se = g.start[c + 1]; sl < se; ++sl) consider(sl);
+    auto scan = [&](int32_t s0, int32_t s1) {
+      for (int32_t base = s0; base < s1; base += 64) {
+        int4 r = make_int4(0, 0, -1, 0);
+        if (base + lane < s1) r = g.rec[base + lane];
+        chunk(base + lane, r);
+      }
+    };
+    auto result = [&]() -> int32_t {
+      if (!have) return -1;
+      // the points on the empty circle: a fan from the smallest id of the polygon p, q, first .. last
+      if (ip < iq && ip < mid) return fs;
+      if (iq < mid) return ls;
+      return ms;
     };
     // the cells around p first: they hold the answer for an interior point and bound the cap for the rows below
-    for (int32_t cy = max(pcy - 1, 0); cy <= min(pcy + 1, G - 1); ++cy)
-      for (int32_t cx = max(pcx - 1, 0); cx <= min(pcx + 1, G - 1); ++cx) scan_cell(cy * G + cx);
-    // every grid row the current cap can reach, outwards from p's row; false: the row is past the disk
+    if (cached) {
+      chunk(cslot, crec);
+      // the whole disk inside the block: nothing else can be in the cap
+      if (have && ccx - rad >= ix0 && ccx + rad < ix1 && ccy - rad >= iy0 && ccy + rad < iy1) return result();
+    } else {
+      for (int32_t cy = max(pcy - 1, 0); cy <= min(pcy + 1, G - 1); ++cy) scan(g.start[cy * G + sxa], g.start[cy * G + sxb + 1]);
+    }
+    // every grid row the current cap can reach, outwards from p's row
     const double A = (double)s * (double)(q.x - p.x), B = (double)s * (double)(q.y - p.y);  // side(x, y) = A (y - py) - B (x - px) > 0
-    auto do_row = [&](int32_t j) -> bool {
-      const double ylo = (double)bx.miny + (double)(((int64_t)j * bx.spany) / G);
-      const double yhi = (double)bx.miny + (double)(((int64_t)(j + 1) * bx.spany) / G) + 1.0;
-      double xa = -INFINITY, xb = INFINITY;
-      if (rad < INFINITY) {
-        const double d = ylo > ccy ? ylo - ccy : (yhi < ccy ? ccy - yhi : 0.0);
-        if (d > rad) return false;
-        const double w = sqrt(rad * rad - d * d) * (1.0 + 1.0e-12) + 1.0;
-        xa = ccx - w; xb = ccx + w;
+    // 64 grid rows at a time, one per lane: past the disk / cannot hold a candidate / the run of cells to scan
+    auto sweep = [&](int dir) {  // +1: rows pcy, pcy + 1, ...; -1: rows pcy - 1, pcy - 2, ...
+      for (int32_t j0 = dir > 0 ? pcy : pcy - 1; j0 >= 0 && j0 < G; j0 += 64 * dir) {
+        const int32_t j = j0 + dir * lane;
+        const bool in = j >= 0 && j < G;
+        bool stop = false, keep = false;
+        int32_t ca = 0, cb = -1;
+        double ylo = 0.0, yhi = 0.0;
+        if (in) {
+          const DtRow rw = g.row[j];
+          ylo = rw.ylo; yhi = rw.yhi;
+          double xa = -INFINITY, xb = INFINITY;
+          if (rad < INFINITY) {
+            const double d = ylo > ccy ? ylo - ccy : (yhi < ccy ? ccy - yhi : 0.0);
+            if (d > rad) {
+              stop = true;
+            } else {
+              const double w = sqrt(rad * rad - d * d) * (1.0 + 1.0e-12) + 1.0;
+              xa = ccx - w; xb = ccx + w;
+            }
+          }
+          if (!stop && rw.xlo <= rw.xhi) {
+            xa = fmax(xa, (double)rw.xlo); xb = fmin(xb, (double)rw.xhi);
+            const double h = A * ((A > 0.0 ? yhi : ylo) - (double)p.y);  // max of A (y - py) over the row
+            // the corner of the row's rectangle that is furthest on side s: not on it (candidates have side >= 1) -> none
+            const double tb = B * ((B > 0.0 ? xa : xb) - (double)p.x);
+            bool may = xa <= xb && !(h - tb + 1.0e-15 * (fabs(h) + fabs(tb)) < 0.5);
+            if (may) {
+              if (B > 0.0) {
+                const double t = h / B;
+                xb = fmin(xb, (double)p.x + t + 1.0 + 1.0e-12 * fabs(t));
+              } else if (B < 0.0) {
+                const double t = h / B;
+                xa = fmax(xa, (double)p.x + t - 1.0 - 1.0e-12 * fabs(t));
+              }
+              may = xa <= xb;
+            }
+            if (may) {
+              const double sc = (double)G / (double)bx.spanx;
+              ca = clampi(floor((xa - (double)bx.minx) * sc - 1.0e-6), 0, G - 1);
+              cb = clampi(floor((xb - (double)bx.minx) * sc + 1.0e-6), 0, G - 1);
+              // (a run that reaches beyond the block meets the block's cells again: a candidate seen twice neither
+              // beats the best nor changes the ties)
+              keep = !(cached && j >= pcy - 1 && j <= pcy + 1 && ca >= sxa && cb <= sxb);
+            }
+          }
+        }
+        ++n_rows;
+        const unsigned long long mstop = __ballot(in && stop);
+        unsigned long long mkeep = __ballot(keep);
+        if (mstop) mkeep &= (1ull << (__ffsll(mstop) - 1)) - 1;  // (lanes are in visiting order: rows before the first one past the disk)
+        while (mkeep) {
+          const int w = __ffsll(mkeep) - 1;
+          mkeep &= mkeep - 1;
+          if (rad < INFINITY) {  // has the disk shrunk past this row meanwhile?
+            const double yl = bcastd(ylo, w), yh = bcastd(yhi, w);
+            const double d = yl > ccy ? yl - ccy : (yh < ccy ? ccy - yh : 0.0);
+            if (d > rad) return;
+          }
+          const int32_t jj = j0 + dir * w;
+          ++n_scans;
+          scan(g.start[jj * G + bcast(ca, w)], g.start[jj * G + bcast(cb, w) + 1]);
+        }
+        if (mstop) return;
       }
-      const int2 rx = g.rowx[j];
-      if (rx.x > rx.y) return true;
-      xa = fmax(xa, (double)rx.x); xb = fmin(xb, (double)rx.y);
-      const double h = A * ((A > 0.0 ? yhi : ylo) - (double)p.y);  // max of A (y - py) over the row
-      if (B > 0.0) {
-        const double t = h / B;
-        xb = fmin(xb, (double)p.x + t + 1.0 + 1.0e-12 * fabs(t));
-      } else if (B < 0.0) {
-        const double t = h / B;
-        xa = fmax(xa, (double)p.x + t - 1.0 - 1.0e-12 * fabs(t));
-      } else if (!(h > 0.0)) {
-        return true;
-      }
-      if (!(xa <= xb)) return true;
-      const double sc = (double)G / (double)bx.spanx;
-      const int32_t ca = clampi(floor((xa - (double)bx.minx) * sc - 1.0e-6), 0, G - 1);
-      const int32_t cb = clampi(floor((xb - (double)bx.minx) * sc + 1.0e-6), 0, G - 1);
-      const bool near_row = j >= pcy - 1 && j <= pcy + 1;
-      for (int32_t cx = ca; cx <= cb; ++cx) {
-        if (near_row && cx >= pcx - 1 && cx <= pcx + 1) continue;  // scanned above
-        scan_cell(j * G + cx);
-      }
-      return true;
     };
-    for (int32_t j = pcy; j < G; ++j)
-      if (!do_row(j)) break;
-    for (int32_t j = pcy - 1; j >= 0; --j)
-      if (!do_row(j)) break;
-    if (!have) return -1;
-    // the points on the empty circle: a fan from the smallest id of the polygon p, q, first .. last
-    if (ip < iq && ip < mid) return fs;
-    if (iq < mid) return ls;
-    return ms;
+    sweep(+1);
+    sweep(-1);
+    return result();
   }
 };
 
@@ -254,29 +392,32 @@ __global__ void k_dt_init(int32_t* cnt, int32_t n, int32_t* flags) {
   }
 }
 
-__global__ void k_dt_snap(const float2* __restrict__ pos, int32_t V, int2* __restrict__ ixy, int32_t* flags) {
-  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// snap to the lattice; bounding box: grid-stride, one set of atomics per workgroup
+__global__ void __launch_bounds__(256) k_dt_snap(const float2* __restrict__ pos, int32_t V, int2* __restrict__ ixy, int32_t* flags) {
+  __shared__ int32_t red[4][4];
   int32_t x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
-  if (i < V) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
     const float2 v = pos[i];
     const double x = (double)v.x * 65536.0, y = (double)v.y * 65536.0;
-    if (!(fabs(x) < 536870912.0) || !(fabs(y) < 536870912.0)) {  // 2^29, NaN
-      atomicOr(&flags[0], kErrRange);
-      ixy[i] = make_int2(0, 0);
-      x0 = x1 = y0 = y1 = 0;
-    } else {
-      const int2 q = make_int2((int32_t)llround(x), (int32_t)llround(y));
-      ixy[i] = q;
-      x0 = x1 = q.x; y0 = y1 = q.y;
-    }
+    int2 q = make_int2(0, 0);
+    if (!(fabs(x) < 536870912.0) || !(fabs(y) < 536870912.0)) atomicOr(&flags[0], kErrRange);  // 2^29, NaN
+    else q = make_int2((int32_t)llround(x), (int32_t)llround(y));
+    ixy[i] = q;
+    x0 = min(x0, q.x); y0 = min(y0, q.y); x1 = max(x1, q.x); y1 = max(y1, q.y);
   }
   for (int o = 32; o > 0; o >>= 1) {
     x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
     x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
   }
-  if ((threadIdx.x & 63) == 0 && x0 <= x1) {
-    atomicMin(&flags[4], x0); atomicMin(&flags[5], y0);
-    atomicMax(&flags[6], x1); atomicMax(&flags[7], y1);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = x0; red[w][1] = y0; red[w][2] = x1; red[w][3] = y1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) { x0 = min(x0, red[k][0]); y0 = min(y0, red[k][1]); x1 = max(x1, red[k][2]); y1 = max(y1, red[k][3]); }
+    if (x0 <= x1) {
+      atomicMin(&flags[4], x0); atomicMin(&flags[5], y0);
+      atomicMax(&flags[6], x1); atomicMax(&flags[7], y1);
+    }
   }
 }
 
@@ -292,127 +433,187 @@ __global__ void k_dt_count(const int2* __restrict__ ixy, int32_t V, int32_t G, c
   atomicAdd(&cnt[c], 1);
 }
 
-// exclusive scan of in[0..n) into out[0..n], out[n] = total, by ONE workgroup; optionally clears in[]
-__global__ void __launch_bounds__(1024) k_dt_scan(int32_t* in, int32_t n, int32_t* out, int32_t clear_in, int32_t* total) {
-  __shared__ int32_t part[1024];
-  const int32_t t = threadIdx.x, chunk = (n + 1023) / 1024;
-  const int32_t i0 = min(t * chunk, n), i1 = min(i0 + chunk, n);
-  int32_t s = 0;
-  for (int32_t i = i0; i < i1; ++i) s += in[i];
-  part[t] = s;
+// ---- exclusive scan of n ints in three launches: sums of 1024-element blocks, scan of the sums, blocks ----
+__device__ inline int32_t block_excl_scan_1024(int32_t v, int32_t* total) {  // 1024 threads; returns the exclusive prefix of v
+  __shared__ int32_t wsum[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int32_t inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) wsum[w] = inc;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int32_t v = t >= o ? part[t - o] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  if (w == 0) {
+    int32_t s = lane < 16 ? wsum[lane] : 0;
+    for (int o = 1; o < 16; o <<= 1) {
+      const int32_t u = __shfl_up(s, o);
+      if (lane >= o) s += u;
+    }
+    if (lane < 16) wsum[lane] = s;
   }
-  int32_t run = part[t] - s;
-  for (int32_t i = i0; i < i1; ++i) {
-    const int32_t v = in[i];
-    out[i] = run;
-    run += v;
+  __syncthreads();
+  const int32_t before = w ? wsum[w - 1] : 0;
+  *total = wsum[15];
+  return before + inc - v;
+}
+__global__ void __launch_bounds__(1024) k_dt_scan_sums(const int32_t* __restrict__ in, int32_t n, int32_t* __restrict__ sums) {
+  const int32_t i = blockIdx.x * 1024 + threadIdx.x;
+  int32_t tot;
+  (void)block_excl_scan_1024(i < n ? in[i] : 0, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(1024) k_dt_scan_top(int32_t* sums, int32_t nb, int32_t* out_n, int32_t* total) {
+  // nb <= 1024 blocks (n <= 2^20); sums become the blocks' offsets
+  int32_t tot;
+  const int32_t v = (int32_t)threadIdx.x < nb ? sums[threadIdx.x] : 0;
+  const int32_t ex = block_excl_scan_1024(v, &tot);
+  if ((int32_t)threadIdx.x < nb) sums[threadIdx.x] = ex;
+  if (threadIdx.x == 0) {
+    *out_n = tot;
+    if (total) *total = tot;
+  }
+}
+__global__ void __launch_bounds__(1024) k_dt_scan_blocks(int32_t* in, int32_t n, const int32_t* __restrict__ sums,
+                                                         int32_t* __restrict__ out, int32_t clear_in) {
+  const int32_t i = blockIdx.x * 1024 + threadIdx.x;
+  int32_t tot;
+  const int32_t ex = block_excl_scan_1024(i < n ? in[i] : 0, &tot);
+  if (i < n) {
+    out[i] = sums[blockIdx.x] + ex;
     if (clear_in) in[i] = 0;
-  }
-  if (t == 1023) {
-    out[n] = part[1023];
-    if (total) *total = part[1023];
   }
 }
 
 __global__ void k_dt_scatter(const int2* __restrict__ ixy, const int32_t* __restrict__ cell_of, int32_t V,
-                             const int32_t* __restrict__ start, int32_t* fill, int2* __restrict__ sxy, int32_t* __restrict__ sid) {
+                             const int32_t* __restrict__ start, int32_t* fill, int4* __restrict__ rec) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= V) return;
   const int32_t c = cell_of[i];
   const int32_t sl = start[c] + atomicAdd(&fill[c], 1);
-  sxy[sl] = ixy[i];
-  sid[sl] = i;
+  const int2 q = ixy[i];
+  rec[sl] = make_int4(q.x, q.y, i, c);
 }
 
-// later copies of a point (same lattice coordinates, larger id) leave the triangulation: sid = ~id
-__global__ void k_dt_dups(const int2* __restrict__ sxy, const int32_t* __restrict__ sid_in, int32_t* __restrict__ sid_out,
-                          const int32_t* __restrict__ cell_of, const int32_t* __restrict__ start, int32_t V, int32_t* flags) {
+// later copies of a point (same lattice coordinates, larger id) leave the triangulation: id -> ~id
+__global__ void k_dt_dups(const int4* __restrict__ rec_in, int4* __restrict__ rec_out, const int32_t* __restrict__ start,
+                          int32_t V, int32_t* flags) {
   const int32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
   if (sl >= V) return;
-  const int32_t id = sid_in[sl];
-  const int2 p = sxy[sl];
-  const int32_t c = cell_of[id];
+  int4 p = rec_in[sl];
+  const int32_t c = p.w;
   bool dup = false;
   for (int32_t o = start[c], e = start[c + 1]; o < e; ++o) {
-    const int2 r = sxy[o];
-    if (r.x == p.x && r.y == p.y && sid_in[o] < id) { dup = true; break; }
+    const int4 r = rec_in[o];
+    if (r.x == p.x && r.y == p.y && r.z < p.z) { dup = true; break; }
   }
-  sid_out[sl] = dup ? ~id : id;
-  if (dup) atomicAdd(&flags[2], 1);
+  if (dup) { p.z = ~p.z; atomicAdd(&flags[2], 1); }
+  rec_out[sl] = p;
 }
 
-__global__ void k_dt_rows(const int2* __restrict__ sxy, const int32_t* __restrict__ sid, const int32_t* __restrict__ start,
-                          int32_t G, int2* __restrict__ rowx) {
-  const int32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= G) return;
+// per grid row its y extent and the x extent of its live points: one wavefront per row
+__global__ void __launch_bounds__(64) k_dt_rows(const int4* __restrict__ rec, const int32_t* __restrict__ start, int32_t G,
+                                                const int32_t* __restrict__ flags, DtRow* __restrict__ row) {
+  const int32_t j = blockIdx.x;
   int32_t lo = INT32_MAX, hi = INT32_MIN;
-  for (int32_t sl = start[j * G], e = start[(j + 1) * G]; sl < e; ++sl) {
-    if (sid[sl] < 0) continue;
-    const int32_t x = sxy[sl].x;
-    lo = min(lo, x); hi = max(hi, x);
+  for (int32_t sl = start[j * G] + threadIdx.x, e = start[(j + 1) * G]; sl < e; sl += 64) {
+    const int4 r = rec[sl];
+    if (r.z >= 0) { lo = min(lo, r.x); hi = max(hi, r.x); }
   }
-  rowx[j] = lo <= hi ? make_int2(lo, hi) : make_int2(1, 0);
+  for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+  if (threadIdx.x == 0) {
+    const DtBox b = dt_box(flags);
+    DtRow rw;
+    // row j holds the points with j spany / G <= y - miny < (j + 1) spany / G
+    rw.ylo = (double)b.miny + (double)(((int64_t)j * b.spany) / G);
+    rw.yhi = (double)b.miny + (double)(((int64_t)(j + 1) * b.spany) / G) + 1.0;
+    rw.xlo = lo <= hi ? lo : 1; rw.xhi = lo <= hi ? hi : 0;
+    row[j] = rw;
+  }
 }
 
+// First pass (WRITE = false): every star counts its triangles and keeps the first kStash of them in `stash`.
+// Second pass: the stashed triangles are copied to their place in the list; a star with more is built again, writing.
 template <bool WRITE>
-__global__ void __launch_bounds__(64) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
-                                                int32_t* __restrict__ tris, int32_t tri_cap) {
-  const int32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
+                                                 int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
+  const int32_t lane = threadIdx.x & 63;
+  const int32_t sl = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (sl >= g.V) return;
-  const int32_t ip = g.sid[sl];
+  const int4 pr = g.rec[sl];
+  const int32_t ip = pr.z;
   if (ip < 0) {
-    if (!WRITE) tcnt[~ip] = 0;
+    if (!WRITE && lane == 0) tcnt[~ip] = 0;
     return;
   }
-  const int2 p = g.sxy[sl];
-  const Star st(g, dt_box(g.flags), sl, ip, p);
+  int32_t* out = nullptr;
+  int32_t room = 0;
+  if (WRITE) {
+    const int32_t o0 = toff[ip], n0 = toff[ip + 1] - o0;
+    if (o0 + n0 > tri_cap) {
+      if (lane == 0) atomicOr(&flags[0], kErrCap);
+      return;
+    }
+    if (n0 <= kStash) {
+      if (lane < 3 * n0) tris[3 * (size_t)o0 + lane] = stash[(size_t)ip * (3 * kStash) + lane];
+      return;
+    }
+    out = tris + 3 * (size_t)o0;
+    room = n0;
+  } else {
+    out = stash + (size_t)ip * (3 * kStash);
+    room = kStash;
+  }
+  const Star st(g, dt_box(g.flags), sl, ip, make_int2(pr.x, pr.y), pr.w, lane);
   int32_t n = 0;
-  int32_t* out = WRITE ? tris + 3 * (size_t)toff[ip] : nullptr;
-  const int32_t room = WRITE ? min(toff[ip + 1], tri_cap) - toff[ip] : 0;
   auto emit = [&](int32_t a, int32_t b) {  // triangle (p, a, b), counter-clockwise
     if (ip < a && ip < b) {
-      if (WRITE) {
-        if (n < room) { out[3 * n] = ip; out[3 * n + 1] = a; out[3 * n + 2] = b; }
-        else atomicOr(&flags[0], kErrCap);
-      }
+      if (n < room && lane == 0) { out[3 * n] = ip; out[3 * n + 1] = a; out[3 * n + 2] = b; }
       ++n;
     }
   };
   const int32_t q0 = st.nearest();
   if (q0 >= 0) {
+    // counter-clockwise from q0 until the star closes; at a hull edge: back to q0 and clockwise to the other hull edge
     int32_t cur = q0, steps = 0;
-    bool open = false;
+    int4 cr = g.rec[cur];
+    int dir = +1;
     for (;;) {
-      const int32_t r = st.next(cur, g.sxy[cur], g.sid[cur], +1);
-      if (r < 0) { open = true; break; }
-      emit(g.sid[cur], g.sid[r]);
-      cur = r;
-      if (r == q0) break;
-      if (++steps > g.V) { atomicOr(&flags[0], kErrWrap); break; }
-    }
-    if (open) {
-      cur = q0;
-      for (;;) {
-        const int32_t r = st.next(cur, g.sxy[cur], g.sid[cur], -1);
-        if (r < 0) break;
-        emit(g.sid[r], g.sid[cur]);
-        cur = r;
-        if (r == q0 || ++steps > g.V) { atomicOr(&flags[0], kErrWrap); break; }
+      const int32_t r = st.next(cur, make_int2(cr.x, cr.y), cr.z, dir);
+      if (r < 0) {
+        if (dir < 0) break;
+        dir = -1; cur = q0; cr = g.rec[cur];
+        if (!WRITE && lane == 0) atomicAdd(&flags[1], 1);  // an open star: a boundary vertex
+        continue;
       }
-      if (!WRITE) atomicAdd(&flags[1], 1);
+      const int4 rr = g.rec[r];
+      if (dir > 0) emit(cr.z, rr.z); else emit(rr.z, cr.z);
+      cur = r; cr = rr;
+      if (r == q0) {
+        if (dir < 0 && lane == 0) atomicOr(&flags[0], kErrWrap);  // (an open star cannot close)
+        break;
+      }
+      if (++steps > g.V) { if (lane == 0) atomicOr(&flags[0], kErrWrap); break; }
     }
   }
-  if (!WRITE) tcnt[ip] = n;
-  else if (n != toff[ip + 1] - toff[ip]) atomicOr(&flags[0], kErrCount);
+  if (lane == 0 && g.dbg && !WRITE) {
+    g.dbg[4 * ip] = n; g.dbg[4 * ip + 1] = st.n_chunks; g.dbg[4 * ip + 2] = st.n_rows; g.dbg[4 * ip + 3] = st.n_scans;
+  }
+  if (lane == 0) {
+    if (!WRITE) tcnt[ip] = n;
+    else if (n != room) atomicOr(&flags[0], kErrCount);
+  }
 }
 
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// out[0..n) = exclusive scan of in[0..n), out[n] = total (also *total when given); n <= 2^20
+void scan_ints(hipStream_t s, int32_t* in, int32_t n, int32_t* out, int32_t* sums, int32_t clear_in, int32_t* total) {
+  const unsigned nb = (unsigned)((n + 1023) / 1024);
+  hipLaunchKernelGGL(k_dt_scan_sums, dim3(nb), dim3(1024), 0, s, in, n, sums);
+  hipLaunchKernelGGL(k_dt_scan_top, dim3(1), dim3(1024), 0, s, sums, (int32_t)nb, out + n, total);
+  hipLaunchKernelGGL(k_dt_scan_blocks, dim3(nb), dim3(1024), 0, s, in, n, sums, out, clear_in);
+}
 
 }  // namespace
 
@@ -428,6 +629,7 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   *T_out = 0;
   sc->last_hull = 0; sc->last_live = V;
   if (V < 3) return 0;
+  if (V > (1 << 20)) return FLAME_HIP_ERR_ARG;  // (the scans; a frame has 10^3..10^5 features)
   const auto t0 = std::chrono::steady_clock::now();
   const int32_t G = std::max(1, std::min(256, (int32_t)std::ceil(std::sqrt(0.5 * (double)V))));
   const int32_t ncell = G * G;
@@ -437,10 +639,10 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   auto take = [&](size_t bytes) { const size_t o = off; off += al256(bytes); return o; };
   const size_t o_flags = take(sizeof(int32_t) * kFlagWords), o_pos = take(sizeof(float2) * (size_t)V), o_ixy = take(sizeof(int2) * (size_t)V);
   const size_t o_cell = take(sizeof(int32_t) * (size_t)V), o_cnt = take(sizeof(int32_t) * ((size_t)ncell + 1));
-  const size_t o_start = take(sizeof(int32_t) * ((size_t)ncell + 1)), o_sxy = take(sizeof(int2) * (size_t)V);
-  const size_t o_sid0 = take(sizeof(int32_t) * (size_t)V), o_sid = take(sizeof(int32_t) * (size_t)V), o_rowx = take(sizeof(int2) * (size_t)G);
+  const size_t o_start = take(sizeof(int32_t) * ((size_t)ncell + 1)), o_rec0 = take(sizeof(int4) * (size_t)V), o_rec = take(sizeof(int4) * (size_t)V);
+  const size_t o_rows = take(sizeof(DtRow) * (size_t)G), o_sums = take(sizeof(int32_t) * 1024);
   const size_t o_tcnt = take(sizeof(int32_t) * ((size_t)V + 1)), o_toff = take(sizeof(int32_t) * ((size_t)V + 1));
-  const size_t o_tris = take(sizeof(int32_t) * 3 * (size_t)tmax);
+  const size_t o_stash = take(sizeof(int32_t) * 3 * kStash * (size_t)V), o_tris = take(sizeof(int32_t) * 3 * (size_t)tmax);
   if (off > sc->dev_cap) {
     DT_HIPCHK(hipStreamSynchronize(s));
     if (sc->dev) (void)hipFree(sc->dev);
@@ -466,12 +668,13 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   int32_t* cell_of = reinterpret_cast<int32_t*>(d + o_cell);
   int32_t* cnt = reinterpret_cast<int32_t*>(d + o_cnt);
   int32_t* start = reinterpret_cast<int32_t*>(d + o_start);
-  int2* sxy = reinterpret_cast<int2*>(d + o_sxy);
-  int32_t* sid0 = reinterpret_cast<int32_t*>(d + o_sid0);
-  int32_t* sid = reinterpret_cast<int32_t*>(d + o_sid);
-  int2* rowx = reinterpret_cast<int2*>(d + o_rowx);
+  int4* rec0 = reinterpret_cast<int4*>(d + o_rec0);
+  int4* rec = reinterpret_cast<int4*>(d + o_rec);
+  DtRow* rows = reinterpret_cast<DtRow*>(d + o_rows);
+  int32_t* sums = reinterpret_cast<int32_t*>(d + o_sums);
   int32_t* tcnt = reinterpret_cast<int32_t*>(d + o_tcnt);
   int32_t* toff = reinterpret_cast<int32_t*>(d + o_toff);
+  int32_t* stash = reinterpret_cast<int32_t*>(d + o_stash);
   int32_t* dtris = reinterpret_cast<int32_t*>(d + o_tris);
   int32_t* hflags = reinterpret_cast<int32_t*>(sc->pin + p_flags);
   int32_t* htris = reinterpret_cast<int32_t*>(sc->pin + p_tris);
@@ -481,32 +684,51 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   const int B = 256;
   const unsigned gv = (unsigned)((V + B - 1) / B);
   hipLaunchKernelGGL(k_dt_init, dim3((unsigned)((ncell + 1 + B - 1) / B)), dim3(B), 0, s, cnt, ncell + 1, flags);
-  hipLaunchKernelGGL(k_dt_snap, dim3(gv), dim3(B), 0, s, dpos, V, ixy, flags);
+  hipLaunchKernelGGL(k_dt_snap, dim3(std::min(gv, 256u)), dim3(B), 0, s, dpos, V, ixy, flags);
   hipLaunchKernelGGL(k_dt_count, dim3(gv), dim3(B), 0, s, ixy, V, G, flags, cell_of, cnt);
-  hipLaunchKernelGGL(k_dt_scan, dim3(1), dim3(1024), 0, s, cnt, ncell, start, 1, (int32_t*)nullptr);
-  hipLaunchKernelGGL(k_dt_scatter, dim3(gv), dim3(B), 0, s, ixy, cell_of, V, start, cnt, sxy, sid0);
-  hipLaunchKernelGGL(k_dt_dups, dim3(gv), dim3(B), 0, s, sxy, sid0, sid, cell_of, start, V, flags);
-  hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, s, sxy, sid, start, G, rowx);
+  scan_ints(s, cnt, ncell, start, sums, 1, nullptr);
+  hipLaunchKernelGGL(k_dt_scatter, dim3(gv), dim3(B), 0, s, ixy, cell_of, V, start, cnt, rec0);
+  hipLaunchKernelGGL(k_dt_dups, dim3(gv), dim3(B), 0, s, rec0, rec, start, V, flags);
+  hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)G), dim3(64), 0, s, rec, start, G, flags, rows);
+  static const bool dt_stats = std::getenv("FLAME_HIP_DT_STATS") != nullptr;
+  int32_t* dbg = nullptr;
+  if (dt_stats) {
+    (void)hipMalloc(reinterpret_cast<void**>(&dbg), sizeof(int32_t) * 4 * (size_t)V);
+    (void)hipMemsetAsync(dbg, 0, sizeof(int32_t) * 4 * (size_t)V, s);
+  }
   DtView view;
-  view.sxy = sxy; view.sid = sid; view.start = start; view.rowx = rowx; view.flags = flags; view.G = G; view.V = V;
-  const unsigned gs = (unsigned)((V + 63) / 64);
-  hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(64), 0, s, view, flags, tcnt, toff, dtris, tmax);
-  hipLaunchKernelGGL(k_dt_scan, dim3(1), dim3(1024), 0, s, tcnt, V, toff, 0, flags + 3);
-  hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(64), 0, s, view, flags, tcnt, toff, dtris, tmax);
+  view.rec = rec; view.start = start; view.row = rows; view.flags = flags; view.G = G; view.V = V; view.dbg = dbg;
+  const unsigned gs = (unsigned)((V + 3) / 4);  // four stars (wavefronts) per workgroup
+  hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
+  hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   DT_HIPCHK(hipGetLastError());
-  // the count first (it bounds the copy of the list), then the list itself
+  // flags and the list leave together (T = 2 n - 2 - h is within a few triangles of the 2 V the buffer holds: copying
+  // the whole buffer costs nothing over copying T triangles, and saves the round trip that would bring T first)
   DT_HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int32_t) * kFlagWords, hipMemcpyDeviceToHost, s));
+  DT_HIPCHK(hipMemcpyAsync(htris, dtris, sizeof(int32_t) * 3 * (size_t)tmax, hipMemcpyDeviceToHost, s));
   DT_HIPCHK(hipStreamSynchronize(s));
+  if (dbg) {
+    std::vector<int32_t> h(4 * (size_t)V);
+    (void)hipMemcpy(h.data(), dbg, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost);
+    (void)hipFree(dbg);
+    int64_t sum[4] = {0, 0, 0, 0};
+    int32_t mx[4] = {0, 0, 0, 0}, arg[4] = {0, 0, 0, 0};
+    for (int32_t v = 0; v < V; ++v)
+      for (int k = 0; k < 4; ++k) {
+        sum[k] += h[4 * (size_t)v + k];
+        if (h[4 * (size_t)v + k] > mx[k]) { mx[k] = h[4 * (size_t)v + k]; arg[k] = v; }
+      }
+    std::fprintf(stderr, "[dt] V %d G %d: own triangles mean %.2f max %d | chunks mean %.1f max %d (point %d at %.1f, %.1f) | row batches mean %.1f max %d | row scans mean %.1f max %d\n",
+                 V, G, (double)sum[0] / V, mx[0], (double)sum[1] / V, mx[1], arg[1], pos[2 * arg[1]], pos[2 * arg[1] + 1],
+                 (double)sum[2] / V, mx[2], (double)sum[3] / V, mx[3]);
+  }
   const int32_t err = hflags[0], hull = hflags[1], live = V - hflags[2], T = hflags[3];
   sc->last_hull = hull; sc->last_live = live;
   if (err & kErrRange) return FLAME_HIP_ERR_ARG;  // a coordinate outside |u|, |v| < 2^13 pixels, or not finite
   if (err || T < 0 || T > tmax || (T > 0 && T != 2 * live - 2 - hull)) return FLAME_HIP_ERR_STATE;
   if (T > tri_cap) return FLAME_HIP_ERR_ARG;
-  if (T > 0) {
-    DT_HIPCHK(hipMemcpyAsync(htris, dtris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyDeviceToHost, s));
-    DT_HIPCHK(hipStreamSynchronize(s));
-    std::memcpy(tris_out, htris, sizeof(int32_t) * 3 * (size_t)T);
-  }
+  if (T > 0) std::memcpy(tris_out, htris, sizeof(int32_t) * 3 * (size_t)T);
   *T_out = T;
   sc->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;

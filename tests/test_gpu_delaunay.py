@@ -4,9 +4,13 @@ by the defining properties -- exact, in Python integers -- on degenerate ones (p
 runs, duplicates, clusters), exactly the cases tests/test_delaunay.py holds for the host triangulator of the same contract.
 (The reference has no test of its own for this step: upstream calls Shewchuk's Triangle; stat key `triangulate`,
 /root/reference/msg/FlameStats.msg:44.)"""
+import os
+import sys
+
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from test_delaunay import canon, check_properties, orient, snapped
 
 pytestmark = pytest.mark.gpu
