@@ -146,241 +146,6 @@ __device__ inline double bcastd(double v, int w) {
   return __hiloint2double(hi, lo);
 }
 
-// One wavefront = one star.  Every member and every local below is wave-uniform except `lane` and what is loaded per lane.
-struct Star {
-  const DtView& g;
-  const DtBox bx;
-  const int32_t ps, ip, pcx, pcy, lane;
-  const int2 p;
-  // the 3 x 3 cells around p, loaded ONCE per star (every step of the wrapping starts there, and an interior star
-  // rarely looks further): the three runs of records (one per grid row) packed into the 64 lanes, if they fit
-  int32_t sxa, sxb;        // the block's cell columns
-  int32_t cslot;           // this lane's slot
-  int4 crec;               // ... and record ({.., id = -1}: none)
-  bool cached;
-  mutable int32_t n_chunks = 0, n_rows = 0, n_scans = 0;
-  double ix0, ix1, iy0, iy1;  // a disk inside [ix0, ix1) x [iy0, iy1) holds points of the block only
-  __device__ Star(const DtView& g_, DtBox b_, int32_t ps_, int32_t ip_, int2 p_, int32_t cell_, int32_t lane_)
-      : g(g_), bx(b_), ps(ps_), ip(ip_), pcx(cell_ % g_.G), pcy(cell_ / g_.G), lane(lane_), p(p_) {
-    const int32_t G = g.G;
-    sxa = max(pcx - 1, 0); sxb = min(pcx + 1, G - 1);
-    const int32_t sya = max(pcy - 1, 0), syb = min(pcy + 1, G - 1);
-    int32_t cbase[3], cn[3], tot = 0;
-    for (int k = 0; k < 3; ++k) {
-      const int32_t cy = pcy - 1 + k;
-      cbase[k] = 0; cn[k] = 0;
-      if (cy >= 0 && cy < G) {
-        cbase[k] = g.start[cy * G + sxa];
-        cn[k] = g.start[cy * G + sxb + 1] - cbase[k];
-      }
-      tot += cn[k];
-    }
-    cached = tot <= 64;
-    crec = make_int4(0, 0, -1, 0);
-    cslot = -1;
-    if (cached && lane < tot) {
-      cslot = lane < cn[0] ? cbase[0] + lane : (lane < cn[0] + cn[1] ? cbase[1] + lane - cn[0] : cbase[2] + lane - cn[0] - cn[1]);
-      crec = g.rec[cslot];
-    }
-    // a point left of column sxa has x < minx + ceil(sxa spanx / G); one right of column sxb has x >= minx + (sxb + 1) spanx / G
-    ix0 = sxa == 0 ? -INFINITY : (double)bx.minx + (double)(((int64_t)sxa * bx.spanx) / G) + 1.0;
-    ix1 = sxb == G - 1 ? INFINITY : (double)bx.minx + (double)(((int64_t)(sxb + 1) * bx.spanx) / G);
-    iy0 = sya == 0 ? -INFINITY : (double)bx.miny + (double)(((int64_t)sya * bx.spany) / G) + 1.0;
-    iy1 = syb == G - 1 ? INFINITY : (double)bx.miny + (double)(((int64_t)(syb + 1) * bx.spany) / G);
-  }
-
-  // ---- the nearest live point (ties: smallest id): ring by ring around p's cell ----
-  __device__ int32_t nearest() const {
-    const int32_t G = g.G;
-    int64_t bd = INT64_MAX;   // per lane, reduced at the end of every ring
-    int32_t bs = -1, bid = INT32_MAX;
-    const double cmin = fmin((double)bx.spanx / G, (double)bx.spany / G);
-    auto scan = [&](int32_t s0, int32_t s1) {
-      for (int32_t base = s0; base < s1; base += 64) {
-        const int32_t sl = base + lane;
-        if (sl < s1) {
-          const int4 r = g.rec[sl];
-          if (r.z >= 0 && sl != ps) {
-            const int64_t dx = r.x - p.x, dy = r.y - p.y, d2 = dx * dx + dy * dy;
-            if (d2 < bd || (d2 == bd && r.z < bid)) { bd = d2; bs = sl; bid = r.z; }
-          }
-        }
-      }
-    };
-    auto reduce = [&]() {  // the result so far, on every lane
-      for (int o = 32; o > 0; o >>= 1) {
-        const int64_t od = __shfl_xor(bd, o);
-        const int32_t os = __shfl_xor(bs, o), oi = __shfl_xor(bid, o);
-        if (od < bd || (od == bd && oi < bid)) { bd = od; bs = os; bid = oi; }
-      }
-    };
-    int32_t k0 = 0;
-    if (cached) {  // rings 0 and 1 are the cached block
-      if (crec.z >= 0 && cslot != ps) {
-        const int64_t dx = crec.x - p.x, dy = crec.y - p.y;
-        bd = dx * dx + dy * dy; bs = cslot; bid = crec.z;
-      }
-      reduce();
-      k0 = 2;
-    }
-    for (int32_t k = k0; k < G; ++k) {
-      // after rings < k every unscanned point is at least (k - 1) cells away from p
-      if (bs >= 0) {
-        const double reach = (double)(k - 1) * cmin - 2.0;
-        if (reach > 0.0 && (double)bd * (1.0 + 1.0e-9) <= reach * reach) break;
-      }
-      const int32_t y0 = pcy - k, y1 = pcy + k, x0 = pcx - k, x1 = pcx + k;
-      if (y0 < 0 && y1 >= G && x0 < 0 && x1 >= G) break;
-      const int32_t xa = max(x0, 0), xb = min(x1, G - 1);
-      for (int32_t cy = max(y0, 0); cy <= min(y1, G - 1); ++cy) {
-        if (cy == y0 || cy == y1) {
-          scan(g.start[cy * G + xa], g.start[cy * G + xb + 1]);
-        } else {
-          if (x0 >= 0) scan(g.start[cy * G + x0], g.start[cy * G + x0 + 1]);
-          if (x1 < G) scan(g.start[cy * G + x1], g.start[cy * G + x1 + 1]);
-        }
-      }
-      reduce();
-    }
-    return bs;
-  }
-
-  // ---- the third vertex of the triangle on side s of the Delaunay edge p -> q (s = +1: left), or -1: hull edge ----
-  __device__ int32_t next(int32_t qs, int2 q, int32_t iq, int s) const {
-    const int32_t G = g.G;
-    bool have = false;
-    int2 b = p, f = p, l = p;
-    int32_t bsl = -1, fs = -1, ls = -1, ms = -1, mid = INT32_MAX;
-    double ccx = 0.0, ccy = 0.0, rad = INFINITY;
-    auto chunk = [&](int32_t sl, int4 r) {  // 64 candidates: this lane's slot and record (r.z < 0: none)
-      ++n_chunks;
-      const int2 rp = make_int2(r.x, r.y);
-      bool ok = r.z >= 0 && sl != ps && sl != qs;
-      if (ok) {
-        const int64_t o = orient64(p, q, rp);
-        ok = s > 0 ? o > 0 : o < 0;
-      }
-      if (!__ballot(ok)) return;
-      int t;
-      bool moved = false;
-      for (;;) {  // candidates that beat the current best: one of them becomes the best, the others are asked again
-        t = !ok ? -1 : (!have ? 1 : (sl == bsl ? 0 : s * incircle_sign(p, q, b, rp)));  // (the best against itself: on the circle)
-        const unsigned long long m = __ballot(t > 0);
-        if (!m) break;
-        const int w = __ffsll(m) - 1;
-        b = make_int2(bcast(r.x, w), bcast(r.y, w));
-        have = true; moved = true; f = b; l = b; bsl = fs = ls = ms = bcast(sl, w); mid = bcast(r.z, w);
-      }
-      if (moved) circle_of(p, q, b, &ccx, &ccy, &rad);
-      // on the current circle: angular order as seen from p, turning towards side s (the best itself is among them already)
-      unsigned long long m0 = __ballot(t == 0);
-      m0 &= ~__ballot(sl == bsl);
-      while (m0) {
-        const int w = __ffsll(m0) - 1;
-        m0 &= m0 - 1;
-        const int2 rt = make_int2(bcast(r.x, w), bcast(r.y, w));
-        const int32_t it = bcast(r.z, w), st = bcast(sl, w);
-        if (s * sgn64(orient64(p, rt, f)) > 0) { f = rt; fs = st; }
-        if (s * sgn64(orient64(p, l, rt)) > 0) { l = rt; ls = st; }
-        if (it < mid) { mid = it; ms = st; }
-      }
-    };
-    auto scan = [&](int32_t s0, int32_t s1) {
-      for (int32_t base = s0; base < s1; base += 64) {
-        int4 r = make_int4(0, 0, -1, 0);
-        if (base + lane < s1) r = g.rec[base + lane];
-        chunk(base + lane, r);
-      }
-    };
-    auto result = [&]() -> int32_t {
-      if (!have) return -1;
-      // the points on the empty circle: a fan from the smallest id of the polygon p, q, first .. last
-      if (ip < iq && ip < mid) return fs;
-      if (iq < mid) return ls;
-      return ms;
-    };
-    // the cells around p first: they hold the answer for an interior point and bound the cap for the rows below
-    if (cached) {
-      chunk(cslot, crec);
-      // the whole disk inside the block: nothing else can be in the cap
-      if (have && ccx - rad >= ix0 && ccx + rad < ix1 && ccy - rad >= iy0 && ccy + rad < iy1) return result();
-    } else {
-      for (int32_t cy = max(pcy - 1, 0); cy <= min(pcy + 1, G - 1); ++cy) scan(g.start[cy * G + sxa], g.start[cy * G + sxb + 1]);
-    }
-    // every grid row the current cap can reach, outwards from p's row
-    const double A = (double)s * (double)(q.x - p.x), B = (double)s * (double)(q.y - p.y);  // side(x, y) = A (y - py) - B (x - px) > 0
-    // 64 grid rows at a time, one per lane: past the disk / cannot hold a candidate / the run of cells to scan
-    auto sweep = [&](int dir) {  // +1: rows pcy, pcy + 1, ...; -1: rows pcy - 1, pcy - 2, ...
-      for (int32_t j0 = dir > 0 ? pcy : pcy - 1; j0 >= 0 && j0 < G; j0 += 64 * dir) {
-        const int32_t j = j0 + dir * lane;
-        const bool in = j >= 0 && j < G;
-        bool stop = false, keep = false;
-        int32_t ca = 0, cb = -1;
-        double ylo = 0.0, yhi = 0.0;
-        if (in) {
-          const DtRow rw = g.row[j];
-          ylo = rw.ylo; yhi = rw.yhi;
-          double xa = -INFINITY, xb = INFINITY;
-          if (rad < INFINITY) {
-            const double d = ylo > ccy ? ylo - ccy : (yhi < ccy ? ccy - yhi : 0.0);
-            if (d > rad) {
-              stop = true;
-            } else {
-              const double w = sqrt(rad * rad - d * d) * (1.0 + 1.0e-12) + 1.0;
-              xa = ccx - w; xb = ccx + w;
-            }
-          }
-          if (!stop && rw.xlo <= rw.xhi) {
-            xa = fmax(xa, (double)rw.xlo); xb = fmin(xb, (double)rw.xhi);
-            const double h = A * ((A > 0.0 ? yhi : ylo) - (double)p.y);  // max of A (y - py) over the row
-            // the corner of the row's rectangle that is furthest on side s: not on it (candidates have side >= 1) -> none
-            const double tb = B * ((B > 0.0 ? xa : xb) - (double)p.x);
-            bool may = xa <= xb && !(h - tb + 1.0e-15 * (fabs(h) + fabs(tb)) < 0.5);
-            if (may) {
-              if (B > 0.0) {
-                const double t = h / B;
-                xb = fmin(xb, (double)p.x + t + 1.0 + 1.0e-12 * fabs(t));
-              } else if (B < 0.0) {
-                const double t = h / B;
-                xa = fmax(xa, (double)p.x + t - 1.0 - 1.0e-12 * fabs(t));
-              }
-              may = xa <= xb;
-            }
-            if (may) {
-              const double sc = (double)G / (double)bx.spanx;
-              ca = clampi(floor((xa - (double)bx.minx) * sc - 1.0e-6), 0, G - 1);
-              cb = clampi(floor((xb - (double)bx.minx) * sc + 1.0e-6), 0, G - 1);
-              // (a run that reaches beyond the block meets the block's cells again: a candidate seen twice neither
-              // beats the best nor changes the ties)
-              keep = !(cached && j >= pcy - 1 && j <= pcy + 1 && ca >= sxa && cb <= sxb);
-            }
-          }
-        }
-        ++n_rows;
-        const unsigned long long mstop = __ballot(in && stop);
-        unsigned long long mkeep = __ballot(keep);
-        if (mstop) mkeep &= (1ull << (__ffsll(mstop) - 1)) - 1;  // (lanes are in visiting order: rows before the first one past the disk)
-        while (mkeep) {
-          const int w = __ffsll(mkeep) - 1;
-          mkeep &= mkeep - 1;
-          if (rad < INFINITY) {  // has the disk shrunk past this row meanwhile?
-            const double yl = bcastd(ylo, w), yh = bcastd(yhi, w);
-            const double d = yl > ccy ? yl - ccy : (yh < ccy ? ccy - yh : 0.0);
-            if (d > rad) return;
-          }
-          const int32_t jj = j0 + dir * w;
-          ++n_scans;
-          scan(g.start[jj * G + bcast(ca, w)], g.start[jj * G + bcast(cb, w) + 1]);
-        }
-        if (mstop) return;
-      }
-    };
-    sweep(+1);
-    sweep(-1);
-    return result();
-  }
-};
-
 // ---------------------------------------------------------------- kernels
 __global__ void k_dt_init(int32_t* cnt, int32_t n, int32_t* flags) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -564,29 +329,262 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
     out = stash + (size_t)ip * (3 * kStash);
     room = kStash;
   }
-  const Star st(g, dt_box(g.flags), sl, ip, make_int2(pr.x, pr.y), pr.w, lane);
+  // ---- one wavefront = one star.  Its state is plain locals (an object holding them, or a reference to the kernel
+  // argument, ends up in scratch memory: measured 250 scratch accesses per star, half of the kernel's time); everything
+  // below is wave-uniform except `lane` and what is loaded per lane ----
+  const int4* const g_rec = g.rec;
+  const int32_t* const g_start = g.start;
+  const DtRow* const g_row = g.row;
+  const int32_t G = g.G, ps = sl;
+  const DtBox bx = dt_box(g.flags);
+  const int2 p = make_int2(pr.x, pr.y);
+  const int32_t pcx = pr.w % G, pcy = pr.w / G;
+  // the 3 x 3 cells around p, loaded ONCE per star (every step of the wrapping starts there, and an interior star
+  // rarely looks further): the three runs of records (one per grid row) packed into the 64 lanes, if they fit
+  int32_t sxa, sxb;            // the block's cell columns
+  int32_t cslot;               // this lane's slot
+  int4 crec;                   // ... and record ({.., id = -1}: none)
+  bool cached;
+  double ix0, ix1, iy0, iy1;   // a disk inside [ix0, ix1) x [iy0, iy1) holds points of the block only
+  int32_t n_chunks = 0, n_rows = 0, n_scans = 0;
+  {
+    sxa = max(pcx - 1, 0); sxb = min(pcx + 1, G - 1);
+    const int32_t sya = max(pcy - 1, 0), syb = min(pcy + 1, G - 1);
+    int32_t cbase[3], cn[3], tot = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int32_t cy = pcy - 1 + k;
+      cbase[k] = 0; cn[k] = 0;
+      if (cy >= 0 && cy < G) {
+        cbase[k] = g_start[cy * G + sxa];
+        cn[k] = g_start[cy * G + sxb + 1] - cbase[k];
+      }
+      tot += cn[k];
+    }
+    cached = tot <= 64;
+    crec = make_int4(0, 0, -1, 0);
+    cslot = -1;
+    if (cached && lane < tot) {
+      cslot = lane < cn[0] ? cbase[0] + lane : (lane < cn[0] + cn[1] ? cbase[1] + lane - cn[0] : cbase[2] + lane - cn[0] - cn[1]);
+      crec = g_rec[cslot];
+    }
+    // a point left of column sxa has x < minx + ceil(sxa spanx / G); one right of column sxb has x >= minx + (sxb + 1) spanx / G
+    ix0 = sxa == 0 ? -INFINITY : (double)bx.minx + (double)(((int64_t)sxa * bx.spanx) / G) + 1.0;
+    ix1 = sxb == G - 1 ? INFINITY : (double)bx.minx + (double)(((int64_t)(sxb + 1) * bx.spanx) / G);
+    iy0 = sya == 0 ? -INFINITY : (double)bx.miny + (double)(((int64_t)sya * bx.spany) / G) + 1.0;
+    iy1 = syb == G - 1 ? INFINITY : (double)bx.miny + (double)(((int64_t)(syb + 1) * bx.spany) / G);
+  }
+
+  // ---- the nearest live point (ties: smallest id): ring by ring around p's cell ----
+  auto nearest = [&]() __attribute__((always_inline)) -> int32_t {
+    int64_t bd = INT64_MAX;   // per lane, reduced at the end of every ring
+    int32_t bs = -1, bid = INT32_MAX;
+    const double cmin = fmin((double)bx.spanx / G, (double)bx.spany / G);
+    auto scan = [&](int32_t s0, int32_t s1) __attribute__((always_inline)) {
+      for (int32_t base = s0; base < s1; base += 64) {
+        const int32_t sl = base + lane;
+        if (sl < s1) {
+          const int4 r = g_rec[sl];
+          if (r.z >= 0 && sl != ps) {
+            const int64_t dx = r.x - p.x, dy = r.y - p.y, d2 = dx * dx + dy * dy;
+            if (d2 < bd || (d2 == bd && r.z < bid)) { bd = d2; bs = sl; bid = r.z; }
+          }
+        }
+      }
+    };
+    auto reduce = [&]() __attribute__((always_inline)) {  // the result so far, on every lane
+      for (int o = 32; o > 0; o >>= 1) {
+        const int64_t od = __shfl_xor(bd, o);
+        const int32_t os = __shfl_xor(bs, o), oi = __shfl_xor(bid, o);
+        if (od < bd || (od == bd && oi < bid)) { bd = od; bs = os; bid = oi; }
+      }
+    };
+    int32_t k0 = 0;
+    if (cached) {  // rings 0 and 1 are the cached block
+      if (crec.z >= 0 && cslot != ps) {
+        const int64_t dx = crec.x - p.x, dy = crec.y - p.y;
+        bd = dx * dx + dy * dy; bs = cslot; bid = crec.z;
+      }
+      reduce();
+      k0 = 2;
+    }
+    for (int32_t k = k0; k < G; ++k) {
+      // after rings < k every unscanned point is at least (k - 1) cells away from p
+      if (bs >= 0) {
+        const double reach = (double)(k - 1) * cmin - 2.0;
+        if (reach > 0.0 && (double)bd * (1.0 + 1.0e-9) <= reach * reach) break;
+      }
+      const int32_t y0 = pcy - k, y1 = pcy + k, x0 = pcx - k, x1 = pcx + k;
+      if (y0 < 0 && y1 >= G && x0 < 0 && x1 >= G) break;
+      const int32_t xa = max(x0, 0), xb = min(x1, G - 1);
+      for (int32_t cy = max(y0, 0); cy <= min(y1, G - 1); ++cy) {
+        if (cy == y0 || cy == y1) {
+          scan(g_start[cy * G + xa], g_start[cy * G + xb + 1]);
+        } else {
+          if (x0 >= 0) scan(g_start[cy * G + x0], g_start[cy * G + x0 + 1]);
+          if (x1 < G) scan(g_start[cy * G + x1], g_start[cy * G + x1 + 1]);
+        }
+      }
+      reduce();
+    }
+    return bs;
+  };
+
+  // ---- the third vertex of the triangle on side s of the Delaunay edge p -> q (s = +1: left), or -1: hull edge ----
+  auto next = [&](int32_t qs, int2 q, int32_t iq, int s) __attribute__((always_inline)) -> int32_t {
+    bool have = false;
+    int2 b = p, f = p, l = p;
+    int32_t bsl = -1, fs = -1, ls = -1, ms = -1, mid = INT32_MAX;
+    double ccx = 0.0, ccy = 0.0, rad = INFINITY;
+    auto chunk = [&](int32_t sl, int4 r) __attribute__((always_inline)) {  // 64 candidates: this lane's slot and record (r.z < 0: none)
+      ++n_chunks;
+      const int2 rp = make_int2(r.x, r.y);
+      bool ok = r.z >= 0 && sl != ps && sl != qs;
+      if (ok) {
+        const int64_t o = orient64(p, q, rp);
+        ok = s > 0 ? o > 0 : o < 0;
+      }
+      if (!__ballot(ok)) return;
+      int t;
+      bool moved = false;
+      for (;;) {  // candidates that beat the current best: one of them becomes the best, the others are asked again
+        t = !ok ? -1 : (!have ? 1 : (sl == bsl ? 0 : s * incircle_sign(p, q, b, rp)));  // (the best against itself: on the circle)
+        const unsigned long long m = __ballot(t > 0);
+        if (!m) break;
+        const int w = __ffsll(m) - 1;
+        b = make_int2(bcast(r.x, w), bcast(r.y, w));
+        have = true; moved = true; f = b; l = b; bsl = fs = ls = ms = bcast(sl, w); mid = bcast(r.z, w);
+      }
+      if (moved) circle_of(p, q, b, &ccx, &ccy, &rad);
+      // on the current circle: angular order as seen from p, turning towards side s (the best itself is among them already)
+      unsigned long long m0 = __ballot(t == 0);
+      m0 &= ~__ballot(sl == bsl);
+      while (m0) {
+        const int w = __ffsll(m0) - 1;
+        m0 &= m0 - 1;
+        const int2 rt = make_int2(bcast(r.x, w), bcast(r.y, w));
+        const int32_t it = bcast(r.z, w), st = bcast(sl, w);
+        if (s * sgn64(orient64(p, rt, f)) > 0) { f = rt; fs = st; }
+        if (s * sgn64(orient64(p, l, rt)) > 0) { l = rt; ls = st; }
+        if (it < mid) { mid = it; ms = st; }
+      }
+    };
+    auto scan = [&](int32_t s0, int32_t s1) __attribute__((always_inline)) {
+      for (int32_t base = s0; base < s1; base += 64) {
+        int4 r = make_int4(0, 0, -1, 0);
+        if (base + lane < s1) r = g_rec[base + lane];
+        chunk(base + lane, r);
+      }
+    };
+    auto result = [&]() __attribute__((always_inline)) -> int32_t {
+      if (!have) return -1;
+      // the points on the empty circle: a fan from the smallest id of the polygon p, q, first .. last
+      if (ip < iq && ip < mid) return fs;
+      if (iq < mid) return ls;
+      return ms;
+    };
+    // the cells around p first: they hold the answer for an interior point and bound the cap for the rows below
+    if (cached) {
+      chunk(cslot, crec);
+      // the whole disk inside the block: nothing else can be in the cap
+      if (have && ccx - rad >= ix0 && ccx + rad < ix1 && ccy - rad >= iy0 && ccy + rad < iy1) return result();
+    } else {
+      for (int32_t cy = max(pcy - 1, 0); cy <= min(pcy + 1, G - 1); ++cy) scan(g_start[cy * G + sxa], g_start[cy * G + sxb + 1]);
+    }
+    // every grid row the current cap can reach, outwards from p's row
+    const double A = (double)s * (double)(q.x - p.x), B = (double)s * (double)(q.y - p.y);  // side(x, y) = A (y - py) - B (x - px) > 0
+    // 64 grid rows at a time, one per lane: past the disk / cannot hold a candidate / the run of cells to scan
+    auto sweep = [&](int dir) __attribute__((always_inline)) {  // +1: rows pcy, pcy + 1, ...; -1: rows pcy - 1, pcy - 2, ...
+      for (int32_t j0 = dir > 0 ? pcy : pcy - 1; j0 >= 0 && j0 < G; j0 += 64 * dir) {
+        const int32_t j = j0 + dir * lane;
+        const bool in = j >= 0 && j < G;
+        bool stop = false, keep = false;
+        int32_t ca = 0, cb = -1;
+        double ylo = 0.0, yhi = 0.0;
+        if (in) {
+          const DtRow rw = g_row[j];
+          ylo = rw.ylo; yhi = rw.yhi;
+          double xa = -INFINITY, xb = INFINITY;
+          if (rad < INFINITY) {
+            const double d = ylo > ccy ? ylo - ccy : (yhi < ccy ? ccy - yhi : 0.0);
+            if (d > rad) {
+              stop = true;
+            } else {
+              const double w = sqrt(rad * rad - d * d) * (1.0 + 1.0e-12) + 1.0;
+              xa = ccx - w; xb = ccx + w;
+            }
+          }
+          if (!stop && rw.xlo <= rw.xhi) {
+            xa = fmax(xa, (double)rw.xlo); xb = fmin(xb, (double)rw.xhi);
+            const double h = A * ((A > 0.0 ? yhi : ylo) - (double)p.y);  // max of A (y - py) over the row
+            // the corner of the row's rectangle that is furthest on side s: not on it (candidates have side >= 1) -> none
+            const double tb = B * ((B > 0.0 ? xa : xb) - (double)p.x);
+            bool may = xa <= xb && !(h - tb + 1.0e-15 * (fabs(h) + fabs(tb)) < 0.5);
+            if (may) {
+              if (B > 0.0) {
+                const double t = h / B;
+                xb = fmin(xb, (double)p.x + t + 1.0 + 1.0e-12 * fabs(t));
+              } else if (B < 0.0) {
+                const double t = h / B;
+                xa = fmax(xa, (double)p.x + t - 1.0 - 1.0e-12 * fabs(t));
+              }
+              may = xa <= xb;
+            }
+            if (may) {
+              const double sc = (double)G / (double)bx.spanx;
+              ca = clampi(floor((xa - (double)bx.minx) * sc - 1.0e-6), 0, G - 1);
+              cb = clampi(floor((xb - (double)bx.minx) * sc + 1.0e-6), 0, G - 1);
+              // (a run that reaches beyond the block meets the block's cells again: a candidate seen twice neither
+              // beats the best nor changes the ties)
+              keep = !(cached && j >= pcy - 1 && j <= pcy + 1 && ca >= sxa && cb <= sxb);
+            }
+          }
+        }
+        ++n_rows;
+        const unsigned long long mstop = __ballot(in && stop);
+        unsigned long long mkeep = __ballot(keep);
+        if (mstop) mkeep &= (1ull << (__ffsll(mstop) - 1)) - 1;  // (lanes are in visiting order: rows before the first one past the disk)
+        while (mkeep) {
+          const int w = __ffsll(mkeep) - 1;
+          mkeep &= mkeep - 1;
+          if (rad < INFINITY) {  // has the disk shrunk past this row meanwhile?
+            const double yl = bcastd(ylo, w), yh = bcastd(yhi, w);
+            const double d = yl > ccy ? yl - ccy : (yh < ccy ? ccy - yh : 0.0);
+            if (d > rad) return;
+          }
+          const int32_t jj = j0 + dir * w;
+          ++n_scans;
+          scan(g_start[jj * G + bcast(ca, w)], g_start[jj * G + bcast(cb, w) + 1]);
+        }
+        if (mstop) return;
+      }
+    };
+    sweep(+1);
+    sweep(-1);
+    return result();
+  };
+
   int32_t n = 0;
-  auto emit = [&](int32_t a, int32_t b) {  // triangle (p, a, b), counter-clockwise
+  auto emit = [&](int32_t a, int32_t b) __attribute__((always_inline)) {  // triangle (p, a, b), counter-clockwise
     if (ip < a && ip < b) {
       if (n < room && lane == 0) { out[3 * n] = ip; out[3 * n + 1] = a; out[3 * n + 2] = b; }
       ++n;
     }
   };
-  const int32_t q0 = st.nearest();
+  const int32_t q0 = nearest();
   if (q0 >= 0) {
     // counter-clockwise from q0 until the star closes; at a hull edge: back to q0 and clockwise to the other hull edge
     int32_t cur = q0, steps = 0;
-    int4 cr = g.rec[cur];
+    int4 cr = g_rec[cur];
     int dir = +1;
     for (;;) {
-      const int32_t r = st.next(cur, make_int2(cr.x, cr.y), cr.z, dir);
+      const int32_t r = next(cur, make_int2(cr.x, cr.y), cr.z, dir);
       if (r < 0) {
         if (dir < 0) break;
-        dir = -1; cur = q0; cr = g.rec[cur];
+        dir = -1; cur = q0; cr = g_rec[cur];
         if (!WRITE && lane == 0) atomicAdd(&flags[1], 1);  // an open star: a boundary vertex
         continue;
       }
-      const int4 rr = g.rec[r];
+      const int4 rr = g_rec[r];
       if (dir > 0) emit(cr.z, rr.z); else emit(rr.z, cr.z);
       cur = r; cr = rr;
       if (r == q0) {
@@ -597,7 +595,7 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
     }
   }
   if (lane == 0 && g.dbg && !WRITE) {
-    g.dbg[4 * ip] = n; g.dbg[4 * ip + 1] = st.n_chunks; g.dbg[4 * ip + 2] = st.n_rows; g.dbg[4 * ip + 3] = st.n_scans;
+    g.dbg[4 * ip] = n; g.dbg[4 * ip + 1] = n_chunks; g.dbg[4 * ip + 2] = n_rows; g.dbg[4 * ip + 3] = n_scans;
   }
   if (lane == 0) {
     if (!WRITE) tcnt[ip] = n;
