@@ -425,7 +425,7 @@ struct flame_hip_graph {
 
 extern "C" {
 
-int flame_hip_version(void) { return 400; }
+int flame_hip_version(void) { return 401; }
 
 const char* flame_hip_strerror(int code) {
   switch (code) {
