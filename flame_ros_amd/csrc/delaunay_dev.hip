@@ -61,7 +61,7 @@ __extension__ typedef __int128 i128;
 // [4] min x, [5] min y, [6] max x, [7] max y (lattice)
 constexpr int kFlagWords = 8;
 constexpr int kErrRange = 1, kErrWrap = 2, kErrCap = 4, kErrCount = 8;
-constexpr int kStash = 12;  // triangles a star keeps beside its count in the first pass (more: the star is rebuilt in the second)
+constexpr int kStash = 20;  // triangles a star keeps beside its count in the first pass (more: the star is rebuilt in the second; 3 * kStash <= 64 lanes copy them)
 
 struct DtRow {
   double ylo, yhi;       // every point of the row has ylo <= y < yhi (lattice)
@@ -430,10 +430,11 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
   };
 
   // ---- the third vertex of the triangle on side s of the Delaunay edge p -> q (s = +1: left), or -1: hull edge ----
-  auto next = [&](int32_t qs, int2 q, int32_t iq, int s) __attribute__((always_inline)) -> int32_t {
+  auto next = [&](int32_t qs, int2 q, int32_t iq, int s, int4* nrec) __attribute__((always_inline)) -> int32_t {
     bool have = false;
     int2 b = p, f = p, l = p;
-    int32_t bsl = -1, fs = -1, ls = -1, ms = -1, mid = INT32_MAX;
+    int32_t bsl = -1, fs = -1, ls = -1, ms = -1, mid = INT32_MAX, fid = -1, lid = -1;
+    int2 mxy = p;  // (first / last / smallest id on the circle: slot, coordinates and id, so the winner needs no load)
     double ccx = 0.0, ccy = 0.0, rad = INFINITY;
     auto chunk = [&](int32_t sl, int4 r) __attribute__((always_inline)) {  // 64 candidates: this lane's slot and record (r.z < 0: none)
       ++n_chunks;
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
         if (!m) break;
         const int w = __ffsll(m) - 1;
         b = make_int2(bcast(r.x, w), bcast(r.y, w));
-        have = true; moved = true; f = b; l = b; bsl = fs = ls = ms = bcast(sl, w); mid = bcast(r.z, w);
+        have = true; moved = true; f = b; l = b; mxy = b; bsl = fs = ls = ms = bcast(sl, w); mid = fid = lid = bcast(r.z, w);
       }
       if (moved) circle_of(p, q, b, &ccx, &ccy, &rad);
       // on the current circle: angular order as seen from p, turning towards side s (the best itself is among them already)
@@ -463,9 +464,9 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
         m0 &= m0 - 1;
         const int2 rt = make_int2(bcast(r.x, w), bcast(r.y, w));
         const int32_t it = bcast(r.z, w), st = bcast(sl, w);
-        if (s * sgn64(orient64(p, rt, f)) > 0) { f = rt; fs = st; }
-        if (s * sgn64(orient64(p, l, rt)) > 0) { l = rt; ls = st; }
-        if (it < mid) { mid = it; ms = st; }
+        if (s * sgn64(orient64(p, rt, f)) > 0) { f = rt; fs = st; fid = it; }
+        if (s * sgn64(orient64(p, l, rt)) > 0) { l = rt; ls = st; lid = it; }
+        if (it < mid) { mid = it; ms = st; mxy = rt; }
       }
     };
     auto scan = [&](int32_t s0, int32_t s1) __attribute__((always_inline)) {
@@ -475,11 +476,12 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
         chunk(base + lane, r);
       }
     };
-    auto result = [&]() __attribute__((always_inline)) -> int32_t {
+    auto result = [&]() __attribute__((always_inline)) -> int32_t {  // the slot; *nrec = its record {x, y, id}
       if (!have) return -1;
       // the points on the empty circle: a fan from the smallest id of the polygon p, q, first .. last
-      if (ip < iq && ip < mid) return fs;
-      if (iq < mid) return ls;
+      if (ip < iq && ip < mid) { *nrec = make_int4(f.x, f.y, fid, 0); return fs; }
+      if (iq < mid) { *nrec = make_int4(l.x, l.y, lid, 0); return ls; }
+      *nrec = make_int4(mxy.x, mxy.y, mid, 0);
       return ms;
     };
     // the cells around p first: they hold the answer for an interior point and bound the cap for the rows below
@@ -574,17 +576,18 @@ __global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32
   if (q0 >= 0) {
     // counter-clockwise from q0 until the star closes; at a hull edge: back to q0 and clockwise to the other hull edge
     int32_t cur = q0, steps = 0;
-    int4 cr = g_rec[cur];
+    const int4 q0rec = g_rec[q0];
+    int4 cr = q0rec;
     int dir = +1;
     for (;;) {
-      const int32_t r = next(cur, make_int2(cr.x, cr.y), cr.z, dir);
+      int4 rr = cr;
+      const int32_t r = next(cur, make_int2(cr.x, cr.y), cr.z, dir, &rr);
       if (r < 0) {
         if (dir < 0) break;
-        dir = -1; cur = q0; cr = g_rec[cur];
+        dir = -1; cur = q0; cr = q0rec;
         if (!WRITE && lane == 0) atomicAdd(&flags[1], 1);  // an open star: a boundary vertex
         continue;
       }
-      const int4 rr = g_rec[r];
       if (dir > 0) emit(cr.z, rr.z); else emit(rr.z, cr.z);
       cur = r; cr = rr;
       if (r == q0) {
