@@ -128,3 +128,21 @@ def test_lattices_at_frame_size(handle):
     check_properties(clus, handle.delaunay(clus))
     pix = np.stack([rng.integers(0, 640, 10000), rng.integers(0, 480, 10000)], 1).astype(np.float32)  # duplicates, ties
     check_properties(pix, handle.delaunay(pix))
+
+
+@pytest.mark.parametrize("workload", ["tum", "5k", "euroc"])
+def test_facade_frames_do_not_depend_on_the_triangulator(gpu, workload):
+    """flame::Flame::update() from features alone (tools/facade_bench.cc with a FrontEnd that only tracks), the built-in
+    triangulation once on the GPU (flame_hip_delaunay, Params::triangulate_on_gpu = true, the default) and once on the host
+    (include/flame/utils/delaunay.h): generic features have ONE Delaunay triangulation, so the frame's edge list and every
+    bit of its regularised idepths are the same (the triangle lists differ in order only) -- and equal to the frame handed
+    over with the triangulation the graph generator made (SciPy's)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import facade_bench
+    on_gpu = facade_bench.run(workload, repeats=1, getters=1, env={"FLAME_BENCH_FRONTEND": "1", "FLAME_BENCH_TRI_GPU": "1"})
+    on_host = facade_bench.run(workload, repeats=1, getters=1, env={"FLAME_BENCH_FRONTEND": "1", "FLAME_BENCH_TRI_GPU": "0"})
+    given = facade_bench.run(workload, repeats=1, getters=1)
+    assert on_gpu["T"] == on_host["T"] == given["T"] and on_gpu["E"] == on_host["E"] == given["E"]
+    assert on_gpu["x_hash"] == on_host["x_hash"] == given["x_hash"], (on_gpu["x_hash"], on_host["x_hash"], given["x_hash"])
+    assert on_gpu["triangulate_ms_p50"] > 0 and on_host["triangulate_ms_p50"] > 0

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <memory>
 #include <string>
@@ -108,6 +109,7 @@ int main(int argc, char** argv) {
   const int warm = 3;
   int n = 0;
   unsigned long checksum = 0;
+  unsigned long long x_hash = 1469598103934665603ull;
   for (int r = 0; r < repeats + warm; ++r)
     for (size_t k = 0; k < frames.size(); ++k, ++n) {
       const Frame& f = frames[k];
@@ -120,7 +122,23 @@ int main(int argc, char** argv) {
         std::printf("{\"error\": \"update failed\", \"hip_error\": %d}\n", static_cast<int>(sensor->stats().stats("hip_error")));
         return 3;
       }
-      if (getters >= 1) sensor->getInverseDepthMesh(&ovtx, &oid, &normals, &otris, &validity, &edges);
+      if (getters >= 1) {
+        sensor->getInverseDepthMesh(&ovtx, &oid, &normals, &otris, &validity, &edges);
+        // FNV-1a over the bits of the regularised idepths (vertex order = feature order, whatever triangulated them) and
+        // the edge list of the frame: equal for two triangulators that return the same triangle SET
+        if (r == repeats + warm - 1) {
+          for (size_t v = 0; v < oid.size(); ++v) {
+            uint32_t bits;
+            std::memcpy(&bits, &oid[v], 4);
+            for (int b8 = 0; b8 < 4; ++b8) { x_hash ^= (bits >> (8 * b8)) & 0xffu; x_hash *= 1099511628211ull; }
+          }
+          for (size_t e = 0; e < edges.size(); ++e) {
+            const int32_t ij[2] = {static_cast<int32_t>(edges[e][0]), static_cast<int32_t>(edges[e][1])};
+            for (int w = 0; w < 2; ++w)
+              for (int b8 = 0; b8 < 4; ++b8) { x_hash ^= (static_cast<uint32_t>(ij[w]) >> (8 * b8)) & 0xffu; x_hash *= 1099511628211ull; }
+          }
+        }
+      }
       if (getters >= 2) {
         const flame::Image3b& a = sensor->getDebugImageWireframe();
         const flame::Image3b& b = sensor->getDebugImageFeatures();
@@ -140,11 +158,11 @@ int main(int argc, char** argv) {
       "{\"V\": %d, \"T\": %d, \"E\": %d, \"iters\": %d, \"frames\": %d, \"getters\": %d, "
       "\"update_ms\": {\"p50\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"max\": %.4f}, "
       "\"update_wall_ms_p50\": %.4f, \"sync_graph_ms_p50\": %.4f, \"nltgv2_ms_p50\": %.4f, "
-      "\"nltgv2_device_ms\": %.4f, \"getters_ms_p50\": %.4f, \"coverage\": %.6f, \"checksum\": %lu, "
+      "\"nltgv2_device_ms\": %.4f, \"getters_ms_p50\": %.4f, \"coverage\": %.6f, \"checksum\": %lu, \"x_hash\": \"%016llx\", "
       "\"triangulate_ms_p50\": %.4f}\n",
       static_cast<int>(frames[0].vtx.size()), static_cast<int>(frames[0].tris.size()),
       static_cast<int>(sensor->stats().stats("num_edges")), iters, static_cast<int>(upd.size()), getters,
       pct(upd, 0.5), pct(upd, 0.1), pct(upd, 0.9), pct(upd, 1.0), pct(wall, 0.5), pct(sync, 0.5), pct(solve, 0.5),
-      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum, pct(tri, 0.5));
+      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum, x_hash, pct(tri, 0.5));
   return 0;
 }
