@@ -299,8 +299,13 @@ __global__ void __launch_bounds__(64) k_dt_rows(const int4* __restrict__ rec, co
 
 // First pass (WRITE = false): every star counts its triangles and keeps the first kStash of them in `stash`.
 // Second pass: the stashed triangles are copied to their place in the list; a star with more is built again, writing.
+#ifdef FLAME_DT_WAVES  /* dev A/B: cap the registers for this many waves per SIMD */
+#define FLAME_DT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(FLAME_DT_WAVES)))
+#else
+#define FLAME_DT_WAVES_ATTR
+#endif
 template <bool WRITE>
-__global__ void __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
+__global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
                                                  int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
   const int32_t lane = threadIdx.x & 63;
   const int32_t sl = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

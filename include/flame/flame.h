@@ -17,7 +17,8 @@
 // this class runs on the GPU: graph sync (row a7), N x nltgv2 step (a2-a5), costs (a6), the
 // per-triangle stage (a8), dense maps / mesh (f1, f2).  The feature pipeline plugs in through
 // FrontEnd (tracked features of the frame; optionally the triangulation of the gated features, whose
-// default is the exact host triangulator of utils/delaunay.h);
+// default is the library's exact Delaunay triangulation on the GPU, flame_hip_delaunay -- row f3's first leg --, or,
+// with Params::triangulate_on_gpu = false, the exact host triangulator of utils/delaunay.h);
 // update() returns false when no `track` is registered, exactly like any other failed update (the
 // frontends warn and skip the frame, src/flame_offline_tum.cc:597-601).  updateGraph() is the GPU
 // tail on its own, for callers that already hold features + triangulation.
@@ -501,7 +502,7 @@ class Flame {
   mutable std::mutex mtx_;
   utils::StatsTracker stats_;
   FrontEnd frontend_;
-  utils::DelaunayTriangulator delaunay_;  // FrontEnd::triangulate's default (scratch kept across frames)
+  utils::DelaunayTriangulator delaunay_;  // the built-in triangulation on the host (Params::triangulate_on_gpu = false; scratch kept across frames)
   optimizers::nltgv2_l1_graph_regularizer::Graph graph_;
   bool device_frame_valid_ = false;  // the device state belongs to the committed frame
   std::vector<Point2f> vtx_, raw_vtx_;

@@ -53,7 +53,7 @@ struct Params {
   // front of the GPU tail: a persistent pool (flame/utils/delaunay.h); 0 = omp_num_threads.  A host that feeds an
   // MI355X has the cores: 10 k points take 2.3 ms on 4 threads of the old fork-per-level scheme, 0.9 ms on 16 of the pool.
   int triangulate_threads = 16;
-  // (this build's own) the built-in triangulation runs on the GPU (flame_hip_delaunay: one thread per feature builds the
+  // (this build's own) the built-in triangulation runs on the GPU (flame_hip_delaunay: one wavefront per feature builds the
   // feature's star from exact predicates; same contract as the host triangulator, which stays the choice when false).
   // A registered FrontEnd::triangulate takes precedence over both.
   bool triangulate_on_gpu = true;

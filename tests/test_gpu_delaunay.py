@@ -146,3 +146,22 @@ def test_facade_frames_do_not_depend_on_the_triangulator(gpu, workload):
     assert on_gpu["T"] == on_host["T"] == given["T"] and on_gpu["E"] == on_host["E"] == given["E"]
     assert on_gpu["x_hash"] == on_host["x_hash"] == given["x_hash"], (on_gpu["x_hash"], on_host["x_hash"], given["x_hash"])
     assert on_gpu["triangulate_ms_p50"] > 0 and on_host["triangulate_ms_p50"] > 0
+
+
+def test_random_sets_fuzz(handle):
+    """150 random sets of 3 .. 3 000 generic points in boxes of random size and aspect (grids of 1 x 1 to 39 x 39 cells, open and
+    closed stars in every proportion): the unique Delaunay triangulation, as SciPy finds it."""
+    rng = np.random.default_rng(123)
+    for trial in range(150):
+        n = int(rng.integers(3, 3000)) if trial % 3 else int(rng.integers(3, 40))
+        w, h = float(rng.uniform(2, 4000)), float(rng.uniform(2, 4000))
+        x0, y0 = float(rng.uniform(-4000, 4000 - w)), float(rng.uniform(-4000, 4000 - h))
+        pts = (rng.random((n, 2)) * np.array([w, h]) + np.array([x0, y0])).astype(np.float32)
+        got = handle.delaunay(pts)
+        snapped_pts = np.round(pts.astype(np.float64) * 65536.0)
+        if len(np.unique(snapped_pts, axis=0)) != n:
+            continue  # (a coincidence after snapping: covered by the degenerate cases)
+        want = scipy_ccw(snapped_pts)
+        if not np.array_equal(canon(got), canon(want)):
+            check_properties(pts, got)  # (nearly cocircular / collinear for floating point: any exact answer)
+            assert len(got) == len(want), trial
