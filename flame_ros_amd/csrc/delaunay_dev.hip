@@ -61,7 +61,7 @@ __extension__ typedef __int128 i128;
 // [4] min x, [5] min y, [6] max x, [7] max y (lattice)
 constexpr int kFlagWords = 8;
 constexpr int kErrRange = 1, kErrWrap = 2, kErrCap = 4, kErrCount = 8;
-constexpr int kStash = 20;  // triangles a star keeps beside its count in the first pass (more: the star is rebuilt in the second; 3 * kStash <= 64 lanes copy them)
+constexpr int kStash = 20;  // triangles a star keeps beside its count in the first pass (more: the star is rebuilt in the second)
 
 struct DtRow {
   double ylo, yhi;       // every point of the row has ylo <= y < yhi (lattice)
@@ -139,12 +139,17 @@ __device__ inline int32_t clampi(double v, int32_t lo, int32_t hi) {
   return v <= (double)lo ? lo : (v >= (double)hi ? hi : (int32_t)v);
 }
 
-// the value lane `w` holds (w wave-uniform: it comes from a ballot)
-__device__ inline int32_t bcast(int32_t v, int w) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(w)); }
-__device__ inline double bcastd(double v, int w) {
-  const int32_t lo = bcast(__double2loint(v), w), hi = bcast(__double2hiint(v), w);
-  return __hiloint2double(hi, lo);
-}
+// A star is built by kSW lanes: 64 = one star per wavefront (the default); 32 = two stars per wavefront, each on its own
+// half -- a step of the wrapping has ~18 candidates, so 64 lanes are mostly idle -- measured (-DFLAME_DT_STAR_LANES=32):
+// the star kernel 193 -> 158 us at 10 k points and 690 -> 600 at 50 k, but 58 -> 72 at 1.2 k and 2 170 -> 2 680 at 200 k
+// (the two stars of a wavefront run each other's loop iterations; nothing of the star's state stays scalar): not kept.
+// "Uniform" below means: the same on every lane of the star.
+#ifndef FLAME_DT_STAR_LANES
+#define FLAME_DT_STAR_LANES 64
+#endif
+constexpr int kSW = FLAME_DT_STAR_LANES;
+constexpr unsigned long long kStarMask = kSW == 64 ? ~0ull : ((1ull << (kSW & 63)) - 1ull);
+static_assert(kSW == 32 || kSW == 64, "a star is a wavefront or half of one");
 
 // ---------------------------------------------------------------- kernels
 __global__ void k_dt_init(int32_t* cnt, int32_t n, int32_t* flags) {
@@ -307,8 +312,18 @@ __global__ void __launch_bounds__(64) k_dt_rows(const int4* __restrict__ rec, co
 template <bool WRITE>
 __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
                                                  int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
-  const int32_t lane = threadIdx.x & 63;
-  const int32_t sl = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int32_t lane = threadIdx.x & (kSW - 1);       // lane within the star
+  const int32_t shift = (threadIdx.x & 63) & ~(kSW - 1);  // first lane of the star within its wavefront
+  const int32_t sl = blockIdx.x * (blockDim.x / kSW) + threadIdx.x / kSW;
+  // ballot over the star's lanes; the value lane w of the star holds (w: the same on every lane of the star)
+  auto sballot = [&](bool pr_) __attribute__((always_inline)) -> unsigned long long { return (__ballot(pr_) >> shift) & kStarMask; };
+  auto bcast = [&](int32_t v, int w) __attribute__((always_inline)) -> int32_t {
+    if constexpr (kSW == 64) return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(w));  // (w is wave-uniform)
+    else return __shfl(v, shift + w);
+  };
+  auto bcastd = [&](double v, int w) __attribute__((always_inline)) -> double {
+    return __hiloint2double(bcast(__double2hiint(v), w), bcast(__double2loint(v), w));
+  };
   if (sl >= g.V) return;
   const int4 pr = g.rec[sl];
   const int32_t ip = pr.z;
@@ -325,7 +340,7 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
       return;
     }
     if (n0 <= kStash) {
-      if (lane < 3 * n0) tris[3 * (size_t)o0 + lane] = stash[(size_t)ip * (3 * kStash) + lane];
+      for (int32_t k = lane; k < 3 * n0; k += kSW) tris[3 * (size_t)o0 + k] = stash[(size_t)ip * (3 * kStash) + k];
       return;
     }
     out = tris + 3 * (size_t)o0;
@@ -365,7 +380,7 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
       }
       tot += cn[k];
     }
-    cached = tot <= 64;
+    cached = tot <= kSW;
     crec = make_int4(0, 0, -1, 0);
     cslot = -1;
     if (cached && lane < tot) {
@@ -385,7 +400,7 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
     int32_t bs = -1, bid = INT32_MAX;
     const double cmin = fmin((double)bx.spanx / G, (double)bx.spany / G);
     auto scan = [&](int32_t s0, int32_t s1) __attribute__((always_inline)) {
-      for (int32_t base = s0; base < s1; base += 64) {
+      for (int32_t base = s0; base < s1; base += kSW) {
         const int32_t sl = base + lane;
         if (sl < s1) {
           const int4 r = g_rec[sl];
@@ -397,7 +412,7 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
       }
     };
     auto reduce = [&]() __attribute__((always_inline)) {  // the result so far, on every lane
-      for (int o = 32; o > 0; o >>= 1) {
+      for (int o = kSW / 2; o > 0; o >>= 1) {
         const int64_t od = __shfl_xor(bd, o);
         const int32_t os = __shfl_xor(bs, o), oi = __shfl_xor(bid, o);
         if (od < bd || (od == bd && oi < bid)) { bd = od; bs = os; bid = oi; }
@@ -441,7 +456,7 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
     int32_t bsl = -1, fs = -1, ls = -1, ms = -1, mid = INT32_MAX, fid = -1, lid = -1;
     int2 mxy = p;  // (first / last / smallest id on the circle: slot, coordinates and id, so the winner needs no load)
     double ccx = 0.0, ccy = 0.0, rad = INFINITY;
-    auto chunk = [&](int32_t sl, int4 r) __attribute__((always_inline)) {  // 64 candidates: this lane's slot and record (r.z < 0: none)
+    auto chunk = [&](int32_t sl, int4 r) __attribute__((always_inline)) {  // kSW candidates: this lane's slot and record (r.z < 0: none)
       ++n_chunks;
       const int2 rp = make_int2(r.x, r.y);
       bool ok = r.z >= 0 && sl != ps && sl != qs;
@@ -449,12 +464,12 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
         const int64_t o = orient64(p, q, rp);
         ok = s > 0 ? o > 0 : o < 0;
       }
-      if (!__ballot(ok)) return;
+      if (!sballot(ok)) return;
       int t;
       bool moved = false;
       for (;;) {  // candidates that beat the current best: one of them becomes the best, the others are asked again
         t = !ok ? -1 : (!have ? 1 : (sl == bsl ? 0 : s * incircle_sign(p, q, b, rp)));  // (the best against itself: on the circle)
-        const unsigned long long m = __ballot(t > 0);
+        const unsigned long long m = sballot(t > 0);
         if (!m) break;
         const int w = __ffsll(m) - 1;
         b = make_int2(bcast(r.x, w), bcast(r.y, w));
@@ -462,8 +477,8 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
       }
       if (moved) circle_of(p, q, b, &ccx, &ccy, &rad);
       // on the current circle: angular order as seen from p, turning towards side s (the best itself is among them already)
-      unsigned long long m0 = __ballot(t == 0);
-      m0 &= ~__ballot(sl == bsl);
+      unsigned long long m0 = sballot(t == 0);
+      m0 &= ~sballot(sl == bsl);
       while (m0) {
         const int w = __ffsll(m0) - 1;
         m0 &= m0 - 1;
@@ -475,7 +490,7 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
       }
     };
     auto scan = [&](int32_t s0, int32_t s1) __attribute__((always_inline)) {
-      for (int32_t base = s0; base < s1; base += 64) {
+      for (int32_t base = s0; base < s1; base += kSW) {
         int4 r = make_int4(0, 0, -1, 0);
         if (base + lane < s1) r = g_rec[base + lane];
         chunk(base + lane, r);
@@ -499,9 +514,9 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
     }
     // every grid row the current cap can reach, outwards from p's row
     const double A = (double)s * (double)(q.x - p.x), B = (double)s * (double)(q.y - p.y);  // side(x, y) = A (y - py) - B (x - px) > 0
-    // 64 grid rows at a time, one per lane: past the disk / cannot hold a candidate / the run of cells to scan
+    // kSW grid rows at a time, one per lane: past the disk / cannot hold a candidate / the run of cells to scan
     auto sweep = [&](int dir) __attribute__((always_inline)) {  // +1: rows pcy, pcy + 1, ...; -1: rows pcy - 1, pcy - 2, ...
-      for (int32_t j0 = dir > 0 ? pcy : pcy - 1; j0 >= 0 && j0 < G; j0 += 64 * dir) {
+      for (int32_t j0 = dir > 0 ? pcy : pcy - 1; j0 >= 0 && j0 < G; j0 += kSW * dir) {
         const int32_t j = j0 + dir * lane;
         const bool in = j >= 0 && j < G;
         bool stop = false, keep = false;
@@ -547,8 +562,8 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, i
           }
         }
         ++n_rows;
-        const unsigned long long mstop = __ballot(in && stop);
-        unsigned long long mkeep = __ballot(keep);
+        const unsigned long long mstop = sballot(in && stop);
+        unsigned long long mkeep = sballot(keep);
         if (mstop) mkeep &= (1ull << (__ffsll(mstop) - 1)) - 1;  // (lanes are in visiting order: rows before the first one past the disk)
         while (mkeep) {
           const int w = __ffsll(mkeep) - 1;
@@ -704,7 +719,8 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   }
   DtView view;
   view.rec = rec; view.start = start; view.row = rows; view.flags = flags; view.G = G; view.V = V; view.dbg = dbg;
-  const unsigned gs = (unsigned)((V + 3) / 4);  // four stars (wavefronts) per workgroup
+  const int per_wg = 256 / kSW;  // stars per workgroup
+  const unsigned gs = (unsigned)((V + per_wg - 1) / per_wg);
   hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
   hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
