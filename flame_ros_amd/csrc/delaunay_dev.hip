@@ -302,6 +302,123 @@ __global__ void __launch_bounds__(64) k_dt_rows(const int4* __restrict__ rec, co
   }
 }
 
+// ---- small frames (V <= kSmallV: the reference's own 640 x 480 frames have ~1.2 k features): everything in front of the
+// star kernel in ONE launch of one workgroup -- snap + bounding box, cell counts, their scan, the scatter, the copies and the
+// row extents -- with counts, offsets and records in LDS; the positions are read straight from the caller's page-locked
+// copy (no DMA in front).  Same arrays as the kernels above produce (the order inside a cell may differ: nothing
+// depends on it).
+constexpr int kSmallV = 2048, kSmallG = 32;
+__global__ void __launch_bounds__(1024) k_dt_prep_small(const float2* __restrict__ pos, int32_t V, int32_t G, int32_t* flags,
+                                                        int32_t* __restrict__ start, int4* __restrict__ rec, DtRow* __restrict__ row) {
+  __shared__ int32_t s_cnt[kSmallG * kSmallG], s_start[kSmallG * kSmallG + 1];
+  __shared__ int4 s_rec[kSmallV];
+  __shared__ int32_t s_red[16][4], s_box[4], s_dups;
+  const int32_t t = threadIdx.x, lane = t & 63, w = t >> 6, ncell = G * G;
+  if (t < ncell) s_cnt[t] = 0;
+  if (t == 0) s_dups = 0;
+  int2 q[2];
+  bool bad = false;
+  int32_t x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
+  for (int k = 0; k < 2; ++k) {
+    const int32_t i = t + 1024 * k;
+    q[k] = make_int2(0, 0);
+    if (i < V) {
+      const float2 v = pos[i];
+      const double x = (double)v.x * 65536.0, y = (double)v.y * 65536.0;
+      if (!(fabs(x) < 536870912.0) || !(fabs(y) < 536870912.0)) bad = true;
+      else q[k] = make_int2((int32_t)llround(x), (int32_t)llround(y));
+      x0 = min(x0, q[k].x); y0 = min(y0, q[k].y); x1 = max(x1, q[k].x); y1 = max(y1, q[k].y);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    x0 = min(x0, __shfl_xor(x0, o)); y0 = min(y0, __shfl_xor(y0, o));
+    x1 = max(x1, __shfl_xor(x1, o)); y1 = max(y1, __shfl_xor(y1, o));
+  }
+  if (lane == 0) { s_red[w][0] = x0; s_red[w][1] = y0; s_red[w][2] = x1; s_red[w][3] = y1; }
+  const unsigned long long anybad = __ballot(bad);
+  __syncthreads();
+  if (t == 0) {
+    for (int k = 1; k < 16; ++k) { x0 = min(x0, s_red[k][0]); y0 = min(y0, s_red[k][1]); x1 = max(x1, s_red[k][2]); y1 = max(y1, s_red[k][3]); }
+    s_box[0] = x0; s_box[1] = y0; s_box[2] = x1; s_box[3] = y1;
+    flags[0] = 0; flags[1] = 0; flags[2] = 0; flags[3] = 0;
+    flags[4] = x0; flags[5] = y0; flags[6] = x1; flags[7] = y1;
+  }
+  __syncthreads();
+  if (anybad && lane == 0) atomicOr(&flags[0], kErrRange);  // (behind thread 0's reset)
+  DtBox b;
+  b.minx = s_box[0]; b.miny = s_box[1];
+  b.spanx = (int64_t)s_box[2] - s_box[0] + 1; b.spany = (int64_t)s_box[3] - s_box[1] + 1;
+  int32_t c[2] = {0, 0};
+  for (int k = 0; k < 2; ++k)
+    if (t + 1024 * k < V) {
+      const int32_t cx = (int32_t)(((int64_t)(q[k].x - b.minx) * G) / b.spanx), cy = (int32_t)(((int64_t)(q[k].y - b.miny) * G) / b.spany);
+      c[k] = cy * G + cx;
+      atomicAdd(&s_cnt[c[k]], 1);
+    }
+  __syncthreads();
+  {
+    int32_t tot;
+    const int32_t ex = block_excl_scan_1024(t < ncell ? s_cnt[t] : 0, &tot);
+    if (t < ncell) { s_start[t] = ex; start[t] = ex; s_cnt[t] = 0; }
+    if (t == 0) { s_start[ncell] = V; start[ncell] = V; }
+  }
+  __syncthreads();
+  for (int k = 0; k < 2; ++k)
+    if (t + 1024 * k < V) {
+      const int32_t sl = s_start[c[k]] + atomicAdd(&s_cnt[c[k]], 1);
+      s_rec[sl] = make_int4(q[k].x, q[k].y, t + 1024 * k, c[k]);
+    }
+  __syncthreads();
+  bool dup[2] = {false, false};
+  for (int k = 0; k < 2; ++k) {
+    const int32_t sl = t + 1024 * k;
+    if (sl < V) {
+      const int4 p = s_rec[sl];
+      for (int32_t o = s_start[p.w], e = s_start[p.w + 1]; o < e; ++o) {
+        const int4 r = s_rec[o];
+        if (r.x == p.x && r.y == p.y && r.z < p.z) { dup[k] = true; break; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < 2; ++k) {
+    const int32_t sl = t + 1024 * k;
+    if (sl < V) {
+      int4 p = s_rec[sl];
+      if (dup[k]) { p.z = ~p.z; s_rec[sl] = p; atomicAdd(&s_dups, 1); }
+      rec[sl] = p;
+    }
+  }
+  __syncthreads();
+  if (t == 0) flags[2] = s_dups;
+  for (int32_t j = w; j < G; j += 16) {
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (int32_t sl = s_start[j * G] + lane, e = s_start[(j + 1) * G]; sl < e; sl += 64) {
+      const int4 r = s_rec[sl];
+      if (r.z >= 0) { lo = min(lo, r.x); hi = max(hi, r.x); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) {
+      DtRow rw;
+      rw.ylo = (double)b.miny + (double)(((int64_t)j * b.spany) / G);
+      rw.yhi = (double)b.miny + (double)(((int64_t)(j + 1) * b.spany) / G) + 1.0;
+      rw.xlo = lo <= hi ? lo : 1; rw.xhi = lo <= hi ? hi : 0;
+      row[j] = rw;
+    }
+  }
+}
+
+// exclusive scan of n <= 2048 ints by one workgroup (out[n] = total, also *total)
+__global__ void __launch_bounds__(1024) k_dt_scan_small(const int32_t* __restrict__ in, int32_t n, int32_t* __restrict__ out, int32_t* total) {
+  const int32_t t = threadIdx.x;
+  const int32_t a = 2 * t < n ? in[2 * t] : 0, b2 = 2 * t + 1 < n ? in[2 * t + 1] : 0;
+  int32_t tot;
+  const int32_t ex = block_excl_scan_1024(a + b2, &tot);
+  if (2 * t < n) out[2 * t] = ex;
+  if (2 * t + 1 < n) out[2 * t + 1] = ex + a;
+  if (t == 0) { out[n] = tot; if (total) *total = tot; }
+}
+
 // First pass (WRITE = false): every star counts its triangles and keeps the first kStash of them in `stash`.
 // Second pass: the stashed triangles are copied to their place in the list; a star with more is built again, writing.
 #ifdef FLAME_DT_WAVES  /* dev A/B: cap the registers for this many waves per SIMD */
@@ -701,16 +818,21 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   int32_t* htris = reinterpret_cast<int32_t*>(sc->pin + p_tris);
 
   std::memcpy(sc->pin + p_pos, pos, sizeof(float2) * (size_t)V);
-  DT_HIPCHK(hipMemcpyAsync(dpos, sc->pin + p_pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
-  const int B = 256;
-  const unsigned gv = (unsigned)((V + B - 1) / B);
-  hipLaunchKernelGGL(k_dt_init, dim3((unsigned)((ncell + 1 + B - 1) / B)), dim3(B), 0, s, cnt, ncell + 1, flags);
-  hipLaunchKernelGGL(k_dt_snap, dim3(std::min(gv, 256u)), dim3(B), 0, s, dpos, V, ixy, flags);
-  hipLaunchKernelGGL(k_dt_count, dim3(gv), dim3(B), 0, s, ixy, V, G, flags, cell_of, cnt);
-  scan_ints(s, cnt, ncell, start, sums, 1, nullptr);
-  hipLaunchKernelGGL(k_dt_scatter, dim3(gv), dim3(B), 0, s, ixy, cell_of, V, start, cnt, rec0);
-  hipLaunchKernelGGL(k_dt_dups, dim3(gv), dim3(B), 0, s, rec0, rec, start, V, flags);
-  hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)G), dim3(64), 0, s, rec, start, G, flags, rows);
+  const bool small = V <= kSmallV && G <= kSmallG;
+  if (small) {
+    hipLaunchKernelGGL(k_dt_prep_small, dim3(1), dim3(1024), 0, s, reinterpret_cast<const float2*>(sc->pin + p_pos), V, G, flags, start, rec, rows);
+  } else {
+    DT_HIPCHK(hipMemcpyAsync(dpos, sc->pin + p_pos, sizeof(float2) * (size_t)V, hipMemcpyHostToDevice, s));
+    const int B = 256;
+    const unsigned gv = (unsigned)((V + B - 1) / B);
+    hipLaunchKernelGGL(k_dt_init, dim3((unsigned)((ncell + 1 + B - 1) / B)), dim3(B), 0, s, cnt, ncell + 1, flags);
+    hipLaunchKernelGGL(k_dt_snap, dim3(std::min(gv, 256u)), dim3(B), 0, s, dpos, V, ixy, flags);
+    hipLaunchKernelGGL(k_dt_count, dim3(gv), dim3(B), 0, s, ixy, V, G, flags, cell_of, cnt);
+    scan_ints(s, cnt, ncell, start, sums, 1, nullptr);
+    hipLaunchKernelGGL(k_dt_scatter, dim3(gv), dim3(B), 0, s, ixy, cell_of, V, start, cnt, rec0);
+    hipLaunchKernelGGL(k_dt_dups, dim3(gv), dim3(B), 0, s, rec0, rec, start, V, flags);
+    hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)G), dim3(64), 0, s, rec, start, G, flags, rows);
+  }
   static const bool dt_stats = std::getenv("FLAME_HIP_DT_STATS") != nullptr;
   int32_t* dbg = nullptr;
   if (dt_stats) {
@@ -722,7 +844,8 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   const int per_wg = 256 / kSW;  // stars per workgroup
   const unsigned gs = (unsigned)((V + per_wg - 1) / per_wg);
   hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
-  scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
+  if (small) hipLaunchKernelGGL(k_dt_scan_small, dim3(1), dim3(1024), 0, s, tcnt, V, toff, flags + 3);
+  else scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
   hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   DT_HIPCHK(hipGetLastError());
   // flags and the list leave together (T = 2 n - 2 - h is within a few triangles of the 2 V the buffer holds: copying
