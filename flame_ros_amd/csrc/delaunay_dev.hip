@@ -408,14 +408,24 @@ __global__ void __launch_bounds__(1024) k_dt_prep_small(const float2* __restrict
   }
 }
 
-// exclusive scan of n <= 2048 ints by one workgroup (out[n] = total, also *total)
-__global__ void __launch_bounds__(1024) k_dt_scan_small(const int32_t* __restrict__ in, int32_t n, int32_t* __restrict__ out, int32_t* total) {
-  const int32_t t = threadIdx.x;
-  const int32_t a = 2 * t < n ? in[2 * t] : 0, b2 = 2 * t + 1 < n ? in[2 * t + 1] : 0;
+// exclusive scan of n <= 1024 * kScanOne ints by ONE workgroup (out[n] = total, also *total): one launch where the general
+// scan takes three
+constexpr int kScanOne = 16;
+__global__ void __launch_bounds__(1024) k_dt_scan_one(int32_t* in, int32_t n, int32_t* __restrict__ out, int32_t clear_in, int32_t* total) {
+  const int32_t t = threadIdx.x, per = (n + 1023) / 1024, i0 = min(t * per, n), i1 = min(i0 + per, n);
+  int32_t v[kScanOne], sum = 0;
+  for (int k = 0; k < kScanOne; ++k) {
+    v[k] = i0 + k < i1 ? in[i0 + k] : 0;
+    sum += v[k];
+  }
   int32_t tot;
-  const int32_t ex = block_excl_scan_1024(a + b2, &tot);
-  if (2 * t < n) out[2 * t] = ex;
-  if (2 * t + 1 < n) out[2 * t + 1] = ex + a;
+  int32_t run = block_excl_scan_1024(sum, &tot);
+  for (int k = 0; k < kScanOne; ++k)
+    if (i0 + k < i1) {
+      out[i0 + k] = run;
+      run += v[k];
+      if (clear_in) in[i0 + k] = 0;
+    }
   if (t == 0) { out[n] = tot; if (total) *total = tot; }
 }
 
@@ -747,6 +757,10 @@ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // out[0..n) = exclusive scan of in[0..n), out[n] = total (also *total when given); n <= 2^20
 void scan_ints(hipStream_t s, int32_t* in, int32_t n, int32_t* out, int32_t* sums, int32_t clear_in, int32_t* total) {
+  if (n <= 1024 * kScanOne) {
+    hipLaunchKernelGGL(k_dt_scan_one, dim3(1), dim3(1024), 0, s, in, n, out, clear_in, total);
+    return;
+  }
   const unsigned nb = (unsigned)((n + 1023) / 1024);
   hipLaunchKernelGGL(k_dt_scan_sums, dim3(nb), dim3(1024), 0, s, in, n, sums);
   hipLaunchKernelGGL(k_dt_scan_top, dim3(1), dim3(1024), 0, s, sums, (int32_t)nb, out + n, total);
@@ -844,8 +858,7 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   const int per_wg = 256 / kSW;  // stars per workgroup
   const unsigned gs = (unsigned)((V + per_wg - 1) / per_wg);
   hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
-  if (small) hipLaunchKernelGGL(k_dt_scan_small, dim3(1), dim3(1024), 0, s, tcnt, V, toff, flags + 3);
-  else scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
+  scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
   hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   DT_HIPCHK(hipGetLastError());
   // flags and the list leave together (T = 2 n - 2 - h is within a few triangles of the 2 V the buffer holds: copying
