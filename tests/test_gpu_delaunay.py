@@ -165,3 +165,26 @@ def test_random_sets_fuzz(handle):
         if not np.array_equal(canon(got), canon(want)):
             check_properties(pts, got)  # (nearly cocircular / collinear for floating point: any exact answer)
             assert len(got) == len(want), trial
+
+
+def test_two_handles_triangulate_concurrently(gpu):
+    """Two handles, two host threads, 60 frames each (sizes on both sides of the small-frame path), the calls interleaving
+    on the device: every list equals the one a quiet handle returns."""
+    import threading
+    from flame_ros_amd.regularizer import GraphRegularizer
+    rng = np.random.default_rng(77)
+    frames = [(rng.random((n, 2)) * np.array([640.0, 480.0])).astype(np.float32) for n in (1200, 5000, 300, 2048, 2049, 10000)]
+    with GraphRegularizer.empty() as h0:
+        want = [h0.delaunay(f) for f in frames]
+    bad = []
+
+    def stream(tid):
+        with GraphRegularizer.empty() as h:
+            for k in range(60):
+                i = (k + tid) % len(frames)
+                if not np.array_equal(h.delaunay(frames[i]), want[i]):
+                    bad.append((tid, k))
+    th = [threading.Thread(target=stream, args=(t,)) for t in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not bad, bad[:5]
