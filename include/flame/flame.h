@@ -267,10 +267,13 @@ class Flame {
             if (!fs.prediction.empty()) g.prediction.push_back(fs.prediction[v]);
           }
         std::vector<Triangle> tris;
+        tris.swap(tri_buf_);  // (last frame's list: its storage -- and, on the GPU branch, its elements -- are reused:
+                              // resizing a fresh vector to 2 V triangles would clear 2 V triangles first, every frame)
         if (ok) {
           stats_.tick("triangulate");
           // (the reference's `omp_num_threads`, cfg/flame_offline_tum.yaml:70, is what its CPU stages run on)
           if (frontend_.triangulate) {
+            tris.clear();
             ok = frontend_.triangulate(g.vtx, &tris);
           } else if (params_.triangulate_on_gpu) {  // row f3's first leg in the library
             static_assert(sizeof(Point2f) == 2 * sizeof(float) && sizeof(Triangle) == 3 * sizeof(int32_t), "boundary types are packed");
@@ -284,13 +287,17 @@ class Flame {
                                      // frame, as the host triangulator's `false` does)
             if (rc) stats_.set("hip_error", rc);
           } else {
+            tris.clear();
             ok = delaunay_.triangulate(g.vtx, &tris, params_.triangulate_threads > 0 ? params_.triangulate_threads : params_.omp_num_threads);
           }
           stats_.tock("triangulate");
+        } else {
+          tris.clear();
         }
         if (ok)
           ok = updateGraphLocked(in.time, in.img_id, g.vtx, g.idepth_mu, g.idepth_var, tris,
                                  g.prediction.empty() ? nullptr : &g.prediction, &fs);
+        tri_buf_.swap(tris);
       }
     }
     stats_.tock("update");
@@ -502,6 +509,7 @@ class Flame {
   mutable std::mutex mtx_;
   utils::StatsTracker stats_;
   FrontEnd frontend_;
+  std::vector<Triangle> tri_buf_;         // storage of the frame's triangle list, kept across frames
   utils::DelaunayTriangulator delaunay_;  // the built-in triangulation on the host (Params::triangulate_on_gpu = false; scratch kept across frames)
   optimizers::nltgv2_l1_graph_regularizer::Graph graph_;
   bool device_frame_valid_ = false;  // the device state belongs to the committed frame
