@@ -258,14 +258,19 @@ class Flame {
         std::vector<uint8_t> keep(fs.vtx.size());
         const int32_t nk = flame_hip_feature_gate(n, fs.idepth_var.data(), params_.idepth_var_max_graph, keep.data());
         ok = nk >= 0;
-        FeatureSet g;
-        for (int32_t v = 0; ok && v < n; ++v)
-          if (keep[v]) {
-            g.vtx.push_back(fs.vtx[v]);
-            g.idepth_mu.push_back(fs.idepth_mu[v]);
-            g.idepth_var.push_back(fs.idepth_var[v]);
-            if (!fs.prediction.empty()) g.prediction.push_back(fs.prediction[v]);
-          }
+        FeatureSet gated;
+        if (ok && nk != n) {  // (every feature through the gate -- the usual frame -- is used where it lies)
+          gated.vtx.reserve(nk); gated.idepth_mu.reserve(nk); gated.idepth_var.reserve(nk);
+          if (!fs.prediction.empty()) gated.prediction.reserve(nk);
+          for (int32_t v = 0; v < n; ++v)
+            if (keep[v]) {
+              gated.vtx.push_back(fs.vtx[v]);
+              gated.idepth_mu.push_back(fs.idepth_mu[v]);
+              gated.idepth_var.push_back(fs.idepth_var[v]);
+              if (!fs.prediction.empty()) gated.prediction.push_back(fs.prediction[v]);
+            }
+        }
+        const FeatureSet& g = (ok && nk != n) ? gated : fs;
         std::vector<Triangle> tris;
         tris.swap(tri_buf_);  // (last frame's list: its storage -- and, on the GPU branch, its elements -- are reused:
                               // resizing a fresh vector to 2 V triangles would clear 2 V triangles first, every frame)
