@@ -188,3 +188,25 @@ def test_two_handles_triangulate_concurrently(gpu):
     for t in th: t.start()
     for t in th: t.join()
     assert not bad, bad[:5]
+
+
+def test_near_cocircular_and_near_collinear_sets(handle):
+    """What the floating-point filters must hand to the exact arithmetic: points within a few lattice units of a common
+    circle (every in-circle test of a star is nearly zero), of a common line, and both at once -- checked by the defining
+    properties in exact integer arithmetic."""
+    rng = np.random.default_rng(31)
+    for trial in range(40):
+        n = int(rng.integers(8, 120))
+        th = np.sort(rng.random(n) * 2 * np.pi)
+        R = float(rng.uniform(20, 2000))
+        c = rng.uniform(-1000, 1000, 2)
+        ring = np.stack([np.cos(th), np.sin(th)], 1) * R + c
+        jitter = rng.integers(-2, 3, (n, 2)) / 65536.0 * (trial % 3)       # 0 .. 2 lattice units
+        line = np.stack([np.linspace(-R, R, n), np.linspace(-R, R, n) * float(rng.uniform(-2, 2))], 1) + c
+        line += rng.integers(-1, 2, (n, 2)) / 65536.0 * (trial % 2)
+        inner = rng.uniform(-0.5, 0.5, (n // 4, 2)) * R + c
+        pts = np.concatenate([ring + jitter, line, inner]).astype(np.float64)
+        pts = np.clip(pts, -8000, 8000).astype(np.float32)
+        tris = handle.delaunay(pts)
+        assert len(tris) > 0
+        check_properties(pts, tris)
