@@ -436,8 +436,14 @@ __global__ void __launch_bounds__(1024) k_dt_scan_one(int32_t* in, int32_t n, in
 #else
 #define FLAME_DT_WAVES_ATTR
 #endif
+// One wavefront per workgroup: a wavefront's slot is free for the next star the moment ITS star is done (with four stars per
+// workgroup a new workgroup waits for a free slot on each of the CU's four SIMDs, i.e. for the slowest of four stars).
+#ifndef FLAME_DT_STAR_WG
+#define FLAME_DT_STAR_WG 64
+#endif
+constexpr int kStarWG = FLAME_DT_STAR_WG;
 template <bool WRITE>
-__global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(256) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
+__global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(kStarWG) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
                                                  int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
   const int32_t lane = threadIdx.x & (kSW - 1);       // lane within the star
   const int32_t shift = (threadIdx.x & 63) & ~(kSW - 1);  // first lane of the star within its wavefront
@@ -855,11 +861,11 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   }
   DtView view;
   view.rec = rec; view.start = start; view.row = rows; view.flags = flags; view.G = G; view.V = V; view.dbg = dbg;
-  const int per_wg = 256 / kSW;  // stars per workgroup
+  const int per_wg = kStarWG / kSW;  // stars per workgroup
   const unsigned gs = (unsigned)((V + per_wg - 1) / per_wg);
-  hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
-  hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(256), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   DT_HIPCHK(hipGetLastError());
   // flags and the list leave together (T = 2 n - 2 - h is within a few triangles of the 2 V the buffer holds: copying
   // the whole buffer costs nothing over copying T triangles, and saves the round trip that would bring T first)
