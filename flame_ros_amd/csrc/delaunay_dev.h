@@ -15,6 +15,10 @@ struct DelaunayScratch {
   float last_ms = 0.f;       // host time of the last call (copies included)
   int32_t last_hull = 0;     // boundary vertices of the last triangulation
   int32_t last_live = 0;     // points that are not later copies of another point
+  // the list of the last successful call, still in the page-locked arena (flame_hip_graph_sync reads it from there when the
+  // caller passes no triangle pointer: an asynchronous DMA instead of a staged copy from pageable memory)
+  int32_t last_V = -1, last_T = -1;
+  const int32_t* last_list = nullptr;
   void release();
 };
 

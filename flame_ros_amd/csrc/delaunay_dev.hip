@@ -779,6 +779,7 @@ void DelaunayScratch::release() {
   if (dev) (void)hipFree(dev);
   if (pin) (void)hipHostFree(pin);
   dev = nullptr; pin = nullptr; dev_cap = pin_cap = 0;
+  last_V = last_T = -1; last_list = nullptr;
 }
 
 int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris_out,
@@ -786,6 +787,7 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   if (!sc || V < 0 || tri_cap < 0 || !T_out || (V > 0 && !pos) || (tri_cap > 0 && !tris_out)) return FLAME_HIP_ERR_ARG;
   *T_out = 0;
   sc->last_hull = 0; sc->last_live = V;
+  sc->last_V = sc->last_T = -1; sc->last_list = nullptr;
   if (V < 3) return 0;
   if (V > (1 << 20)) return FLAME_HIP_ERR_ARG;  // (the scans; a frame has 10^3..10^5 features)
   const auto t0 = std::chrono::steady_clock::now();
@@ -894,6 +896,7 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   if (T > tri_cap) return FLAME_HIP_ERR_ARG;
   if (T > 0) std::memcpy(tris_out, htris, sizeof(int32_t) * 3 * (size_t)T);
   *T_out = T;
+  sc->last_V = V; sc->last_T = T; sc->last_list = htris;
   sc->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }

@@ -1152,7 +1152,11 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
                          const int32_t* tris, const float* prediction, float* scale) {
   RoctxRange roctx_("flame_hip_graph_sync");
   if (!g || !sp || V < 0 || T < 0) return FLAME_HIP_ERR_ARG;
-  if ((V > 0 && (!pos || !idepth_mu || !idepth_var)) || (T > 0 && !tris)) return FLAME_HIP_ERR_ARG;
+  if (T > 0 && !tris) {  // the triangulation flame_hip_delaunay made last on this handle, read where the library left it
+    if (g->dt.last_T != T || g->dt.last_V != V || !g->dt.last_list) return FLAME_HIP_ERR_ARG;
+    tris = g->dt.last_list;
+  }
+  if (V > 0 && (!pos || !idepth_mu || !idepth_var)) return FLAME_HIP_ERR_ARG;
   const auto t_entry = std::chrono::steady_clock::now();
   const GraphOptScope opt_scope(g, V);
   // input validation on the host: non-finite positions / idepths, NaN variances, the variance gate.

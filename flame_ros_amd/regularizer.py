@@ -123,13 +123,17 @@ class GraphRegularizer:
         data terms, initial x; resizes this handle and uploads.  Returns the data scale."""
         pos = _f32(pos).reshape(-1, 2)
         mu, var = _f32(idepth_mu), _f32(idepth_var)
-        tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        if isinstance(tris, (int, np.integer)):  # T of the list this handle's delaunay() made last: read where the library holds it
+            T, tptr = int(tris), None
+        else:
+            tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+            T, tptr = len(tris), (_ptr(tris) if len(tris) else None)
         pred = None if prediction is None else _f32(prediction)
         scale = C.c_float()
-        _l.check(self._lib.flame_hip_graph_sync(self._h, C.byref(sync_params), len(mu), len(tris), _ptr(pos),
-                                                _ptr(mu), _ptr(var), _ptr(tris) if len(tris) else None,
+        _l.check(self._lib.flame_hip_graph_sync(self._h, C.byref(sync_params), len(mu), T, _ptr(pos),
+                                                _ptr(mu), _ptr(var), tptr,
                                                 _ptr(pred), C.byref(scale)), "flame_hip_graph_sync")
-        self.V, self.T, self.E = len(mu), len(tris), self.info("E")
+        self.V, self.T, self.E = len(mu), T, self.info("E")
         return scale.value
 
     def delaunay(self, pos):

@@ -288,7 +288,8 @@ class Flame {
             const int rc = graph_.triangulate(params_.hip_device, nv, nv ? reinterpret_cast<const float*>(g.vtx.data()) : nullptr,
                                               static_cast<int32_t>(tris.size()), reinterpret_cast<int32_t*>(tris.data()), &nt);
             tris.resize(rc ? 0 : nt);
-            ok = rc == 0 && nt > 0;  // (nothing to triangulate -- fewer than three distinct points, or all on a line -- fails the
+            ok = rc == 0 && nt > 0;
+            tris_in_library_ = ok;  // (nothing to triangulate -- fewer than three distinct points, or all on a line -- fails the
                                      // frame, as the host triangulator's `false` does)
             if (rc) stats_.set("hip_error", rc);
           } else {
@@ -329,7 +330,9 @@ class Flame {
     static_assert(sizeof(Point2f) == 2 * sizeof(float) && sizeof(Triangle) == 3 * sizeof(int32_t) &&
                       sizeof(Edge) == 2 * sizeof(int32_t), "boundary types are packed");
     const float* pos = V ? reinterpret_cast<const float*>(vtx.data()) : nullptr;
-    const int32_t* tidx = T ? reinterpret_cast<const int32_t*>(triangles.data()) : nullptr;
+    // (a list flame_hip_delaunay made for this very frame is read where the library still holds it)
+    const int32_t* tidx = (T && !tris_in_library_) ? reinterpret_cast<const int32_t*>(triangles.data()) : nullptr;
+    tris_in_library_ = false;
     flame_hip_sync_params sp;
     sp.adaptive_data_weights = params_.adaptive_data_weights;
     sp.rescale_data = params_.rescale_data;
@@ -515,6 +518,7 @@ class Flame {
   utils::StatsTracker stats_;
   FrontEnd frontend_;
   std::vector<Triangle> tri_buf_;         // storage of the frame's triangle list, kept across frames
+  bool tris_in_library_ = false;          // the list in hand is the one flame_hip_delaunay just made on graph_'s handle
   utils::DelaunayTriangulator delaunay_;  // the built-in triangulation on the host (Params::triangulate_on_gpu = false; scratch kept across frames)
   optimizers::nltgv2_l1_graph_regularizer::Graph graph_;
   bool device_frame_valid_ = false;  // the device state belongs to the committed frame

@@ -162,7 +162,9 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
  * list is a function of the input alone.  Independent of the graph held by g (own scratch, the handle's staging
  * stream); returns when the list is in tris.  Errors: ARG (coordinate out of range, tri_cap too small), NAN, STATE
  * (no device; or the result failed Euler's check T = 2 n - 2 - h: never seen, reported rather than handed out).
- * flame_hip_get_info: "delaunay_hull" (h), "delaunay_live" (n), "delaunay_us" (host time of the call). */
+ * flame_hip_get_info: "delaunay_hull" (h), "delaunay_live" (n), "delaunay_us" (host time of the call).
+ * A flame_hip_graph_sync on the same handle with the same V and T and tris = NULL uses this list as the library still
+ * holds it (page-locked: no staged copy of the caller's array). */
 int flame_hip_delaunay(flame_hip_graph* g, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris, int32_t* T);
 /* keep[v] = var[v] < var_max; returns the number kept (or a negative error).  No device needed. */
 int32_t flame_hip_feature_gate(int32_t n, const float* idepth_var, float var_max, uint8_t* keep);

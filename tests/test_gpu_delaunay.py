@@ -210,3 +210,32 @@ def test_near_cocircular_and_near_collinear_sets(handle):
         tris = handle.delaunay(pts)
         assert len(tris) > 0
         check_properties(pts, tris)
+
+
+@pytest.mark.parametrize("n", [1200, 10000])
+def test_graph_sync_on_the_library_s_own_list(gpu, n):
+    """flame_hip_graph_sync with tris = NULL and the T of the last flame_hip_delaunay on the handle reads the list where
+    the library still holds it (page-locked): the same graph, the same bits after 50 iterations as with the list handed
+    over -- and a T / V that does not match that list is refused."""
+    from flame_ros_amd.lib import FlameHipError
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_sync_params
+    rng = np.random.default_rng(n)
+    pts = (rng.random((n, 2)) * np.array([640.0, 480.0])).astype(np.float32)
+    mu = (0.5 + 0.001 * pts[:, 0] + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    var = np.full(n, 1e-4, np.float32)
+    sp = default_sync_params()
+    out = []
+    for own_list in (False, True):
+        with GraphRegularizer.empty() as h:
+            tris = h.delaunay(pts)
+            h.sync_features(pts, mu, var, len(tris) if own_list else tris, sp)
+            edges = h.edges().copy()
+            h.step(default_params(), 50)
+            out.append((edges, h.download()[0].copy()))
+            if own_list:
+                with pytest.raises(FlameHipError):
+                    h.sync_features(pts, mu, var, len(tris) - 1, sp)
+                with pytest.raises(FlameHipError):
+                    h.sync_features(pts[:-1], mu[:-1], var[:-1], len(tris), sp)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
