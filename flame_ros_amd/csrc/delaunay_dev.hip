@@ -74,6 +74,7 @@ struct DtView {
   const DtRow* row;      // per grid row: its y extent and the x extent of its live points
   const int32_t* flags;
   int32_t G, V;
+  const int32_t* order;  // wavefront -> slot: the stars of the grid's boundary cells first (NULL: slot order)
   int32_t* dbg;          // dev aid (FLAME_HIP_DT_STATS): per point {own triangles, chunks, row batches, row scans}
 };
 
@@ -429,6 +430,59 @@ __global__ void __launch_bounds__(1024) k_dt_scan_one(int32_t* in, int32_t n, in
   if (t == 0) { out[n] = tot; if (total) *total = tot; }
 }
 
+// ---- launch order of the stars.  A star of a boundary cell of the grid is a hull star (or next to one): long thin triangles,
+// big circles, three to five times the life of an interior star.  In slot order the last grid row -- all of them -- starts
+// last and IS the tail of the launch (10 k points: 96 us of work on 2 048 wavefront slots, 170 us of launch).  So: the
+// boundary cells first (row 0, row G - 1, then columns 0 and G - 1 of the rows between), the interior in slot order
+// behind them (neighbouring wavefronts still share their cells).
+__global__ void __launch_bounds__(256) k_dt_order_rows(const int32_t* __restrict__ start, int32_t G, int32_t* __restrict__ rowb,
+                                                       int32_t* __restrict__ rowi) {
+  // rows j = 1 .. G - 2 (G >= 3): exclusive prefix sums of their boundary slots (columns 0, G - 1) and interior slots
+  __shared__ int32_t sb[256], si[256];
+  const int32_t t = threadIdx.x, j = t + 1;
+  int32_t cb = 0, ci = 0;
+  if (j <= G - 2) {
+    cb = (start[j * G + 1] - start[j * G]) + (start[j * G + G] - start[j * G + G - 1]);
+    ci = start[j * G + G - 1] - start[j * G + 1];
+  }
+  sb[t] = cb; si[t] = ci;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int32_t vb = t >= o ? sb[t - o] : 0, vi = t >= o ? si[t - o] : 0;
+    __syncthreads();
+    sb[t] += vb; si[t] += vi;
+    __syncthreads();
+  }
+  if (t <= G - 2) { rowb[t] = sb[t] - cb; rowi[t] = si[t] - ci; }  // (entry G - 2: the totals)
+}
+__global__ void k_dt_order_fill(const int32_t* __restrict__ start, const int32_t* __restrict__ rowb, const int32_t* __restrict__ rowi,
+                                int32_t G, int32_t V, int32_t* __restrict__ order) {
+  const int32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= V) return;
+  const int32_t nr = G - 2, nb0 = start[G], s1 = start[(G - 1) * G], nb1 = V - s1, nb = nb0 + nb1 + rowb[nr];
+  auto row_of = [&](const int32_t* pre, int32_t k) {  // the last of the rows r with pre[r] <= k
+    int32_t lo = 0, hi = nr - 1;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi + 1) >> 1;
+      if (pre[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  int32_t slot;
+  if (w < nb0) {
+    slot = w;
+  } else if (w < nb0 + nb1) {
+    slot = s1 + (w - nb0);
+  } else if (w < nb) {
+    const int32_t k = w - nb0 - nb1, r = row_of(rowb, k), j = r + 1, off = k - rowb[r], c0 = start[j * G + 1] - start[j * G];
+    slot = off < c0 ? start[j * G] + off : start[j * G + G - 1] + (off - c0);
+  } else {
+    const int32_t m = w - nb, r = row_of(rowi, m), j = r + 1;
+    slot = start[j * G + 1] + (m - rowi[r]);
+  }
+  order[w] = slot;
+}
+
 // First pass (WRITE = false): every star counts its triangles and keeps the first kStash of them in `stash`.
 // Second pass: the stashed triangles are copied to their place in the list; a star with more is built again, writing.
 #ifdef FLAME_DT_WAVES  /* dev A/B: cap the registers for this many waves per SIMD */
@@ -447,7 +501,8 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(kStarWG) k_dt_star(DtView 
                                                  int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
   const int32_t lane = threadIdx.x & (kSW - 1);       // lane within the star
   const int32_t shift = (threadIdx.x & 63) & ~(kSW - 1);  // first lane of the star within its wavefront
-  const int32_t sl = blockIdx.x * (blockDim.x / kSW) + threadIdx.x / kSW;
+  const int32_t w0 = blockIdx.x * (blockDim.x / kSW) + threadIdx.x / kSW;
+  const int32_t sl = (g.order && w0 < g.V) ? g.order[w0] : w0;
   // ballot over the star's lanes; the value lane w of the star holds (w: the same on every lane of the star)
   auto sballot = [&](bool pr_) __attribute__((always_inline)) -> unsigned long long { return (__ballot(pr_) >> shift) & kStarMask; };
   auto bcast = [&](int32_t v, int w) __attribute__((always_inline)) -> int32_t {
@@ -802,6 +857,7 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   const size_t o_start = take(sizeof(int32_t) * ((size_t)ncell + 1)), o_rec0 = take(sizeof(int4) * (size_t)V), o_rec = take(sizeof(int4) * (size_t)V);
   const size_t o_rows = take(sizeof(DtRow) * (size_t)G), o_sums = take(sizeof(int32_t) * 1024);
   const size_t o_tcnt = take(sizeof(int32_t) * ((size_t)V + 1)), o_toff = take(sizeof(int32_t) * ((size_t)V + 1));
+  const size_t o_order = take(sizeof(int32_t) * (size_t)V), o_rowb = take(sizeof(int32_t) * 2 * 256);
   const size_t o_stash = take(sizeof(int32_t) * 3 * kStash * (size_t)V), o_tris = take(sizeof(int32_t) * 3 * (size_t)tmax);
   if (off > sc->dev_cap) {
     DT_HIPCHK(hipStreamSynchronize(s));
@@ -834,6 +890,8 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   int32_t* sums = reinterpret_cast<int32_t*>(d + o_sums);
   int32_t* tcnt = reinterpret_cast<int32_t*>(d + o_tcnt);
   int32_t* toff = reinterpret_cast<int32_t*>(d + o_toff);
+  int32_t* order = reinterpret_cast<int32_t*>(d + o_order);
+  int32_t* rowb = reinterpret_cast<int32_t*>(d + o_rowb);
   int32_t* stash = reinterpret_cast<int32_t*>(d + o_stash);
   int32_t* dtris = reinterpret_cast<int32_t*>(d + o_tris);
   int32_t* hflags = reinterpret_cast<int32_t*>(sc->pin + p_flags);
@@ -854,6 +912,8 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
     hipLaunchKernelGGL(k_dt_scatter, dim3(gv), dim3(B), 0, s, ixy, cell_of, V, start, cnt, rec0);
     hipLaunchKernelGGL(k_dt_dups, dim3(gv), dim3(B), 0, s, rec0, rec, start, V, flags);
     hipLaunchKernelGGL(k_dt_rows, dim3((unsigned)G), dim3(64), 0, s, rec, start, G, flags, rows);
+    hipLaunchKernelGGL(k_dt_order_rows, dim3(1), dim3(256), 0, s, start, G, rowb, rowb + 256);
+    hipLaunchKernelGGL(k_dt_order_fill, dim3(gv), dim3(B), 0, s, start, rowb, rowb + 256, G, V, order);
   }
   static const bool dt_stats = std::getenv("FLAME_HIP_DT_STATS") != nullptr;
   int32_t* dbg = nullptr;
@@ -863,6 +923,7 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   }
   DtView view;
   view.rec = rec; view.start = start; view.row = rows; view.flags = flags; view.G = G; view.V = V; view.dbg = dbg;
+  view.order = small ? nullptr : order;  // (a small frame's stars all run at once)
   const int per_wg = kStarWG / kSW;  // stars per workgroup
   const unsigned gs = (unsigned)((V + per_wg - 1) / per_wg);
   hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
