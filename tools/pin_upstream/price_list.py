@@ -82,6 +82,31 @@ def main():
         o.solve(default_params(), iters)
         price("edge orientation i<j -> j<i (K1 uses w of the SOURCE)", o.x, "orientation rule of graph sync is recalled")
         rows.append((name, "sign of the edge vector d (option d_sign)", 0.0, 0.0, "provably none: K10"))
+        # ---- the triangulation in front (row f3's first leg): which diagonal cuts a cocircular cell.  Integer-pixel features
+        # (what a detector produces) are full of cocircular quadruples; the built-in triangulators cut them by their own
+        # rules (GPU: a fan from the smallest vertex id; host: the divide-and-conquer's), upstream's Triangle by another.
+        # Two valid Delaunay triangulations of the SAME integer-pixel features: SciPy's on the points as they are and on
+        # the points moved by < 1e-3 pixel (every tie broken at random) ----
+        if name != "5k":
+            from scipy.spatial import Delaunay
+            pix = np.round(g.pos).astype(np.float32)
+            pix = pix[np.unique(pix, axis=0, return_index=True)[1]]
+            zz = (0.5 + 0.001 * pix[:, 0]).astype(np.float32) + (0.02 * rng.standard_normal(len(pix))).astype(np.float32)
+
+            def run_on(points_for_ties):
+                t = Delaunay(points_for_ties.astype(np.float64)).simplices.astype(np.int32)
+                P = pix.astype(np.float64)
+                d = (P[t[:, 1], 0] - P[t[:, 0], 0]) * (P[t[:, 2], 1] - P[t[:, 0], 1]) - (P[t[:, 1], 1] - P[t[:, 0], 1]) * (P[t[:, 2], 0] - P[t[:, 0], 0])
+                t = t[d != 0]
+                s_ = graph_sync(SyncParams(0, 0, 1, 0.01, 0, 0.0, 0.0), pix, zz, np.full(len(pix), 1e-4, np.float32), t, None)
+                o_ = COracle(pix, s_["edges"], s_["alpha"], s_["beta"], s_["z"], s_["wgt"], x0=s_["x0"])
+                o_.solve(default_params(), iters)
+                return o_.x.copy(), len(s_["edges"])
+            xa, ea = run_on(pix)
+            xb, eb = run_on(pix + rng.uniform(-1e-3, 1e-3, pix.shape))
+            dd = xa.astype(np.float64) - xb
+            rows.append((name, "Delaunay ties of integer-pixel features cut another way (%d features)" % len(pix), float(np.sqrt(np.mean(dd * dd))),
+                         float(np.abs(dd).max()), "a frame-level pin needs upstream's triangles; the graph-level pin (this directory) hands the edges over"))
         # ---- triangle stage (row a8): validity flips at the regularised state ----
         Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
         W, H = g.width, g.height
