@@ -322,6 +322,10 @@ struct flame_hip_graph {
   // RESIDENT tiles (kernels.hip k_tile_persist: round-tagged hand-offs through uncached memory instead of a kernel
   // boundary per `depth` iterations); 0: launches
   bool persist = true, persist_used = false;
+  float4 *snapA = nullptr, *snapB = nullptr, *snapq = nullptr;  // flame_hip_state_snapshot / _rollback
+  bool snap_valid = false;
+  int64_t persist_launches = 0;     // launches of resident tiles so far (info "persist_launches")
+  int32_t snap_V = 0, snap_E = 0;
   PersistBufs xp;                   // hand-off buffers (uncached, from the process-wide pool: NOT in caps) + dev-aid words
   size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
   int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
@@ -477,6 +481,7 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
 
 static void persist_lease_drop(flame_hip_graph* g, bool gave_up);
 static int persist_gave_up_count(int device);
+static int persist_backoff(int device);
 
 void flame_hip_graph_destroy(flame_hip_graph* g) {
   if (!g) return;
@@ -635,6 +640,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "persist") *value = g->persist ? 1 : 0;
   else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
   else if (k == "persist_recovered") *value = g->persist_recovered;
+  else if (k == "persist_launches") *value = g->persist_launches;
   else if (k == "persist_gave_up") *value = persist_gave_up_count(g->device);  // (give-ups of any handle on this device)
   else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF=<tile + 1>): 10 ns ticks of that tile, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
@@ -700,7 +706,10 @@ struct GraphOptScope {
   int saved_single_max, saved_depth;
   GraphOptScope(flame_hip_graph* g_, int32_t V) : g(g_), saved_single_max(g_->opt.single_max), saved_depth(g_->opt.tile_depth) {
     g->opt.single_max = std::min(g->opt.single_max, g->single_cap);
-    g->opt.resident = g->persist;  // (plan-only handles size their tiles the same way: they are the device plans' reference)
+    // (plan-only handles size their tiles the same way: they are the device plans' reference.  ADVICE r4: the depth follows
+    // whether resident tiles can actually be taken -- not while the device's lease sits out a back-off after a give-up, not
+    // under the in-kernel timeline -- because depth 5 by ordinary launches is the slower configuration)
+    g->opt.resident = g->persist && !g->prof && (g->device < 0 || persist_backoff(g->device) == 0);
     if (g->stream_depth > 0 && g->opt.tile_depth == 0 && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() && V <= 64 * 32)
       g->opt.tile_depth = g->stream_depth;
   }
@@ -1513,6 +1522,8 @@ struct PersistLease {
   std::mutex m;
   flame_hip_graph* holder = nullptr;
   hipEvent_t holder_done = nullptr;  // (the holder's ev1)
+  hipStream_t holder_stream = nullptr;  // the stream its launch went to: a launch queued BEHIND it on the same stream can
+                                     // never be co-resident with it (the partition mode's parts of one rank)
   bool recorded = false;             // the holder's end event has been recorded behind its launch (until then: busy)
   int backoff = 0;                   // solves (of any handle) to sit out
   int backoff_next = 16;
@@ -1522,13 +1533,15 @@ static PersistLease& persist_lease(int device) {
   static PersistLease leases[64];
   return leases[(unsigned)device & 63];
 }
-static bool persist_lease_take(flame_hip_graph* g) {
+static bool persist_lease_take(flame_hip_graph* g, hipStream_t s) {
   PersistLease& L = persist_lease(g->device);
   std::lock_guard<std::mutex> lk(L.m);
   if (L.backoff > 0) { --L.backoff; return false; }
-  if (L.holder && L.holder != g && (!L.recorded || hipEventQuery(L.holder_done) != hipSuccess)) return false;
+  if (L.holder && L.holder != g && (!L.recorded || (L.holder_stream != s && hipEventQuery(L.holder_done) != hipSuccess)))
+    return false;
   L.holder = g;
   L.holder_done = g->ev1;
+  L.holder_stream = s;
   L.recorded = false;  // (flame_hip_solve records ev1 behind the launch, then persist_lease_recorded())
   return true;
 }
@@ -1542,10 +1555,15 @@ static int persist_gave_up_count(int device) {
   std::lock_guard<std::mutex> lk(L.m);
   return L.gave_up;
 }
+static int persist_backoff(int device) {
+  PersistLease& L = persist_lease(device);
+  std::lock_guard<std::mutex> lk(L.m);
+  return L.backoff;
+}
 static void persist_lease_drop(flame_hip_graph* g, bool gave_up) {
   PersistLease& L = persist_lease(g->device);
   std::lock_guard<std::mutex> lk(L.m);
-  if (L.holder == g) { L.holder = nullptr; L.holder_done = nullptr; }
+  if (L.holder == g) { L.holder = nullptr; L.holder_done = nullptr; L.holder_stream = nullptr; }
   if (gave_up) {
     ++L.gave_up;
     L.backoff = L.backoff_next;
@@ -1604,7 +1622,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
-    if (persist_applies(g, num_iters) && persist_lease_take(g)) {
+    if (persist_applies(g, num_iters) && persist_lease_take(g, s)) {
       PersistBufs& x = g->xp;
       int rc;
       if (!g->persist_err) {
@@ -1645,6 +1663,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       g->persist_used = true;
       g->persist_unchecked = true;
       ++g->persist_unchecked_n;
+      ++g->persist_launches;
       g->last_src = cur;
       *launches = 1;
       *cur_out = cur ^ 1;  // (written once, by the last round; the source buffers are only read)
@@ -1701,6 +1720,9 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   }
   HIPCHK(hipEventRecord(g->ev0, s));
   g->last_sp = sp; g->last_iters = num_iters; g->last_stream = s;
+  // (a hipGraph replay or a solve of 0 iterations does not pass through enqueue_iterations(); without this a
+  // stale `persist_used` made persist_check() repeat the SHORT solve from buffers the replay had already overwritten)
+  g->persist_used = false;
   int launches = 0, cur_out = g->cur;
   if (num_iters > 0 && g->V > 0) {
     if (g->use_graph && g->solves_since_upload > 0 && !persist_applies(g, num_iters)) {  // a frame stream that re-uploads before
@@ -2257,6 +2279,68 @@ int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* st
   HIPCHK(launch_halo_unpack(s, g->n_recv_v, g->n_recv_e, g->halo_recv_v, g->halo_recv_e,
                             (const float*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
   g->state_serial++;
+  return 0;
+}
+
+// ---- state snapshot / rollback: what makes a give-up of resident tiles recoverable where the handle alone cannot repeat
+// the solve (partition mode: by the time the host looks, the halo unpack has rewritten the state and peers have received
+// records of the unfinished solve).  The partition layer snapshots every part in front of the solves it queues between
+// two synchronising calls, and, when ANY rank reports a give-up at the next one, rolls all parts back and repeats those
+// solves by launches (csrc/part.cpp).  Device-to-device copies on the caller's stream; a few MB, once per synchronising
+// call -- not per exchange period.
+int flame_hip_state_snapshot(flame_hip_graph* g, void* stream) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  const size_t V = (size_t)g->V, E = (size_t)std::max(g->E, 1);
+  if ((rc = dev_alloc(g->caps, &g->snapA, V)) || (rc = dev_alloc(g->caps, &g->snapB, V)) || (rc = dev_alloc(g->caps, &g->snapq, E)))
+    return rc;
+  HIPCHK(order_after_state(g, s));
+  if (g->timed && g->last_stream && g->last_stream != s) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));
+  HIPCHK(hipMemcpyAsync(g->snapA, g->A[g->cur], sizeof(float4) * V, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->snapB, g->B[g->cur], sizeof(float4) * V, hipMemcpyDeviceToDevice, s));
+  if (g->E > 0) HIPCHK(hipMemcpyAsync(g->snapq, g->q[g->cur], sizeof(float4) * (size_t)g->E, hipMemcpyDeviceToDevice, s));
+  g->snap_valid = true;
+  g->snap_V = g->V; g->snap_E = g->E;
+  return 0;
+}
+
+int flame_hip_state_rollback(flame_hip_graph* g, void* stream) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!g->snap_valid || g->snap_V != g->V || g->snap_E != g->E) return FLAME_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  HIPCHK(order_after_state(g, s));
+  if (g->timed && g->last_stream && g->last_stream != s) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));
+  const size_t V = (size_t)g->V;
+  HIPCHK(hipMemcpyAsync(g->A[g->cur], g->snapA, sizeof(float4) * V, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->B[g->cur], g->snapB, sizeof(float4) * V, hipMemcpyDeviceToDevice, s));
+  if (g->E > 0) HIPCHK(hipMemcpyAsync(g->q[g->cur], g->snapq, sizeof(float4) * (size_t)g->E, hipMemcpyDeviceToDevice, s));
+  g->state_serial++;
+  g->uploaded = true;  // (a give-up the handle could not repeat had marked the state unfinished)
+  return 0;
+}
+
+// Did a launch of resident tiles of this handle give up since the last look?  For a caller that has synchronised the
+// stream(s) the solves ran on and owns the recovery (the partition layer): reads and clears the error word, puts the
+// device's lease into its back-off, and does NOT try to repeat anything on this handle alone.
+int flame_hip_persist_take_error(flame_hip_graph* g, int32_t* gave_up) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!gave_up) return FLAME_HIP_ERR_ARG;
+  static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
+  *gave_up = 0;
+  const bool had = g->persist_unchecked;
+  g->persist_unchecked = false;
+  g->persist_unchecked_n = 0;
+  if (had && g->persist_err && (*g->persist_err != 0 || force_fail)) {
+    *g->persist_err = 0;
+    persist_lease_drop(g, true);
+    g->persist_used = false;
+    *gave_up = 1;
+  }
   return 0;
 }
 

@@ -13,6 +13,7 @@
 // RCCL is loaded with dlopen at the first use (librccl.so.1): the solver library itself keeps no link-time dependency
 // on it, and a process that already holds an RCCL (PyTorch) shares that copy.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -48,6 +49,8 @@ struct Rccl {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   bool ok = false;
 };
 
@@ -63,9 +66,10 @@ Rccl& rccl() {
 #define SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, #sym))
     SYM(GetUniqueId, ncclGetUniqueId); SYM(CommInitRank, ncclCommInitRank); SYM(CommDestroy, ncclCommDestroy);
     SYM(GroupStart, ncclGroupStart); SYM(GroupEnd, ncclGroupEnd); SYM(Send, ncclSend); SYM(Recv, ncclRecv);
-    SYM(AllReduce, ncclAllReduce);
+    SYM(AllReduce, ncclAllReduce); SYM(AllGather, ncclAllGather); SYM(CommCount, ncclCommCount);
 #undef SYM
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce;
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.AllReduce &&
+           r.AllGather && r.CommCount;
   });
   return r;
 }
@@ -213,6 +217,11 @@ struct flame_hip_comm {
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
   double* red = nullptr;  // device: 2 doubles (cost reduction)
+  int32_t* flag = nullptr;  // device: the ranks' "a launch of resident tiles gave up" word (flame_hip_part_sync)
+  int rccl_ranks = 0;       // ncclCommCount
+  bool shared_gpu = false;  // two ranks of this communicator sit on one GPU: their parts solve by launches (resident
+                            // tiles assume the whole chip; dist.py / bench.py guard the same case)
+  std::vector<flame_hip_part*> parts;  // the parts built on this communicator (destroyed first, or detached)
 };
 
 struct flame_hip_part {
@@ -224,6 +233,14 @@ struct flame_hip_part {
   std::vector<P2P> ops;      // this rank's sends, then its receives, each sorted by (src, dst, kind)
   int rings_left = 0;
   int64_t exchanges = 0;
+  int device = -1;
+  bool persist = true;       // the parts solve with resident tiles (off when ranks share a GPU)
+  // the solves queued since the last synchronising call, and the rings the first of them started on: what
+  // flame_hip_part_sync repeats by launches, from the snapshot, when any rank's resident tiles gave up
+  struct Call { flame_hip_params p; int32_t n; };
+  std::vector<Call> txn;
+  int txn_rings = 0;
+  int64_t recovered = 0;
 };
 
 namespace {
@@ -385,9 +402,50 @@ int flame_hip_comm_create(flame_hip_comm** out, int device, int rank, int world,
   if (e != hipSuccess) { flame_hip_comm_destroy(c); return FLAME_HIP_ERR_HIP - (int)e; }
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
-  const ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+  ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
   if (r != ncclSuccess) { c->comm = nullptr; flame_hip_comm_destroy(c); return FLAME_HIP_ERR_RCCL - (int)r; }
+  r = rccl().CommCount(c->comm, &c->rccl_ranks);
+  if (r != ncclSuccess) { flame_hip_comm_destroy(c); return FLAME_HIP_ERR_RCCL - (int)r; }
+  // which GPU every rank sits on: {host name hash, PCI domain:bus:device} gathered over the communicator itself
+  {
+    long long* ids = nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&ids), sizeof(long long) * 2 * (size_t)world);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->flag), sizeof(int32_t));
+    std::vector<long long> host(2 * (size_t)world, 0);
+    if (e == hipSuccess) {
+      char name[256] = {0};
+      (void)gethostname(name, sizeof(name) - 1);
+      unsigned long long h = 1469598103934665603ull;
+      for (const char* q = name; *q; ++q) h = (h ^ (unsigned char)*q) * 1099511628211ull;
+      hipDeviceProp_t pr;
+      long long pci = device;
+      if (hipGetDeviceProperties(&pr, device) == hipSuccess) pci = ((long long)pr.pciDomainID << 32) | ((long long)pr.pciBusID << 8) | pr.pciDeviceID;
+      const long long mine[2] = {(long long)h, pci};
+      e = hipMemcpyAsync(ids + 2 * rank, mine, sizeof(mine), hipMemcpyHostToDevice, c->stream);
+      if (e == hipSuccess) r = rccl().AllGather(ids + 2 * rank, ids, 2, ncclInt64, c->comm, c->stream);
+      if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(host.data(), ids, sizeof(long long) * 2 * (size_t)world, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (ids) (void)hipFree(ids);
+    if (r != ncclSuccess) { flame_hip_comm_destroy(c); return FLAME_HIP_ERR_RCCL - (int)r; }
+    if (e != hipSuccess) { flame_hip_comm_destroy(c); return FLAME_HIP_ERR_HIP - (int)e; }
+    for (int a = 0; a < world && !c->shared_gpu; ++a)
+      for (int b = a + 1; b < world; ++b)
+        if (host[2 * (size_t)a] == host[2 * (size_t)b] && host[2 * (size_t)a + 1] == host[2 * (size_t)b + 1]) { c->shared_gpu = true; break; }
+  }
   *out = c;
+  return 0;
+}
+
+int flame_hip_comm_info(const flame_hip_comm* c, const char* key, int64_t* value) {
+  if (!c || !key || !value) return FLAME_HIP_ERR_ARG;
+  const std::string k(key);
+  if (k == "rank") *value = c->rank;
+  else if (k == "world") *value = c->world;
+  else if (k == "rccl_ranks") *value = c->rccl_ranks;
+  else if (k == "device") *value = c->device;
+  else if (k == "shared_gpu") *value = c->shared_gpu ? 1 : 0;
+  else return FLAME_HIP_ERR_ARG;
   return 0;
 }
 
@@ -395,8 +453,12 @@ void flame_hip_comm_destroy(flame_hip_comm* c) {
   if (!c) return;
   if (c->device >= 0) (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  // (a part keeps a pointer to its communicator.  Parts that outlive it are detached here -- they can still be
+  // destroyed, nothing else: every other entry point refuses a part without a communicator)
+  for (flame_hip_part* P : c->parts) P->comm = nullptr;
   if (c->comm) (void)rccl().CommDestroy(c->comm);
   if (c->red) (void)hipFree(c->red);
+  if (c->flag) (void)hipFree(c->flag);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -405,9 +467,11 @@ void* flame_hip_comm_stream(flame_hip_comm* c) { return c ? (void*)c->stream : n
 
 void flame_hip_part_destroy(flame_hip_part* P) {
   if (!P) return;
+  if (P->device >= 0) (void)hipSetDevice(P->device);
   if (P->comm) {
-    (void)hipSetDevice(P->comm->device);
     (void)hipStreamSynchronize(P->comm->stream);
+    auto& v = P->comm->parts;
+    v.erase(std::remove(v.begin(), v.end(), P), v.end());
   }
   for (LocalPart& L : P->parts) {
     if (L.g) flame_hip_graph_destroy(L.g);
@@ -424,7 +488,7 @@ int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t pl
   if (!out) return FLAME_HIP_ERR_ARG;
   *out = nullptr;
   if (parts_per_rank < 1 || halo_depth < 1 || halo_depth > 16 || V < 1 || E < 0 || !pos || (E > 0 && !edges)) return FLAME_HIP_ERR_ARG;
-  if (comm && (!alpha || !beta || !z || !wgt) && E > 0) return FLAME_HIP_ERR_ARG;
+  if (comm && (!z || !wgt || (E > 0 && (!alpha || !beta)))) return FLAME_HIP_ERR_ARG;  // (z / wgt are read whatever E is)
   for (int32_t e = 0; e < E; ++e)
     if (edges[2 * e] < 0 || edges[2 * e] >= V || edges[2 * e + 1] < 0 || edges[2 * e + 1] >= V) return FLAME_HIP_ERR_ARG;
   flame_hip_part* P = new (std::nothrow) flame_hip_part();
@@ -437,6 +501,9 @@ int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t pl
   int rc = plan_parts(P, pos, edges);
   if (rc) { flame_hip_part_destroy(P); return rc; }
   if (comm) {
+    P->device = comm->device;
+    P->persist = !comm->shared_gpu;
+    try { comm->parts.push_back(P); } catch (...) { P->comm = nullptr; flame_hip_part_destroy(P); return FLAME_HIP_ERR_ALLOC; }
     if (hipSetDevice(comm->device) != hipSuccess) { flame_hip_part_destroy(P); return FLAME_HIP_ERR_NODEVICE; }
     for (LocalPart& L : P->parts) {
       const Subdomain& s = L.sub;
@@ -451,6 +518,7 @@ int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t pl
       }
       for (int32_t k = 0; k < ne; ++k) { la[(size_t)k] = alpha[(size_t)s.eid[(size_t)k]]; lb[(size_t)k] = beta[(size_t)s.eid[(size_t)k]]; }
       if ((rc = flame_hip_graph_create(&L.g, comm->device, nv, ne, 0)) ||
+          (rc = flame_hip_set_option(L.g, "persist", P->persist ? 1 : 0)) ||
           (rc = flame_hip_graph_upload(L.g, lp.data(), s.ledges.data(), la.data(), lb.data(), lz.data(), lw.data(),
                                        x0 ? lx.data() : nullptr, nullptr)) ||
           (rc = flame_hip_halo_register(L.g, (int32_t)L.send_v.size(), L.send_v.data(), (int32_t)L.send_e.size(), L.send_e.data(),
@@ -476,8 +544,8 @@ int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t pl
 // initial x of the whole graph (caller's order; x0 may be NULL = z).  The state restarts exact on every ring.
 int flame_hip_part_update_data(flame_hip_part* P, const float* z, const float* wgt, const float* x0) {
   if (!P || !P->comm || !z || !wgt) return FLAME_HIP_ERR_ARG;
-  HIPCHK(hipSetDevice(P->comm->device));
-  HIPCHK(hipStreamSynchronize(P->comm->stream));
+  int rc0;
+  if ((rc0 = flame_hip_part_sync(P))) return rc0;
   for (LocalPart& L : P->parts) {
     const size_t nv = L.sub.vid.size();
     std::vector<float> lz(nv), lw(nv), lx;
@@ -497,9 +565,8 @@ int flame_hip_part_update_data(flame_hip_part* P, const float* z, const float* w
 // Every local iteration invalidates one halo ring; an exchange (the owners' exact state) makes all `depth` rings
 // valid again.  Successive calls continue on whatever rings the previous one left.  Everything is enqueued on the
 // communicator's stream: no host synchronisation inside.
-int flame_hip_part_solve(flame_hip_part* P, const flame_hip_params* p, int32_t num_iters) {
-  if (!P || !P->comm || !p || num_iters < 0) return FLAME_HIP_ERR_ARG;
-  HIPCHK(hipSetDevice(P->comm->device));
+// (the iterations themselves: shared by flame_hip_part_solve and the repeat of a give-up)
+static int run_iterations(flame_hip_part* P, const flame_hip_params* p, int32_t num_iters) {
   int rc;
   for (int32_t done = 0; done < num_iters;) {
     if (P->rings_left == 0) {
@@ -515,13 +582,57 @@ int flame_hip_part_solve(flame_hip_part* P, const flame_hip_params* p, int32_t n
   return 0;
 }
 
+int flame_hip_part_solve(flame_hip_part* P, const flame_hip_params* p, int32_t num_iters) {
+  if (!P || !P->comm || !p || num_iters < 0) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(P->comm->device));
+  int rc;
+  if (P->txn.empty() && P->persist) {  // the first solve since a synchronising call: what a give-up rolls back to
+    for (LocalPart& L : P->parts)
+      if ((rc = flame_hip_state_snapshot(L.g, P->comm->stream))) return rc;
+    P->txn_rings = P->rings_left;
+  }
+  if (P->persist) {
+    try { P->txn.push_back({*p, num_iters}); } catch (...) { return FLAME_HIP_ERR_ALLOC; }
+  }
+  return run_iterations(P, p, num_iters);
+}
+
+// Resident tiles that gave up (a wait of theirs timed out: a foreign kernel held CUs) leave an unfinished solve behind,
+// and by now its records have travelled to the peers.  The ranks agree on it (one 4-byte all-reduce), every rank rolls
+// its parts back to the snapshot and repeats the queued solves by ordinary launches.
 int flame_hip_part_sync(flame_hip_part* P) {
   if (!P || !P->comm) return FLAME_HIP_ERR_ARG;
-  HIPCHK(hipSetDevice(P->comm->device));
-  HIPCHK(hipStreamSynchronize(P->comm->stream));
+  flame_hip_comm* C = P->comm;
+  HIPCHK(hipSetDevice(C->device));
+  HIPCHK(hipStreamSynchronize(C->stream));
   int rc;
+  int32_t bad = 0;
+  for (LocalPart& L : P->parts) {
+    int32_t one = 0;
+    if ((rc = flame_hip_persist_take_error(L.g, &one))) return rc;
+    bad |= one;
+  }
+  if (P->txn.empty()) return 0;  // (nothing queued since the last call: no rank has anything to agree on)
+  if (C->world > 1) {
+    HIPCHK(hipMemcpyAsync(C->flag, &bad, sizeof(bad), hipMemcpyHostToDevice, C->stream));
+    NCCLCHK(rccl().AllReduce(C->flag, C->flag, 1, ncclInt32, ncclMax, C->comm, C->stream));
+    HIPCHK(hipMemcpyAsync(&bad, C->flag, sizeof(bad), hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipStreamSynchronize(C->stream));
+  }
+  std::vector<flame_hip_part::Call> calls;
+  calls.swap(P->txn);
+  if (!bad) return 0;
   for (LocalPart& L : P->parts)
-    if ((rc = flame_hip_sync(L.g))) return rc;
+    if ((rc = flame_hip_state_rollback(L.g, C->stream)) || (rc = flame_hip_set_option(L.g, "persist", 0))) return rc;
+  P->rings_left = P->txn_rings;
+  for (const flame_hip_part::Call& c : calls)
+    if ((rc = run_iterations(P, &c.p, c.n))) return rc;
+  HIPCHK(hipStreamSynchronize(C->stream));
+  for (LocalPart& L : P->parts) {
+    int32_t one = 0;
+    if ((rc = flame_hip_persist_take_error(L.g, &one)) || (rc = flame_hip_set_option(L.g, "persist", 1))) return rc;
+  }
+  P->recovered += (int64_t)calls.size();
   return 0;
 }
 
@@ -532,11 +643,13 @@ int flame_hip_part_costs(flame_hip_part* P, const flame_hip_params* p, double* s
   flame_hip_comm* C = P->comm;
   HIPCHK(hipSetDevice(C->device));
   int rc;
+  if ((rc = flame_hip_part_sync(P))) return rc;  // (first: a give-up is repeated from the snapshot, which an exchange queued
+                                                  // in front of it would not survive)
   if (P->rings_left == 0 && P->depth > 0 && P->world * P->k > 1) {  // an owned edge reads its target in ring 1
     if ((rc = exchange(P))) return rc;
     P->rings_left = P->depth;
+    HIPCHK(hipStreamSynchronize(C->stream));
   }
-  if ((rc = flame_hip_part_sync(P))) return rc;
   double acc[2] = {0.0, 0.0};
   for (LocalPart& L : P->parts) {
     double s = 0.0, d = 0.0;
@@ -602,6 +715,8 @@ int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_
   if (k == "exchanges") { *value = P->exchanges; return 0; }
   if (k == "p2p_ops") { *value = (int64_t)P->ops.size(); return 0; }
   if (k == "rings_left") { *value = P->rings_left; return 0; }
+  if (k == "recovered") { *value = P->recovered; return 0; }
+  if (k == "persist") { *value = P->persist ? 1 : 0; return 0; }
   if (local_part < 0 || local_part >= P->k) return FLAME_HIP_ERR_ARG;
   const LocalPart& L = P->parts[(size_t)local_part];
   if (k == "part_id") *value = L.sub.part_id;
@@ -611,7 +726,7 @@ int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_
   else if (k == "num_peers") *value = (int64_t)L.peers.size();
   else if (k == "send_bytes") *value = 4 * (int64_t)(kVRec * L.send_v.size() + kERec * L.send_e.size());
   else if (k == "recv_bytes") *value = 4 * (int64_t)(kVRec * L.recv_v.size() + kERec * L.recv_e.size());
-  else if (k == "persist_used") { return L.g ? flame_hip_get_info(L.g, "persist_used", value) : FLAME_HIP_ERR_STATE; }
+  else if (k == "persist_used" || k == "persist_launches") { return L.g ? flame_hip_get_info(L.g, key, value) : FLAME_HIP_ERR_STATE; }
   else return FLAME_HIP_ERR_ARG;
   return 0;
 }

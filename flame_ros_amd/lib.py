@@ -86,6 +86,10 @@ SYMBOLS = {
     "flame_hip_comm_create": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int, C.c_int, _VP]),
     "flame_hip_comm_destroy": (None, [_VP]),
     "flame_hip_comm_stream": (_VP, [_VP]),
+    "flame_hip_comm_info": (C.c_int, [_VP, C.c_char_p, C.POINTER(_I64)]),
+    "flame_hip_state_snapshot": (C.c_int, [_VP, _VP]),
+    "flame_hip_state_rollback": (C.c_int, [_VP, _VP]),
+    "flame_hip_persist_take_error": (C.c_int, [_VP, C.POINTER(_I32)]),
     "flame_hip_part_create": (C.c_int, [C.POINTER(_VP), _VP, _I32, _I32, _I32, _I32, _I32, _I32] + [_VP] * 7),
     "flame_hip_part_destroy": (None, [_VP]),
     "flame_hip_part_solve": (C.c_int, [_VP, C.POINTER(Params), _I32]),

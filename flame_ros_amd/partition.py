@@ -29,6 +29,12 @@ class Communicator:
         _l.check(self._lib.flame_hip_comm_create(C.byref(self._h), device, rank, world, self._uid), "flame_hip_comm_create")
         self.rank, self.world = rank, world
 
+    def info(self, key):
+        """"rank", "world", "rccl_ranks" (ncclCommCount), "device", "shared_gpu"."""
+        v = C.c_int64()
+        _l.check(self._lib.flame_hip_comm_info(self._h, key.encode(), C.byref(v)), "flame_hip_comm_info(%s)" % key)
+        return v.value
+
     def close(self):
         if self._h:
             self._lib.flame_hip_comm_destroy(self._h)

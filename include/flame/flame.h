@@ -303,6 +303,7 @@ class Flame {
         if (ok)
           ok = updateGraphLocked(in.time, in.img_id, g.vtx, g.idepth_mu, g.idepth_var, tris,
                                  g.prediction.empty() ? nullptr : &g.prediction, &fs);
+        tris_in_library_ = false;  // (also when the graph update was not reached)
         tri_buf_.swap(tris);
       }
     }
@@ -318,6 +319,10 @@ class Flame {
     (void)time;
     (void)img_id;
     const int32_t V = static_cast<int32_t>(vtx.size()), T = static_cast<int32_t>(triangles.size());
+    // (read and cleared before anything can return -- a frame that fails its size check must not leave the flag
+    // set for a later updateGraph() with caller-supplied triangles, which would then silently use the library's old list)
+    const bool tris_in_library = tris_in_library_;
+    tris_in_library_ = false;
     if (idepth_mu.size() != vtx.size() || idepth_var.size() != vtx.size() ||
         (prediction && prediction->size() != vtx.size()))
       return fail(FLAME_HIP_ERR_ARG);
@@ -331,8 +336,7 @@ class Flame {
                       sizeof(Edge) == 2 * sizeof(int32_t), "boundary types are packed");
     const float* pos = V ? reinterpret_cast<const float*>(vtx.data()) : nullptr;
     // (a list flame_hip_delaunay made for this very frame is read where the library still holds it)
-    const int32_t* tidx = (T && !tris_in_library_) ? reinterpret_cast<const int32_t*>(triangles.data()) : nullptr;
-    tris_in_library_ = false;
+    const int32_t* tidx = (T && !tris_in_library) ? reinterpret_cast<const int32_t*>(triangles.data()) : nullptr;
     flame_hip_sync_params sp;
     sp.adaptive_data_weights = params_.adaptive_data_weights;
     sp.rescale_data = params_.rescale_data;

@@ -292,6 +292,16 @@ int flame_hip_halo_register(flame_hip_graph* g, int32_t n_send_v, const int32_t*
 int flame_hip_halo_bytes(const flame_hip_graph* g, int64_t* send_bytes, int64_t* recv_bytes);
 int flame_hip_halo_pack(flame_hip_graph* g, void* send_buf_dev, void* stream);
 int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* stream);
+/* State snapshot / rollback (device-to-device, on `stream` or the handle's) and the resident tiles' give-up word, for a
+ * caller that owns the recovery of several handles at once -- the partition layer below: a give-up of ONE part cannot
+ * be repeated by that handle alone (its peers already hold records of the unfinished solve), so flame_hip_part_solve
+ * snapshots every part in front of the solves it queues, and flame_hip_part_sync, when any rank reports a give-up, rolls
+ * every part back and repeats those solves by launches.  take_error: call after synchronising the solve's stream;
+ * *gave_up = 1 when a launch of resident tiles of this handle timed out since the last look (the word is cleared, the
+ * device's lease backs off; nothing is repeated here). */
+int flame_hip_state_snapshot(flame_hip_graph* g, void* stream);
+int flame_hip_state_rollback(flame_hip_graph* g, void* stream);
+int flame_hip_persist_take_error(flame_hip_graph* g, int32_t* gave_up);
 
 /* ---- partition mode without Python (BASELINE.json configs 4 / 5): ONE graph cut into world x
  * parts_per_rank subdomains by recursive coordinate bisection (METIS is not in the image), every rank solves its parts
@@ -312,7 +322,7 @@ typedef struct flame_hip_part flame_hip_part;
 int flame_hip_rccl_available(void); /* 1: librccl.so loads and exports every entry point this file needs */
 int flame_hip_comm_get_unique_id(char id[FLAME_HIP_COMM_ID_BYTES]);
 int flame_hip_comm_create(flame_hip_comm** out, int device, int rank, int world, const char id[FLAME_HIP_COMM_ID_BYTES]);
-void flame_hip_comm_destroy(flame_hip_comm* c);
+void flame_hip_comm_destroy(flame_hip_comm* c); /* destroy the parts built on it FIRST (a part keeps the pointer) */
 void* flame_hip_comm_stream(flame_hip_comm* c); /* the hipStream_t everything of this communicator is ordered on */
 int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t plan_rank, int32_t plan_world,
                           int32_t parts_per_rank, int32_t halo_depth, int32_t V, int32_t E, const float* pos,
@@ -322,15 +332,23 @@ void flame_hip_part_destroy(flame_hip_part* p);
 /* num_iters more PD iterations, an exchange whenever the halo rings are used up; asynchronous on the communicator's
  * stream (no host synchronisation inside); successive calls continue on the rings the last one left */
 int flame_hip_part_solve(flame_hip_part* p, const flame_hip_params* params, int32_t num_iters);
+/* Waits for everything queued.  COLLECTIVE when world > 1 (one 4-byte ncclAllReduce): the ranks agree whether any launch
+ * of resident tiles gave up since the last synchronising call; if so EVERY rank rolls its parts back to the snapshot taken
+ * in front of the first solve since then and repeats those solves by ordinary launches (info "recovered" counts them) --
+ * a give-up costs time, never the result.  _costs, _gather and _update_data synchronise through this call. */
 int flame_hip_part_sync(flame_hip_part* p);
+/* "rank", "world", "rccl_ranks" (what RCCL itself reports: ncclCommCount), "device" */
+int flame_hip_comm_info(const flame_hip_comm* c, const char* key, int64_t* value);
 /* new frame on the unchanged topology: data terms, weights, initial x of the WHOLE graph (x0 NULL = z); state reset */
 int flame_hip_part_update_data(flame_hip_part* p, const float* z, const float* wgt, const float* x0);
 /* the whole graph's cost terms: owned sums of every part + one ncclAllReduce of 2 doubles.  Synchronises. */
 int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, double* smooth, double* data);
 /* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */
 int flame_hip_part_gather(flame_hip_part* p, float* x, float* w1, float* w2, float* q);
-/* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left"; per local part: "part_id", "n_own",
- * "n_ext", "e_loc", "num_peers", "send_bytes", "recv_bytes", "persist_used" */
+/* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left", "recovered" (solves repeated by launches after
+ * a give-up of resident tiles on any rank), "persist" (the parts solve with resident tiles); per local part: "part_id",
+ * "n_own", "n_ext", "e_loc", "num_peers", "send_bytes", "recv_bytes", "persist_used" (the part's LAST local solve was one launch
+ * of resident tiles), "persist_launches" (how many were, so far) */
 int flame_hip_part_info(const flame_hip_part* p, const char* key, int32_t local_part, int64_t* value);
 /* int32 arrays: "part" (V: the part of every vertex), per local part "vid", "eid", "edges", "e_owned", "peers",
  * "send_v", "send_e", "recv_v", "recv_e", "send_cnt", "recv_cnt"; returns the element count or a negative error */

@@ -30,8 +30,11 @@ with partition.Communicator(0, 0, 1, uid) as comm:
             p = default_params()
             ps.step(p, iters // 2)
             ps.step(p, iters - iters // 2)
+            was_resident = int(all(ps.info("persist_launches", i) > 0 for i in range(k)))  # (parts of one rank queue behind
+            assert was_resident == int(any(ps.info("persist_launches", i) > 0 for i in range(k)))  # each other on ONE stream)
             assert ps.info("p2p_ops") >= 2 * k and ps.info("exchanges") == (iters - 1) // depth, (ps.info("p2p_ops"), ps.info("exchanges"))
             x, w1, w2, q = ps.gather_solution()
+            assert ps.info("recovered") == (EXPECT_RECOVERED if was_resident else 0), (ps.info("recovered"), was_resident)
             sm, da = ps.costs(p)
             o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
             o.solve(oparams(), iters)
@@ -45,15 +48,32 @@ with partition.Communicator(0, 0, 1, uid) as comm:
                 ps.step(p, 33)
                 o2 = COracle(g.pos, g.edges, g.alpha, g.beta, z2, g.wgt); o2.solve(oparams(), 33)
                 assert np.array_equal(ps.gather_solution()[0].view(np.uint32), o2.x.view(np.uint32)), "update_data"
-            print("V %%d, %%d parts on rank 0, depth %%d: %%d P2P ops per exchange, %%d exchanges, resident tiles on part 0: %%d, bit-exact" %% (
-                V, k, depth, ps.info("p2p_ops"), ps.info("exchanges"), ps.info("persist_used", 0)))
+            if V == 50000:
+                assert was_resident == 1, "resident tiles in partition mode, on every part of the rank"
+            print("V %%d, %%d parts on rank 0, depth %%d: %%d P2P ops per exchange, %%d exchanges, resident tiles: %%d, "
+                  "solves repeated after a give-up: %%d, bit-exact" %% (
+                V, k, depth, ps.info("p2p_ops"), ps.info("exchanges"), was_resident, ps.info("recovered")))
+    assert comm.info("rccl_ranks") == 1 and comm.info("world") == 1 and comm.info("shared_gpu") == 0
 print("native partition ok")
 ''' % ROOT
 
 
 def test_native_rccl_partition_with_itself(gpu):
-    out = subprocess.run([sys.executable, "-c", CODE], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CODE.replace("EXPECT_RECOVERED", "0")], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
     assert out.returncode == 0 and "native partition ok" in out.stdout, out.stdout[-3000:] + out.stderr[-5000:]
+
+
+def test_native_partition_repeats_a_give_up(gpu):
+    """VERDICT r04 item 4 / ADVICE r04: a launch of resident tiles that gives up inside a partitioned solve used to be
+    FLAME_HIP_ERR_STATE (the halo unpack had rewritten the state, the peers held records of the unfinished solve).  Now
+    flame_hip_part_sync rolls every part back to the snapshot in front of the queued solves and repeats them by launches:
+    FLAME_HIP_PERSIST_FAIL makes every resident launch report a give-up; every result must still be the oracle's."""
+    env = dict(os.environ, FLAME_HIP_PERSIST_FAIL="1")
+    out = subprocess.run([sys.executable, "-c", CODE.replace("EXPECT_RECOVERED", "2")], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0 and "native partition ok" in out.stdout, out.stdout[-3000:] + out.stderr[-5000:]
+    assert "repeated after a give-up: 2" in out.stdout, out.stdout[-3000:]
 
 
 @pytest.mark.parametrize("parts,depth,iters,V", [(2, 8, 60, 8000), (3, 4, 25, 12000)])
