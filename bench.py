@@ -58,15 +58,36 @@ def parity_check(g, iters, device, opts):
             "oracle_smoothness_cost": so, "oracle_data_cost": do}
 
 
+def _summarize():
+    """profiles/summarize.py as a module: the LDS floor / roofline functions live beside the counter summaries they are
+    checked against (`python profiles/summarize.py --roofline <summary.json>` recomputes a line's block)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("flame_profiles_summarize", os.path.join(ROOT, "profiles", "summarize.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
 def kernel_src_sha():
     """Hash of the sources the committed PMC passes belong to (profiles/summarize.py writes the same):
     counters of an older kernel are not quoted."""
-    import hashlib
-    h = hashlib.sha256()
-    for rel in ("flame_ros_amd/csrc/kernels.hip", "flame_ros_amd/csrc/kernels.h", "flame_ros_amd/csrc/common.h",
-                "flame_ros_amd/csrc/plan.cpp"):
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
-    return h.hexdigest()[:16]
+    return _summarize().kernel_src_sha()
+
+
+def lds_block(r, us_per_iteration, iters_per_launch, counters=None, iterate_frac=None, measured_hbm_frac=None,
+              contract_frac=None):
+    """The on-chip roofline of a tile-path line: the LDS issue floor of the vertices / edges the
+    tiles OWN (from the plan, priced with the guide's LDS table, slowest CU) over the measured shader cycles per
+    iteration -- a fraction that cannot exceed 1 -- with the counters' redundancy / busy / conflict shares beside it."""
+    import numpy as np
+    S = _summarize()
+    fl = S.lds_floor(r.plan_array("tiles", np.int32), r.plan_array("t_srow", np.uint32), num_cus=r.info("num_cus") or 256)
+    if not fl:
+        return None
+    blk = S.lds_roofline(fl, us_per_iteration, r.info("clock_khz") / 1e3, iters_per_launch, counters, iterate_frac,
+                         measured_hbm_frac, contract_frac)
+    blk["lds_floor"] = fl
+    return blk
 
 
 def profiled_counters(workload, kernel):
@@ -190,21 +211,31 @@ def config_line(name, device, budget_s=2.0):
                         "num_tiles": r.info("num_tiles"), "tile_depth": r.info("tile_depth"),
                         "contract_frac": alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS})
             resident = bool(r.info("persist_used"))
-        kern = "k_tile_persist<" if resident else "k_tile<"
-        tr = profiled_counters(name, kern)
-        if tr and tr.get("bytes_per_launch") and not tr.get("stale"):
-            per_solve = tr["bytes_per_launch"] * launches
-            out["measured_hbm_frac"] = per_solve / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS
-            out["traffic_source"] = tr["source"]
-        if resident:
-            sp = resident_round_split(g, iters, device, {}, med * 1e3)
-            if sp:
-                out["iterate_frac"] = sp["iterate_frac_of_round"]
-                out["round_split_us"] = [sp["iterate_and_store"], sp["poll"], sp["apply_and_barrier"]]
-        else:
-            sp = tile_phase_split(g, iters, device, {}, med * 1e3 / max(launches, 1))
-            if sp:
-                out["iterate_frac"] = sp["iterate_frac_of_launch"]
+            kern = "k_tile_persist<" if resident else "k_tile<"
+            tr = profiled_counters(name, kern)
+            counters = None
+            if tr and not tr.get("stale"):
+                if tr.get("bytes_per_launch"):
+                    per_solve = tr["bytes_per_launch"] * launches
+                    out["measured_hbm_frac"] = per_solve / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                    out["traffic_source"] = tr["source"]
+                counters = tr.get("lds")
+            if resident:
+                sp = resident_round_split(g, iters, device, {}, med * 1e3)
+                if sp:
+                    out["iterate_frac"] = sp["iterate_frac_of_round"]
+                    out["round_split_us"] = [sp["iterate_and_store"], sp["poll"], sp["apply_and_barrier"]]
+            else:
+                sp = tile_phase_split(g, iters, device, {}, med * 1e3 / max(launches, 1))
+                if sp:
+                    out["iterate_frac"] = sp["iterate_frac_of_launch"]
+            blk = lds_block(r, med * 1e3 / iters, iters / max(launches, 1), counters, out.get("iterate_frac"),
+                            out.get("measured_hbm_frac"), out["contract_frac"])
+            if blk:  # the same keys as the headline line's roofline block
+                out["roofline"] = {k: blk[k] for k in ("bound", "frac", "floor_cycles_per_iteration",
+                                                        "measured_cycles_per_iteration", "work_redundancy", "lds_busy",
+                                                        "bank_conflict_share", "handoff_share", "measured_hbm_frac",
+                                                        "contract_frac") if k in blk}
     except Exception as e:  # noqa: BLE001 -- a side measurement
         out["error"] = str(e)[:200]
     return out
@@ -534,19 +565,14 @@ def main():
                          "note": "the same K-step window repeated after the timed one"} if repeat_ips else None),
             "frames_per_s": (1 if partition else world) * args.steps * nfr / elapsed,
             "us_per_iteration": elapsed / (args.steps * iters) * 1e6,
-            "roofline": {"bound": "hbm" if path != 2 else "lds+latency", "contract_bound": "hbm",
+            "roofline": {"bound": "hbm", "contract_bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": ("k_tile_persist" if resident else "k_tile") if path == 2 else "k_dual+k_primal",
                          "launch_us": launch_us, "iters_per_launch": iters_per_launch,
                          "alg_bytes_per_iter": alg_bytes_iter,
-                         "note": "achieved / frac = (84E+60V) x iterations per launch / mean launch "
-                                 "duration (HIP events on the solve stream, incl. launch gaps) against the HBM "
-                                 "peak: the contract's figure (contract_bound). The tile path keeps state in "
-                                 "LDS across iterations -- with resident tiles (k_tile_persist: ONE launch per solve) across "
-                                 "the whole solve -- so HBM does not bound it and frac may exceed 1 (measured_hbm_frac is the "
-                                 "counters' figure); `bound` names what does: the LDS pipeline inside an iteration and the "
-                                 "hand-off latency between rounds (round_split / phase_split, lds_frac, iterate_frac)."},
+                         "note": "global path: achieved / frac = (84E+60V) x iterations per launch / mean launch duration "
+                                 "(HIP events on the solve stream, incl. launch gaps) against the HBM peak (SURVEY 8d)."},
         }
         if part_info:
             out["partition"] = part_info
@@ -578,41 +604,43 @@ def main():
                 rl["measured_hbm_frac"] = rl["measured_hbm_gbps"] / HBM_PEAK_GBPS
                 if rl.get("blocked_floor_bytes_per_launch"):
                     rl["traffic_over_blocked_floor"] = tr["bytes_per_launch"] / rl["blocked_floor_bytes_per_launch"]
-            if tr.get("lds"):
-                L = tr["lds"]
-                ntl = max(r.info("num_tiles"), 1)
-                cus = 256.0
-                act = L.get("SQ_LDS_IDX_ACTIVE", 0.0) / min(ntl, cus)        # LDS-array cycles per busy CU
-                # issue floor from the guide's LDS table (cycles per wave-instruction): the kernel's
-                # LDS instructions are ds_read_b128 (4) and ds_write_b96 (array 8); take 4 as the floor
-                rl["lds"] = {"idx_active_cycles_per_cu_launch": act,
-                             "bank_conflict_cycles_per_cu_launch": L.get("SQ_LDS_BANK_CONFLICT", 0.0) / min(ntl, cus),
-                             "bank_conflict_share": L.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(L.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
-                             "insts_lds_per_cu_launch": L.get("SQ_INSTS_LDS", 0.0) / min(ntl, cus),
-                             "issue_floor_cycles_per_cu_launch": 4.0 * L.get("SQ_INSTS_LDS", 0.0) / min(ntl, cus),
-                             "note": "SQ_* from a separate rocprofv3 --pmc pass; floor = 4 LDS-array cycles per "
-                                     "wave-instruction (ds_read_b128, conflict-free; MI355X guide LDS table)"}
         if path == 2 and not args.batch and not partition:
             if resident:
                 rs_ = resident_round_split(g, iters, local_rank, opts, launch_us)
                 if rs_:
                     rl["round_split"] = rs_
                     rl["iterate_frac"] = rs_["iterate_frac_of_round"]
-                    if rl.get("lds"):
-                        rl["lds_frac"] = rl["lds"]["idx_active_cycles_per_cu_launch"] / max(launch_us * r.info("clock_khz") / 1e3, 1.0)
             else:
                 ps_ = tile_phase_split(g, iters, local_rank, opts, launch_us)
                 if ps_:
                     rl["phase_split"] = ps_
                     rl["iterate_frac"] = ps_["iterate_frac_of_launch"]
-                    if rl.get("lds"):
-                        rl["lds_frac"] = rl["lds"]["idx_active_cycles_per_cu_launch"] / max(launch_us * ps_["clock_mhz_assumed"], 1.0)
+        if path == 2 and not partition:
+            # The tile path keeps the state on chip across the iterations of a launch (resident tiles: of the whole solve),
+            # so the contract's HBM figure does not bound it (it read 1.36 at 50 k and 5.6 on the batch line in r04).  The
+            # primary roofline is the ON-CHIP one: LDS issue floor of the work the tiles OWN over the measured cycles per
+            # iteration (<= 1 by construction); the contract's number stays beside it as contract_frac.
+            contract = {"bound": "hbm", "achieved": rl["achieved"], "peak": rl["peak"], "unit": rl["unit"], "frac": rl["frac"],
+                        "note": "(84E+60V) x iterations per launch / launch duration / 8 TB/s: SURVEY 8d's figure; not a bound for "
+                                "a kernel whose state stays in LDS (may exceed 1)"}
+            blk = lds_block(r, launch_us / iters_per_launch, iters_per_launch, (tr or {}).get("lds") if tr and not tr.get("stale") else None,
+                            rl.get("iterate_frac"), rl.get("measured_hbm_frac"), contract["frac"])
+            if blk:
+                rl.update(blk)
+                rl["contract"] = contract
+                rl["note"] = ("bound = lds: frac = LDS issue floor of the slowest CU (2 ds_read_b128 + 2 ds_write_b96 per 64 own "
+                              "edges, max-degree slot reads + 1 store per 64 own vertices, priced 4 / 10 cycles: MI355X guide LDS "
+                              "table) / measured shader cycles per iteration (HIP events on the solve stream).  work_redundancy = "
+                              "executed / useful LDS wave-instructions (halo rings, padding lanes); lds_busy = SQ_LDS_IDX_ACTIVE per "
+                              "CU / cycles; handoff_share = 1 - iterate_frac (round_split); contract_frac = the SURVEY 8d HBM figure; "
+                              "measured_hbm_frac = PMC FETCH x2 + WRITE per launch / time / 8 TB/s.  Counters come from the committed "
+                              "rocprofv3 --pmc pass of the same sources (traffic_source); profiles/summarize.py --roofline recomputes.")
         if args.batch:
             out["metric"] = "primal-dual iterations/sec over a batch of %d independent %d-vertex graphs" % (
                 args.batch, frames[0].V)
             out["config"]["workload"] = "batch of %d feature-grid graphs (640x480, win %d), %d PD iterations each" % (
                 args.batch, args.batch_win, iters)
-            out["roofline"]["note"] += " Batch mode: value counts frame-iterations."
+            out["roofline"]["note"] += " Batch mode: value counts frame-iterations; one isolated tile (one CU) per frame."
         if world == 1 and not args.batch and not args.no_facade:
             out["facade_frame_ms"] = facade_frames()
             out["facade_frame_ms"]["note"] = ("median flame::Flame::update of a 40-frame stream through the C++ "

@@ -653,6 +653,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "delaunay_live") *value = g->dt.last_live;
   else if (k == "delaunay_us") *value = (int64_t)(g->dt.last_ms * 1000.0f);
   else if (k == "lds_bytes") *value = g->opt.lds_bytes;
+  else if (k == "num_cus") *value = g->num_cus;
   else if (k == "clock_khz") {  // peak engine clock of the handle's device (timeline cycles -> time)
     int khz = 0;
     if (g->device < 0 || hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, g->device) != hipSuccess) return FLAME_HIP_ERR_NODEVICE;
