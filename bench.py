@@ -170,9 +170,9 @@ def resident_round_split(g, iters, device, opts, solve_us):
         for t in sorted(set(int(x) for x in np.linspace(0, nt - 1, 12))):
             r.set_option("persist_prof", t + 1)
             r.step(pr, iters)
-            v = [r.info("persist_prof_%d" % k) for k in range(4)]
+            v = [r.info("persist_prof_%d" % k) for k in range(5)]
             if v[3] > 1:
-                rows.append([v[0] / (v[3] - 1) / 100.0, v[1] / (v[3] - 1) / 100.0, v[2] / (v[3] - 1) / 100.0])
+                rows.append([v[0] / (v[3] - 1) / 100.0, v[1] / (v[3] - 1) / 100.0, v[2] / (v[3] - 1) / 100.0, v[4] / (v[3] - 1)])
         r.set_option("persist_prof", 0)
     if not rows:
         return None
@@ -180,8 +180,8 @@ def resident_round_split(g, iters, device, opts, solve_us):
     rounds = -(-iters // d)
     return {"unit": "us per round, p50 over %d sampled tiles (wall_clock64 stamps, 10 ns ticks)" % len(rows),
             "iterations_per_round": int(d), "rounds": int(rounds), "iterate_and_store": float(a[0]), "poll": float(a[1]),
-            "apply_and_barrier": float(a[2]), "round_us_from_solve": solve_us / rounds,
-            "iterate_frac_of_round": float(a[0] / max(a.sum(), 1e-9)),
+            "apply_and_barrier": float(a[2]), "poll_passes_per_round_wave0": float(a[3]), "round_us_from_solve": solve_us / rounds,
+            "iterate_frac_of_round": float(a[0] / max(a[:3].sum(), 1e-9)),
             "note": "one launch per solve: no kernel boundary, no reload; a round ends with the tile's results stored "
                     "into uncached hand-off copies tagged with the round, then a poll of the neighbours' entries"}
 
@@ -313,6 +313,64 @@ def small_graphs(device):
     return out
 
 
+def library_partition(rank, world, device, uid, barrier, max_over_ranks, workload=None, parts_per_rank=1, halo_depth=16,
+                      steps=5, persist=None):
+    """BASELINE configs 4 / 5 through the LIBRARY's partition mode (include/flame_hip.h flame_hip_comm_* / flame_hip_part_*,
+    csrc/part.cpp: RCB cut, resident tiles per part, ncclSend / ncclRecv halo records on the solve stream) -- not the torch
+    harness: ONE graph strong-scaled over world x parts_per_rank subdomains.  50 k vertices below 8 subdomains, 200 k from
+    8 on.  Timed: `steps` solves of the config's iterations between barriers, max over ranks.  Beside it the device time of
+    an exchange (HIP events inside the library), the bytes a rank moves per exchange, what RCCL says the communicator's
+    size is, and the bits of the gathered solution against ONE handle solving the whole graph on this rank's GPU."""
+    import numpy as np
+    from flame_ros_amd import graphgen, partition
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+    nparts = world * parts_per_rank
+    name = workload or ("200k" if nparts >= 8 else "50k")
+    g, iters = graphgen.named(name, seed=0)
+    p = default_params()
+    out = {"workload": name, "V": g.V, "E": g.E, "iters_per_step": iters, "ranks": world, "parts_per_rank": parts_per_rank,
+           "halo_depth": halo_depth, "steps": steps, "api": "flame_hip_comm_* / flame_hip_part_* (csrc/part.cpp)"}
+    with partition.Communicator(device, rank, world, uid) as comm:
+        out["rccl_ranks"] = comm.info("rccl_ranks")
+        out["ranks_share_a_gpu"] = bool(comm.info("shared_gpu"))
+        with partition.Partition(comm, g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, parts_per_rank=parts_per_rank,
+                                 halo_depth=halo_depth) as ps:
+            # parity first (fresh state): the partitioned solve against one handle on the whole graph
+            ps.step(p, iters)
+            x, w1, w2, q = ps.gather_solution()
+            if rank == 0:
+                with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=device) as one:
+                    one.step(p, iters)
+                    x1, _, _, q1 = one.download()
+                out["bit_exact_vs_one_gpu"] = bool(np.array_equal(x.view(np.uint32), x1.view(np.uint32)) and
+                                                   np.array_equal(q.view(np.uint32), q1.view(np.uint32)))
+            ps.step(p, iters)  # (the second solve of a plan applies the lane order)
+            ps.sync()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ps.step(p, iters)
+            ps.sync()
+            barrier()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            ex0 = ps.info("exchanges")
+            ps.set_option("time_exchanges", 1)
+            ps.step(p, iters)
+            ps.sync()
+            out.update({"iterations_per_s": steps * iters / dt, "us_per_iteration": dt / (steps * iters) * 1e6,
+                        "ms_per_step": dt / steps * 1e3,
+                        "exchanges_per_step": ps.info("exchanges") - ex0, "exchange_us": ps.info("exchange_ns") / 1e3,
+                        "p2p_ops_per_exchange_rank0": ps.info("p2p_ops"),
+                        "send_bytes_per_exchange_rank0": sum(ps.info("send_bytes", i) for i in range(parts_per_rank)),
+                        "recv_bytes_per_exchange_rank0": sum(ps.info("recv_bytes", i) for i in range(parts_per_rank)),
+                        "own_vertices_rank0": sum(ps.info("n_own", i) for i in range(parts_per_rank)),
+                        "local_vertices_rank0": sum(ps.info("n_ext", i) for i in range(parts_per_rank)),
+                        "resident_tiles": bool(ps.info("persist_launches", 0) > 0),
+                        "solves_repeated_after_a_give_up": ps.info("recovered")})
+            out["exchange_share"] = out["exchange_us"] * out["exchanges_per_step"] / max(out["ms_per_step"] * 1e3, 1e-9)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,6 +396,7 @@ def main():
                     help="N>1: independent frames per GPU (default) or ONE graph cut into N "
                          "subdomains with RCCL halo exchange")
     ap.add_argument("--halo-depth", type=int, default=16)
+    ap.add_argument("--no-partition", action="store_true", help="N>1: skip the library-partition block beside the replicas line")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames axis: B independent feature-grid graphs (640x480, one feature per "
                          "--batch-win cell) per step in ONE handle, one LDS tile per frame")
@@ -525,6 +584,26 @@ def main():
         ts = sorted(ts[2:])  # (frame 1 builds the partition, frame 2 is the first to reuse it)
         frame_ms = ts[len(ts) // 2]
 
+    lib_part = None
+    if world > 1 and backend == "nccl" and not args.batch and not args.no_partition:  # (gloo development runs: ranks share a GPU)
+        # the LIBRARY's partition mode beside the replicas line: the unique id travels over the torch
+        # store, everything else is flame_hip_comm_* / flame_hip_part_* -- RCCL by the library itself, on its own stream
+        from flame_ros_amd import partition as fpart
+        box = [fpart.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+
+        def _max(v):
+            t = torch.tensor([v], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def _bar():
+            torch.cuda.synchronize()
+            dist.barrier()
+        lib_part = library_partition(rank, world, local_rank, box[0], _bar, _max, halo_depth=args.halo_depth)
+        if lib_part["rccl_ranks"] != world:
+            sys.exit("bench.py: RCCL reports %d ranks in the library's communicator, launched with %d" % (lib_part["rccl_ranks"], world))
+
     part_info = None
     if partition:  # per-exchange cost, measured apart from the timed region: pack + P2P + unpack
         torch.cuda.synchronize(); dist.barrier()
@@ -575,7 +654,9 @@ def main():
                                  "(HIP events on the solve stream, incl. launch gaps) against the HBM peak (SURVEY 8d)."},
         }
         if part_info:
-            out["partition"] = part_info
+            out["partition_torch_harness"] = part_info
+        if lib_part:
+            out["partition"] = lib_part
         if frame_ms:
             out["host_inclusive"] = {"ms_per_frame": frame_ms, "frames_per_s": 1e3 / frame_ms,
                                      "iterations_per_s": iters * 1e3 / frame_ms,

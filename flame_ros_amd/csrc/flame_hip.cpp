@@ -645,7 +645,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF=<tile + 1>): 10 ns ticks of that tile, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
     int32_t v = 0;
-    if (i < 0 || i > 3 || !g->xp.prof) return FLAME_HIP_ERR_ARG;
+    if (i < 0 || i > 4 || !g->xp.prof) return FLAME_HIP_ERR_ARG;
     if (hipMemcpy(&v, g->xp.prof + 2 + i, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
     *value = v;
   }

@@ -131,6 +131,9 @@ __device__ __forceinline__ void lds_store3(float4* slot, float a, float b, float
 #ifndef FLAME_EARLY_Q
 #define FLAME_EARLY_Q 1
 #endif
+#ifndef FLAME_POLL_SKIP
+#define FLAME_POLL_SKIP 1
+#endif
 // Write-back of a tile's results.  FLAME_WT_STORE 1: write-through (sc0 sc1) so the lines drain
 // while slower tiles still compute instead of at the end-of-kernel release (guide, "boundary":
 // dirty bytes / 6 TB/s are added to the kernel boundary); 2: nontemporal.
@@ -427,7 +430,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   if (PERSIST && tid == 0) s_abort = 0;
   const bool pprof = PERSIST && pa.prof[0] != 0 && tile_id == pa.prof[1];  // (dev aid, see the end of the round)
   unsigned long long pround = pprof ? wall_clock64() : 0ull;
-  int32_t pacc[3] = {0, 0, 0};
+  int32_t pacc[4] = {0, 0, 0, 0};
   int done = 0, round = 0;
   for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
   const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
@@ -562,8 +565,21 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
           const float4* pb = &hB[needv[0] ? gi[0] : vstart];  // the requests, and the poll is bound by their number)
           const float4* pv = &hA[needa[0] ? gi[0] : vstart];
           const float4* p0 = &hq[neede[0] ? qi[0] : estart];
-          const float4* p1 = &hq[neede[1] ? qi[1] : estart];
+          const float4* p1 = &hq[neede[EPT > 1 ? 1 : 0] ? qi[EPT > 1 ? 1 : 0] : estart];
           const float4* p2 = &hq[neede[EPT - 1] ? qi[EPT - 1] : estart];
+#if FLAME_POLL_SKIP
+          // r05: a request goes out only when a lane of the wave (still) needs that array -- every wave used to issue all
+          // five each pass (80 wave-instructions of 1 KB through the CU's one address path, most of them for the
+          // placeholder address: own vertices have no halo entries, the last lanes no vertices, EPT = 2 no third edge)
+          f4v r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+          if (__any(needv[0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r0) : "v"(pb) : "memory");
+          if (__any(needa[0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r1) : "v"(pv) : "memory");
+          if (__any(neede[0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r2) : "v"(p0) : "memory");
+          if (EPT > 1 && __any(neede[EPT > 1 ? 1 : 0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r3) : "v"(p1) : "memory");
+          if (EPT > 2 && __any(neede[EPT - 1])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r4) : "v"(p2) : "memory");
+          // (the values are tied to the wait: nothing that reads them can be scheduled in front of it)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : : "memory");
+#else
           f4v r0, r1, r2, r3, r4;
           asm volatile(
               "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
@@ -572,11 +588,12 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
               : "v"(pb), "v"(pv), "v"(p0), "v"(p1), "v"(p2)
               : "memory");
+#endif
           nb[0] = make_float4(r0.x, r0.y, r0.z, r0.w);
           na[0] = make_float4(r1.x, r1.y, r1.z, r1.w);
           nq[0] = make_float4(r2.x, r2.y, r2.z, r2.w);
-          nq[1] = make_float4(r3.x, r3.y, r3.z, r3.w);
-          nq[EPT - 1] = make_float4(r4.x, r4.y, r4.z, r4.w);
+          if (EPT > 1) nq[EPT > 1 ? 1 : 0] = make_float4(r3.x, r3.y, r3.z, r3.w);
+          if (EPT > 2) nq[EPT - 1] = make_float4(r4.x, r4.y, r4.z, r4.w);
         } else {
 #pragma unroll
           for (int k = 0; k < VPT; ++k) {
@@ -595,6 +612,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) ok = ok && (!neede[k] || __float_as_int(nq[k].w) == target);
         stale = !ok;
+        if (pprof) ++pacc[3];  // (dev aid: poll passes of the profiled wave)
       }
       if (!__any(stale)) break;
       if (wall_clock64() - w0 > 400000ull) {  // 4 ms: give up, never hang (the host repeats the solve by launches)
@@ -630,7 +648,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
   }  // rounds
   if (PERSIST && pprof && tid == 0) {
-    pa.prof[2] = pacc[0]; pa.prof[3] = pacc[1]; pa.prof[4] = pacc[2]; pa.prof[5] = round;
+    pa.prof[2] = pacc[0]; pa.prof[3] = pacc[1]; pa.prof[4] = pacc[2]; pa.prof[5] = round; pa.prof[6] = pacc[3];
   }
   if (!PERSIST && prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }

@@ -241,6 +241,12 @@ struct flame_hip_part {
   std::vector<Call> txn;
   int txn_rings = 0;
   int64_t recovered = 0;
+  // option "time_exchanges": HIP events around every exchange (pack -> group of sends / receives -> unpack) of the solves
+  // that follow, up to kMaxTimed of them; info "exchange_ns" = their mean once the stream has been synchronised
+  static constexpr int kMaxTimed = 64;
+  bool time_exchanges = false;
+  std::vector<hipEvent_t> tev;  // 2 per timed exchange
+  int timed = 0;
 };
 
 namespace {
@@ -354,6 +360,15 @@ int exchange(flame_hip_part* P) {
   flame_hip_comm* C = P->comm;
   if (P->world * P->k == 1 || P->ops.empty()) return 0;
   int rc;
+  const bool timed = P->time_exchanges && P->timed < flame_hip_part::kMaxTimed;
+  if (timed) {
+    while ((int)P->tev.size() < 2 * (P->timed + 1)) {
+      hipEvent_t e = nullptr;
+      HIPCHK(hipEventCreate(&e));
+      try { P->tev.push_back(e); } catch (...) { (void)hipEventDestroy(e); return FLAME_HIP_ERR_ALLOC; }
+    }
+    HIPCHK(hipEventRecord(P->tev[2 * (size_t)P->timed], C->stream));
+  }
   for (LocalPart& L : P->parts)
     if ((rc = flame_hip_halo_pack(L.g, L.sbuf, C->stream))) return rc;
   Rccl& R = rccl();
@@ -366,6 +381,10 @@ int exchange(flame_hip_part* P) {
   NCCLCHK(R.GroupEnd());
   for (LocalPart& L : P->parts)
     if ((rc = flame_hip_halo_unpack(L.g, L.rbuf, C->stream))) return rc;
+  if (timed) {
+    HIPCHK(hipEventRecord(P->tev[2 * (size_t)P->timed + 1], C->stream));
+    ++P->timed;
+  }
   ++P->exchanges;
   return 0;
 }
@@ -478,6 +497,7 @@ void flame_hip_part_destroy(flame_hip_part* P) {
     if (L.sbuf) (void)hipFree(L.sbuf);
     if (L.rbuf) (void)hipFree(L.rbuf);
   }
+  for (hipEvent_t e : P->tev) (void)hipEventDestroy(e);
   delete P;
 }
 
@@ -706,6 +726,14 @@ int flame_hip_part_gather(flame_hip_part* P, float* x, float* w1, float* w2, flo
   return 0;
 }
 
+// "time_exchanges" (0 / 1): see flame_hip_part_info "exchange_ns"; setting it (either way) forgets the exchanges timed so far
+int flame_hip_part_set_option(flame_hip_part* P, const char* key, int32_t value) {
+  if (!P || !key) return FLAME_HIP_ERR_ARG;
+  const std::string k(key);
+  if (k == "time_exchanges") { P->time_exchanges = value != 0; P->timed = 0; return 0; }
+  return FLAME_HIP_ERR_ARG;
+}
+
 // Introspection (tests, bench): scalars and arrays of the plan.  local_part in [0, parts_per_rank).
 int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_part, int64_t* value) {
   if (!P || !key || !value) return FLAME_HIP_ERR_ARG;
@@ -716,6 +744,17 @@ int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_
   if (k == "p2p_ops") { *value = (int64_t)P->ops.size(); return 0; }
   if (k == "rings_left") { *value = P->rings_left; return 0; }
   if (k == "recovered") { *value = P->recovered; return 0; }
+  if (k == "exchanges_timed") { *value = P->timed; return 0; }
+  if (k == "exchange_ns") {  // mean device time of the timed exchanges (the caller has synchronised: flame_hip_part_sync)
+    double sum = 0.0;
+    for (int i = 0; i < P->timed; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, P->tev[2 * (size_t)i], P->tev[2 * (size_t)i + 1]) != hipSuccess) return FLAME_HIP_ERR_STATE;
+      sum += ms;
+    }
+    *value = P->timed > 0 ? (int64_t)(sum / P->timed * 1e6) : 0;
+    return 0;
+  }
   if (k == "persist") { *value = P->persist ? 1 : 0; return 0; }
   if (local_part < 0 || local_part >= P->k) return FLAME_HIP_ERR_ARG;
   const LocalPart& L = P->parts[(size_t)local_part];

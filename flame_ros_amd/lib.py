@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libflame_hip.so")
+# (FLAME_HIP_LIB: dev aid -- A/B of kernel variants built side by side by tools/exp/build_variant.sh)
+LIB_PATH = os.environ.get("FLAME_HIP_LIB") or os.path.join(HERE, "libflame_hip.so")
 
 ERR_ARG, ERR_STATE, ERR_NAN, ERR_ALLOC, ERR_NODEVICE, ERR_NORCCL, ERR_HIP, ERR_RCCL = -1, -2, -3, -4, -5, -6, -1000, -3000
 PATH_AUTO, PATH_GLOBAL, PATH_TILE = 0, 1, 2
@@ -97,6 +98,7 @@ SYMBOLS = {
     "flame_hip_part_update_data": (C.c_int, [_VP, _VP, _VP, _VP]),
     "flame_hip_part_costs": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flame_hip_part_gather": (C.c_int, [_VP] + [_VP] * 4),
+    "flame_hip_part_set_option": (C.c_int, [_VP, C.c_char_p, _I32]),
     "flame_hip_part_info": (C.c_int, [_VP, C.c_char_p, _I32, C.POINTER(_I64)]),
     "flame_hip_part_array": (_I64, [_VP, C.c_char_p, _I32, _VP, _I64]),
     "flame_hip_debug_plan_array": (_I64, [_VP, C.c_char_p, _VP, _I64]),

@@ -89,6 +89,9 @@ class Partition:
         _l.check(self._lib.flame_hip_part_gather(self._h, _p(x), _p(w1), _p(w2), _p(q)), "flame_hip_part_gather")
         return x, w1, w2, q
 
+    def set_option(self, key, value):
+        _l.check(self._lib.flame_hip_part_set_option(self._h, key.encode(), int(value)), "flame_hip_part_set_option(%s)" % key)
+
     def info(self, key, local_part=0):
         v = C.c_int64()
         _l.check(self._lib.flame_hip_part_info(self._h, key.encode(), local_part, C.byref(v)), "flame_hip_part_info(%s)" % key)

@@ -345,7 +345,10 @@ int flame_hip_part_update_data(flame_hip_part* p, const float* z, const float* w
 int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, double* smooth, double* data);
 /* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */
 int flame_hip_part_gather(flame_hip_part* p, float* x, float* w1, float* w2, float* q);
-/* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left", "recovered" (solves repeated by launches after
+/* "time_exchanges" 0 / 1: HIP events around the next (up to 64) exchanges -- pack, the group of sends / receives, unpack */
+int flame_hip_part_set_option(flame_hip_part* p, const char* key, int32_t value);
+/* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left", "exchanges_timed", "exchange_ns" (mean device
+ * time of the timed exchanges; synchronise first), "recovered" (solves repeated by launches after
  * a give-up of resident tiles on any rank), "persist" (the parts solve with resident tiles); per local part: "part_id",
  * "n_own", "n_ext", "e_loc", "num_peers", "send_bytes", "recv_bytes", "persist_used" (the part's LAST local solve was one launch
  * of resident tiles), "persist_launches" (how many were, so far) */

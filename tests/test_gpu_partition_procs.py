@@ -79,7 +79,7 @@ def test_bench_runs_with_two_ranks(gpu, mode):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 3
     assert d["scaling"] == ("strong" if mode == "partition" else "weak")
     if mode == "partition":
-        assert d["partition"]["send_bytes_rank0"] > 0 and d["partition"]["exchange_us"] > 0
+        assert d["partition_torch_harness"]["send_bytes_rank0"] > 0 and d["partition_torch_harness"]["exchange_us"] > 0
         assert d["config"]["parallelism"].startswith("partition2")
     else:
         assert d["config"]["parallelism"] == "replicas2"
@@ -99,3 +99,30 @@ def test_bench_starts_its_own_ranks(gpu):
     if torch.cuda.device_count() < 2:
         p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode != 0 and "only 1 GPU(s) visible" in (p.stdout + p.stderr), p.stdout[-1000:] + p.stderr[-2000:]
+
+
+LIBPART = r"""
+import json, sys
+sys.path.insert(0, %r)
+import bench
+from flame_ros_amd import partition
+import torch
+d = bench.library_partition(0, 1, 0, partition.unique_id(), torch.cuda.synchronize, lambda v: v, parts_per_rank=PARTS, steps=3)
+print("LIBPART " + json.dumps(d))
+"""
+
+
+@pytest.mark.parametrize("parts", [2, 8])
+def test_bench_library_partition_block_world_1(gpu, parts):
+    """the `partition` block `bench.py --gpus N` prints at N > 1 is measured through flame_hip_comm_* /
+    flame_hip_part_* (not the torch harness).  The same function on the one GPU there is: world 1 x 2 parts (the 50 k graph of
+    BASELINE config 4) and x 8 parts (the 200 k graph of config 5) -- every halo record an ncclSend / ncclRecv of the rank
+    with itself; what the driver's first multi-GPU run will execute, minus the second GPU."""
+    p = subprocess.run([sys.executable, "-c", (LIBPART % ROOT).replace("PARTS", str(parts))], cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("LIBPART ")][-1][8:])
+    assert d["workload"] == ("50k" if parts == 2 else "200k") and d["rccl_ranks"] == 1 and d["bit_exact_vs_one_gpu"] is True
+    assert d["iterations_per_s"] > 0 and d["exchange_us"] > 0 and d["exchanges_per_step"] in (d["iters_per_step"] // 16, d["iters_per_step"] // 16 + 1)
+    assert d["send_bytes_per_exchange_rank0"] > 0 and d["resident_tiles"] is True and d["solves_repeated_after_a_give_up"] == 0
+    print(d)
