@@ -155,7 +155,7 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
 // runtime, call by call -- ~10 us each, the larger part of a small frame's upload).
 // frame_results: outputs up to this size are written to host memory by the kernels themselves (measured on
 // the facade stream, direct vs one copy: 1.2 k -14 us, 5 k -10 us, 10 k (185 KB) -15 us, 50 k (925 KB) +65 us)
-constexpr int kPollDelayDefault = 1;  // x 256 clocks (tools/exp/poll_delay_sweep.sh: 50k 1.56 -> 1.52 us per iteration before the hand-off stores moved into the last iteration, 0..2 alike since; 6 and up lose); FLAME_HIP_POLL_DELAY overrides
+constexpr int kPollDelayDefault = 0;  // r05: with the per-wave request skipping 0..3 are alike (profiles/r05_poll_delay.txt); r04:  // x 256 clocks (tools/exp/poll_delay_sweep.sh: 50k 1.56 -> 1.52 us per iteration before the hand-off stores moved into the last iteration, 0..2 alike since; 6 and up lose); FLAME_HIP_POLL_DELAY overrides
 constexpr int kMapMinTiles = 6;  // partitions of at least this many tiles leave a tile map for the next frame (partition reuse)
 constexpr size_t kDirectOutBytes = 256 * 1024;
 
@@ -325,6 +325,9 @@ struct flame_hip_graph {
   float4 *snapA = nullptr, *snapB = nullptr, *snapq = nullptr;  // flame_hip_state_snapshot / _rollback
   bool snap_valid = false;
   int64_t persist_launches = 0;     // launches of resident tiles so far (info "persist_launches")
+  float persist_round_us = 0.f;     // device time of a round of the last resident solve that was looked at (0 = none yet)
+  int32_t last_rounds = 0;          // rounds of the last resident launch
+  int32_t persist_timeout_us = 0;   // what the last resident launch was given (info "persist_timeout_us")
   int32_t snap_V = 0, snap_E = 0;
   PersistBufs xp;                   // hand-off buffers (uncached, from the process-wide pool: NOT in caps) + dev-aid words
   size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
@@ -641,6 +644,21 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
   else if (k == "persist_recovered") *value = g->persist_recovered;
   else if (k == "persist_launches") *value = g->persist_launches;
+  else if (k == "persist_timeout_us") *value = g->persist_timeout_us;
+  else if (k == "persist_torn") {  // torn hand-off entries seen so far (only a FLAME_TORN_CHECK build counts; synchronise first)
+    int32_t v = 0;
+    if (g->xp.prof && hipMemcpy(&v, g->xp.prof + 8, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FLAME_HIP_ERR_HIP;
+    *value = v;
+  }
+  else if (k == "torn_check_build") *value = tile_torn_check_build() ? 1 : 0;
+  else if (k == "persist_round_ns") *value = (int64_t)(g->persist_round_us * 1e3f);
+  else if (k == "persist_wait_us_max") {  // the longest a poll of any wave waited since the last look (read and cleared; synchronise first)
+    int32_t v = 0;
+    if (!g->xp.prof) { *value = 0; return 0; }
+    if (hipMemcpy(&v, g->xp.prof + 7, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemset(g->xp.prof + 7, 0, sizeof(v)) != hipSuccess) return FLAME_HIP_ERR_HIP;
+    *value = v / 100;
+  }
   else if (k == "persist_gave_up") *value = persist_gave_up_count(g->device);  // (give-ups of any handle on this device)
   else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF=<tile + 1>): 10 ns ticks of that tile, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
@@ -1587,7 +1605,14 @@ static int persist_check(flame_hip_graph* g, int own_marks = 0) {
   g->persist_unchecked = false;  // (every caller has synchronised the solve's stream)
   const int unchecked = g->persist_unchecked_n;
   g->persist_unchecked_n = 0;
-  if (!g->persist_err || *g->persist_err == 0) return 0;
+  if (!g->persist_err || *g->persist_err == 0) {
+    if (g->persist_used && g->last_rounds > 0 && unchecked == 1) {  // the round time the next launch's time-out follows
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess && ms > 0.f) g->persist_round_us = ms * 1e3f / (float)g->last_rounds;
+      else (void)hipGetLastError();
+    }
+    return 0;
+  }
   *g->persist_err = 0;
   persist_lease_drop(g, true);
   // (several solves queued without a synchronisation in between: an earlier one may have been the one that gave up, and
@@ -1631,8 +1656,8 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         *g->persist_err = 0;
       }
       if (!x.prof || g->persist_prof_set != g->persist_prof_want) {  // dev aid: which tile (if any) splits its rounds' time
-        if ((rc = dev_alloc(g->caps, &x.prof, 8))) return rc;
-        int32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((rc = dev_alloc(g->caps, &x.prof, 16))) return rc;
+        int32_t w[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         int want = g->persist_prof_want;
         if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) want = std::atoi(pp);
         if (want > 0) { w[0] = 1; w[1] = want - 1; }
@@ -1640,7 +1665,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         g->persist_prof_set = g->persist_prof_want;
       }
       const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
-      bool rezero = g->persist_base > (1 << 30);  // (the tags only grow)
+      bool rezero = g->persist_base > (1 << 23);  // (the tags only grow; 2^23: the torn-read debug build compares 24 bits)
       if (rezero) g->persist_base = 0;
       for (int b = 0; b < 2; ++b) {  // (a new or recycled buffer is zeroed: tag 0 is never a round's)
         float4** pp[3] = {&x.hA[b], &x.hB[b], &x.hq[b]};
@@ -1657,7 +1682,14 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       {
         static const char* pd = std::getenv("FLAME_HIP_POLL_DELAY");  // dev A/B
         x.poll_delay = pd ? std::atoi(pd) : kPollDelayDefault;
+        // A poll waits at most max(0.5 ms, 8 x the handle's last measured round) -- r04's flat 4 ms was 5.5 headline
+        // solves; 4 ms while nothing has been measured.  FLAME_HIP_PERSIST_TIMEOUT_US overrides.
+        static const char* to = std::getenv("FLAME_HIP_PERSIST_TIMEOUT_US");
+        const float us = to ? (float)std::atof(to) : (g->persist_round_us > 0.f ? std::max(500.f, 8.f * g->persist_round_us) : 4000.f);
+        g->persist_timeout_us = (int32_t)std::min(us, 1.0e6f);
+        x.timeout_ticks = g->persist_timeout_us * 100;
       }
+      g->last_rounds = rounds;
       HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
                                  g->persist_base));
       g->persist_base += rounds - 1;

@@ -51,8 +51,10 @@ struct PersistBufs {
   float4* hq[2] = {nullptr, nullptr};
   int32_t* prof = nullptr;
   int32_t poll_delay = 0;  // x 256 clocks between a round's stores and the first poll pass
+  int32_t timeout_ticks = 0;  // 10 ns ticks a poll may wait (0 = 4 ms)
 };
 bool tile_persist_exists(int nt, int ept, int vpt);
+bool tile_torn_check_build();  // compiled with FLAME_TORN_CHECK (debug: hashed hand-off tags, torn entries counted)
 hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,
                                int32_t* err_host, int32_t base);
 

