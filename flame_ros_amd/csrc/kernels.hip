@@ -590,11 +590,20 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
       const int lv = k * NT + tid;
       needv[k] = lv >= n_own && lv < n_ext;
       needa[k] = needv[k] && lv < n_upd;
+#ifdef FLAME_EXP_NO_APOLL  // (timing experiment only -- WRONG results)
+      needa[k] = false;
+#endif
+#ifdef FLAME_EXP_NO_VPOLL  // (timing experiment only -- WRONG results)
+      needv[k] = false; needa[k] = false;
+#endif
       want = want || needv[k];
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       neede[k] = (k * NT + tid) < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own);
+#ifdef FLAME_EXP_NO_QPOLL  // (timing experiment only -- WRONG results: what would the hand-off cost without the duals' bytes?)
+      neede[k] = false;
+#endif
       want = want || neede[k];
     }
     // (the neighbours finish their round at about the same time and their stores take ~0.7 us to land: a poll pass

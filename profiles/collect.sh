@@ -4,9 +4,10 @@
 # for the HBM traffic (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md "HBM" prescribes, one PMC pass
 # for the LDS counters, then a summary (summary.md / summary.json / kernel_stats.csv) that is copied
 # by hand into profiles/.  Every rocprofv3 run uses --kernel-trace only (no sys/hip/hsa trace).
+here="$(cd "$(dirname "$0")/.." && pwd)"   # (the tree this script lies in: tools/gpu.sh runs a frozen copy)
 cd /tmp && export TMPDIR=/tmp
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
-tag=${1:-r04}; shift
+cd "$here"
+tag=${1:-r05}; shift
 out=gpurun_out/$tag; mkdir -p $out gpurun_out
 BENCH="python bench.py --no-cpu --no-facade --steps 10 --warmup 2 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o p -- $BENCH > $out/bench_trace.log 2>&1
