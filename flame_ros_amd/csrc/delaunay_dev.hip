@@ -831,18 +831,33 @@ void scan_ints(hipStream_t s, int32_t* in, int32_t n, int32_t* out, int32_t* sum
 }  // namespace
 
 void DelaunayScratch::release() {
+  if (list_pending) (void)host_list();
   if (dev) (void)hipFree(dev);
   if (pin) (void)hipHostFree(pin);
+  if (ev_list) (void)hipEventDestroy(ev_list);
+  if (ev_done) (void)hipEventDestroy(ev_done);
+  if (s_list) (void)hipStreamDestroy(s_list);
+  ev_done = nullptr; s_list = nullptr;
   dev = nullptr; pin = nullptr; dev_cap = pin_cap = 0;
-  last_V = last_T = -1; last_list = nullptr;
+  last_V = last_T = -1; last_list = nullptr; last_dev = nullptr; ev_list = nullptr; list_pending = false;
+}
+
+const int32_t* DelaunayScratch::host_list() {
+  if (list_pending) {
+    list_pending = false;
+    if (hipEventSynchronize(ev_list) != hipSuccess) { (void)hipGetLastError(); last_list = nullptr; last_V = last_T = -1; }
+  }
+  return last_list;
 }
 
 int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris_out,
                     int32_t* T_out) {
   if (!sc || V < 0 || tri_cap < 0 || !T_out || (V > 0 && !pos) || (tri_cap > 0 && !tris_out)) return FLAME_HIP_ERR_ARG;
   *T_out = 0;
+  const bool keep = tri_cap == 0 && tris_out == nullptr;  // the list stays in the library (device + asynchronous host copy)
+  if (sc->list_pending) (void)sc->host_list();           // (the arena is about to be rewritten)
   sc->last_hull = 0; sc->last_live = V;
-  sc->last_V = sc->last_T = -1; sc->last_list = nullptr;
+  sc->last_V = sc->last_T = -1; sc->last_list = nullptr; sc->last_dev = nullptr;
   if (V < 3) return 0;
   if (V > (1 << 20)) return FLAME_HIP_ERR_ARG;  // (the scans; a frame has 10^3..10^5 features)
   const auto t0 = std::chrono::steady_clock::now();
@@ -932,8 +947,9 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   DT_HIPCHK(hipGetLastError());
   // flags and the list leave together (T = 2 n - 2 - h is within a few triangles of the 2 V the buffer holds: copying
   // the whole buffer costs nothing over copying T triangles, and saves the round trip that would bring T first)
+  // (keep mode: only the flags come back now -- one round trip for T --; the list follows behind the caller's back)
   DT_HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int32_t) * kFlagWords, hipMemcpyDeviceToHost, s));
-  DT_HIPCHK(hipMemcpyAsync(htris, dtris, sizeof(int32_t) * 3 * (size_t)tmax, hipMemcpyDeviceToHost, s));
+  if (!keep) DT_HIPCHK(hipMemcpyAsync(htris, dtris, sizeof(int32_t) * 3 * (size_t)tmax, hipMemcpyDeviceToHost, s));
   DT_HIPCHK(hipStreamSynchronize(s));
   if (dbg) {
     std::vector<int32_t> h(4 * (size_t)V);
@@ -954,10 +970,21 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   sc->last_hull = hull; sc->last_live = live;
   if (err & kErrRange) return FLAME_HIP_ERR_ARG;  // a coordinate outside |u|, |v| < 2^13 pixels, or not finite
   if (err || T < 0 || T > tmax || (T > 0 && T != 2 * live - 2 - hull)) return FLAME_HIP_ERR_STATE;
-  if (T > tri_cap) return FLAME_HIP_ERR_ARG;
-  if (T > 0) std::memcpy(tris_out, htris, sizeof(int32_t) * 3 * (size_t)T);
+  if (keep) {
+    if (T > 0) {
+      if (!sc->ev_list) DT_HIPCHK(hipEventCreateWithFlags(&sc->ev_list, hipEventDisableTiming));
+      if (!sc->s_list) DT_HIPCHK(hipStreamCreateWithFlags(&sc->s_list, hipStreamNonBlocking));
+      // (`s` has been synchronised: the list is complete; its copy-out runs beside whatever the caller stages in next)
+      DT_HIPCHK(hipMemcpyAsync(htris, dtris, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyDeviceToHost, sc->s_list));
+      DT_HIPCHK(hipEventRecord(sc->ev_list, sc->s_list));
+      sc->list_pending = true;
+    }
+  } else {
+    if (T > tri_cap) return FLAME_HIP_ERR_ARG;
+    if (T > 0) std::memcpy(tris_out, htris, sizeof(int32_t) * 3 * (size_t)T);
+  }
   *T_out = T;
-  sc->last_V = V; sc->last_T = T; sc->last_list = htris;
+  sc->last_V = V; sc->last_T = T; sc->last_list = htris; sc->last_dev = dtris;
   sc->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }

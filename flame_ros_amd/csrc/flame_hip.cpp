@@ -1180,9 +1180,11 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
                          const int32_t* tris, const float* prediction, float* scale) {
   RoctxRange roctx_("flame_hip_graph_sync");
   if (!g || !sp || V < 0 || T < 0) return FLAME_HIP_ERR_ARG;
+  const int32_t* tris_dev = nullptr;  // ... the same list on the device (r05: the device paths never take it through the host)
   if (T > 0 && !tris) {  // the triangulation flame_hip_delaunay made last on this handle, read where the library left it
     if (g->dt.last_T != T || g->dt.last_V != V || !g->dt.last_list) return FLAME_HIP_ERR_ARG;
-    tris = g->dt.last_list;
+    tris = g->dt.last_list;  // (page-locked; in keep mode its copy may still be in flight on the staging stream: DMAs queued
+    tris_dev = g->dt.last_dev;  // there are ordered behind it, a HOST read has to wait -- dt.host_list())
   }
   if (V > 0 && (!pos || !idepth_mu || !idepth_var)) return FLAME_HIP_ERR_ARG;
   const auto t_entry = std::chrono::steady_clock::now();
@@ -1280,7 +1282,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
       const size_t in_total = o_pred + (prediction ? al(sizeof(float) * (size_t)V) : 0);
       if ((rc = dev_alloc(g->caps, &g->in_stage, in_total))) return rc;
       HIPCHK(g->pin_in.reserve(in_total));
-      std::memcpy(g->pin_in.base + o_tris, tris, sizeof(int32_t) * 3 * (size_t)T);
+      if (!tris_dev) std::memcpy(g->pin_in.base + o_tris, tris, sizeof(int32_t) * 3 * (size_t)T);
       std::memcpy(g->pin_in.base + o_pos, pos, sizeof(float2) * (size_t)V);
       std::memcpy(g->pin_in.base + o_mu, idepth_mu, sizeof(float) * (size_t)V);
       std::memcpy(g->pin_in.base + o_var, idepth_var, sizeof(float) * (size_t)V);
@@ -1293,7 +1295,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
       if (!zero_copy) HIPCHK(hipMemcpyAsync(g->in_stage, g->pin_in.base, in_total, hipMemcpyHostToDevice, s));
       lap("H2D all");
       DevPlanner::MiniSync ms;
-      ms.tris = reinterpret_cast<const int32_t*>(src + o_tris);
+      ms.tris = tris_dev ? tris_dev : reinterpret_cast<const int32_t*>(src + o_tris);  // (the library's own list: read where it lies)
       ms.pos = reinterpret_cast<const float2*>(src + o_pos);
       ms.mu = reinterpret_cast<const float*>(src + o_mu);
       ms.var = reinterpret_cast<const float*>(src + o_var);
@@ -1341,8 +1343,13 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     // The copies from the caller's (pageable) arrays block the host, so they are issued in the order the
     // kernels need them, each batch of kernels enqueued before the next copy starts: triangles ->
     // half-edge count / scan / fill; positions -> unique edges + alpha; idepths -> data terms.
-    HIPCHK(stage(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T));
-    HIPCHK(staged_for());
+    if (tris_dev) {  // the library's own list is complete on the device (flame_hip_delaunay returned behind its last kernel):
+      // a device-to-device copy on the build's stream, nothing through the host link and nothing to wait for
+      HIPCHK(hipMemcpyAsync(g->in_tris, tris_dev, sizeof(int32_t) * 3 * (size_t)T, hipMemcpyDeviceToDevice, s));
+    } else {
+      HIPCHK(stage(g->in_tris, tris, sizeof(int32_t) * 3 * (size_t)T));
+      HIPCHK(staged_for());
+    }
     lap("H2D triangles");
     HIPCHK(g->planner.edges_from_tris(s, V, T, g->in_tris, g->in_pos, g->in_edges, g->in_alpha, &E, &index_error, g->dflags,
                                       [&]() {
@@ -1404,6 +1411,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
     // not eligible for the device plan (e.g. one isolated tile): fall through to the host builder
   }
   if ((rc = validate())) return rc;
+  if (tris_dev && !(tris = g->dt.host_list())) return FLAME_HIP_ERR_HIP;  // (the host builder reads the list: its copy-out must be complete)
   rc = graph_sync_host(*sp, V, T, pos, idepth_mu, idepth_var, tris, prediction, &g->sync);
   if (rc) return rc;
   const int32_t E = (int32_t)(g->sync.edges.size() / 2);
@@ -1424,6 +1432,19 @@ int flame_hip_delaunay(flame_hip_graph* g, int32_t V, const float* pos, int32_t 
   if (V > 0 && !all_finite(pos, 2 * (size_t)V)) return FLAME_HIP_ERR_NAN;
   HIPCHK(hipSetDevice(g->device));
   return delaunay_device(g->stream_in, &g->dt, V, pos, tri_cap, tris, T);
+}
+
+// The list of the last flame_hip_delaunay on this handle (tri_cap >= its T).  After a call in keep mode (tri_cap = 0, tris =
+// NULL) this is where the host copy is waited for: it travelled on a stream of its own while the caller went on.
+int flame_hip_delaunay_list(flame_hip_graph* g, int32_t tri_cap, int32_t* tris) {
+  if (!g || tri_cap < 0 || (tri_cap > 0 && !tris)) return FLAME_HIP_ERR_ARG;
+  if (g->device < 0 || g->dt.last_T < 0) return FLAME_HIP_ERR_STATE;
+  if (g->dt.last_T > tri_cap) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(g->device));
+  const int32_t* h = g->dt.host_list();
+  if (!h) return FLAME_HIP_ERR_HIP;
+  if (g->dt.last_T > 0) std::memcpy(tris, h, sizeof(int32_t) * 3 * (size_t)g->dt.last_T);
+  return 0;
 }
 
 int flame_hip_graph_edges(const flame_hip_graph* g, int32_t* edges) {

@@ -58,6 +58,7 @@ SYMBOLS = {
     "flame_hip_graph_sync": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_float)]),
     "flame_hip_feature_gate": (_I32, [_I32, _VP, C.c_float, _VP]),
     "flame_hip_delaunay": (C.c_int, [_VP, _I32, _VP, _I32, _VP, C.POINTER(_I32)]),
+    "flame_hip_delaunay_list": (C.c_int, [_VP, _I32, _VP]),
     "flame_hip_graph_edges": (C.c_int, [_VP, _VP]),
     "flame_hip_scale_state": (C.c_int, [_VP, C.c_float]),
     "flame_hip_graph_update_data": (C.c_int, [_VP, _VP, _VP, _VP]),

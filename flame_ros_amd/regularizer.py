@@ -146,6 +146,21 @@ class GraphRegularizer:
                                               C.byref(T)), "flame_hip_delaunay")
         return tris[:T.value].copy()
 
+    def delaunay_keep(self, pos):
+        """flame_hip_delaunay in KEEP mode: the list stays in the library (sync_features(..., tris=T, ...) reads it on the
+        device), only T comes back; delaunay_list() hands the triangles out later."""
+        pos = _f32(pos).reshape(-1, 2)
+        T = C.c_int32()
+        _l.check(self._lib.flame_hip_delaunay(self._h, len(pos), _ptr(pos) if len(pos) else None, 0, None, C.byref(T)),
+                 "flame_hip_delaunay (keep)")
+        self._kept_T = T.value
+        return T.value
+
+    def delaunay_list(self):
+        tris = np.empty((max(getattr(self, "_kept_T", 0), 1), 3), np.int32)
+        _l.check(self._lib.flame_hip_delaunay_list(self._h, len(tris), _ptr(tris)), "flame_hip_delaunay_list")
+        return tris[:getattr(self, "_kept_T", 0)].copy()
+
     def edges(self):
         """The edge list derived by sync_features ([E,2] int32, i < j, lexicographic)."""
         e = np.empty((self.E, 2), np.int32)

@@ -284,9 +284,10 @@ class Flame {
             static_assert(sizeof(Point2f) == 2 * sizeof(float) && sizeof(Triangle) == 3 * sizeof(int32_t), "boundary types are packed");
             const int32_t nv = static_cast<int32_t>(g.vtx.size());
             int32_t nt = 0;
-            tris.resize(2 * g.vtx.size() + 1);
+            // KEEP mode (r05): only the triangle count comes back; the list stays on the device for the graph sync and is
+            // fetched while the GPU iterates (updateGraphLocked).  `tris` only carries the count until then.
             const int rc = graph_.triangulate(params_.hip_device, nv, nv ? reinterpret_cast<const float*>(g.vtx.data()) : nullptr,
-                                              static_cast<int32_t>(tris.size()), reinterpret_cast<int32_t*>(tris.data()), &nt);
+                                              0, nullptr, &nt);
             tris.resize(rc ? 0 : nt);
             ok = rc == 0 && nt > 0;
             tris_in_library_ = ok;  // (nothing to triangulate -- fewer than three distinct points, or all on a line -- fails the
@@ -383,7 +384,13 @@ class Flame {
     // solve above is asynchronous, the call below is the frame's one synchronisation.  They go into
     // staging members and are swapped in only when the frame succeeded (atomic commit).
     st_vtx_ = vtx;
-    st_tris_ = triangles;
+    if (tris_in_library) {  // the list flame_hip_delaunay kept: its host copy has been travelling since; taken over here
+      st_tris_.resize(triangles.size());
+      rc = graph_.triangleList(T, T ? reinterpret_cast<int32_t*>(st_tris_.data()) : nullptr);
+      if (rc) return fail(rc);
+    } else {
+      st_tris_ = triangles;
+    }
     if (raw) { st_raw_vtx_ = raw->vtx; st_raw_mu_ = raw->idepth_mu; st_raw_var_ = raw->idepth_var; }
     else { st_raw_vtx_ = vtx; st_raw_mu_ = idepth_mu; st_raw_var_ = idepth_var; }
     st_edges_.resize(E);

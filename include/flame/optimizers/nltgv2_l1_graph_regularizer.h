@@ -81,6 +81,9 @@ class Graph {
     const int rc = acquire(device);
     return rc ? rc : flame_hip_delaunay(g_, V, pos, tri_cap, tris, T);
   }
+  // ... in KEEP mode (tri_cap = 0, tris = NULL above): the list stays on the device for the sync() that follows, its host
+  // copy travels meanwhile; this hands it out (and waits for it) -- flame::Flame calls it while the GPU iterates
+  int triangleList(int32_t tri_cap, int32_t* tris) { return g_ ? flame_hip_delaunay_list(g_, tri_cap, tris) : FLAME_HIP_ERR_STATE; }
   // a graph is resident (the last build / sync succeeded)
   bool valid() const { return g_ != nullptr && resident_; }
   int32_t numVertices() const { return V_; }

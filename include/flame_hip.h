@@ -164,8 +164,12 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
  * (no device; or the result failed Euler's check T = 2 n - 2 - h: never seen, reported rather than handed out).
  * flame_hip_get_info: "delaunay_hull" (h), "delaunay_live" (n), "delaunay_us" (host time of the call).
  * A flame_hip_graph_sync on the same handle with the same V and T and tris = NULL uses this list as the library still
- * holds it (page-locked: no staged copy of the caller's array). */
+ * holds it -- on the DEVICE (r05): nothing of it crosses the host link on the frame path.
+ * KEEP mode, tri_cap = 0 and tris = NULL: only *T comes back (one round trip behind the last kernel); the list stays on the
+ * device for that graph sync and its host copy travels on a stream of its own meanwhile -- flame_hip_delaunay_list hands
+ * it out (and waits for it) when the caller wants the triangles, e.g. while the GPU iterates. */
 int flame_hip_delaunay(flame_hip_graph* g, int32_t V, const float* pos, int32_t tri_cap, int32_t* tris, int32_t* T);
+int flame_hip_delaunay_list(flame_hip_graph* g, int32_t tri_cap, int32_t* tris);
 /* keep[v] = var[v] < var_max; returns the number kept (or a negative error).  No device needed. */
 int32_t flame_hip_feature_gate(int32_t n, const float* idepth_var, float var_max, uint8_t* keep);
 /* The edge list flame_hip_graph_sync derived (2E ints; E from flame_hip_get_info "E"). */

@@ -239,3 +239,30 @@ def test_graph_sync_on_the_library_s_own_list(gpu, n):
                     h.sync_features(pts[:-1], mu[:-1], var[:-1], len(tris), sp)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("n", [600, 1200, 10000, 50000])
+def test_keep_mode_list_stays_on_the_device(gpu, n):
+    """r05: flame_hip_delaunay with tri_cap = 0 / tris = NULL returns only T; the graph sync that
+    follows reads the list on the DEVICE (one-launch plan at 600 / 1.2 k, the staged build above; 600 vertices: the host
+    builder, which has to wait for the list's host copy), and flame_hip_delaunay_list hands the same triangles out afterwards.
+    Same edges, same bits after 50 iterations as with the list handed over by the caller."""
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_sync_params
+    rng = np.random.default_rng(n + 5)
+    pts = (rng.random((n, 2)) * np.array([640.0, 480.0])).astype(np.float32)
+    mu = (0.5 + 0.001 * pts[:, 0] + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    var = np.full(n, 1e-4, np.float32)
+    sp = default_sync_params()
+    with GraphRegularizer.empty(tile_single_max=640) as ref, GraphRegularizer.empty(tile_single_max=640) as h:
+        tris = ref.delaunay(pts)
+        ref.sync_features(pts, mu, var, tris, sp)
+        ref.step(default_params(), 50)
+        for frame in range(3):  # (a stream: the second and third frame reuse the partition / the one-launch plan)
+            T = h.delaunay_keep(pts)
+            assert T == len(tris)
+            h.sync_features(pts, mu, var, T, sp)
+            h.step(default_params(), 50, sync=False)
+            got = h.delaunay_list()  # (while the GPU iterates)
+            assert np.array_equal(got, tris), frame
+            assert np.array_equal(h.edges(), ref.edges())
+            assert np.array_equal(h.download()[0].view(np.uint32), ref.download()[0].view(np.uint32)), frame
