@@ -136,12 +136,17 @@ def roofline_from_summary(path):
         raise SystemExit("%s holds no lds_floor / bench line (a summary of r05 or later is needed)" % path)
     rl = b["roofline"]
     kern = rl.get("kernel", "k_tile")
-    cnt = None
+    cnt, hbm = None, rl.get("measured_hbm_frac")
     for k, v in s.get("lds_per_launch", {}).items():
         if kern + "<" in k:
             cnt = v
-    return lds_roofline(fl, rl["launch_us"] / rl["iters_per_launch"], rl["clock_mhz"], rl["iters_per_launch"], cnt,
-                        rl.get("iterate_frac"), rl.get("measured_hbm_frac"), rl.get("contract_frac"))
+    for k, v in s.get("traffic_bytes_per_launch", {}).items():  # this summary's own FETCH x2 + WRITE passes
+        if kern + "<" in k and v > 0:
+            hbm = v / (rl["launch_us"] * 1e-6) / 1e9 / 8000.0
+    out = lds_roofline(fl, rl["launch_us"] / rl["iters_per_launch"], rl["clock_mhz"], rl["iters_per_launch"], cnt,
+                       rl.get("iterate_frac"), hbm, (rl.get("contract") or {}).get("frac", rl.get("contract_frac")))
+    out["kernel"] = kern
+    return out
 
 
 def summarize(d):
