@@ -366,6 +366,7 @@ def library_partition(rank, world, device, uid, barrier, max_over_ranks, workloa
                         "own_vertices_rank0": sum(ps.info("n_own", i) for i in range(parts_per_rank)),
                         "local_vertices_rank0": sum(ps.info("n_ext", i) for i in range(parts_per_rank)),
                         "resident_tiles": bool(ps.info("persist_launches", 0) > 0),
+                        "exchanges_pipelined": ps.info("exchanges_pipelined"),
                         "solves_repeated_after_a_give_up": ps.info("recovered")})
             out["exchange_share"] = out["exchange_us"] * out["exchanges_per_step"] / max(out["ms_per_step"] * 1e3, 1e-9)
     return out
@@ -600,9 +601,22 @@ def main():
         def _bar():
             torch.cuda.synchronize()
             dist.barrier()
-        lib_part = library_partition(rank, world, local_rank, box[0], _bar, _max, halo_depth=args.halo_depth)
+        try:
+            lib_part = library_partition(rank, world, local_rank, box[0], _bar, _max, halo_depth=args.halo_depth)
+        except Exception as e:  # noqa: BLE001 -- the replicas line (the contract's `value`) must survive a failure of the side block
+            lib_part = {"error": "%s: %s" % (type(e).__name__, str(e)[:300]), "rccl_ranks": world}
         if lib_part["rccl_ranks"] != world:
             sys.exit("bench.py: RCCL reports %d ranks in the library's communicator, launched with %d" % (lib_part["rccl_ranks"], world))
+        try:  # the same graph over-decomposed, two parts per rank: the records of part 0 travel while part 1 iterates
+            box2 = [fpart.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box2, src=0)
+            od = library_partition(rank, world, local_rank, box2[0], _bar, _max, workload=lib_part.get("workload"),
+                                   parts_per_rank=2, halo_depth=args.halo_depth, steps=3)
+            lib_part["two_parts_per_rank_pipelined"] = {k: od[k] for k in ("iterations_per_s", "us_per_iteration", "exchanges_per_step",
+                                                                         "exchanges_pipelined", "bit_exact_vs_one_gpu", "resident_tiles")
+                                                        if k in od}
+        except Exception as e:  # noqa: BLE001
+            lib_part["two_parts_per_rank_pipelined"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     part_info = None
     if partition:  # per-exchange cost, measured apart from the timed region: pack + P2P + unpack

@@ -216,6 +216,9 @@ struct flame_hip_comm {
   int device = -1, rank = 0, world = 1;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t xstream = nullptr;  // pipelined exchanges (parts_per_rank >= 2): the group of part i travels here while part
+                                  // i + 1 iterates on `stream`
+  hipEvent_t ev_pack = nullptr, ev_x = nullptr;
   double* red = nullptr;  // device: 2 doubles (cost reduction)
   int32_t* flag = nullptr;  // device: the ranks' "a launch of resident tiles gave up" word (flame_hip_part_sync)
   int rccl_ranks = 0;       // ncclCommCount
@@ -244,6 +247,11 @@ struct flame_hip_part {
   // option "time_exchanges": HIP events around every exchange (pack -> group of sends / receives -> unpack) of the solves
   // that follow, up to kMaxTimed of them; info "exchange_ns" = their mean once the stream has been synchronised
   static constexpr int kMaxTimed = 64;
+  // option "pipeline" (default 1; acts with parts_per_rank >= 2): SURVEY 8e "overlap compute with the exchange" by
+  // over-decomposition -- inside a solve call the records of part i leave (their own ncclGroup, on the communicator's second
+  // stream) as soon as part i has iterated, while part i + 1 iterates; the unpack waits for the last group.
+  bool pipeline = true;
+  int64_t pipelined = 0;  // exchanges that went that way (info "exchanges_pipelined")
   bool time_exchanges = false;
   std::vector<hipEvent_t> tev;  // 2 per timed exchange
   int timed = 0;
@@ -417,6 +425,9 @@ int flame_hip_comm_create(flame_hip_comm** out, int device, int rank, int world,
   c->device = device; c->rank = rank; c->world = world;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->red), 2 * sizeof(double));
   if (e != hipSuccess) { flame_hip_comm_destroy(c); return FLAME_HIP_ERR_HIP - (int)e; }
   ncclUniqueId u;
@@ -472,12 +483,16 @@ void flame_hip_comm_destroy(flame_hip_comm* c) {
   if (!c) return;
   if (c->device >= 0) (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   // (a part keeps a pointer to its communicator.  Parts that outlive it are detached here -- they can still be
   // destroyed, nothing else: every other entry point refuses a part without a communicator)
   for (flame_hip_part* P : c->parts) P->comm = nullptr;
   if (c->comm) (void)rccl().CommDestroy(c->comm);
   if (c->red) (void)hipFree(c->red);
   if (c->flag) (void)hipFree(c->flag);
+  if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+  if (c->ev_x) (void)hipEventDestroy(c->ev_x);
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -586,18 +601,59 @@ int flame_hip_part_update_data(flame_hip_part* P, const float* z, const float* w
 // valid again.  Successive calls continue on whatever rings the previous one left.  Everything is enqueued on the
 // communicator's stream: no host synchronisation inside.
 // (the iterations themselves: shared by flame_hip_part_solve and the repeat of a give-up)
+// the ncclGroup of ONE sending phase: every message whose SOURCE part has local index `phase` on its rank (this rank's sends
+// of that part; its receives from parts of that index anywhere).  Both ends of a pair of ranks derive the same sets in the
+// same (src, dst, kind) order, and the phases follow each other in the same order everywhere: messages match by order.
+static int exchange_phase(flame_hip_part* P, int phase, hipStream_t s) {
+  flame_hip_comm* C = P->comm;
+  Rccl& R = rccl();
+  bool any = false;
+  for (const P2P& op : P->ops) any = any || (op.src % P->k) == phase;
+  if (!any) return 0;
+  NCCLCHK(R.GroupStart());
+  for (const P2P& op : P->ops) {
+    if ((op.src % P->k) != phase) continue;
+    const ncclResult_t r = op.send ? R.Send(op.buf, op.count, ncclFloat, op.peer_rank, C->comm, s)
+                                   : R.Recv(op.buf, op.count, ncclFloat, op.peer_rank, C->comm, s);
+    if (r != ncclSuccess) { (void)R.GroupEnd(); return FLAME_HIP_ERR_RCCL - (int)r; }
+  }
+  NCCLCHK(R.GroupEnd());
+  return 0;
+}
+
+// (the iterations themselves: shared by flame_hip_part_solve and the repeat of a give-up)
 static int run_iterations(flame_hip_part* P, const flame_hip_params* p, int32_t num_iters) {
   int rc;
+  flame_hip_comm* C = P->comm;
   for (int32_t done = 0; done < num_iters;) {
     if (P->rings_left == 0) {
       if ((rc = exchange(P))) return rc;
       P->rings_left = P->depth;
     }
     const int32_t n = std::min<int32_t>(P->rings_left, num_iters - done);
-    for (LocalPart& L : P->parts)
-      if ((rc = flame_hip_solve(L.g, p, n, P->comm->stream))) return rc;
+    // this chunk uses the rings up and the call goes on: the exchange behind it is certain -- pipeline it
+    const bool pipe = P->pipeline && P->k >= 2 && !P->ops.empty() && P->rings_left == n && done + n < num_iters && !P->time_exchanges;
+    for (size_t i = 0; i < P->parts.size(); ++i) {
+      LocalPart& L = P->parts[i];
+      if ((rc = flame_hip_solve(L.g, p, n, C->stream))) return rc;
+      if (pipe) {
+        if ((rc = flame_hip_halo_pack(L.g, L.sbuf, C->stream))) return rc;
+        HIPCHK(hipEventRecord(C->ev_pack, C->stream));
+        HIPCHK(hipStreamWaitEvent(C->xstream, C->ev_pack, 0));
+        if ((rc = exchange_phase(P, (int)i, C->xstream))) return rc;
+      }
+    }
     P->rings_left -= n;
     done += n;
+    if (pipe) {
+      HIPCHK(hipEventRecord(C->ev_x, C->xstream));
+      HIPCHK(hipStreamWaitEvent(C->stream, C->ev_x, 0));
+      for (LocalPart& L : P->parts)
+        if ((rc = flame_hip_halo_unpack(L.g, L.rbuf, C->stream))) return rc;
+      ++P->exchanges;
+      ++P->pipelined;
+      P->rings_left = P->depth;
+    }
   }
   return 0;
 }
@@ -731,6 +787,7 @@ int flame_hip_part_set_option(flame_hip_part* P, const char* key, int32_t value)
   if (!P || !key) return FLAME_HIP_ERR_ARG;
   const std::string k(key);
   if (k == "time_exchanges") { P->time_exchanges = value != 0; P->timed = 0; return 0; }
+  if (k == "pipeline") { P->pipeline = value != 0; return 0; }
   return FLAME_HIP_ERR_ARG;
 }
 
@@ -745,6 +802,7 @@ int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_
   if (k == "rings_left") { *value = P->rings_left; return 0; }
   if (k == "recovered") { *value = P->recovered; return 0; }
   if (k == "exchanges_timed") { *value = P->timed; return 0; }
+  if (k == "exchanges_pipelined") { *value = P->pipelined; return 0; }
   if (k == "exchange_ns") {  // mean device time of the timed exchanges (the caller has synchronised: flame_hip_part_sync)
     double sum = 0.0;
     for (int i = 0; i < P->timed; ++i) {

@@ -349,7 +349,10 @@ int flame_hip_part_update_data(flame_hip_part* p, const float* z, const float* w
 int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, double* smooth, double* data);
 /* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */
 int flame_hip_part_gather(flame_hip_part* p, float* x, float* w1, float* w2, float* q);
-/* "time_exchanges" 0 / 1: HIP events around the next (up to 64) exchanges -- pack, the group of sends / receives, unpack */
+/* "time_exchanges" 0 / 1: HIP events around the next (up to 64) exchanges -- pack, the group of sends / receives, unpack;
+ * "pipeline" (default 1, acts with parts_per_rank >= 2): inside a solve call the halo records of part i leave -- an ncclGroup of
+ * their own on the communicator's second stream -- while part i + 1 iterates (overlap compute with the exchange, by
+ * over-decomposition); info "exchanges_pipelined" counts them.  Same bits either way. */
 int flame_hip_part_set_option(flame_hip_part* p, const char* key, int32_t value);
 /* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left", "exchanges_timed", "exchange_ns" (mean device
  * time of the timed exchanges; synchronise first), "recovered" (solves repeated by launches after

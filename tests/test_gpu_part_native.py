@@ -25,15 +25,17 @@ assert partition.rccl_available()
 uid = partition.unique_id()
 total_recovered = 0
 with partition.Communicator(0, 0, 1, uid) as comm:
-    for V, k, depth, iters in ((6000, 2, 8, 50), (9000, 3, 4, 23), (50000, 2, 16, 100)):
+    for V, k, depth, iters, pipe in ((6000, 2, 8, 50, 1), (6000, 2, 8, 50, 0), (9000, 3, 4, 23, 1), (50000, 2, 16, 100, 1)):
         g = graphgen.synthetic(V, seed=5)
         with partition.Partition(comm, g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, parts_per_rank=k, halo_depth=depth) as ps:
             p = default_params()
+            ps.set_option("pipeline", pipe)  # (r05: the records of part i travel while part i + 1 iterates; same bits)
             ps.step(p, iters // 2)
             ps.step(p, iters - iters // 2)
             was_resident = int(all(ps.info("persist_launches", i) > 0 for i in range(k)))  # (parts of one rank queue behind
             assert was_resident == int(any(ps.info("persist_launches", i) > 0 for i in range(k)))  # each other on ONE stream)
             assert ps.info("p2p_ops") >= 2 * k and ps.info("exchanges") == (iters - 1) // depth, (ps.info("p2p_ops"), ps.info("exchanges"))
+            assert (ps.info("exchanges_pipelined") > 0) == bool(pipe), (ps.info("exchanges_pipelined"), pipe)
             x, w1, w2, q = ps.gather_solution()
             assert ps.info("recovered") == (EXPECT_RECOVERED if was_resident else 0), (ps.info("recovered"), was_resident)
             sm, da = ps.costs(p)
@@ -43,7 +45,7 @@ with partition.Communicator(0, 0, 1, uid) as comm:
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (V, k, name)
             so, do = o.costs(oparams())
             assert abs(sm - so) <= 1e-9 * so and abs(da - do) <= 1e-9 * do, (sm, so, da, do)
-            if V == 6000:  # a second frame on the same topology: new data terms, state reset
+            if V == 6000 and pipe:  # a second frame on the same topology: new data terms, state reset
                 z2 = (g.z * 1.07 + 0.01).astype(np.float32)
                 ps.update_data(z2, g.wgt)
                 ps.step(p, 33)

@@ -36,6 +36,14 @@ def test_no_cpu_fallback():
     g = graphgen.synthetic(300, seed=1)
     r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
     p = default_params()
+    import ctypes as C2
+    L = lib.load()
+    gave = C2.c_int32()
+    assert L.flame_hip_state_snapshot(r._h, None) == lib.ERR_NODEVICE and L.flame_hip_state_rollback(r._h, None) == lib.ERR_NODEVICE
+    assert L.flame_hip_persist_take_error(r._h, C2.byref(gave)) == lib.ERR_NODEVICE
+    tcount = C2.c_int32()
+    assert L.flame_hip_delaunay(r._h, 3, g.pos.ctypes.data_as(C2.c_void_p), 0, None, C2.byref(tcount)) == lib.ERR_STATE  # (plan-only handle: no GPU)
+    assert L.flame_hip_delaunay_list(r._h, 0, None) == lib.ERR_STATE
     for call in (lambda: r.step(p, 1), lambda: r.costs(p), lambda: r.download(),
                  lambda: r.set_state(x=g.z), lambda: r.sync(),
                  lambda: r.triangles(np.eye(3), default_tri_params())):
