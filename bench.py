@@ -314,7 +314,7 @@ def small_graphs(device):
 
 
 def library_partition(rank, world, device, uid, barrier, max_over_ranks, workload=None, parts_per_rank=1, halo_depth=16,
-                      steps=5, persist=None):
+                      steps=5, pipeline=None):
     """BASELINE configs 4 / 5 through the LIBRARY's partition mode (include/flame_hip.h flame_hip_comm_* / flame_hip_part_*,
     csrc/part.cpp: RCB cut, resident tiles per part, ncclSend / ncclRecv halo records on the solve stream) -- not the torch
     harness: ONE graph strong-scaled over world x parts_per_rank subdomains.  50 k vertices below 8 subdomains, 200 k from
@@ -335,6 +335,8 @@ def library_partition(rank, world, device, uid, barrier, max_over_ranks, workloa
         out["ranks_share_a_gpu"] = bool(comm.info("shared_gpu"))
         with partition.Partition(comm, g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, parts_per_rank=parts_per_rank,
                                  halo_depth=halo_depth) as ps:
+            if pipeline is not None:
+                ps.set_option("pipeline", int(pipeline))
             # parity first (fresh state): the partitioned solve against one handle on the whole graph
             ps.step(p, iters)
             x, w1, w2, q = ps.gather_solution()
@@ -607,11 +609,21 @@ def main():
             lib_part = {"error": "%s: %s" % (type(e).__name__, str(e)[:300]), "rccl_ranks": world}
         if lib_part["rccl_ranks"] != world:
             sys.exit("bench.py: RCCL reports %d ranks in the library's communicator, launched with %d" % (lib_part["rccl_ranks"], world))
+        try:  # a deeper halo: half the exchanges for more redundant work (the parts stay resident up to ~49 k local vertices)
+            box3 = [fpart.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box3, src=0)
+            dh = library_partition(rank, world, local_rank, box3[0], _bar, _max, workload=lib_part.get("workload"),
+                                   halo_depth=2 * args.halo_depth, steps=3)
+            lib_part["halo_depth_x2"] = {k: dh[k] for k in ("halo_depth", "iterations_per_s", "us_per_iteration", "exchanges_per_step",
+                                                            "exchange_us", "bit_exact_vs_one_gpu", "resident_tiles", "local_vertices_rank0")
+                                         if k in dh}
+        except Exception as e:  # noqa: BLE001
+            lib_part["halo_depth_x2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         try:  # the same graph over-decomposed, two parts per rank: the records of part 0 travel while part 1 iterates
             box2 = [fpart.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box2, src=0)
             od = library_partition(rank, world, local_rank, box2[0], _bar, _max, workload=lib_part.get("workload"),
-                                   parts_per_rank=2, halo_depth=args.halo_depth, steps=3)
+                                   parts_per_rank=2, halo_depth=args.halo_depth, steps=3, pipeline=1)
             lib_part["two_parts_per_rank_pipelined"] = {k: od[k] for k in ("iterations_per_s", "us_per_iteration", "exchanges_per_step",
                                                                          "exchanges_pipelined", "bit_exact_vs_one_gpu", "resident_tiles")
                                                         if k in od}

@@ -250,7 +250,10 @@ struct flame_hip_part {
   // option "pipeline" (default 1; acts with parts_per_rank >= 2): SURVEY 8e "overlap compute with the exchange" by
   // over-decomposition -- inside a solve call the records of part i leave (their own ncclGroup, on the communicator's second
   // stream) as soon as part i has iterated, while part i + 1 iterates; the unpack waits for the last group.
-  bool pipeline = true;
+  // Measured on ONE GPU (every record a send / receive of the rank with itself, profiles/r05_part_pipeline_ab.txt): 2 parts
+  // 6.8 -> 9.0 us per iteration (two ncclGroups cost more than the 19 us of a part's iterations hide), 4 parts 22.1 -> 20.6,
+  // 8 parts of the 200 k graph 92 -> 67: the default is ON from 4 parts per rank (-1 = that rule; 0 / 1 force it).
+  int pipeline = -1;
   int64_t pipelined = 0;  // exchanges that went that way (info "exchanges_pipelined")
   bool time_exchanges = false;
   std::vector<hipEvent_t> tev;  // 2 per timed exchange
@@ -522,7 +525,7 @@ int flame_hip_part_create(flame_hip_part** out, flame_hip_comm* comm, int32_t pl
                           const float* x0) {
   if (!out) return FLAME_HIP_ERR_ARG;
   *out = nullptr;
-  if (parts_per_rank < 1 || halo_depth < 1 || halo_depth > 16 || V < 1 || E < 0 || !pos || (E > 0 && !edges)) return FLAME_HIP_ERR_ARG;
+  if (parts_per_rank < 1 || halo_depth < 1 || halo_depth > 64 || V < 1 || E < 0 || !pos || (E > 0 && !edges)) return FLAME_HIP_ERR_ARG;
   if (comm && (!z || !wgt || (E > 0 && (!alpha || !beta)))) return FLAME_HIP_ERR_ARG;  // (z / wgt are read whatever E is)
   for (int32_t e = 0; e < E; ++e)
     if (edges[2 * e] < 0 || edges[2 * e] >= V || edges[2 * e + 1] < 0 || edges[2 * e + 1] >= V) return FLAME_HIP_ERR_ARG;
@@ -632,7 +635,7 @@ static int run_iterations(flame_hip_part* P, const flame_hip_params* p, int32_t 
     }
     const int32_t n = std::min<int32_t>(P->rings_left, num_iters - done);
     // this chunk uses the rings up and the call goes on: the exchange behind it is certain -- pipeline it
-    const bool pipe = P->pipeline && P->k >= 2 && !P->ops.empty() && P->rings_left == n && done + n < num_iters && !P->time_exchanges;
+    const bool pipe = (P->pipeline < 0 ? P->k >= 4 : P->pipeline != 0) && P->k >= 2 && !P->ops.empty() && P->rings_left == n && done + n < num_iters && !P->time_exchanges;
     for (size_t i = 0; i < P->parts.size(); ++i) {
       LocalPart& L = P->parts[i];
       if ((rc = flame_hip_solve(L.g, p, n, C->stream))) return rc;
@@ -787,7 +790,7 @@ int flame_hip_part_set_option(flame_hip_part* P, const char* key, int32_t value)
   if (!P || !key) return FLAME_HIP_ERR_ARG;
   const std::string k(key);
   if (k == "time_exchanges") { P->time_exchanges = value != 0; P->timed = 0; return 0; }
-  if (k == "pipeline") { P->pipeline = value != 0; return 0; }
+  if (k == "pipeline") { P->pipeline = value < 0 ? -1 : (value != 0 ? 1 : 0); return 0; }
   return FLAME_HIP_ERR_ARG;
 }
 

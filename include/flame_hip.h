@@ -350,7 +350,7 @@ int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, doub
 /* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */
 int flame_hip_part_gather(flame_hip_part* p, float* x, float* w1, float* w2, float* q);
 /* "time_exchanges" 0 / 1: HIP events around the next (up to 64) exchanges -- pack, the group of sends / receives, unpack;
- * "pipeline" (default 1, acts with parts_per_rank >= 2): inside a solve call the halo records of part i leave -- an ncclGroup of
+ * "pipeline" (-1 = automatic, the default: on from 4 parts per rank; 0 / 1 force it; acts with parts_per_rank >= 2): inside a solve call the halo records of part i leave -- an ncclGroup of
  * their own on the communicator's second stream -- while part i + 1 iterates (overlap compute with the exchange, by
  * over-decomposition); info "exchanges_pipelined" counts them.  Same bits either way. */
 int flame_hip_part_set_option(flame_hip_part* p, const char* key, int32_t value);

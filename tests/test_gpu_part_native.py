@@ -29,7 +29,7 @@ with partition.Communicator(0, 0, 1, uid) as comm:
         g = graphgen.synthetic(V, seed=5)
         with partition.Partition(comm, g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, parts_per_rank=k, halo_depth=depth) as ps:
             p = default_params()
-            ps.set_option("pipeline", pipe)  # (r05: the records of part i travel while part i + 1 iterates; same bits)
+            ps.set_option("pipeline", pipe)  # (forced either way; the default is on from 4 parts per rank.  r05: the records of part i travel while part i + 1 iterates; same bits)
             ps.step(p, iters // 2)
             ps.step(p, iters - iters // 2)
             was_resident = int(all(ps.info("persist_launches", i) > 0 for i in range(k)))  # (parts of one rank queue behind
