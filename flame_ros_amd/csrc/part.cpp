@@ -247,7 +247,7 @@ struct flame_hip_part {
   // option "time_exchanges": HIP events around every exchange (pack -> group of sends / receives -> unpack) of the solves
   // that follow, up to kMaxTimed of them; info "exchange_ns" = their mean once the stream has been synchronised
   static constexpr int kMaxTimed = 64;
-  // option "pipeline" (default 1; acts with parts_per_rank >= 2): SURVEY 8e "overlap compute with the exchange" by
+  // option "pipeline" (acts with parts_per_rank >= 2): SURVEY 8e "overlap compute with the exchange" by
   // over-decomposition -- inside a solve call the records of part i leave (their own ncclGroup, on the communicator's second
   // stream) as soon as part i has iterated, while part i + 1 iterates; the unpack waits for the last group.
   // Measured on ONE GPU (every record a send / receive of the rank with itself, profiles/r05_part_pipeline_ab.txt): 2 parts
@@ -603,7 +603,6 @@ int flame_hip_part_update_data(flame_hip_part* P, const float* z, const float* w
 // Every local iteration invalidates one halo ring; an exchange (the owners' exact state) makes all `depth` rings
 // valid again.  Successive calls continue on whatever rings the previous one left.  Everything is enqueued on the
 // communicator's stream: no host synchronisation inside.
-// (the iterations themselves: shared by flame_hip_part_solve and the repeat of a give-up)
 // the ncclGroup of ONE sending phase: every message whose SOURCE part has local index `phase` on its rank (this rank's sends
 // of that part; its receives from parts of that index anywhere).  Both ends of a pair of ranks derive the same sets in the
 // same (src, dst, kind) order, and the phases follow each other in the same order everywhere: messages match by order.
