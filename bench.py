@@ -399,6 +399,7 @@ def main():
                     help="N>1: independent frames per GPU (default) or ONE graph cut into N "
                          "subdomains with RCCL halo exchange")
     ap.add_argument("--halo-depth", type=int, default=16)
+    ap.add_argument("--partition-timeout", type=int, default=420, help="seconds the library-partition block may take (N>1)")
     ap.add_argument("--no-partition", action="store_true", help="N>1: skip the library-partition block beside the replicas line")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames axis: B independent feature-grid graphs (640x480, one feature per "
@@ -442,7 +443,18 @@ def main():
         shared_gpu = True
     shared_gpu = shared_gpu or (backend == "gloo" and world > ndev)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FLAME_BENCH_FORCE_PARTITION: run the N > 1 library-partition block at world 1 too (tests: the glue around it -- process
+    # group, unique id over the store, watchdog -- on the one GPU there is)
+    force_part = bool(os.environ.get("FLAME_BENCH_FORCE_PARTITION")) and world == 1
+    if force_part:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_part:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -587,49 +599,6 @@ def main():
         ts = sorted(ts[2:])  # (frame 1 builds the partition, frame 2 is the first to reuse it)
         frame_ms = ts[len(ts) // 2]
 
-    lib_part = None
-    if world > 1 and backend == "nccl" and not args.batch and not args.no_partition:  # (gloo development runs: ranks share a GPU)
-        # the LIBRARY's partition mode beside the replicas line (VERDICT r04 item 4): the unique id travels over the torch
-        # store, everything else is flame_hip_comm_* / flame_hip_part_* -- RCCL by the library itself, on its own stream
-        from flame_ros_amd import partition as fpart
-        box = [fpart.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-
-        def _max(v):
-            t = torch.tensor([v], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-
-        def _bar():
-            torch.cuda.synchronize()
-            dist.barrier()
-        try:
-            lib_part = library_partition(rank, world, local_rank, box[0], _bar, _max, halo_depth=args.halo_depth)
-        except Exception as e:  # noqa: BLE001 -- the replicas line (the contract's `value`) must survive a failure of the side block
-            lib_part = {"error": "%s: %s" % (type(e).__name__, str(e)[:300]), "rccl_ranks": world}
-        if lib_part["rccl_ranks"] != world:
-            sys.exit("bench.py: RCCL reports %d ranks in the library's communicator, launched with %d" % (lib_part["rccl_ranks"], world))
-        try:  # a deeper halo: half the exchanges for more redundant work (the parts stay resident up to ~49 k local vertices)
-            box3 = [fpart.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box3, src=0)
-            dh = library_partition(rank, world, local_rank, box3[0], _bar, _max, workload=lib_part.get("workload"),
-                                   halo_depth=2 * args.halo_depth, steps=3)
-            lib_part["halo_depth_x2"] = {k: dh[k] for k in ("halo_depth", "iterations_per_s", "us_per_iteration", "exchanges_per_step",
-                                                            "exchange_us", "bit_exact_vs_one_gpu", "resident_tiles", "local_vertices_rank0")
-                                         if k in dh}
-        except Exception as e:  # noqa: BLE001
-            lib_part["halo_depth_x2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        try:  # the same graph over-decomposed, two parts per rank: the records of part 0 travel while part 1 iterates
-            box2 = [fpart.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box2, src=0)
-            od = library_partition(rank, world, local_rank, box2[0], _bar, _max, workload=lib_part.get("workload"),
-                                   parts_per_rank=2, halo_depth=args.halo_depth, steps=3, pipeline=1)
-            lib_part["two_parts_per_rank_pipelined"] = {k: od[k] for k in ("iterations_per_s", "us_per_iteration", "exchanges_per_step",
-                                                                         "exchanges_pipelined", "bit_exact_vs_one_gpu", "resident_tiles")
-                                                        if k in od}
-        except Exception as e:  # noqa: BLE001
-            lib_part["two_parts_per_rank_pipelined"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-
     part_info = None
     if partition:  # per-exchange cost, measured apart from the timed region: pack + P2P + unpack
         torch.cuda.synchronize(); dist.barrier()
@@ -681,8 +650,6 @@ def main():
         }
         if part_info:
             out["partition_torch_harness"] = part_info
-        if lib_part:
-            out["partition"] = lib_part
         if frame_ms:
             out["host_inclusive"] = {"ms_per_frame": frame_ms, "frames_per_s": 1e3 / frame_ms,
                                      "iterations_per_s": iters * 1e3 / frame_ms,
@@ -765,8 +732,69 @@ def main():
                 out["parity_vs_oracle"] = parity_check(g, iters, local_rank, opts)
             out["speedup_vs_cpu_1thread"] = out["value"] / (1 if partition else world) / cb["value"]
             out["speedup_vs_cpu_best"] = out["value"] / (1 if partition else world) / max(cb["best_value"], cb["value"])
+    else:
+        out = None
+    lib_part = None
+    if (world > 1 or force_part) and backend == "nccl" and not args.batch and not args.no_partition and not partition:  # (gloo development runs: ranks share a GPU)
+        # the LIBRARY's partition mode beside the replicas line (VERDICT r04 item 4): the unique id travels over the torch
+        # store, everything else is flame_hip_comm_* / flame_hip_part_* -- RCCL by the library itself, on its own stream
+        from flame_ros_amd import partition as fpart
+        # A collective that never completes (a rank that died, an RCCL mismatch) must not cost the replicas line: a watchdog
+        # THREAD (the main thread may sit in a C call for good) prints the line without the block and ends the process.
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out["partition"] = {"error": "the library-partition block did not finish within %d s" % args.partition_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.partition_timeout, _bail)
+        dog.daemon = True
+        dog.start()
+        box = [fpart.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+
+        def _max(v):
+            t = torch.tensor([v], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        def _bar():
+            torch.cuda.synchronize()
+            dist.barrier()
+        try:
+            lib_part = library_partition(rank, world, local_rank, box[0], _bar, _max, halo_depth=args.halo_depth)
+        except Exception as e:  # noqa: BLE001 -- the replicas line (the contract's `value`) must survive a failure of the side block
+            lib_part = {"error": "%s: %s" % (type(e).__name__, str(e)[:300]), "rccl_ranks": world}
+        if lib_part["rccl_ranks"] != world:
+            sys.exit("bench.py: RCCL reports %d ranks in the library's communicator, launched with %d" % (lib_part["rccl_ranks"], world))
+        try:  # a deeper halo: half the exchanges for more redundant work (the parts stay resident up to ~49 k local vertices)
+            box3 = [fpart.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box3, src=0)
+            dh = library_partition(rank, world, local_rank, box3[0], _bar, _max, workload=lib_part.get("workload"),
+                                   halo_depth=2 * args.halo_depth, steps=3)
+            lib_part["halo_depth_x2"] = {k: dh[k] for k in ("halo_depth", "iterations_per_s", "us_per_iteration", "exchanges_per_step",
+                                                            "exchange_us", "bit_exact_vs_one_gpu", "resident_tiles", "local_vertices_rank0")
+                                         if k in dh}
+        except Exception as e:  # noqa: BLE001
+            lib_part["halo_depth_x2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        try:  # the same graph over-decomposed, two parts per rank: the records of part 0 travel while part 1 iterates
+            box2 = [fpart.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box2, src=0)
+            od = library_partition(rank, world, local_rank, box2[0], _bar, _max, workload=lib_part.get("workload"),
+                                   parts_per_rank=2, halo_depth=args.halo_depth, steps=3, pipeline=1)
+            lib_part["two_parts_per_rank_pipelined"] = {k: od[k] for k in ("iterations_per_s", "us_per_iteration", "exchanges_per_step",
+                                                                         "exchanges_pipelined", "bit_exact_vs_one_gpu", "resident_tiles")
+                                                        if k in od}
+        except Exception as e:  # noqa: BLE001
+            lib_part["two_parts_per_rank_pipelined"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+        dog.cancel()
+    if rank == 0:
+        if lib_part:
+            out["partition"] = lib_part
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_part:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -126,3 +126,21 @@ def test_bench_library_partition_block_world_1(gpu, parts):
     assert d["iterations_per_s"] > 0 and d["exchange_us"] > 0 and d["exchanges_per_step"] in (d["iters_per_step"] // 16, d["iters_per_step"] // 16 + 1), d
     assert d["send_bytes_per_exchange_rank0"] > 0 and d["resident_tiles"] is True and d["solves_repeated_after_a_give_up"] == 0, d
     print(d)
+
+
+def test_bench_partition_glue_at_world_1(gpu):
+    """The N > 1 branch of bench.py that nobody can run here -- process group on nccl, the unique id over the torch store, the
+    three library-partition variants, the watchdog, the block joined to the ONE JSON line -- forced at world 1
+    (FLAME_BENCH_FORCE_PARTITION): the line must carry `partition` with RCCL's own rank count and bit-exact variants."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FLAME_BENCH_FORCE_PARTITION"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu", "--no-facade"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    pt = d["partition"]
+    assert "error" not in pt and pt["rccl_ranks"] == 1 and pt["bit_exact_vs_one_gpu"] is True, pt
+    assert pt["halo_depth_x2"].get("bit_exact_vs_one_gpu") is True and pt["halo_depth_x2"]["halo_depth"] == 32, pt["halo_depth_x2"]
+    assert pt["two_parts_per_rank_pipelined"].get("bit_exact_vs_one_gpu") is True, pt["two_parts_per_rank_pipelined"]
+    assert pt["two_parts_per_rank_pipelined"]["exchanges_pipelined"] > 0
+    assert d["n_gpus"] == 1 and d["value"] > 0
