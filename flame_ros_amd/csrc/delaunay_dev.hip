@@ -95,6 +95,17 @@ __device__ inline int64_t orient64(int2 a, int2 b, int2 c) {
 }
 __device__ inline int sgn64(int64_t v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
 
+// the exact evaluation behind the filter: differences < 2^30: squared norms and 2 x 2 minors < 2^61 fit 64 bits; three
+// 64 x 64 -> 128-bit products, sum < 2^124.  NOT inlined (r05 experiment): it is rare, and its temporaries inflate the
+// star kernel's register allocation
+__device__ __attribute__((noinline)) int incircle_exact(int2 a, int2 b, int2 c, int2 d) {
+  const int64_t ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+  const int64_t a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
+  const int64_t mbc = bx * cy - by * cx, mac = ax * cy - ay * cx, mab = ax * by - ay * bx;
+  const i128 det = (i128)a2 * mbc - (i128)b2 * mac + (i128)c2 * mab;
+  return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+
 // > 0: d strictly inside the circle through a, b, c when those are counter-clockwise (the sign flips with their
 // orientation); 0: on it.  Filter and exact evaluation as include/flame/utils/delaunay.h in_circle.
 __device__ inline int incircle_sign(int2 a, int2 b, int2 c, int2 d) {
@@ -109,12 +120,7 @@ __device__ inline int incircle_sign(int2 a, int2 b, int2 c, int2 d) {
     if (det > bound) return 1;
     if (det < -bound) return -1;
   }
-  // differences < 2^30: squared norms and 2 x 2 minors < 2^61 fit 64 bits; three 64 x 64 -> 128-bit products, sum < 2^124
-  const int64_t ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
-  const int64_t a2 = ax * ax + ay * ay, b2 = bx * bx + by * by, c2 = cx * cx + cy * cy;
-  const int64_t mbc = bx * cy - by * cx, mac = ax * cy - ay * cx, mab = ax * by - ay * bx;
-  const i128 det = (i128)a2 * mbc - (i128)b2 * mac + (i128)c2 * mab;
-  return det > 0 ? 1 : (det < 0 ? -1 : 0);
+  return incircle_exact(a, b, c, d);
 }
 
 // Disk through p, q, r: centre and a radius padded by the rounding bounds of the centre (pruning only).  A triangle
