@@ -503,8 +503,8 @@ __global__ void k_dt_order_fill(const int32_t* __restrict__ start, const int32_t
 #endif
 constexpr int kStarWG = FLAME_DT_STAR_WG;
 template <bool WRITE>
-__global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(kStarWG) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
-                                                 int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
+__device__ __forceinline__ void dt_star_body(const DtView& g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
+                                             int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
   const int32_t lane = threadIdx.x & (kSW - 1);       // lane within the star
   const int32_t shift = (threadIdx.x & 63) & ~(kSW - 1);  // first lane of the star within its wavefront
   const int32_t w0 = blockIdx.x * (blockDim.x / kSW) + threadIdx.x / kSW;
@@ -820,6 +820,23 @@ __global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(kStarWG) k_dt_star(DtView 
   }
 }
 
+// The star kernel twice (r05): as the compiler allocates it (197 VGPRs, 2 waves per SIMD: the shortest star, best while the
+// wavefront slots are not saturated -- frames below ~30 k features) and with the registers capped for 3 waves per SIMD
+// (168 VGPRs + 112 B of scratch: each star a little slower, half as many again in flight -- 50 k points 0.78 -> 0.74 ms,
+// 200 k 2.54 -> 2.41, but 1.2 k 0.105 -> 0.109: profiles/r05_delaunay_variants.txt).
+template <bool WRITE>
+__global__ void FLAME_DT_WAVES_ATTR __launch_bounds__(kStarWG) k_dt_star(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
+                                                 int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
+  dt_star_body<WRITE>(g, flags, tcnt, toff, stash, tris, tri_cap);
+}
+template <bool WRITE>
+__global__ void __attribute__((amdgpu_waves_per_eu(3))) __launch_bounds__(kStarWG) k_dt_star_dense(DtView g, int32_t* flags, int32_t* tcnt, const int32_t* __restrict__ toff,
+                                                 int32_t* __restrict__ stash, int32_t* __restrict__ tris, int32_t tri_cap) {
+  dt_star_body<WRITE>(g, flags, tcnt, toff, stash, tris, tri_cap);
+}
+constexpr int32_t kStarDenseFrom = 30000;  // points from which the 3-waves variant runs
+
+
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // out[0..n) = exclusive scan of in[0..n), out[n] = total (also *total when given); n <= 2^20
@@ -947,9 +964,12 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
   view.order = small ? nullptr : order;  // (a small frame's stars all run at once)
   const int per_wg = kStarWG / kSW;  // stars per workgroup
   const unsigned gs = (unsigned)((V + per_wg - 1) / per_wg);
-  hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  const bool dense = V >= kStarDenseFrom;
+  if (dense) hipLaunchKernelGGL(k_dt_star_dense<false>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  else hipLaunchKernelGGL(k_dt_star<false>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   scan_ints(s, tcnt, V, toff, sums, 0, flags + 3);
-  hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  if (dense) hipLaunchKernelGGL(k_dt_star_dense<true>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
+  else hipLaunchKernelGGL(k_dt_star<true>, dim3(gs), dim3(kStarWG), 0, s, view, flags, tcnt, toff, stash, dtris, tmax);
   DT_HIPCHK(hipGetLastError());
   // flags and the list leave together (T = 2 n - 2 - h is within a few triangles of the 2 V the buffer holds: copying
   // the whole buffer costs nothing over copying T triangles, and saves the round trip that would bring T first)
