@@ -68,7 +68,7 @@ def test_host_plan_equals_the_python_harness(world, k, depth, V):
 
 def test_bad_arguments():
     g = graphgen.synthetic(300, seed=2)
-    for kw in (dict(parts_per_rank=0), dict(halo_depth=0), dict(halo_depth=17), dict(plan_rank=2, plan_world=2)):
+    for kw in (dict(parts_per_rank=0), dict(halo_depth=0), dict(halo_depth=65), dict(plan_rank=2, plan_world=2)):
         with pytest.raises(lib.FlameHipError) as e:
             partition.Partition(None, g.pos, g.edges, None, None, None, None, **kw)
         assert e.value.code == lib.ERR_ARG
