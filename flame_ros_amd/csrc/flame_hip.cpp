@@ -155,7 +155,7 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
 // runtime, call by call -- ~10 us each, the larger part of a small frame's upload).
 // frame_results: outputs up to this size are written to host memory by the kernels themselves (measured on
 // the facade stream, direct vs one copy: 1.2 k -14 us, 5 k -10 us, 10 k (185 KB) -15 us, 50 k (925 KB) +65 us)
-constexpr int kPollDelayDefault = 0;  // r05: with the per-wave request skipping 0..3 are alike (profiles/r05_poll_delay.txt); r04:  // x 256 clocks (tools/exp/poll_delay_sweep.sh: 50k 1.56 -> 1.52 us per iteration before the hand-off stores moved into the last iteration, 0..2 alike since; 6 and up lose); FLAME_HIP_POLL_DELAY overrides
+constexpr int kPollDelayDefault = 2;  // x 256 clocks.  r05, address-sorted poll: a pass is short enough to sample memory before the neighbours' stores have landed (passes per round 1.35 at 0, 1.10 at 2, 1.01 at 3; 50 k 1.316 / 1.319 / 1.304 / 1.303 / 1.357 us per iteration at 0 / 1 / 2 / 3 / 4, profiles/r05_sorted_poll_delay.txt); FLAME_HIP_POLL_DELAY overrides
 constexpr int kMapMinTiles = 6;  // partitions of at least this many tiles leave a tile map for the next frame (partition reuse)
 constexpr size_t kDirectOutBytes = 256 * 1024;
 
@@ -397,6 +397,8 @@ struct flame_hip_graph {
   PinnedArena pout;            // page-locked landing area of the results (frame_results, download)
   char* harena = nullptr;      // device arena the host-built plan of the current upload lives in
   bool lanes_applied = false;  // lane_order = 1: the conflict-avoiding lane order is in the device arrays
+  bool poll_valid = false;     // the resident tiles' poll lists (xp.poll_*) belong to the current tile arrays
+  bool poll_sorted = false;    // ... and are the address-sorted ones (from a plan's second solve on)
 
   void drop_execs() {
     for (auto& e : execs) (void)hipGraphExecDestroy(e.exec);
@@ -422,6 +424,7 @@ struct flame_hip_graph {
       }
     }
     xp.prof = nullptr;  // (was in caps)
+    xp.poll_v = nullptr; xp.poll_e = nullptr; xp.poll_ne = nullptr;
     pin.release();
     pin_in.release();
     pout.release();
@@ -1146,6 +1149,7 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
 
 // buffers every uploaded graph needs, whichever builder made its plan
 static int finish_upload(flame_hip_graph* g) {
+  g->poll_valid = false;  // (new tile arrays: the resident tiles' poll lists are rebuilt at their next launch)
   const int32_t V = g->V, E = g->E;
   const Plan& P = g->plan;
   int rc;
@@ -1540,6 +1544,8 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
 // Returns the buffer index holding the result through *cur_out.
 // one launch of resident tiles instead of ceil(num_iters / depth) launches?
 // one launch of resident tiles instead of ceil(num_iters / depth) launches?
+static size_t persist_stage_bytes(const TileDesc& D) { return sizeof(float4) * (size_t)std::max(D.n_upd - D.n_own, 0); }
+
 static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
   const Plan& P = g->plan;
   if (!g->persist || g->persist_skip_once || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 ||
@@ -1548,8 +1554,13 @@ static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
   const size_t nt = P.tiles.size();
   if (nt < 2 || nt > (size_t)kPersistMaxTiles || (int)nt > g->num_cus) return false;  // (one workgroup per CU is always resident)
   if (!tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return false;
-  for (const TileDesc& D : P.tiles)
+  size_t stage = 0;
+  for (const TileDesc& D : P.tiles) {
     if (D.n_ext <= 0) return false;  // (an empty tile has nothing to hand over, but its neighbours would not know)
+    stage = std::max(stage, persist_stage_bytes(D));
+  }
+  // (r05: what a tile polls is delivered through an LDS staging area behind its incidence slots)
+  if ((size_t)P.tile_lds_bytes + stage > (size_t)g->opt.lds_bytes) return false;
   return true;
 }
 
@@ -1688,6 +1699,22 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       const int rounds = (num_iters + P.tile_depth - 1) / P.tile_depth;
       bool rezero = g->persist_base > (1 << 23);  // (the tags only grow; 2^23: the torn-read debug build compares 24 bits)
       if (rezero) g->persist_base = 0;
+      // the tiles' poll lists: in local order for the FIRST solve of a plan (a frame of a stream is solved once and would
+      // not earn the sorts back), address-sorted from the second solve on (a resident graph; the lane order, applied then,
+      // invalidates them anyway)
+      const bool want_sorted = g->solves_since_upload > 0;
+      if (!g->poll_valid || (want_sorted && !g->poll_sorted)) {
+        size_t nv_loc = 0, ne_loc = 0;
+        for (const TileDesc& D : P.tiles) { nv_loc += (size_t)D.n_ext; ne_loc += (size_t)D.e_loc; }
+        if ((rc = dev_alloc(g->caps, &x.poll_v, std::max<size_t>(nv_loc, 1))) || (rc = dev_alloc(g->caps, &x.poll_e, std::max<size_t>(ne_loc, 1))) ||
+            (rc = dev_alloc(g->caps, &x.poll_ne, P.tiles.size())))
+          return rc;
+        HIPCHK(launch_poll_lists(s, (int32_t)P.tiles.size(), g->tiles, g->t_vmap, g->t_emap, g->t_eij, x.poll_v, x.poll_e, x.poll_ne, want_sorted));
+        g->poll_sorted = want_sorted;
+        x.stage_bytes = 0;
+        for (const TileDesc& D : P.tiles) x.stage_bytes = std::max(x.stage_bytes, persist_stage_bytes(D));
+        g->poll_valid = true;
+      }
       for (int b = 0; b < 2; ++b) {  // (a new or recycled buffer is zeroed: tag 0 is never a round's)
         float4** pp[3] = {&x.hA[b], &x.hB[b], &x.hq[b]};
         const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
@@ -1702,7 +1729,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       a.iters = num_iters;
       {
         static const char* pd = std::getenv("FLAME_HIP_POLL_DELAY");  // dev A/B
-        x.poll_delay = pd ? std::atoi(pd) : kPollDelayDefault;
+        x.poll_delay = pd ? std::atoi(pd) : (g->poll_sorted ? kPollDelayDefault : 0);  // (the lists in local order: a pass is long enough, 0)
         // A poll waits at most max(0.5 ms, 8 x the handle's last measured round) -- r04's flat 4 ms was 5.5 headline
         // solves; 4 ms while nothing has been measured.  FLAME_HIP_PERSIST_TIMEOUT_US overrides.
         static const char* to = std::getenv("FLAME_HIP_PERSIST_TIMEOUT_US");
@@ -1771,6 +1798,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
     if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));  // (the first solve may have run on another stream)
     HIPCHK(launch_assign_lanes(s, (int32_t)g->plan.tiles.size(), e_max, g->tiles, g->t_eij, g->t_ew, g->t_emap));
     g->lanes_applied = true;
+    g->poll_valid = false;  // (edges moved inside their 64-blocks: a poll record names a position)
   }
   HIPCHK(hipEventRecord(g->ev0, s));
   g->last_sp = sp; g->last_iters = num_iters; g->last_stream = s;

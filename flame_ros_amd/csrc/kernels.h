@@ -49,11 +49,19 @@ struct PersistBufs {
   float4* hA[2] = {nullptr, nullptr};
   float4* hB[2] = {nullptr, nullptr};
   float4* hq[2] = {nullptr, nullptr};
+  // r05: the tiles' address-sorted poll lists (launch_poll_lists): slot vmap_off + j / emap_off + j = the tile's j-th halo
+  // vertex / halo edge in ascending global id, {global id, local id (| bit 31: needs the primal state too)}
+  uint2* poll_v = nullptr;   // sum of n_ext (capacity)
+  uint2* poll_e = nullptr;   // sum of e_loc
+  int32_t* poll_ne = nullptr;  // per tile: its halo edges
+  size_t stage_bytes = 0;    // LDS behind the incidence slots: (n_upd - n_own) x 16 B of the largest tile
   int32_t* prof = nullptr;
   int32_t poll_delay = 0;  // x 256 clocks between a round's stores and the first poll pass
   int32_t timeout_ticks = 0;  // 10 ns ticks a poll may wait (0 = 4 ms)
 };
 bool tile_persist_exists(int nt, int ept, int vpt);
+hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tiles, const int32_t* t_vmap, const int32_t* t_emap,
+                             const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted);
 bool tile_torn_check_build();  // compiled with FLAME_TORN_CHECK (debug: hashed hand-off tags, torn entries counted)
 hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,
                                int32_t* err_host, int32_t base);

@@ -288,6 +288,17 @@ struct PersistArgs {
   float4* hA[2];      // uncached, zeroed once: hand-off copies of vtxA / vtxB / q (same indices), [round & 1]
   float4* hB[2];
   float4* hq[2];
+  // r05, the ADDRESS-SORTED poll: the poll is bound by the CU's request rate (~one 64-byte line request per clock), and a
+  // wave whose lanes poll the entries of THEIR OWN local vertices / edges (ring-major, level-major) touches 0.63 lines per
+  // entry.  So which lane polls what is decoupled from who needs it: slot j of a tile's poll list (vmap_off + j /
+  // emap_off + j; k_poll_lists) is its j-th halo entry in ascending GLOBAL id -- owner by owner, in the owner's order: 0.36
+  // lines per entry --, {global id, local id (| bit 31: the tile updates the vertex: needs A too)}; what arrives is
+  // delivered through LDS (x_bar straight into bar[], the duals through the polled edge's own incidence slot -- dead between
+  // rounds --, the primal state through a small staging area behind the slots; picked up by the lanes that hold them after the
+  // round's barrier).  Edge records name that slot instead of a local id.
+  const uint2* poll_v;
+  const uint2* poll_e;
+  const int32_t* poll_ne;  // halo edges per tile
   int32_t* err_host;  // page-locked: set when a wait timed out
   int32_t base;       // tags of this launch are base + 1 .. base + rounds - 1 (they only grow)
   int32_t* prof;      // device memory (16 words), dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]; [7] the
@@ -394,6 +405,17 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
   // (debug timeline start: taken here so that the index loads above do not wait for its kernel
   // argument, which is not among the preloaded ones)
+  // resident tiles: this thread's slots of the tile's address-sorted poll list
+  uint2 pvr[VPT], per[EPT];
+  int n_hv = 0, n_he = 0;
+  if (PERSIST) {
+    n_hv = n_ext - n_own;
+    n_he = pa.poll_ne[tile_id];
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) pvr[k] = pa.poll_v[vmap_off + min(k * NT + tid, max(n_hv - 1, 0))];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) per[k] = pa.poll_e[emap_off + min(k * NT + tid, max(n_he - 1, 0))];
+  }
   const unsigned long long t_start = a.prof ? __builtin_readcyclecounter() : 0ull;
   // Loads return in issue order, so they are issued in the order of first need: x_bar (B) of every
   // local vertex fills bar[] and is all the first workgroup barrier waits for; the edge constants,
@@ -587,9 +609,8 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     bool needv[VPT], needa[VPT], neede[EPT], want = false;
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      const int lv = k * NT + tid;
-      needv[k] = lv >= n_own && lv < n_ext;
-      needa[k] = needv[k] && lv < n_upd;
+      needv[k] = (k * NT + tid) < n_hv;          // (poll slot j = k NT + tid of this tile's list, not local vertex j)
+      needa[k] = needv[k] && (pvr[k].y >> 31);
 #ifdef FLAME_EXP_NO_APOLL  // (timing experiment only -- WRONG results)
       needa[k] = false;
 #endif
@@ -600,7 +621,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      neede[k] = (k * NT + tid) < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own);
+      neede[k] = (k * NT + tid) < n_he && per[k].x != 0xffffffffu;  // (an unsorted list marks the owned edges invalid)
 #ifdef FLAME_EXP_NO_QPOLL  // (timing experiment only -- WRONG results: what would the hand-off cost without the duals' bytes?)
       neede[k] = false;
 #endif
@@ -614,11 +635,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     for (;;) {
       if (stale) {
         if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice
-          const float4* pb = &hB[needv[0] ? gi[0] : vstart];  // the requests, and the poll is bound by their number)
-          const float4* pv = &hA[needa[0] ? gi[0] : vstart];
-          const float4* p0 = &hq[neede[0] ? qi[0] : estart];
-          const float4* p1 = &hq[neede[EPT > 1 ? 1 : 0] ? qi[EPT > 1 ? 1 : 0] : estart];
-          const float4* p2 = &hq[neede[EPT - 1] ? qi[EPT - 1] : estart];
+          const float4* pb = &hB[needv[0] ? (int)pvr[0].x : vstart];  // the requests, and the poll is bound by their number)
+          const float4* pv = &hA[needa[0] ? (int)pvr[0].x : vstart];
+          const float4* p0 = &hq[neede[0] ? (int)per[0].x : estart];
+          const float4* p1 = &hq[neede[EPT > 1 ? 1 : 0] ? (int)per[EPT > 1 ? 1 : 0].x : estart];
+          const float4* p2 = &hq[neede[EPT - 1] ? (int)per[EPT - 1].x : estart];
 #if FLAME_POLL_SKIP
           // r05: a request goes out only when a lane of the wave (still) needs that array -- every wave used to issue all
           // five each pass (80 wave-instructions of 1 KB through the CU's one address path, most of them for the
@@ -649,11 +670,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         } else {
 #pragma unroll
           for (int k = 0; k < VPT; ++k) {
-            nb[k] = load_agent(&hB[needv[k] ? gi[k] : vstart]);
-            na[k] = load_agent(&hA[needa[k] ? gi[k] : vstart]);
+            nb[k] = load_agent(&hB[needv[k] ? (int)pvr[k].x : vstart]);
+            na[k] = load_agent(&hA[needa[k] ? (int)pvr[k].x : vstart]);
           }
 #pragma unroll
-          for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&hq[neede[k] ? qi[k] : estart]);
+          for (int k = 0; k < EPT; ++k) nq[k] = load_agent(&hq[neede[k] ? (int)per[k].x : estart]);
         }
         bool ok = true;
 #pragma unroll
@@ -676,24 +697,41 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     wait_max = max(wait_max, __builtin_amdgcn_readfirstlane((int32_t)(wall_clock64() - w0)));  // (scalar: no VGPR)  // (the longest any poll of this wave waited: info "persist_wait_us_max")
   }
   const unsigned long long pt1 = pprof ? wall_clock64() : 0ull;
+  // what this lane polled goes where it is needed: x_bar into bar[] (phase D gathers it there); the duals into the polled
+  // edge's OWN incidence slot (dead between rounds: the first phase D of the next round rewrites every real slot before a
+  // phase P reads one; the zero padding of the rows is never touched); the primal state into a small staging area behind
+  // the slots ((n_upd - n_own) x 16 B)
+  float4* const stA = cs + nslots + kDummySlots + 1;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if ((k * NT + tid) < n_hv) {
+      const int lv = (int)(pvr[k].y & 0x7fffffffu);
+      bar[lv] = make_float4(nb[k].y, nb[k].z, nb[k].x, 0.f);
+      if (pvr[k].y >> 31) stA[lv - n_own] = na[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k)
+    if ((k * NT + tid) < n_he && per[k].x != 0xffffffffu) cs[per[k].y] = nq[k];
+  __syncthreads();
+  if (s_abort) break;
+  // ... and the lanes that hold a halo vertex / halo edge pick their state up
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     const int lv = k * NT + tid;
-    if (lv >= n_own && lv < n_ext) {  // halo vertices: the owners' results of this round
-      vxb[k] = nb[k].x; vwb[k].x = nb[k].y; vwb[k].y = nb[k].z;
-      bar[lv] = make_float4(nb[k].y, nb[k].z, nb[k].x, 0.f);
-      if (lv < n_upd) { vx[k] = na[k].x; vw[k].x = na[k].y; vw[k].y = na[k].z; }
+    if (lv >= n_own && lv < n_upd) {
+      const float4 t = stA[lv - n_own];
+      vx[k] = t.x; vw[k].x = t.y; vw[k].y = t.z;
     }
   }
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const int le = k * NT + tid;
-    if (le < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own)) {  // halo edges
-      q1[k] = nq[k].x; q23[k].x = nq[k].y; q23[k].y = nq[k].z;
+    if (le < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own)) {  // halo edges: staged in the source's slot, else the target's
+      const float4 t = *((es[k] != cs + dummy) ? es[k] : ed[k]);
+      q1[k] = t.x; q23[k].x = t.y; q23[k].y = t.z;
     }
   }
-  __syncthreads();
-  if (s_abort) break;
   if (pprof) {  // dev aid: where a round's time goes (10 ns ticks, summed over the rounds of one tile)
     const unsigned long long pt2 = wall_clock64();
     pacc[0] += (int32_t)(pt0 - pround); pacc[1] += (int32_t)(pt1 - pt0); pacc[2] += (int32_t)(pt2 - pt1);
@@ -1576,6 +1614,109 @@ hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes
 // persistent variant: the configurations small graphs get
 #define FLAME_PERSIST_CFGS(X) X(256, 2, 1) X(256, 3, 1) X(512, 2, 1) X(512, 3, 1) X(1024, 2, 1) X(1024, 3, 1)
 
+// ---- the resident tiles' address-sorted poll lists (PersistArgs::poll_*): per tile, its halo vertices and its halo edges in
+// ascending GLOBAL id.  Derived from the finished tile arrays whoever made them (host builder, device builder, one-launch
+// plan), after the lane order has been applied (it moves edges inside their 64-blocks; a record names a position).  One
+// workgroup per tile, bitonic sort of <= 4 096 64-bit keys {global id, local id} in LDS.
+constexpr int kPollCap = 4096, kPollThreads = 1024;
+// thread t handles elements t, t + 1024, ...: partners i ^ j with j < 64 lie in the same wavefront's 64-block, and a
+// wavefront's LDS operations complete in order -- only the steps with j >= 64, and the step in front of one, need the
+// workgroup barrier (27 instead of 78 at 4 096 keys)
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* key, int m, int tid) {
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < m; i += kPollThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = key[i], b = key[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { key[i] = b; key[l] = a; }
+        }
+      }
+      // (the workgroup barrier behind every step that paired elements of different wavefronts, j >= 64, and behind the last
+      // step of a merge when the next merge starts with such a step, j = k >= 64)
+      if (j >= 64 || (j == 1 && k >= 64)) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    }
+  __syncthreads();
+}
+
+// SORT = false: the lists in LOCAL order, unsorted -- a plan that is solved once (a frame of a stream) does not pay for the
+// sorts (28 us at 1.2 k vertices against the ~5 us its one solve would gain); every local edge gets a record, the owned
+// ones marked invalid (global id ~0), so a lane polls what it holds, as before r05.
+template <bool SORT>
+__global__ __launch_bounds__(kPollThreads) void k_poll_lists(const TileDesc* __restrict__ tiles, const int32_t* __restrict__ t_vmap,
+                                                             const int32_t* __restrict__ t_emap, const uint2* __restrict__ t_eij,
+                                                             uint2* __restrict__ poll_v, uint2* __restrict__ poll_e,
+                                                             int32_t* __restrict__ poll_ne) {
+  __shared__ unsigned long long key[kPollCap];
+  __shared__ int s_n;
+  const TileDesc& D = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (D.n_ext <= 0) { if (tid == 0) poll_ne[blockIdx.x] = 0; return; }
+  // halo vertices
+  const int nhv = D.n_ext - D.n_own;
+  if (nhv > kPollCap || D.e_loc > kPollCap) { if (tid == 0) poll_ne[blockIdx.x] = -1; return; }  // (never with the resident configurations)
+  if (!SORT) {
+    for (int i = tid; i < nhv; i += kPollThreads) {
+      const int lv = D.n_own + i;
+      poll_v[D.vmap_off + i] = make_uint2((uint32_t)t_vmap[D.vmap_off + lv], (uint32_t)lv | (lv < D.n_upd ? 0x80000000u : 0u));
+    }
+    for (int le = tid; le < D.e_loc; le += kPollThreads) {
+      const int32_t eid = t_emap[D.emap_off + le];
+      const bool owned = (uint32_t)(eid - D.estart) < (uint32_t)D.e_own;
+      const uint32_t sl = t_eij[D.erec_off + le].y, ss = sl & 0xffffu, sd = sl >> 16;
+      const uint32_t slot = ss != 0xffffu ? ss : (sd != 0xffffu ? sd : (uint32_t)(D.nslots + (le & 63)));
+      poll_e[D.emap_off + le] = make_uint2(owned ? 0xffffffffu : (uint32_t)eid, slot);
+    }
+    if (tid == 0) poll_ne[blockIdx.x] = D.e_loc;
+    return;
+  }
+  int m = 64;
+  while (m < nhv) m <<= 1;
+  for (int i = tid; i < m; i += kPollThreads) {
+    unsigned long long kk = ~0ull;
+    if (i < nhv) {
+      const int lv = D.n_own + i;
+      kk = ((unsigned long long)(uint32_t)t_vmap[D.vmap_off + lv] << 32) | (uint32_t)lv | (lv < D.n_upd ? 0x80000000u : 0u);
+    }
+    key[i] = kk;
+  }
+  __syncthreads();
+  bitonic_sort_u64(key, m, tid);
+  for (int i = tid; i < nhv; i += kPollThreads) poll_v[D.vmap_off + i] = make_uint2((uint32_t)(key[i] >> 32), (uint32_t)key[i]);
+  __syncthreads();
+  // halo edges (the owned ones are the internal ids [estart, estart + e_own)); the record names the incidence slot the dual
+  // is staged in: the source's, else the target's, else (no endpoint is ever updated) the lane's trash slot
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int le = tid; le < D.e_loc; le += kPollThreads) {
+    const int32_t eid = t_emap[D.emap_off + le];
+    if ((uint32_t)(eid - D.estart) < (uint32_t)D.e_own) continue;
+    const uint32_t sl = t_eij[D.erec_off + le].y, ss = sl & 0xffffu, sd = sl >> 16;
+    const uint32_t slot = ss != 0xffffu ? ss : (sd != 0xffffu ? sd : (uint32_t)(D.nslots + (le & 63)));
+    const int p = atomicAdd(&s_n, 1);
+    key[p] = ((unsigned long long)(uint32_t)eid << 32) | slot;
+  }
+  __syncthreads();
+  const int nhe = s_n;
+  m = 64;
+  while (m < nhe) m <<= 1;
+  for (int i = nhe + tid; i < m; i += kPollThreads) key[i] = ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(key, m, tid);
+  for (int i = tid; i < nhe; i += kPollThreads) poll_e[D.emap_off + i] = make_uint2((uint32_t)(key[i] >> 32), (uint32_t)key[i]);
+  if (tid == 0) poll_ne[blockIdx.x] = nhe;
+}
+
+hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tiles, const int32_t* t_vmap, const int32_t* t_emap,
+                             const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted) {
+  if (ntiles <= 0) return hipSuccess;
+  if (sorted) hipLaunchKernelGGL(k_poll_lists<true>, dim3(ntiles), dim3(kPollThreads), 0, s, tiles, t_vmap, t_emap, t_eij, poll_v, poll_e, poll_ne);
+  else hipLaunchKernelGGL(k_poll_lists<false>, dim3(ntiles), dim3(kPollThreads), 0, s, tiles, t_vmap, t_emap, t_eij, poll_v, poll_e, poll_ne);
+  return hipGetLastError();
+}
+
 bool tile_torn_check_build() { return FLAME_TORN_CHECK != 0; }
 
 bool tile_persist_exists(int nt, int ept, int vpt) {
@@ -1605,7 +1746,8 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   pa.err_host = err_host; pa.base = base; pa.prof = x.prof; pa.poll_delay = x.poll_delay;
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
-#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes, a, pa);
+  pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes + x.stage_bytes, a, pa);
   FLAME_PERSIST_CFGS(X)
 #undef X
   return hipErrorInvalidConfiguration;
