@@ -740,6 +740,9 @@ struct GraphOptScope {
   GraphOptScope& operator=(const GraphOptScope&) = delete;
 };
 
+// LDS the resident tiles' poll delivery needs behind a tile's incidence slots: the primal state of the halo vertices it updates
+static size_t persist_stage_bytes(const TileDesc& D) { return sizeof(float4) * (size_t)std::max(D.n_upd - D.n_own, 0); }
+
 static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_t* edges,
                               const float* alpha, const float* beta, const float* z, const float* wgt,
                               const float* x0, const int32_t* tris, bool staged = false, bool have_x0 = false) {
@@ -892,6 +895,15 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       }
       ok = lds_max <= g->opt.lds_bytes &&
            pick_tile_config(g->opt.tile_threads, e_max, upd_max, &cfg_nt, &cfg_ept, &cfg_vpt);
+      // A stream that solves by ONE launch of resident tiles takes over the previous frame's partition only if this frame
+      // can be resident on it.  One hull tile of THIS frame with a halo twice the others' (the old partition knows nothing
+      // of its long edges) is enough for a configuration the resident kernels do not have, and the whole solve went by
+      // launches (r05: every 4th frame of the 50 k stream, 2.8 ms instead of 1.3): such a frame is bisected anew.
+      if (ok && reusing && g->opt.resident && ntiles >= 2 && ntiles <= std::min(kPersistMaxTiles, g->num_cus)) {
+        size_t stage = 0;
+        for (const TileDesc& D : tiles) stage = std::max(stage, persist_stage_bytes(D));
+        if (!tile_persist_exists(cfg_nt, cfg_ept, cfg_vpt) || (size_t)lds_max + stage > (size_t)g->opt.lds_bytes) ok = false;
+      }
     }
     if (reusing) {
       if (ok) { built = true; g->plan_reused = true; g->reuse_backoff = 0; break; }
@@ -1544,8 +1556,6 @@ int flame_hip_set_state(flame_hip_graph* g, const float* x, const float* w1, con
 // Returns the buffer index holding the result through *cur_out.
 // one launch of resident tiles instead of ceil(num_iters / depth) launches?
 // one launch of resident tiles instead of ceil(num_iters / depth) launches?
-static size_t persist_stage_bytes(const TileDesc& D) { return sizeof(float4) * (size_t)std::max(D.n_upd - D.n_own, 0); }
-
 static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
   const Plan& P = g->plan;
   if (!g->persist || g->persist_skip_once || g->path != FLAME_HIP_PATH_TILE || g->prof || P.tile_depth <= 0 ||

@@ -163,6 +163,36 @@ def test_facade_frames_on_resident_tiles(gpu):
     r.close()
 
 
+def test_headline_size_stream_stays_resident(gpu):
+    """A stream of four different 50 k graphs (what tools/facade_bench.py cycles through): every frame is solved by one launch
+    of resident tiles.  r05 found every 4th frame on launches (2.8 ms instead of 1.3): graph 2 on the partition taken over
+    from graph 1 had one hull tile beyond 1 024 local vertices, a configuration the resident kernels do not have -- such a
+    frame is bisected anew now.  The bits of that graph are the oracle's either way."""
+    from flame_ros_amd.regularizer import default_sync_params
+    from oracle import COracle
+    from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
+    graphs = [graphgen.named("50k", seed=k)[0] for k in range(4)]
+    r = GraphRegularizer.empty(device=0, tile_single_max=640, stream_depth=5)
+    p, sp = default_params(), default_sync_params()
+    seen = []
+    for k in range(12):
+        g = graphs[k & 3]
+        var = np.full(g.V, 1e-4, np.float32)
+        r.sync_features(g.pos, g.z, var, g.tris, sp)
+        r.step(p, 40)
+        seen.append((k & 3, r.info("num_tiles"), r.info("tile_ept"), r.info("tile_vpt"), r.info("plan_reused"), r.info("persist_used")))
+        if k == 6:
+            s = oracle_sync(OSync(0, 0, 1, 0.01), g.pos, g.z, var, g.tris, None)
+            o = COracle(g.pos, s["edges"], s["alpha"], s["beta"], s["z"], s["wgt"], x0=s["x0"])
+            o.solve(oracle_params(), 40)
+            x, w1, w2, q = r.download()
+            assert_bit_equal(x, o.x, "x"); assert_bit_equal(q, o.q, "q")
+    assert all(u == 1 for *_, u in seen), seen
+    assert sum(reused for *_, reused, _u in seen) >= 6, seen  # (and the stream still takes partitions over)
+    assert r.info("persist_recovered") == 0
+    r.close()
+
+
 def _frame_set(sizes, iters, seed0):
     """(graph, var, expected x) per size: the oracle's result of a graph sync + `iters` iterations."""
     from oracle import COracle

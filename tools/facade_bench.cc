@@ -109,6 +109,7 @@ int main(int argc, char** argv) {
   const int warm = 3;
   int n = 0;
   unsigned long checksum = 0;
+  int resident_frames = 0, recovered_frames = 0;  // frames solved by one launch of resident tiles; of those, repeated after a give-up
   unsigned long long x_hash = 1469598103934665603ull;
   for (int r = 0; r < repeats + warm; ++r)
     for (size_t k = 0; k < frames.size(); ++k, ++n) {
@@ -147,6 +148,8 @@ int main(int argc, char** argv) {
       }
       const auto t2 = std::chrono::steady_clock::now();
       if (r < warm) continue;
+      resident_frames += sensor->stats().stats("persist_used") > 0.5;
+      recovered_frames = static_cast<int>(sensor->stats().stats("persist_recovered"));  // (cumulative in the library)
       upd.push_back(sensor->stats().timings("update"));
       sync.push_back(sensor->stats().timings("sync_graph"));
       solve.push_back(sensor->stats().timings("nltgv2"));
@@ -154,15 +157,20 @@ int main(int argc, char** argv) {
       wall.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
       get.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
     }
+  if (std::getenv("FLAME_BENCH_SERIES")) {  // dev: update() time of every measured frame, in stream order
+    std::fprintf(stderr, "update_ms series:");
+    for (size_t i = 0; i < upd.size(); ++i) std::fprintf(stderr, " %.2f", upd[i]);
+    std::fprintf(stderr, "\n");
+  }
   std::printf(
       "{\"V\": %d, \"T\": %d, \"E\": %d, \"iters\": %d, \"frames\": %d, \"getters\": %d, "
       "\"update_ms\": {\"p50\": %.4f, \"p10\": %.4f, \"p90\": %.4f, \"max\": %.4f}, "
       "\"update_wall_ms_p50\": %.4f, \"sync_graph_ms_p50\": %.4f, \"nltgv2_ms_p50\": %.4f, "
       "\"nltgv2_device_ms\": %.4f, \"getters_ms_p50\": %.4f, \"coverage\": %.6f, \"checksum\": %lu, \"x_hash\": \"%016llx\", "
-      "\"triangulate_ms_p50\": %.4f}\n",
+      "\"triangulate_ms_p50\": %.4f, \"resident_frames\": %d, \"recovered_frames\": %d}\n",
       static_cast<int>(frames[0].vtx.size()), static_cast<int>(frames[0].tris.size()),
       static_cast<int>(sensor->stats().stats("num_edges")), iters, static_cast<int>(upd.size()), getters,
       pct(upd, 0.5), pct(upd, 0.1), pct(upd, 0.9), pct(upd, 1.0), pct(wall, 0.5), pct(sync, 0.5), pct(solve, 0.5),
-      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum, x_hash, pct(tri, 0.5));
+      sensor->stats().timings("nltgv2_device"), pct(get, 0.5), sensor->stats().stats("coverage"), checksum, x_hash, pct(tri, 0.5), resident_frames, recovered_frames);
   return 0;
 }

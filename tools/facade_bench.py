@@ -57,6 +57,8 @@ def run(workload, repeats=25, getters=1, nframes=4, env=None):
                              capture_output=True, text=True, env=dict(os.environ, **(env or {})), timeout=900)
     if out.returncode != 0:
         raise RuntimeError("facade_bench %s failed (%d): %s %s" % (workload, out.returncode, out.stdout[-500:], out.stderr[-500:]))
+    if os.environ.get("FLAME_BENCH_SERIES"):  # dev: the per-frame series goes to stderr
+        sys.stderr.write(out.stderr[-8000:])
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
