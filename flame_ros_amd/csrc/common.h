@@ -49,6 +49,13 @@ struct TileDesc {
   int32_t level_end[kMaxDepth + 1];  // level_end[l] = #local edges with level <= l
 };
 
+// LDS of a tile's workgroup: bar[n_ext] (16 B) + the incidence slots, 16 B each -- or, slot12 (fat tiles), 12 B each as a
+// 4-byte and an 8-byte array, the slot count rounded up to 4 (kernels.hip SlotMem).  Resident tiles add their staging area.
+inline int64_t tile_lds_bytes(int32_t n_ext, int32_t nslots, bool slot12) {
+  const int64_t n = (int64_t)nslots + kDummySlots + 1;
+  return slot12 ? (int64_t)n_ext * 16 + ((n + 3) & ~(int64_t)3) * 12 : (int64_t)n_ext * 16 + n * 16;
+}
+
 // Local edge record halves.
 //   t_eij[e] = {li | lj << 16, slot_src | slot_dst << 16}   (local vertex ids / incidence slots)
 //   t_ew[e]  = {alpha, beta, dx, dy}

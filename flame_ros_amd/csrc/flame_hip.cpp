@@ -634,6 +634,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "tile_vpt") *value = P.tile_vpt;
   else if (k == "tile_depth") *value = P.tile_depth;
   else if (k == "tile_lds_bytes") *value = P.tile_lds_bytes;
+  else if (k == "tile_slot12") *value = P.tile_slot12 ? 1 : 0;
   else if (k == "tile_ext_vertices") { int64_t s = 0; for (auto& t : P.tiles) s += t.n_ext; *value = s; }
   else if (k == "tile_loc_edges") { int64_t s = 0; for (auto& t : P.tiles) s += t.e_loc; *value = s; }
   else if (k == "device") *value = g->device;
@@ -843,7 +844,9 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
                              g->B[0], g->pos, E > 0 ? E : 1, g->q[0], g->q[1]);
   };
   int tile_own = sz.tile_own;
-  const int depth = sz.depth;
+  int depth = sz.depth;
+  bool fat = sz.fat;
+  bool slot12 = false;
   bool balanced = false, built = false;
   int refine_left = 0;
   int ntiles = 0, cfg_nt = 0, cfg_ept = 0, cfg_vpt = 0;
@@ -856,7 +859,8 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
                    g->opt.tile_own == g->reuse_tile_own_opt;
   if (try_reuse && g->reuse_skip > 0) { --g->reuse_skip; try_reuse = false; }  // back-off after rejections
   g->plan_reused = false;
-  for (int attempt = 0; attempt < 8 + kBalanceRefinePasses && !built; ++attempt) {
+  const int max_attempts = 8 + kBalanceRefinePasses + (sz.fat ? 4 * (2 + kBalanceRefinePasses) : 0);  // (plan.cpp)
+  for (int attempt = 0; attempt < max_attempts && !built; ++attempt) {
     const bool reusing = try_reuse;
     try_reuse = false;
     ntiles = reusing ? g->planner.map_tiles() : (V + tile_own - 1) / tile_own;
@@ -886,15 +890,10 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     if (index_error) return FLAME_HIP_ERR_ARG;
     const bool tiles_valid = ok;  // every tile was built (it may still be too large for LDS / a kernel config)
     if (ok) {
-      int e_max = 0, upd_max = 0;
-      lds_max = 0;
-      for (const TileDesc& D : tiles) {
-        e_max = std::max(e_max, D.e_loc);
-        upd_max = std::max(upd_max, D.n_ext);
-        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots + 1) * 16);
-      }
-      ok = lds_max <= g->opt.lds_bytes &&
-           pick_tile_config(g->opt.tile_threads, e_max, upd_max, &cfg_nt, &cfg_ept, &cfg_vpt);
+      const TileFit fit = tile_fit(g->opt, fat, tiles);  // (LDS, kernel configuration, 12-byte slots: plan.cpp)
+      ok = fit.ok;
+      lds_max = fit.lds_bytes; slot12 = fit.slot12;
+      cfg_nt = fit.nt; cfg_ept = fit.ept; cfg_vpt = fit.vpt;
       // A stream that solves by ONE launch of resident tiles takes over the previous frame's partition only if this frame
       // can be resident on it.  One hull tile of THIS frame with a halo twice the others' (the old partition knows nothing
       // of its long edges) is enough for a configuration the resident kernels do not have, and the whole solve went by
@@ -902,7 +901,9 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
       if (ok && reusing && g->opt.resident && ntiles >= 2 && ntiles <= std::min(kPersistMaxTiles, g->num_cus)) {
         size_t stage = 0;
         for (const TileDesc& D : tiles) stage = std::max(stage, persist_stage_bytes(D));
-        if (!tile_persist_exists(cfg_nt, cfg_ept, cfg_vpt) || (size_t)lds_max + stage > (size_t)g->opt.lds_bytes) ok = false;
+        if (!(slot12 ? tile_slot12_exists(cfg_nt, cfg_ept, cfg_vpt) : tile_persist_exists(cfg_nt, cfg_ept, cfg_vpt)) ||
+            (size_t)lds_max + stage > (size_t)g->opt.lds_bytes)
+          ok = false;
       }
     }
     if (reusing) {
@@ -940,7 +941,9 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     g->planner.drop_grid();
     balanced = false;
     refine_left = 0;
-    tile_own = std::max(16, tile_own / 2);
+    if (fat && depth > 1 && g->opt.tile_depth <= 0) --depth;  // fat tiles: a shallower halo first, then two rounds of smaller tiles
+    else if (fat) { fat = false; tile_own = sz.fallback_own; depth = sz.fallback_depth; }
+    else tile_own = std::max(16, tile_own / 2);
   }
   if (!built) return 0;
   lap("plan build");
@@ -966,14 +969,15 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   P.tile_threads = cfg_nt; P.tile_ept = cfg_ept; P.tile_vpt = cfg_vpt;
   P.tile_depth = depth;
   P.tile_lds_bytes = lds_max;
+  P.tile_slot12 = slot12;
   P.note.clear();
   P.v_o2i.clear(); P.v_i2o.clear(); P.e_o2i.clear(); P.e_i2o.clear();
   P.eij.clear(); P.ew.clear(); P.grow.clear(); P.ginc.clear(); P.tris.clear(); P.trow.clear(); P.tinc.clear();
   P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
   g->host_perms = false;
   g->path = FLAME_HIP_PATH_TILE;
-  if (!tile_config_exists(cfg_nt, cfg_ept, cfg_vpt)) return FLAME_HIP_ERR_STATE;
-  HIPCHK(prepare_tile(cfg_nt, cfg_ept, cfg_vpt, (size_t)lds_max));
+  if (!(slot12 ? tile_slot12_exists(cfg_nt, cfg_ept, cfg_vpt) : tile_config_exists(cfg_nt, cfg_ept, cfg_vpt))) return FLAME_HIP_ERR_STATE;
+  HIPCHK(prepare_tile(cfg_nt, cfg_ept, cfg_vpt, (size_t)lds_max, slot12));
   g->cur = 0;  // (the state was written inside the build: after_order)
   if ((rc = dev_alloc(g->caps, &g->tri_normals, (size_t)T)) || (rc = dev_alloc(g->caps, &g->tri_valid, (size_t)T)))
     return rc;
@@ -1083,8 +1087,10 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
   }
   if (!dev_plan) {
     if (P.has_tiles) {
-      if (!tile_config_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return FLAME_HIP_ERR_STATE;
-      HIPCHK(prepare_tile(P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes));
+      if (!(P.tile_slot12 ? tile_slot12_exists(P.tile_threads, P.tile_ept, P.tile_vpt)
+                          : tile_config_exists(P.tile_threads, P.tile_ept, P.tile_vpt)))
+        return FLAME_HIP_ERR_STATE;
+      HIPCHK(prepare_tile(P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, P.tile_slot12));
     }
     // initial state in internal order
     std::vector<float4> hA(V), hB(V);
@@ -1563,7 +1569,9 @@ static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
     return false;
   const size_t nt = P.tiles.size();
   if (nt < 2 || nt > (size_t)kPersistMaxTiles || (int)nt > g->num_cus) return false;  // (one workgroup per CU is always resident)
-  if (!tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)) return false;
+  if (!(P.tile_slot12 ? tile_slot12_exists(P.tile_threads, P.tile_ept, P.tile_vpt)
+                      : tile_persist_exists(P.tile_threads, P.tile_ept, P.tile_vpt)))
+    return false;
   size_t stage = 0;
   for (const TileDesc& D : P.tiles) {
     if (D.n_ext <= 0) return false;  // (an empty tile has nothing to hand over, but its neighbours would not know)
@@ -1690,6 +1698,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.tiles = g->tiles; a.t_vmap = g->t_vmap; a.t_emap = g->t_emap; a.t_eij = g->t_eij;
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
+    a.slot12 = P.tile_slot12 ? 1 : 0;
     if (persist_applies(g, num_iters) && persist_lease_take(g, s)) {
       PersistBufs& x = g->xp;
       int rc;

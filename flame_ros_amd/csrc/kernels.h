@@ -23,6 +23,7 @@ struct TileArgs {
   int32_t iters;   // iterations in this launch (<= tile depth unless depth == 0)
   int32_t ntiles;
   unsigned long long* prof;  // debug timeline, kProfWords words per tile, or nullptr
+  int32_t slot12 = 0;  // 12-byte incidence slots (fat tiles: Plan::tile_slot12; lds_bytes is then tile_lds_bytes(.., true))
 };
 
 // ---- global path: one dual + one primal kernel per PD iteration ----
@@ -35,8 +36,9 @@ hipError_t launch_primal(hipStream_t s, int32_t V, const int32_t* grow, const in
 hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes,
                        const TileArgs& a);
 bool tile_config_exists(int nt, int ept, int vpt);
+bool tile_slot12_exists(int nt, int ept, int vpt);  // ... with 12-byte incidence slots (resident or by launches)
 // one-time per configuration: opt in to > 48 KiB of dynamic LDS (not capturable in a hipGraph)
-hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes);
+hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes, bool slot12 = false);
 // resident tiles (ONE launch for the whole solve; graphs of 2 .. kPersistMaxTiles tiles, at most one per CU: every
 // workgroup of the launch must be on the chip at once).  a.iters = the TOTAL iteration count, rounds of `depth`
 // iterations inside; neighbours hand their results over through uncached, round-tagged copies of the state arrays

@@ -10,6 +10,7 @@
 // ascending ORIGINAL edge id.  The projection v / max(1,|v|) equals clamp(v,-1,1) bit-for-bit
 // for every non-NaN v (v/1 = v; v/|v| = +-1), so it is one v_med3_f32.
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -169,11 +170,43 @@ __device__ __forceinline__ int wave_max(int v) {
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
 
+// Incidence slots come in two layouts.  S12 = false (the default): one float4 per slot {c1, c2, cx, -}, a slot is named by its
+// LDS address.  S12 = true (r05, FAT tiles: one tile per CU beyond 196 own vertices, where 16 bytes per slot do not fit 160 KiB):
+// 12 bytes per slot, split so that every access stays naturally aligned (a 12-byte slot read as ds_read_b96 off its 16-byte
+// alignment is replayed at 64 cycles, MI355X guide, LDS) -- the (c1, c2) pairs in one array of 8-byte entries, the cx words
+// in another of 4-byte entries that sits at the START of the dynamic LDS: a slot is named by 4 x its index, which IS the
+// address of its cx word, and 2 x that + the pair array's offset (one v_lshl_add_u32) is the address of its pair.  Same LDS
+// cycles as the 16-byte layout by the guide's table (ds_write_b64 + ds_write_b32 = 6 + 4 vs ds_write_b96 = 10; ds_read_b64 +
+// ds_read_b32 = 2 + 2 vs ds_read_b128 = 4), twice the DS instructions; odd row pitches are conflict-free for both reads.
+template <bool S12> struct SlotT { typedef float4* ref; };
+template <> struct SlotT<true> { typedef uint32_t ref; };
+template <bool S12> struct SlotMem { float4* cs; };
+template <> struct SlotMem<true> { char* f1; char* f2; };
+template <bool S12>
+__device__ __forceinline__ void slot_store(const SlotMem<S12>& m, typename SlotT<S12>::ref r, float a, float b, float c) {
+  if constexpr (S12) {
+    *reinterpret_cast<f2v*>(m.f2 + 2u * r) = f2v{a, b};
+    *reinterpret_cast<float*>(m.f1 + r) = c;
+  } else {
+    lds_store3(r, a, b, c);
+  }
+}
+__device__ __forceinline__ char* sm_f2_end(float4* cs, int n_slot_pad) { return reinterpret_cast<char*>(cs) + 8 * n_slot_pad; }
+template <bool S12>
+__device__ __forceinline__ float4 slot_load(const SlotMem<S12>& m, typename SlotT<S12>::ref r) {
+  if constexpr (S12) {
+    const f2v p = *reinterpret_cast<const f2v*>(m.f2 + 2u * r);
+    return make_float4(p.x, p.y, *reinterpret_cast<const float*>(m.f1 + r), 0.f);
+  } else {
+    return *r;
+  }
+}
+
 // Phase D on the first K of this thread's edges: every gather is issued before the first use.
 // ew = {alpha, beta, dx, dy}; es/ed = LDS addresses of the source / target incidence slot.
-template <int K, int EPT>
-__device__ __forceinline__ void tile_phase_d(const float4* bar, const uint32_t (&eij)[EPT],
-                                             float4* const (&es)[EPT], float4* const (&ed)[EPT],
+template <int K, int EPT, bool S12>
+__device__ __forceinline__ void tile_phase_d(const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
+                                             const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
                                              f2v (&q23)[EPT], float sigma) {
   float4 bi[K], bj[K];
@@ -206,27 +239,27 @@ __device__ __forceinline__ void tile_phase_d(const float4* bar, const uint32_t (
     const f2v s23 = pk_fma(nd, aq2, b23);  // {fmaf(-dx, aq, b2), fmaf(-dy, aq, b3)}
     // one 12-byte store per endpoint; -(a*b) == (-a)*b bit-for-bit, so the target side is two
     // multiplies with a negated operand instead of three sign flips
-    lds_store3(es[k], s23.x, s23.y, aq);
+    slot_store<S12>(sm, es[k], s23.x, s23.y, aq);
     const f2v n23 = (-be) * u;
-    lds_store3(ed[k], n23.x, n23.y, -ew[k].x * q1[k]);
+    slot_store<S12>(sm, ed[k], n23.x, n23.y, -ew[k].x * q1[k]);
   }
 }
 
 // nk (number of active edge blocks) is wave-uniform: dispatch to the matching unrolled body
-template <int K, int EPT>
+template <int K, int EPT, bool S12>
 struct PhaseD {
-  static __device__ __forceinline__ void run(int nk, const float4* bar, const uint32_t (&eij)[EPT],
-                                             float4* const (&es)[EPT], float4* const (&ed)[EPT],
+  static __device__ __forceinline__ void run(int nk, const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
+                                             const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
                                              f2v (&q23)[EPT], float sigma) {
-    if (nk == K) tile_phase_d<K, EPT>(bar, eij, es, ed, ew, q1, q23, sigma);
-    else PhaseD<K - 1, EPT>::run(nk, bar, eij, es, ed, ew, q1, q23, sigma);
+    if (nk == K) tile_phase_d<K, EPT, S12>(bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    else PhaseD<K - 1, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
   }
 };
-template <int EPT>
-struct PhaseD<0, EPT> {
-  static __device__ __forceinline__ void run(int, const float4*, const uint32_t (&)[EPT],
-                                             float4* const (&)[EPT], float4* const (&)[EPT],
+template <int EPT, bool S12>
+struct PhaseD<0, EPT, S12> {
+  static __device__ __forceinline__ void run(int, const float4*, const SlotMem<S12>&, const uint32_t (&)[EPT],
+                                             const typename SlotT<S12>::ref (&)[EPT], const typename SlotT<S12>::ref (&)[EPT],
                                              const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],
                                              float) {}
 };
@@ -235,6 +268,35 @@ constexpr int kPRound = kSlotRound;  // incidence slots read per round of phase 
 
 // Phase P: K consecutive incidence slots of this lane's row, all reads issued before the first use
 // (constant offsets: no address arithmetic), then the dependent fma chain in slot order.
+// (12-byte slots: `row` is 4 x the row's first slot index)
+template <int K>
+__device__ __forceinline__ void sum_slots12(const SlotMem<true>& m, uint32_t row, f2v nt2, float ntau, f2v& w, float& x) {
+  const f2v* p2 = reinterpret_cast<const f2v*>(m.f2 + 2u * row);
+  const float* p1 = reinterpret_cast<const float*>(m.f1 + row);
+  f2v c[K];
+  float cx[K];
+#pragma unroll
+  for (int u = 0; u < K; ++u) c[u] = p2[u];
+#pragma unroll
+  for (int u = 0; u < K; ++u) cx[u] = p1[u];
+#pragma unroll
+  for (int u = 0; u < K; ++u) {
+    w = pk_fma(nt2, c[u], w);
+    x = fmaf(ntau, cx[u], x);
+  }
+}
+template <int K>
+struct SlotTail12 {  // n (wave-uniform, < kPRound) remaining slots
+  static __device__ __forceinline__ void run(int n, const SlotMem<true>& m, uint32_t row, f2v nt2, float ntau, f2v& w, float& x) {
+    if (n == K) sum_slots12<K>(m, row, nt2, ntau, w, x);
+    else SlotTail12<K - 1>::run(n, m, row, nt2, ntau, w, x);
+  }
+};
+template <>
+struct SlotTail12<0> {
+  static __device__ __forceinline__ void run(int, const SlotMem<true>&, uint32_t, f2v, float, f2v&, float&) {}
+};
+
 template <int K>
 __device__ __forceinline__ void sum_slots(const float4* row, f2v nt2, float ntau, f2v& w, float& x) {
   float4 t[K];
@@ -354,8 +416,9 @@ __device__ __forceinline__ bool tag_ok(const float4& v, int32_t target, int32_t*
 #endif
 }
 
-template <int NT, int EPT, int VPT, bool PERSIST>
+template <int NT, int EPT, int VPT, bool PERSIST, bool S12>
 __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
+  typedef typename SlotT<S12>::ref slot_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware block -> tile map (speed only): block b runs on XCD b % 8, tiles are numbered in
   // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
@@ -376,8 +439,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   asm volatile("" ::"s"(vstart), "s"(estart), "s"(nslots), "s"(vmap_off), "s"(emap_off), "s"(erec_off),
                "s"(srow_off), "s"(n_own), "s"(n_upd), "s"(e_own), "s"(e_loc), "s"(depth));
   if (n_ext == 0) return;  // empty tile (more tiles than vertices)
-  float4* bar = reinterpret_cast<float4*>(smem);
+  // LDS: bar[n_ext] | cs[nslots + kDummySlots + 1] (| the resident tiles' staging area); 12-byte slots: the cx words of the
+  // slots FIRST (a slot's name is that word's offset), then bar[], then the (c1, c2) pairs -- tile_lds_bytes() in common.h
+  const int n_slot_all = nslots + kDummySlots + 1;
+  const int n_slot_pad = (n_slot_all + 3) & ~3;  // (12-byte slots: keeps bar[] 16-byte and the pairs 8-byte aligned)
+  float4* bar = reinterpret_cast<float4*>(S12 ? smem + 4 * n_slot_pad : smem);
   float4* cs = bar + n_ext;  // nslots + kDummySlots incidence slots
+  SlotMem<S12> sm;
+  if constexpr (S12) { sm.f1 = smem; sm.f2 = reinterpret_cast<char*>(cs); }
+  else sm.cs = cs;
   const int lane = tid & 63;
   const int wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
   const uint32_t dummy = (uint32_t)(nslots + lane);  // per-lane trash slot: inert writes/reads
@@ -449,12 +519,25 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   // to the group's pitch) is never written: phase P sums a wave-uniform number of slots per row
   // without a per-lane bound, because fmaf(-tau, +0, x) == x bit-for-bit.  The stores go out while
   // the global loads above are in flight.
-  for (int i = tid; i < nslots; i += NT) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (S12) {
+    for (int i = tid; i < n_slot_all; i += NT) {
+      reinterpret_cast<float*>(sm.f1)[i] = 0.f;
+      reinterpret_cast<f2v*>(sm.f2)[i] = f2v{0.f, 0.f};
+    }
+  } else {
+    for (int i = tid; i < nslots; i += NT) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // fat tiles: local vertices beyond one per thread lie in the outermost ring (the configuration holds every UPDATED vertex,
+  // pick_cfg()): they have no lane, only their x_bar in bar[] -- loaded here, refreshed by the poll's deliveries
+  for (int lv = VPT * NT + tid; lv < n_ext; lv += NT) {
+    const float4 b = a.B_src[a.t_vmap[vmap_off + lv]];
+    bar[lv] = make_float4(b.y, b.z, b.x, 0.f);
+  }
 
   float vx[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT];
   f2v vw[VPT], vwb[VPT];
   int wdeg[VPT];
-  const float4* vrow[VPT];
+  typename std::conditional<S12, uint32_t, const float4*>::type vrow[VPT];
   const float tl = a.p.tl;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
@@ -466,18 +549,24 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
                                  // somebody else's slots into a value that is never published)
     if (lv < n_ext) bar[lv] = make_float4(vB[k].y, vB[k].z, vB[k].x, 0.f);
     wdeg[k] = wave_max((int)(vs[k] >> 16));
-    vrow[k] = cs + (vs[k] & 0xffffu);
+    if constexpr (S12) vrow[k] = 4u * (vs[k] & 0xffffu);
+    else vrow[k] = cs + (vs[k] & 0xffffu);
   }
   uint32_t eij[EPT];
-  float4 *es[EPT], *ed[EPT];
+  slot_t es[EPT], ed[EPT];
   f2v q23[EPT];
 #pragma unroll
   for (int k = 0; k < EPT; ++k) {
     const bool real = (k * NT + tid) < e_loc;
     eij[k] = real ? er[k].x : 0u;  // padding edges gather local vertex 0 and write trash slots
     const uint32_t ss = er[k].y & 0xffffu, sd = er[k].y >> 16;
-    es[k] = cs + ((real && ss != 0xffffu) ? ss : dummy);
-    ed[k] = cs + ((real && sd != 0xffffu) ? sd : dummy);
+    if constexpr (S12) {
+      es[k] = 4u * ((real && ss != 0xffffu) ? ss : dummy);
+      ed[k] = 4u * ((real && sd != 0xffffu) ? sd : dummy);
+    } else {
+      es[k] = cs + ((real && ss != 0xffffu) ? ss : dummy);
+      ed[k] = cs + ((real && sd != 0xffffu) ? sd : dummy);
+    }
     q23[k].x = q2[k]; q23[k].y = q3[k];
   }
   __syncthreads();
@@ -508,7 +597,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     // wave-uniform: this wave's k-th edge block covers local edges [k NT + wbase, +64)
     const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
     // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
-    PhaseD<EPT, EPT>::run(nk, bar, eij, es, ed, ew, q1, q23, sigma);
+    PhaseD<EPT, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
 #if FLAME_EARLY_Q
     // resident tiles: the duals of a round are final after its last phase D -- their hand-off entries (58 % of what
     // a tile hands over) leave now and travel while phase P still runs
@@ -536,10 +625,16 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         f2v w = wp;
         // incidence j of this lane is at row[j] (rows have an odd pitch: a column read is
         // conflict-free across lanes); the wave sums the longest row's length from every row
-        const float4* row = vrow[k];
         int j = wdeg[k];  // wave-uniform
-        for (; j >= kPRound; j -= kPRound, row += kPRound) sum_slots<kPRound>(row, nt2, ntau, w, x);
-        SlotTail<kPRound - 1>::run(j, row, nt2, ntau, w, x);
+        if constexpr (S12) {
+          uint32_t row = vrow[k];
+          for (; j >= kPRound; j -= kPRound, row += 4u * kPRound) sum_slots12<kPRound>(sm, row, nt2, ntau, w, x);
+          SlotTail12<kPRound - 1>::run(j, sm, row, nt2, ntau, w, x);
+        } else {
+          const float4* row = vrow[k];
+          for (; j >= kPRound; j -= kPRound, row += kPRound) sum_slots<kPRound>(row, nt2, ntau, w, x);
+          SlotTail<kPRound - 1>::run(j, row, nt2, ntau, w, x);
+        }
         x = prox_l1(x, vz[k], vt[k], x_min, x_max);
         vxb[k] = fmaf(theta, x - xp, x);
         vwb[k] = pk_fma(th2, w - wp, w);
@@ -701,7 +796,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   // edge's OWN incidence slot (dead between rounds: the first phase D of the next round rewrites every real slot before a
   // phase P reads one; the zero padding of the rows is never touched); the primal state into a small staging area behind
   // the slots ((n_upd - n_own) x 16 B)
-  float4* const stA = cs + nslots + kDummySlots + 1;
+  float4* const stA = S12 ? reinterpret_cast<float4*>(sm_f2_end(cs, n_slot_pad)) : cs + nslots + kDummySlots + 1;
 #pragma unroll
   for (int k = 0; k < VPT; ++k) {
     if ((k * NT + tid) < n_hv) {
@@ -712,7 +807,10 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
 #pragma unroll
   for (int k = 0; k < EPT; ++k)
-    if ((k * NT + tid) < n_he && per[k].x != 0xffffffffu) cs[per[k].y] = nq[k];
+    if ((k * NT + tid) < n_he && per[k].x != 0xffffffffu) {
+      if constexpr (S12) slot_store<S12>(sm, 4u * per[k].y, nq[k].x, nq[k].y, nq[k].z);
+      else cs[per[k].y] = nq[k];
+    }
   __syncthreads();
   if (s_abort) break;
   // ... and the lanes that hold a halo vertex / halo edge pick their state up
@@ -728,7 +826,9 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   for (int k = 0; k < EPT; ++k) {
     const int le = k * NT + tid;
     if (le < e_loc && !((uint32_t)(qi[k] - estart) < (uint32_t)e_own)) {  // halo edges: staged in the source's slot, else the target's
-      const float4 t = *((es[k] != cs + dummy) ? es[k] : ed[k]);
+      float4 t;
+      if constexpr (S12) t = slot_load<S12>(sm, (es[k] != 4u * dummy) ? es[k] : ed[k]);
+      else t = *((es[k] != cs + dummy) ? es[k] : ed[k]);
       q1[k] = t.x; q23[k].x = t.y; q23[k].y = t.z;
     }
   }
@@ -750,7 +850,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   if (!PERSIST && prof && tid == 0) prof[kProfWords - 1] = __builtin_readcyclecounter();
 }
 
-template <int NT, int EPT, int VPT>
+template <int NT, int EPT, int VPT, bool S12 = false>
 __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_arg,
                                              const int32_t* __restrict__ t_vmap,
                                              const uint32_t* __restrict__ t_srow,
@@ -766,10 +866,10 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_arg; a.ntiles = ntiles; a.prof = prof_arg;
-  tile_body<NT, EPT, VPT, false>(a, PersistArgs{});
+  tile_body<NT, EPT, VPT, false, S12>(a, PersistArgs{});
 }
 
-template <int NT, int EPT, int VPT>
+template <int NT, int EPT, int VPT, bool S12 = false>
 __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_total,
                                                      const int32_t* __restrict__ t_vmap, const uint32_t* __restrict__ t_srow,
                                                      const uint2* __restrict__ t_eij, const int32_t* __restrict__ t_emap,
@@ -781,21 +881,21 @@ __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict_
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_total; a.ntiles = ntiles; a.prof = nullptr;
-  tile_body<NT, EPT, VPT, true>(a, pa);
+  tile_body<NT, EPT, VPT, true, S12>(a, pa);
 }
 
-template <int NT, int EPT, int VPT>
+template <int NT, int EPT, int VPT, bool S12 = false>
 hipError_t launch_tile_t(hipStream_t s, size_t lds, const TileArgs& a) {
-  hipLaunchKernelGGL((k_tile<NT, EPT, VPT>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
+  hipLaunchKernelGGL((k_tile<NT, EPT, VPT, S12>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
                      a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, a.prof,
                      a.p);
   return hipGetLastError();
 }
 
-template <int NT, int EPT, int VPT>
+template <int NT, int EPT, int VPT, bool S12 = false>
 hipError_t prepare_tile_t(size_t lds) {
   if (lds <= 48 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<NT, EPT, VPT>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<NT, EPT, VPT, S12>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -1595,9 +1695,19 @@ hipError_t launch_primal(hipStream_t s, int32_t V, const int32_t* grow, const in
   X(512, 2, 1) X(512, 3, 1) X(512, 4, 1) X(512, 6, 1) X(512, 4, 2) X(512, 6, 2)         \
   X(1024, 2, 1) X(1024, 3, 1) X(1024, 4, 1) X(1024, 6, 1) X(1024, 4, 2) X(1024, 6, 2)
 
+// 12-byte incidence slots (fat tiles, SlotMem<true>): the configurations a one-tile-per-CU partition of a graph beyond
+// 256 x 196 vertices gets
+#define FLAME_S12_CFGS(X) X(1024, 2, 1) X(1024, 3, 1)
+
 bool tile_config_exists(int nt, int ept, int vpt) {
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return true;
   FLAME_TILE_CFGS(X)
+#undef X
+  return false;
+}
+bool tile_slot12_exists(int nt, int ept, int vpt) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return true;
+  FLAME_S12_CFGS(X)
 #undef X
   return false;
 }
@@ -1605,6 +1715,12 @@ bool tile_config_exists(int nt, int ept, int vpt) {
 hipError_t launch_tile(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes,
                        const TileArgs& a) {
   if (a.ntiles <= 0 || a.iters <= 0) return hipSuccess;
+  if (a.slot12) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_t<N, Ep, Vp, true>(s, lds_bytes, a);
+    FLAME_S12_CFGS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+  }
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_t<N, Ep, Vp>(s, lds_bytes, a);
   FLAME_TILE_CFGS(X)
 #undef X
@@ -1726,15 +1842,15 @@ bool tile_persist_exists(int nt, int ept, int vpt) {
   return false;
 }
 
-template <int NT, int EPT, int VPT>
+template <int NT, int EPT, int VPT, bool S12 = false>
 hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, const PersistArgs& pa) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT, S12>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   // the launches' grid: one workgroup per tile, all of them resident (the caller keeps ntiles <= the number of CUs)
-  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
+  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, S12>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
                      a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, pa, a.p);
   return hipGetLastError();
 }
@@ -1747,13 +1863,25 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
   pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
+  if (a.slot12) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, true>(s, lds_bytes + x.stage_bytes, a, pa);
+    FLAME_S12_CFGS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+  }
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp>(s, lds_bytes + x.stage_bytes, a, pa);
   FLAME_PERSIST_CFGS(X)
 #undef X
   return hipErrorInvalidConfiguration;
 }
 
-hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes) {
+hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes, bool slot12) {
+  if (slot12) {
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return prepare_tile_t<N, Ep, Vp, true>(lds_bytes);
+    FLAME_S12_CFGS(X)
+#undef X
+    return hipErrorInvalidConfiguration;
+  }
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return prepare_tile_t<N, Ep, Vp>(lds_bytes);
   FLAME_TILE_CFGS(X)
 #undef X

@@ -131,6 +131,10 @@ const TileCfg kCfgs[] = {
     {1024, 2, 1}, {1024, 3, 1}, {1024, 4, 1}, {1024, 6, 1}, {1024, 4, 2}, {1024, 6, 2},
 };
 
+// ... of the resident kernels, and of the 12-byte-slot kernels (FLAME_PERSIST_CFGS / FLAME_S12_CFGS in kernels.hip)
+bool tile_persist_cfg(int nt, int ept, int vpt) { return vpt == 1 && (ept == 2 || ept == 3) && (nt == 256 || nt == 512 || nt == 1024); }
+bool tile_slot12_cfg(int nt, int ept, int vpt) { return vpt == 1 && (ept == 2 || ept == 3) && nt == 1024; }
+
 // Lane order inside every block of 64 local edges (the edges one wave handles together in phase D).
 // Which edges share a block is fixed by the level / source order; WHICH LANE takes which edge is
 // free, and it decides the LDS bank conflicts of the four accesses of phase D (MI355X guide, LDS):
@@ -221,7 +225,12 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // Beyond one tile per CU (V > 256 * 196) two rounds of fat depth-3 tiles beat four rounds of
   // small ones (200 k vertices: 392 own / depth 3 = 98 k it/s vs 196 / 3 = 71 k it/s).
   const bool one_round = V <= 256 * 196;
+  // r05: beyond that, a caller that solves by resident tiles keeps one tile per CU as long as the FAT tiles fit at some depth
+  // (measured: 200 k vertices 5.9 us per iteration by 167 launches of two rounds of tiles -> resident)
+  const bool fat = !one_round && opt.resident && opt.tile_own <= 0 && V <= 256 * 940 && opt.batch_voff.empty();
+  const int fat_own = (V + 255) / 256;
   const int auto_own = one_round ? std::max(32, std::min(196, (V + 255) / 256))
+                       : fat     ? fat_own
                                  : std::max(196, std::min(400, (V + 511) / 512));
   // few tiles (a small lone graph): CUs are idle anyway, so redundant halo work is free and deeper
   // halos amortise the per-launch load (1.2 k vertices: depth 8 = 652 k it/s vs depth 4 = 573 k)
@@ -229,7 +238,11 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // (resident tiles, r04: a round's hand-off costs ~2 us where a launch cost ~3.5: shallower halos win -- depth 5 up to
   // ~100 tiles, 4 above; tools/exp/xpersist_bench.py: 1.2 k / 38 tiles depth 5 / 8 = 0.92 / 1.00 us per iteration, 5 k /
   // 157 tiles depth 4 / 5 = 1.01 / 1.04, 4 k / 125 tiles 1.00 / 1.01)
-  const int auto_depth = !one_round ? 3
+  // fat tiles, measured (profiles/r05_fat_tiles.txt): two edges per thread on 16-byte slots beat three edges / 12-byte slots
+  // at one level deeper (80 k: depth 3 1.62 vs depth 4 1.74 us per iteration; 130 k: depth 2 2.22 vs depth 3 2.49); from ~540
+  // own vertices on only the 12-byte layout fits and the deepest halo that does wins (160 k: depth 3 2.79, 2 3.10, 1 3.12)
+  const int auto_depth = fat ? (fat_own <= 280 ? 4 : (fat_own <= 420 ? 3 : (fat_own <= 540 ? 2 : (fat_own <= 640 ? 3 : (fat_own <= 800 ? 2 : 1)))))
+                         : !one_round ? 3
                          : opt.resident ? (auto_tiles <= 100 ? 5 : 4)
                                         : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
   int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
@@ -245,7 +258,43 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   PlanSizing sz;
   sz.auto_own = auto_own; sz.auto_depth = auto_depth;
   sz.tile_own = tile_own; sz.depth = depth; sz.single = single;
+  sz.fat = fat && !single;
+  sz.fallback_own = std::max(196, std::min(400, (V + 511) / 512));
+  sz.fallback_depth = opt.tile_depth > 0 ? depth : 3;
   return sz;
+}
+
+TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles) {
+  TileFit f;
+  int e_max = 0, ext_max = 0, upd_max = 0, hv_max = 0;
+  int64_t lds16 = 0, lds12 = 0, stage = 0;
+  for (const TileDesc& D : tiles) {
+    e_max = std::max(e_max, D.e_loc);
+    ext_max = std::max(ext_max, D.n_ext);  // every local vertex gets a register slot ...
+    upd_max = std::max(upd_max, D.n_upd);
+    hv_max = std::max(hv_max, D.n_ext - D.n_own);
+    lds16 = std::max(lds16, tile_lds_bytes(D.n_ext, D.nslots, false));
+    lds12 = std::max(lds12, tile_lds_bytes(D.n_ext, D.nslots, true));
+    stage = std::max<int64_t>(stage, 16 * (int64_t)std::max(D.n_upd - D.n_own, 0));
+  }
+  TileCfg c{};
+  if (!fat) {
+    f.ok = lds16 <= opt.lds_bytes && pick_cfg(opt.tile_threads, e_max, ext_max, &c);
+    f.lds_bytes = lds16;
+  } else {
+    // ... except in fat tiles: a thread per UPDATED vertex and per halo vertex of the poll list is enough (the outermost
+    // ring only needs its x_bar in LDS, kernels.hip), the staging area of the resident launch must fit too (a fat partition
+    // that cannot be resident is pointless), and 12-byte slots take over where 16 do not fit
+    bool cfg_ok = pick_cfg(opt.tile_threads, e_max, ext_max, &c) && tile_persist_cfg(c.nt, c.ept, c.vpt);
+    if (!cfg_ok) cfg_ok = pick_cfg(opt.tile_threads, e_max, std::max(upd_max, hv_max), &c) && tile_persist_cfg(c.nt, c.ept, c.vpt);
+    if (cfg_ok && tile_persist_cfg(c.nt, c.ept, c.vpt) && lds16 + stage <= opt.lds_bytes) {
+      f.ok = true; f.lds_bytes = lds16;
+    } else if (cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt) && lds12 + stage <= opt.lds_bytes) {
+      f.ok = true; f.slot12 = true; f.lds_bytes = lds12;
+    }
+  }
+  f.nt = c.nt; f.ept = c.ept; f.vpt = c.vpt;
+  return f;
 }
 
 int balance_refine_passes() {
@@ -270,6 +319,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   P.has_tiles = false;
   P.tile_threads = P.tile_ept = P.tile_vpt = P.tile_depth = 0;
   P.tile_lds_bytes = 0;
+  P.tile_slot12 = false;
   P.note.clear();
   P.tiles.clear();
   P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
@@ -294,8 +344,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   const PlanSizing sz = plan_sizing(opt, V, E);
   const int auto_own = sz.auto_own, auto_depth = sz.auto_depth;
   int tile_own = sz.tile_own, depth = sz.depth;
-  bool single = sz.single;
-  const int64_t lds_cap = opt.lds_bytes;
+  bool single = sz.single, fat = sz.fat;
   const bool batch = !opt.batch_voff.empty();
   if (batch) {  // every graph of the batch is one isolated tile; edges must not cross graphs
     const std::vector<int32_t>& vo = opt.batch_voff;
@@ -339,7 +388,9 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       balanced = true;
     }
   }
-  for (int attempt = 0; attempt < (batch ? 1 : 7 + kBalanceRefinePasses); ++attempt) {
+  // (fat tiles: every halo depth that does not fit costs a balance sequence of its own before the next one is tried)
+  const int max_attempts = batch ? 1 : 7 + kBalanceRefinePasses + (sz.fat ? 4 * (2 + kBalanceRefinePasses) : 0);
+  for (int attempt = 0; attempt < max_attempts; ++attempt) {
     const int ntiles = batch ? (int)opt.batch_voff.size() - 1 : (V == 0 ? 0 : (V + tile_own - 1) / tile_own);
     // ---- vertex order: RCB leaves = tiles ----
     std::vector<int32_t> idx(V);
@@ -470,8 +521,6 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     // ---- tiles ----
     P.tiles.assign(ntiles, TileDesc());
     P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
-    int e_max = 0, upd_max = 0;
-    int64_t lds_max = 0;
     bool ok = true;
     // internal edge ranges per owner tile
     std::vector<int32_t> estart(ntiles + 1, 0);
@@ -635,9 +684,6 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
         if (!O.ok) { ok = false; if (O.note) P.note = O.note; break; }
         D.vmap_off = (int32_t)nv; D.emap_off = (int32_t)ne; D.erec_off = (int32_t)ne; D.srow_off = (int32_t)ns;
         nv += O.vmap.size(); ne += O.emap.size(); ns += O.srow.size();
-        e_max = std::max(e_max, D.e_loc);
-        upd_max = std::max(upd_max, D.n_ext);  // every local vertex gets a register slot
-        lds_max = std::max<int64_t>(lds_max, (int64_t)D.n_ext * 16 + (int64_t)(D.nslots + kDummySlots + 1) * 16);
       }
       if (ok) {
         P.t_vmap.resize(nv); P.t_emap.resize(ne); P.t_eij.resize(ne); P.t_ew.resize(ne); P.t_srow.resize(ns);
@@ -653,10 +699,9 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       }
     }
     lap("concat");
-    TileCfg cfg{};
     const bool tiles_valid = ok;
-    if (ok && lds_max > lds_cap) ok = false;
-    if (ok && !pick_cfg(opt.tile_threads, e_max, upd_max, &cfg)) ok = false;
+    TileFit fit;
+    if (ok) { fit = tile_fit(opt, fat, P.tiles); ok = fit.ok; }
     // only the LARGEST tile decides whether a partition fits, and before the cost balance that is a
     // border tile: balance first, shrink only if the balanced partition does not fit either
     // (same rule in flame_hip.cpp upload_device_plan)
@@ -705,9 +750,10 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     }
     if (ok) {
       P.has_tiles = true;
-      P.tile_threads = cfg.nt; P.tile_ept = cfg.ept; P.tile_vpt = cfg.vpt;
+      P.tile_threads = fit.nt; P.tile_ept = fit.ept; P.tile_vpt = fit.vpt;
       P.tile_depth = depth;
-      P.tile_lds_bytes = lds_max;
+      P.tile_lds_bytes = fit.lds_bytes;
+      P.tile_slot12 = fit.slot12;
       if (opt.balance && !batch && !single && ntiles >= 16) {  // remember the cost-density field
         for (int a = 0; a < 2; ++a) { P.wgrid_mn[a] = INFINITY; P.wgrid_mx[a] = -INFINITY; }
         for (int32_t v = 0; v < V; ++v)
@@ -742,6 +788,8 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     P.tiles.clear();
     if (single && opt.single_only) { P.has_tiles = false; return kPlanSingleNoFit; }
     if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }
+    else if (fat && depth > 1 && opt.tile_depth <= 0) --depth;  // fat tiles: a shallower halo first ...
+    else if (fat) { fat = false; tile_own = sz.fallback_own; depth = sz.fallback_depth; }  // ... then two rounds of smaller tiles
     else tile_own = std::max(16, tile_own / 2);
   }
   P.has_tiles = false;

@@ -75,6 +75,7 @@ struct Plan {
   bool has_tiles = false;
   int tile_threads = 0, tile_ept = 0, tile_vpt = 0, tile_depth = 0;
   int64_t tile_lds_bytes = 0;
+  bool tile_slot12 = false;  // 12-byte incidence slots (fat tiles; kernels.hip SlotMem<true>): tile_lds_bytes is priced that way
   std::vector<TileDesc> tiles;
   std::vector<int32_t> t_vmap, t_emap;
   std::vector<UInt2> t_eij;
@@ -108,7 +109,23 @@ struct PlanSizing {
   int auto_own = 0, auto_depth = 0;  // what "auto" resolves to
   int tile_own = 0, depth = 0;       // first attempt (a single isolated tile: tile_own = V, depth 0)
   bool single = false;
+  // r05 FAT resident tiles: a graph beyond 256 x 196 vertices still gets ONE tile per CU (V / 256 own vertices each, up to
+  // ~940) so that it can be solved by one launch of resident tiles; the halo gets shallower as the tiles grow and the
+  // incidence slots shrink to 12 bytes where 16 do not fit (tile_fit()).  A partition that fits at no depth falls back to
+  // fallback_own / fallback_depth (two rounds of smaller tiles, solved by launches).
+  bool fat = false;
+  int fallback_own = 0, fallback_depth = 0;
 };
+// what one build attempt produced, priced: does it fit (LDS, a kernel configuration), and how
+struct TileFit {
+  bool ok = false;
+  int nt = 0, ept = 0, vpt = 0;
+  bool slot12 = false;
+  int64_t lds_bytes = 0;
+};
+// e_max / ext_max / upd_max / hv_max: the largest tile's local edges, local vertices, updated vertices, halo vertices;
+// lds16 / lds12: max over the tiles of tile_lds_bytes() (+ the resident tiles' staging area when `resident`)
+TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles);
 PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E);
 // smallest instantiated kernel configuration that holds e_max local edges / upd_max local vertices
 bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt);

@@ -18,7 +18,7 @@ ARRAYS = [("v_i2o", np.int32), ("v_o2i", np.int32), ("e_i2o", np.int32), ("e_o2i
           ("tris", np.int32), ("trow", np.int32), ("tinc", np.int32), ("tiles", np.int32),
           ("t_vmap", np.int32), ("t_emap", np.int32), ("t_eij", np.uint32), ("t_ew", np.float32),
           ("t_srow", np.uint32)]
-INFO = ["path", "num_tiles", "tile_threads", "tile_ept", "tile_vpt", "tile_depth", "tile_lds_bytes"]
+INFO = ["path", "num_tiles", "tile_threads", "tile_ept", "tile_vpt", "tile_depth", "tile_lds_bytes", "tile_slot12"]
 
 
 def compare_plans(host, dev, what):
@@ -46,7 +46,10 @@ CASES = [
     ("euroc", dict()),
     ("50k", dict()),
     ("50k", dict(tile_own=100, tile_depth=3)),
-    ("200k", dict()),
+    ("200k", dict()),       # (r05: fat resident tiles, 12-byte slots, depth 2)
+    ("v100000", dict()),    # (fat tiles, 16-byte slots, depth 3)
+    ("v160000", dict()),    # (fat tiles with more local vertices than threads)
+    ("v100000", dict(persist=0)),  # (not resident: two rounds of smaller tiles, as in r04)
 ]
 
 
