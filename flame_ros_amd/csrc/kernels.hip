@@ -132,6 +132,13 @@ __device__ __forceinline__ void lds_store3(float4* slot, float a, float b, float
 #ifndef FLAME_EARLY_Q
 #define FLAME_EARLY_Q 1
 #endif
+// EXPERIMENT r05, measured and LOST (profiles/r05_interior_first.txt; off): the next round's first phase D on the interior
+// edge blocks in front of the poll.  Bit-exact, but 50 k 1.336 -> 1.388 us per iteration, 200 k 3.24 -> 3.55, 5 k +4.5 %
+// (only 100 k gained, 2.5 %): what a round waits for is the slowest neighbour's chain, on which the poll's LOAD latency is
+// no longer overlapped with anything, and a phase D cut in two loses the overlap of its gathers.
+#ifndef FLAME_INTERIOR_FIRST
+#define FLAME_INTERIOR_FIRST 0
+#endif
 #ifndef FLAME_POLL_SKIP
 #define FLAME_POLL_SKIP 1
 #endif
@@ -202,9 +209,9 @@ __device__ __forceinline__ float4 slot_load(const SlotMem<S12>& m, typename Slot
   }
 }
 
-// Phase D on the first K of this thread's edges: every gather is issued before the first use.
-// ew = {alpha, beta, dx, dy}; es/ed = LDS addresses of the source / target incidence slot.
-template <int K, int EPT, bool S12>
+// Phase D on K of this thread's edges, the O-th on: every gather is issued before the first use.
+// ew = {alpha, beta, dx, dy}; es/ed = the source / target incidence slot.
+template <int O, int K, int EPT, bool S12>
 __device__ __forceinline__ void tile_phase_d(const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
                                              const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
@@ -212,53 +219,72 @@ __device__ __forceinline__ void tile_phase_d(const float4* bar, const SlotMem<S1
   float4 bi[K], bj[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    bi[k] = bar[eij[k] & 0xffffu];
-    bj[k] = bar[eij[k] >> 16];
+    bi[k] = bar[eij[O + k] & 0xffffu];
+    bj[k] = bar[eij[O + k] >> 16];
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) { keep_w(bi[k]); keep_w(bj[k]); }
   const f2v sg = {sigma, sigma};
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+    const int e = O + k;
     // same expressions as dual_edge(), the (w1, w2) pair packed
     const f2v wi = {bi[k].x, bi[k].y}, wj = {bj[k].x, bj[k].y};
-    const f2v be = {ew[k].y, ew[k].y}, nd = {-ew[k].z, -ew[k].w};
+    const f2v be = {ew[e].y, ew[e].y}, nd = {-ew[e].z, -ew[e].w};
     float t = bi[k].z - bj[k].z;
-    t = fmaf(-bi[k].x, ew[k].z, t);
-    t = fmaf(-bi[k].y, ew[k].w, t);
-    const float K1 = ew[k].x * t;
+    t = fmaf(-bi[k].x, ew[e].z, t);
+    t = fmaf(-bi[k].y, ew[e].w, t);
+    const float K1 = ew[e].x * t;
     const f2v K23 = be * (wi - wj);
-    q1[k] = proj_unit(fmaf(sigma, K1, q1[k]));
-    f2v u = pk_fma(sg, K23, q23[k]);
+    q1[e] = proj_unit(fmaf(sigma, K1, q1[e]));
+    f2v u = pk_fma(sg, K23, q23[e]);
     u.x = proj_unit(u.x);
     u.y = proj_unit(u.y);
-    q23[k] = u;
-    const float aq = ew[k].x * q1[k];
+    q23[e] = u;
+    const float aq = ew[e].x * q1[e];
     const f2v aq2 = {aq, aq};
     const f2v b23 = be * u;
     const f2v s23 = pk_fma(nd, aq2, b23);  // {fmaf(-dx, aq, b2), fmaf(-dy, aq, b3)}
     // one 12-byte store per endpoint; -(a*b) == (-a)*b bit-for-bit, so the target side is two
     // multiplies with a negated operand instead of three sign flips
-    slot_store<S12>(sm, es[k], s23.x, s23.y, aq);
+    slot_store<S12>(sm, es[e], s23.x, s23.y, aq);
     const f2v n23 = (-be) * u;
-    slot_store<S12>(sm, ed[k], n23.x, n23.y, -ew[k].x * q1[k]);
+    slot_store<S12>(sm, ed[e], n23.x, n23.y, -ew[e].x * q1[e]);
   }
 }
 
-// nk (number of active edge blocks) is wave-uniform: dispatch to the matching unrolled body
-template <int K, int EPT, bool S12>
+// blocks [O, O + n) of this wave's edge blocks, n (wave-uniform) <= K: dispatch to the matching unrolled body
+template <int O, int K, int EPT, bool S12>
 struct PhaseD {
-  static __device__ __forceinline__ void run(int nk, const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
+  static __device__ __forceinline__ void run(int n, const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
                                              const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
                                              f2v (&q23)[EPT], float sigma) {
-    if (nk == K) tile_phase_d<K, EPT, S12>(bar, sm, eij, es, ed, ew, q1, q23, sigma);
-    else PhaseD<K - 1, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    if (n == K) tile_phase_d<O, K, EPT, S12>(bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    else PhaseD<O, K - 1, EPT, S12>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+  }
+};
+template <int O, int EPT, bool S12>
+struct PhaseD<O, 0, EPT, S12> {
+  static __device__ __forceinline__ void run(int, const float4*, const SlotMem<S12>&, const uint32_t (&)[EPT],
+                                             const typename SlotT<S12>::ref (&)[EPT], const typename SlotT<S12>::ref (&)[EPT],
+                                             const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],
+                                             float) {}
+};
+// blocks [lo, hi) (resident tiles: a round's first phase D skips the interior blocks it ran before the hand-off arrived)
+template <int O, int EPT, bool S12>
+struct PhaseDFrom {
+  static __device__ __forceinline__ void run(int lo, int hi, const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
+                                             const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
+                                             const float4 (&ew)[EPT], float (&q1)[EPT],
+                                             f2v (&q23)[EPT], float sigma) {
+    if (lo == O) PhaseD<O, EPT - O, EPT, S12>::run(hi - O, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    else PhaseDFrom<O + 1, EPT, S12>::run(lo, hi, bar, sm, eij, es, ed, ew, q1, q23, sigma);
   }
 };
 template <int EPT, bool S12>
-struct PhaseD<0, EPT, S12> {
-  static __device__ __forceinline__ void run(int, const float4*, const SlotMem<S12>&, const uint32_t (&)[EPT],
+struct PhaseDFrom<EPT, EPT, S12> {
+  static __device__ __forceinline__ void run(int, int, const float4*, const SlotMem<S12>&, const uint32_t (&)[EPT],
                                              const typename SlotT<S12>::ref (&)[EPT], const typename SlotT<S12>::ref (&)[EPT],
                                              const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],
                                              float) {}
@@ -585,6 +611,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   int32_t pacc[4] = {0, 0, 0, 0};
   int32_t wait_max = 0;
   int done = 0, round = 0;
+  int k_pre = 0;  // resident tiles: edge blocks of this wave whose first phase D of the round already ran (interior-first)
   for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
   const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
   for (int it = 1; it <= iters; ++it) {
@@ -597,7 +624,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     // wave-uniform: this wave's k-th edge block covers local edges [k NT + wbase, +64)
     const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
     // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
-    PhaseD<EPT, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    if (PERSIST && FLAME_INTERIOR_FIRST) {
+      PhaseDFrom<0, EPT, S12>::run(it == 1 ? min(k_pre, nk) : 0, nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    } else {
+      PhaseD<0, EPT, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    }
 #if FLAME_EARLY_Q
     // resident tiles: the duals of a round are final after its last phase D -- their hand-off entries (58 % of what
     // a tile hands over) leave now and travel while phase P still runs
@@ -691,6 +722,18 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   done += iters;
   ++round;
   if (done >= a.iters) break;
+#if FLAME_INTERIOR_FIRST
+  // ---- interior first (r05): the next round's first phase D on this wave's edge blocks that lie wholly among the
+  // level-0 edges (both ends own: their inputs -- bar[] of own vertices, own duals -- are final since the barrier above)
+  // runs NOW, while the neighbours' hand-off entries are still on their way (store -> uncached memory -> load ~ 1.3 us);
+  // it touches own vertices' bar[] entries and owned edges' slots only, the poll's deliveries the halo's.  The round's
+  // first iteration then starts its phase D at block k_pre.
+  {
+    const int e0 = __builtin_amdgcn_readlane(cut, 32);  // level_end[0]
+    k_pre = (e0 - wbase - 64 >= 0) ? min(EPT, (e0 - wbase - 64) / NT + 1) : 0;
+    PhaseD<0, EPT, EPT, S12>::run(k_pre, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+  }
+#endif
   // ---- end of a round: the halo state of the next one = the owners' hand-off entries, polled until they carry this
   // round's tag.  A lane re-issues its loads until all of ITS entries are there; every load of a pass goes out before
   // the first one is looked at; entries a lane does not need point at one address per tile (one request per wave) ----
