@@ -319,6 +319,33 @@ def test_isolated_tile_sizing_prices_the_slot_rows():
     assert np.array_equal(np.sort(v_o2i), np.arange(V))
 
 
+def test_fat_tile_sizing():
+    """r05: beyond 256 x 196 vertices a handle that solves by resident tiles keeps ONE tile per CU: the halo gets shallower as
+    the tiles grow, a tile may hold more local vertices than threads (only updated vertices and poll slots need a lane), and
+    the incidence slots shrink to 12 bytes where 16 do not fit 160 KiB (the resident staging area included).  Without resident
+    tiles, or with a forced tile size, the r04 partition (two rounds of smaller tiles) stays."""
+    for V, depth, s12 in ((60000, 4, 0), (100000, 3, 0), (160000, 3, 1), (200000, 2, 1)):
+        g = graphgen.synthetic(V, seed=V)
+        r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1)
+        tiles = tiles_of(r)
+        assert len(tiles) == 256 and r.info("tile_depth") == depth and r.info("tile_slot12") == s12, (V, len(tiles), r.info("tile_depth"))
+        nt, ept, vpt = r.info("tile_threads"), r.info("tile_ept"), r.info("tile_vpt")
+        assert vpt == 1 and ept in (2, 3) and (nt == 1024 or not s12)  # a configuration the resident kernels have
+        assert max(t.e_loc for t in tiles) <= nt * ept
+        assert max(t.n_upd for t in tiles) <= nt and max(t.n_ext - t.n_own for t in tiles) <= nt
+        stage = max(16 * max(t.n_upd - t.n_own, 0) for t in tiles)
+        per_slot = 12 if s12 else 16
+        need = max(16 * t.n_ext + per_slot * ((t.nslots + 64 + 1 + (3 if s12 else 0)) // (4 if s12 else 1) * (4 if s12 else 1)) for t in tiles)
+        assert need == r.info("tile_lds_bytes") and need + stage <= 160 * 1024
+        if V == 160000:
+            assert max(t.n_ext for t in tiles) > nt  # the lane-less outermost ring
+        if V == 100000:
+            r0 = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, persist=0)
+            assert r0.info("num_tiles") > 256 and r0.info("tile_slot12") == 0 and r0.info("tile_depth") == 3
+            r1 = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, tile_own=300)
+            assert r1.info("num_tiles") > 256 and r1.info("tile_slot12") == 0
+
+
 def test_batch_plan():
     gs = [graphgen.dataset_shaped(640, 480, 16, seed=s) for s in range(3)] + [graphgen.synthetic(200, seed=1)]
     r = GraphRegularizer.from_batch(gs, device=-1)

@@ -50,3 +50,11 @@ with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, 
     A = np.stack([t[:, 2], t[:, 5], np.ones(nt)], 1).astype(np.float64)
     coef, *_ = np.linalg.lstsq(A, rows[:, 0], rcond=None)
     print("  fit iterate_us = %.5f n_ext + %.5f e_loc + %.3f (residual rms %.3f)" % (coef[0], coef[1], coef[2], np.sqrt(np.mean((A @ coef - rows[:, 0]) ** 2))))
+    # ... with the incidence slots (phase P walks every row to its 64-group's pitch) and the updated vertices
+    for cols, names in (((12, 5), "nslots e_loc"), ((12, 5, 6), "nslots e_loc n_upd"), ((12,), "nslots")):
+        A = np.stack([t[:, c] for c in cols] + [np.ones(nt)], 1).astype(np.float64)
+        coef, *_ = np.linalg.lstsq(A, rows[:, 0], rcond=None)
+        pred = A @ coef
+        print("  fit iterate_us ~ [%s, 1] = %s (residual rms %.3f, corr %.3f, pred max/mean %.3f)" % (
+            names, " ".join("%.5f" % c for c in coef), np.sqrt(np.mean((pred - rows[:, 0]) ** 2)), np.corrcoef(pred, rows[:, 0])[0, 1], pred.max() / pred.mean()))
+    np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gpurun_out", "tile_rounds_%s.npy" % name), np.concatenate([t[:, :13], (rows * 1000).astype(np.int64)], 1))
