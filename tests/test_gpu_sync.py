@@ -183,9 +183,22 @@ print("frames ok, planned by one launch:", mini)
 def test_large_frames_take_the_unfused_chains(gpu):
     """Two frames of 120 k vertices through the graph sync: beyond 114 k vertices the edge derivation is the
     unfused rows / mark / scan / compact chain, and 512 tiles exceed the fused tile pass's look-back grid
-    (plain pass 1 / offsets / pass 2) -- the same edges and the oracle's bits all the same."""
+    (plain pass 1 / offsets / pass 2) -- the same edges and the oracle's bits all the same.  (persist = 0: a handle that solves
+    by resident tiles gets 256 FAT tiles at this size since r05 -- the second handle below, same frames, same bits.)"""
     sp, p = default_sync_params(), default_params()
-    r = GraphRegularizer.empty(device=0)
+    for k in range(2):
+        g = graphgen.synthetic(120000, 1280, 1024, seed=90 + k)
+        var = np.full(g.V, 1e-4, np.float32)
+        with GraphRegularizer.empty(device=0) as rf:
+            rf.sync_features(g.pos, g.z, var, g.tris, sp)
+            assert rf.info("plan_on_device") == 1 and rf.info("num_tiles") == 256
+            assert np.array_equal(rf.edges(), g.edges)
+            o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+            o.solve(oracle_params(), 9)
+            rf.step(p, 9)
+            assert rf.info("persist_used") == 1
+            assert_bit_equal(rf.download()[0], o.x, "fat frame %d x" % k)
+    r = GraphRegularizer.empty(device=0, persist=0)
     for k in range(2):
         g = graphgen.synthetic(120000, 1280, 1024, seed=90 + k)
         var = np.full(g.V, 1e-4, np.float32)
