@@ -425,6 +425,7 @@ struct flame_hip_graph {
     }
     xp.prof = nullptr;  // (was in caps)
     xp.poll_v = nullptr; xp.poll_e = nullptr; xp.poll_ne = nullptr;
+    xp.need_v = nullptr; xp.need_e = nullptr; xp.need_valid = false;
     pin.release();
     pin_in.release();
     pout.release();
@@ -1728,7 +1729,19 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         if ((rc = dev_alloc(g->caps, &x.poll_v, std::max<size_t>(nv_loc, 1))) || (rc = dev_alloc(g->caps, &x.poll_e, std::max<size_t>(ne_loc, 1))) ||
             (rc = dev_alloc(g->caps, &x.poll_ne, P.tiles.size())))
           return rc;
-        HIPCHK(launch_poll_lists(s, (int32_t)P.tiles.size(), g->tiles, g->t_vmap, g->t_emap, g->t_eij, x.poll_v, x.poll_e, x.poll_ne, want_sorted));
+        // (r05: the sorted lists' kernel also marks what anybody polls; the rest of a tile's own entries is not handed over.
+        // A plan's first solve -- a frame of a stream -- stores everything and pays neither the marks nor their memsets)
+        static const bool need_off = std::getenv("FLAME_HIP_NO_NEED_MARKS") != nullptr;  // dev A/B
+        x.need_valid = false;
+        if (want_sorted && !need_off) {
+          if ((rc = dev_alloc(g->caps, &x.need_v, std::max<size_t>((size_t)g->V, 1))) || (rc = dev_alloc(g->caps, &x.need_e, std::max<size_t>((size_t)g->E, 1))))
+            return rc;
+          HIPCHK(hipMemsetAsync(x.need_v, 0, sizeof(int32_t) * std::max<size_t>((size_t)g->V, 1), s));
+          HIPCHK(hipMemsetAsync(x.need_e, 0, sizeof(int32_t) * std::max<size_t>((size_t)g->E, 1), s));
+          x.need_valid = true;
+        }
+        HIPCHK(launch_poll_lists(s, (int32_t)P.tiles.size(), g->tiles, g->t_vmap, g->t_emap, g->t_eij, x.poll_v, x.poll_e, x.poll_ne, want_sorted,
+                                 x.need_valid ? x.need_v : nullptr, x.need_valid ? x.need_e : nullptr));
         g->poll_sorted = want_sorted;
         x.stage_bytes = 0;
         for (const TileDesc& D : P.tiles) x.stage_bytes = std::max(x.stage_bytes, persist_stage_bytes(D));

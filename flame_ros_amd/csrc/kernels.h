@@ -56,6 +56,11 @@ struct PersistBufs {
   uint2* poll_v = nullptr;   // sum of n_ext (capacity)
   uint2* poll_e = nullptr;   // sum of e_loc
   int32_t* poll_ne = nullptr;  // per tile: its halo edges
+  // r05: which owned entries anybody polls (V / E ints, marked by the SORTED lists' kernel after the caller zeroed them):
+  // the rest is not handed over.  need_valid: the marks belong to the current lists
+  int32_t* need_v = nullptr;
+  int32_t* need_e = nullptr;
+  bool need_valid = false;
   size_t stage_bytes = 0;    // LDS behind the incidence slots: (n_upd - n_own) x 16 B of the largest tile
   int32_t* prof = nullptr;
   int32_t poll_delay = 0;  // x 256 clocks between a round's stores and the first poll pass
@@ -63,7 +68,8 @@ struct PersistBufs {
 };
 bool tile_persist_exists(int nt, int ept, int vpt);
 hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tiles, const int32_t* t_vmap, const int32_t* t_emap,
-                             const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted);
+                             const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted,
+                             int32_t* need_v = nullptr, int32_t* need_e = nullptr);
 bool tile_torn_check_build();  // compiled with FLAME_TORN_CHECK (debug: hashed hand-off tags, torn entries counted)
 hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,
                                int32_t* err_host, int32_t base);

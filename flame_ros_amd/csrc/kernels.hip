@@ -387,6 +387,12 @@ struct PersistArgs {
   const uint2* poll_v;
   const uint2* poll_e;
   const int32_t* poll_ne;  // halo edges per tile
+  // r05: what NOBODY polls is not handed over.  need_v[v] bit 0: some tile holds v in its halo (polls its x_bar entry), bit 1:
+  // some tile updates it (polls the primal entry too); need_e[e] != 0: some tile holds e as a halo edge.  Marked by
+  // k_poll_lists<true> (the lists of a plan's second solve on); nullptr = every owned entry is stored (a plan's first solve).
+  // A fat tile hands over a third of what it owns (200 k vertices: 4.0 GB of hand-off stores per 500 iterations before).
+  const int32_t* need_v;
+  const int32_t* need_e;
   int32_t* err_host;  // page-locked: set when a wait timed out
   int32_t base;       // tags of this launch are base + 1 .. base + rounds - 1 (they only grow)
   int32_t* prof;      // device memory (16 words), dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]; [7] the
@@ -512,6 +518,13 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
 #pragma unroll
     for (int k = 0; k < EPT; ++k) per[k] = pa.poll_e[emap_off + min(k * NT + tid, max(n_he - 1, 0))];
   }
+  int nbits[VPT], nedge[EPT];
+  if (PERSIST) {
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) nbits[k] = (pa.need_v && k * NT + tid < n_own) ? pa.need_v[gi[k]] : 3;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) nedge[k] = (pa.need_e && e_loc > 0) ? pa.need_e[qi[k]] : 1;
+  }
   const unsigned long long t_start = a.prof ? __builtin_readcyclecounter() : 0ull;
   // Loads return in issue order, so they are issued in the order of first need: x_bar (B) of every
   // local vertex fills bar[] and is all the first workgroup barrier waits for; the edge constants,
@@ -578,6 +591,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     if constexpr (S12) vrow[k] = 4u * (vs[k] & 0xffffu);
     else vrow[k] = cs + (vs[k] & 0xffffu);
   }
+  bool hand_a[VPT], hand_b[VPT], hand_q[EPT];  // resident tiles: is this lane's own entry polled by anybody?
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) { hand_a[k] = PERSIST && (nbits[k] & 2); hand_b[k] = PERSIST && (nbits[k] & 1); }
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) hand_q[k] = PERSIST && nedge[k] != 0;
   uint32_t eij[EPT];
   slot_t es[EPT], ed[EPT];
   f2v q23[EPT];
@@ -638,7 +656,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
         const int le = k * NT + tid;
-        if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own)
+        if (le < e_loc && (uint32_t)(qi[k] - estart) < (uint32_t)e_own && hand_q[k])
           oq_[qi[k]] = make_float4(q1[k], q23[k].x, q23[k].y, tag_word(tagq, q1[k], q23[k].x, q23[k].y));
       }
     }
@@ -676,8 +694,8 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         // front of the workgroup barrier)
         if (PERSIST && it == iters && done + iters < a.iters && lv < n_own) {
           const int32_t tagv = pa.base + round + 1;
-          pa.hA[(round + 1) & 1][vstart + lv] = make_float4(x, w.x, w.y, tag_word(tagv, x, w.x, w.y));
-          pa.hB[(round + 1) & 1][vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, tag_word(tagv, vxb[k], vwb[k].x, vwb[k].y));
+          if (hand_a[k]) pa.hA[(round + 1) & 1][vstart + lv] = make_float4(x, w.x, w.y, tag_word(tagv, x, w.x, w.y));
+          if (hand_b[k]) pa.hB[(round + 1) & 1][vstart + lv] = make_float4(vxb[k], vwb[k].x, vwb[k].y, tag_word(tagv, vxb[k], vwb[k].x, vwb[k].y));
         }
 #endif
       }
@@ -1807,7 +1825,8 @@ template <bool SORT>
 __global__ __launch_bounds__(kPollThreads) void k_poll_lists(const TileDesc* __restrict__ tiles, const int32_t* __restrict__ t_vmap,
                                                              const int32_t* __restrict__ t_emap, const uint2* __restrict__ t_eij,
                                                              uint2* __restrict__ poll_v, uint2* __restrict__ poll_e,
-                                                             int32_t* __restrict__ poll_ne) {
+                                                             int32_t* __restrict__ poll_ne, int32_t* __restrict__ need_v,
+                                                             int32_t* __restrict__ need_e) {
   __shared__ unsigned long long key[kPollCap];
   __shared__ int s_n;
   const TileDesc& D = tiles[blockIdx.x];
@@ -1843,7 +1862,10 @@ __global__ __launch_bounds__(kPollThreads) void k_poll_lists(const TileDesc* __r
   }
   __syncthreads();
   bitonic_sort_u64(key, m, tid);
-  for (int i = tid; i < nhv; i += kPollThreads) poll_v[D.vmap_off + i] = make_uint2((uint32_t)(key[i] >> 32), (uint32_t)key[i]);
+  for (int i = tid; i < nhv; i += kPollThreads) {
+    poll_v[D.vmap_off + i] = make_uint2((uint32_t)(key[i] >> 32), (uint32_t)key[i]);
+    if (need_v) atomicOr(&need_v[(uint32_t)(key[i] >> 32)], ((uint32_t)key[i] >> 31) ? 3 : 1);  // (zeroed by the caller)
+  }
   __syncthreads();
   // halo edges (the owned ones are the internal ids [estart, estart + e_own)); the record names the incidence slot the dual
   // is staged in: the source's, else the target's, else (no endpoint is ever updated) the lane's trash slot
@@ -1864,15 +1886,19 @@ __global__ __launch_bounds__(kPollThreads) void k_poll_lists(const TileDesc* __r
   for (int i = nhe + tid; i < m; i += kPollThreads) key[i] = ~0ull;
   __syncthreads();
   bitonic_sort_u64(key, m, tid);
-  for (int i = tid; i < nhe; i += kPollThreads) poll_e[D.emap_off + i] = make_uint2((uint32_t)(key[i] >> 32), (uint32_t)key[i]);
+  for (int i = tid; i < nhe; i += kPollThreads) {
+    poll_e[D.emap_off + i] = make_uint2((uint32_t)(key[i] >> 32), (uint32_t)key[i]);
+    if (need_e) need_e[(uint32_t)(key[i] >> 32)] = 1;
+  }
   if (tid == 0) poll_ne[blockIdx.x] = nhe;
 }
 
 hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tiles, const int32_t* t_vmap, const int32_t* t_emap,
-                             const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted) {
+                             const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted, int32_t* need_v,
+                             int32_t* need_e) {
   if (ntiles <= 0) return hipSuccess;
-  if (sorted) hipLaunchKernelGGL(k_poll_lists<true>, dim3(ntiles), dim3(kPollThreads), 0, s, tiles, t_vmap, t_emap, t_eij, poll_v, poll_e, poll_ne);
-  else hipLaunchKernelGGL(k_poll_lists<false>, dim3(ntiles), dim3(kPollThreads), 0, s, tiles, t_vmap, t_emap, t_eij, poll_v, poll_e, poll_ne);
+  if (sorted) hipLaunchKernelGGL(k_poll_lists<true>, dim3(ntiles), dim3(kPollThreads), 0, s, tiles, t_vmap, t_emap, t_eij, poll_v, poll_e, poll_ne, need_v, need_e);
+  else hipLaunchKernelGGL(k_poll_lists<false>, dim3(ntiles), dim3(kPollThreads), 0, s, tiles, t_vmap, t_emap, t_eij, poll_v, poll_e, poll_ne, (int32_t*)nullptr, (int32_t*)nullptr);
   return hipGetLastError();
 }
 
@@ -1906,6 +1932,7 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
   pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
+  pa.need_v = x.need_valid ? x.need_v : nullptr; pa.need_e = x.need_valid ? x.need_e : nullptr;
   if (a.slot12) {
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, true>(s, lds_bytes + x.stage_bytes, a, pa);
     FLAME_S12_CFGS(X)
