@@ -1761,7 +1761,11 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       a.iters = num_iters;
       {
         static const char* pd = std::getenv("FLAME_HIP_POLL_DELAY");  // dev A/B
-        x.poll_delay = pd ? std::atoi(pd) : (g->poll_sorted ? kPollDelayDefault : 0);  // (the lists in local order: a pass is long enough, 0)
+        // (the lists in local order: a pass is long enough, 0; fat tiles with a 1- or 2-iteration round: the hand-off is the
+        // larger part of the round and the first pass should not wait -- 200 k 3.02 / 3.05 / 3.13 / 3.15 / 3.23 us per
+        // iteration at 0 .. 4, 160 k and 100 k (depth 3) flat: profiles/r05_fat_poll_delay.txt)
+        const bool short_fat_round = g->V > 256 * 196 && P.tile_depth <= 2;
+        x.poll_delay = pd ? std::atoi(pd) : ((g->poll_sorted && !short_fat_round) ? kPollDelayDefault : 0);
         // A poll waits at most max(0.5 ms, 8 x the handle's last measured round) -- r04's flat 4 ms was 5.5 headline
         // solves; 4 ms while nothing has been measured.  FLAME_HIP_PERSIST_TIMEOUT_US overrides.
         static const char* to = std::getenv("FLAME_HIP_PERSIST_TIMEOUT_US");
