@@ -636,6 +636,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "tile_depth") *value = P.tile_depth;
   else if (k == "tile_lds_bytes") *value = P.tile_lds_bytes;
   else if (k == "tile_slot12") *value = P.tile_slot12 ? 1 : 0;
+  else if (k == "tile_fat") *value = P.tile_fat ? 1 : 0;
   else if (k == "tile_ext_vertices") { int64_t s = 0; for (auto& t : P.tiles) s += t.n_ext; *value = s; }
   else if (k == "tile_loc_edges") { int64_t s = 0; for (auto& t : P.tiles) s += t.e_loc; *value = s; }
   else if (k == "device") *value = g->device;
@@ -847,7 +848,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   int tile_own = sz.tile_own;
   int depth = sz.depth;
   bool fat = sz.fat;
-  bool slot12 = false;
+  bool slot12 = false, fat_cfg = false;
   bool balanced = false, built = false;
   int refine_left = 0;
   int ntiles = 0, cfg_nt = 0, cfg_ept = 0, cfg_vpt = 0;
@@ -893,7 +894,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     if (ok) {
       const TileFit fit = tile_fit(g->opt, fat, tiles);  // (LDS, kernel configuration, 12-byte slots: plan.cpp)
       ok = fit.ok;
-      lds_max = fit.lds_bytes; slot12 = fit.slot12;
+      lds_max = fit.lds_bytes; slot12 = fit.slot12; fat_cfg = fit.fat;
       cfg_nt = fit.nt; cfg_ept = fit.ept; cfg_vpt = fit.vpt;
       // A stream that solves by ONE launch of resident tiles takes over the previous frame's partition only if this frame
       // can be resident on it.  One hull tile of THIS frame with a halo twice the others' (the old partition knows nothing
@@ -971,6 +972,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   P.tile_depth = depth;
   P.tile_lds_bytes = lds_max;
   P.tile_slot12 = slot12;
+  P.tile_fat = fat_cfg;
   P.note.clear();
   P.v_o2i.clear(); P.v_i2o.clear(); P.e_o2i.clear(); P.e_i2o.clear();
   P.eij.clear(); P.ew.clear(); P.grow.clear(); P.ginc.clear(); P.tris.clear(); P.trow.clear(); P.tinc.clear();
@@ -1700,6 +1702,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.t_ew = g->t_ew; a.t_srow = g->t_srow; a.p = sp; a.ntiles = (int32_t)P.tiles.size();
     a.prof = g->prof;
     a.slot12 = P.tile_slot12 ? 1 : 0;
+    a.fat = P.tile_fat ? 1 : 0;
     if (persist_applies(g, num_iters) && persist_lease_take(g, s)) {
       PersistBufs& x = g->xp;
       int rc;
@@ -1733,7 +1736,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         // A plan's first solve -- a frame of a stream -- stores everything and pays neither the marks nor their memsets)
         static const bool need_off = std::getenv("FLAME_HIP_NO_NEED_MARKS") != nullptr;  // dev A/B
         x.need_valid = false;
-        if (want_sorted && !need_off) {
+        if (want_sorted && !need_off && P.tile_fat) {  // (the FAT kernel variants read the marks)
           if ((rc = dev_alloc(g->caps, &x.need_v, std::max<size_t>((size_t)g->V, 1))) || (rc = dev_alloc(g->caps, &x.need_e, std::max<size_t>((size_t)g->E, 1))))
             return rc;
           HIPCHK(hipMemsetAsync(x.need_v, 0, sizeof(int32_t) * std::max<size_t>((size_t)g->V, 1), s));

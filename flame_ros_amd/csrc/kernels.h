@@ -24,6 +24,7 @@ struct TileArgs {
   int32_t ntiles;
   unsigned long long* prof;  // debug timeline, kProfWords words per tile, or nullptr
   int32_t slot12 = 0;  // 12-byte incidence slots (fat tiles: Plan::tile_slot12; lds_bytes is then tile_lds_bytes(.., true))
+  int32_t fat = 0;     // fat tiles (Plan::tile_fat): the resident launch takes the FAT kernel variants (tile_slot12_exists())
 };
 
 // ---- global path: one dual + one primal kernel per PD iteration ----

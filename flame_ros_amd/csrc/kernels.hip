@@ -448,7 +448,10 @@ __device__ __forceinline__ bool tag_ok(const float4& v, int32_t target, int32_t*
 #endif
 }
 
-template <int NT, int EPT, int VPT, bool PERSIST, bool S12>
+// FAT (resident kernels only; the launch-by-launch kernels always carry it): the variant fat tiles get -- the lane-less
+// outermost ring's loads and the hand-off filtered by what somebody polls.  Kept out of the kernels of graphs up to one
+// regular tile per CU: measured +1.2 % per iteration at 50 k with both compiled in (profiles/r05_fat_variant_ab.txt).
+template <int NT, int EPT, int VPT, bool PERSIST, bool S12, bool FAT>
 __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   typedef typename SlotT<S12>::ref slot_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -519,7 +522,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     for (int k = 0; k < EPT; ++k) per[k] = pa.poll_e[emap_off + min(k * NT + tid, max(n_he - 1, 0))];
   }
   int nbits[VPT], nedge[EPT];
-  if (PERSIST) {
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) nbits[k] = 3;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) nedge[k] = 1;
+  if constexpr (PERSIST && FAT) {
 #pragma unroll
     for (int k = 0; k < VPT; ++k) nbits[k] = (pa.need_v && k * NT + tid < n_own) ? pa.need_v[gi[k]] : 3;
 #pragma unroll
@@ -568,9 +575,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   }
   // fat tiles: local vertices beyond one per thread lie in the outermost ring (the configuration holds every UPDATED vertex,
   // pick_cfg()): they have no lane, only their x_bar in bar[] -- loaded here, refreshed by the poll's deliveries
-  for (int lv = VPT * NT + tid; lv < n_ext; lv += NT) {
-    const float4 b = a.B_src[a.t_vmap[vmap_off + lv]];
-    bar[lv] = make_float4(b.y, b.z, b.x, 0.f);
+  if constexpr (!PERSIST || FAT) {
+    for (int lv = VPT * NT + tid; lv < n_ext; lv += NT) {
+      const float4 b = a.B_src[a.t_vmap[vmap_off + lv]];
+      bar[lv] = make_float4(b.y, b.z, b.x, 0.f);
+    }
   }
 
   float vx[VPT], vz[VPT], vt[VPT], vwgt[VPT], vxb[VPT];
@@ -927,10 +936,10 @@ __global__ __launch_bounds__(NT) void k_tile(const TileDesc* __restrict__ tiles,
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_arg; a.ntiles = ntiles; a.prof = prof_arg;
-  tile_body<NT, EPT, VPT, false, S12>(a, PersistArgs{});
+  tile_body<NT, EPT, VPT, false, S12, true>(a, PersistArgs{});
 }
 
-template <int NT, int EPT, int VPT, bool S12 = false>
+template <int NT, int EPT, int VPT, bool S12 = false, bool FAT = false>
 __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict__ tiles, int32_t ntiles, int32_t iters_total,
                                                      const int32_t* __restrict__ t_vmap, const uint32_t* __restrict__ t_srow,
                                                      const uint2* __restrict__ t_eij, const int32_t* __restrict__ t_emap,
@@ -942,7 +951,7 @@ __global__ __launch_bounds__(NT) void k_tile_persist(const TileDesc* __restrict_
   a.tiles = tiles; a.t_vmap = t_vmap; a.t_emap = t_emap; a.t_eij = t_eij; a.t_ew = t_ew; a.t_srow = t_srow;
   a.A_src = A_src; a.B_src = B_src; a.q_src = q_src; a.A_dst = A_dst; a.B_dst = B_dst; a.q_dst = q_dst;
   a.p = p_arg; a.iters = iters_total; a.ntiles = ntiles; a.prof = nullptr;
-  tile_body<NT, EPT, VPT, true, S12>(a, pa);
+  tile_body<NT, EPT, VPT, true, S12, FAT>(a, pa);
 }
 
 template <int NT, int EPT, int VPT, bool S12 = false>
@@ -1911,15 +1920,15 @@ bool tile_persist_exists(int nt, int ept, int vpt) {
   return false;
 }
 
-template <int NT, int EPT, int VPT, bool S12 = false>
+template <int NT, int EPT, int VPT, bool S12 = false, bool FAT = false>
 hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, const PersistArgs& pa) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT, S12>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_persist<NT, EPT, VPT, S12, FAT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   // the launches' grid: one workgroup per tile, all of them resident (the caller keeps ntiles <= the number of CUs)
-  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, S12>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
+  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, S12, FAT>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
                      a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, pa, a.p);
   return hipGetLastError();
 }
@@ -1932,9 +1941,10 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
   pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
-  pa.need_v = x.need_valid ? x.need_v : nullptr; pa.need_e = x.need_valid ? x.need_e : nullptr;
-  if (a.slot12) {
-#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return launch_tile_persist_t<N, Ep, Vp, true>(s, lds_bytes + x.stage_bytes, a, pa);
+  pa.need_v = (x.need_valid && a.fat) ? x.need_v : nullptr; pa.need_e = (x.need_valid && a.fat) ? x.need_e : nullptr;
+  if (a.slot12 || a.fat) {  // the fat variants: 1 024 threads, 2 or 3 edges per thread, either slot layout
+#define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return a.slot12 ? launch_tile_persist_t<N, Ep, Vp, true, true>(s, lds_bytes + x.stage_bytes, a, pa) \
+                                                                            : launch_tile_persist_t<N, Ep, Vp, false, true>(s, lds_bytes + x.stage_bytes, a, pa);
     FLAME_S12_CFGS(X)
 #undef X
     return hipErrorInvalidConfiguration;

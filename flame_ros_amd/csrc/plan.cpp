@@ -286,7 +286,9 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
     // ring only needs its x_bar in LDS, kernels.hip), the staging area of the resident launch must fit too (a fat partition
     // that cannot be resident is pointless), and 12-byte slots take over where 16 do not fit
     bool cfg_ok = pick_cfg(opt.tile_threads, e_max, ext_max, &c) && tile_persist_cfg(c.nt, c.ept, c.vpt);
-    if (!cfg_ok) cfg_ok = pick_cfg(opt.tile_threads, e_max, std::max(upd_max, hv_max), &c) && tile_persist_cfg(c.nt, c.ept, c.vpt);
+    if (!cfg_ok)  // (the lane-less outermost ring is the FAT kernel variants': 1 024 threads)
+      cfg_ok = pick_cfg(opt.tile_threads, e_max, std::max(upd_max, hv_max), &c) && tile_slot12_cfg(c.nt, c.ept, c.vpt);
+    f.fat = cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt);
     if (cfg_ok && tile_persist_cfg(c.nt, c.ept, c.vpt) && lds16 + stage <= opt.lds_bytes) {
       f.ok = true; f.lds_bytes = lds16;
     } else if (cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt) && lds12 + stage <= opt.lds_bytes) {
@@ -320,6 +322,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   P.tile_threads = P.tile_ept = P.tile_vpt = P.tile_depth = 0;
   P.tile_lds_bytes = 0;
   P.tile_slot12 = false;
+  P.tile_fat = false;
   P.note.clear();
   P.tiles.clear();
   P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
@@ -754,6 +757,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
       P.tile_depth = depth;
       P.tile_lds_bytes = fit.lds_bytes;
       P.tile_slot12 = fit.slot12;
+      P.tile_fat = fit.fat;
       if (opt.balance && !batch && !single && ntiles >= 16) {  // remember the cost-density field
         for (int a = 0; a < 2; ++a) { P.wgrid_mn[a] = INFINITY; P.wgrid_mx[a] = -INFINITY; }
         for (int32_t v = 0; v < V; ++v)

@@ -75,6 +75,7 @@ struct Plan {
   bool has_tiles = false;
   int tile_threads = 0, tile_ept = 0, tile_vpt = 0, tile_depth = 0;
   int64_t tile_lds_bytes = 0;
+  bool tile_fat = false;     // fat tiles on a 1 024-thread configuration: the resident launch takes the FAT kernel variants
   bool tile_slot12 = false;  // 12-byte incidence slots (fat tiles; kernels.hip SlotMem<true>): tile_lds_bytes is priced that way
   std::vector<TileDesc> tiles;
   std::vector<int32_t> t_vmap, t_emap;
@@ -121,6 +122,7 @@ struct TileFit {
   bool ok = false;
   int nt = 0, ept = 0, vpt = 0;
   bool slot12 = false;
+  bool fat = false;  // fat sizing and a 1 024-thread configuration (the FAT kernel variants exist for those)
   int64_t lds_bytes = 0;
 };
 // e_max / ext_max / upd_max / hv_max: the largest tile's local edges, local vertices, updated vertices, halo vertices;
