@@ -934,7 +934,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     if (ok && balanced && refine_left > 0 && ntiles >= 16) {  // refinement passes (plan.cpp)
       --refine_left;
       long long total = 0;
-      for (const TileDesc& D : tiles) total += (long long)D.e_loc + 2 * (long long)D.n_ext;
+      for (const TileDesc& D : tiles) total += tile_cost(D, tile_cost_mode());
       HIPCHK(g->planner.weights_scale_by_tiles(s, V, ntiles, total, A));
       continue;
     }
@@ -952,7 +952,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   {  // how even the tiles are (a launch lasts as long as its slowest tile): max / mean of the cost model
     long long sum = 0, mx = 0;
     for (const TileDesc& D : tiles) {
-      const long long c = (long long)D.e_loc + 2 * (long long)D.n_ext;
+      const long long c = tile_cost(D, tile_cost_mode());
       sum += c; mx = std::max(mx, c);
     }
     g->tile_imbalance_pct = sum > 0 ? (int)(100 * mx * (long long)tiles.size() / sum) : 100;

@@ -119,7 +119,7 @@ void rcb_par(const float* pos, const int32_t* w, std::vector<int32_t>& idx, int 
 // Integer cost density of a tile (x 1024): what one own vertex of the tile "costs" a launch --
 // local edges + 2 x local vertices, per own vertex.  Integer so that sums of it are exact.
 int32_t tile_weight(const TileDesc& D) {
-  const int64_t cost = (int64_t)D.e_loc + 2 * (int64_t)D.n_ext;
+  const int64_t cost = tile_cost(D, tile_cost_mode());
   return (int32_t)std::max<int64_t>(1, cost * 1024 / std::max(D.n_own, 1));
 }
 
@@ -298,6 +298,13 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
   f.nt = c.nt; f.ept = c.ept; f.vpt = c.vpt;
   return f;
 }
+
+}  // namespace flamehip
+int flamehip::tile_cost_mode() {
+  static const int m = [] { const char* e = std::getenv("FLAME_HIP_COST_MODEL"); return e ? std::atoi(e) : 0; }();
+  return m;
+}
+namespace flamehip {
 
 int balance_refine_passes() {
   static const int n = [] {
@@ -727,10 +734,10 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     if (ok && balanced && refine_left > 0 && !vweight.empty() && !batch && !single && ntiles >= 16) {
       --refine_left;
       int64_t total = 0;
-      for (int t = 0; t < ntiles; ++t) total += (int64_t)P.tiles[t].e_loc + 2 * (int64_t)P.tiles[t].n_ext;
+      for (int t = 0; t < ntiles; ++t) total += tile_cost(P.tiles[t], tile_cost_mode());
       for (int t = 0; t < ntiles; ++t) {
         const TileDesc& D = P.tiles[t];
-        const int64_t cost = (int64_t)D.e_loc + 2 * (int64_t)D.n_ext;
+        const int64_t cost = tile_cost(D, tile_cost_mode());
         for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k) {
           int32_t& w = vweight[P.v_i2o[k]];
           w = (int32_t)std::min<int64_t>(1 << 28, std::max<int64_t>(1, (int64_t)w * cost * ntiles / std::max<int64_t>(total, 1)));

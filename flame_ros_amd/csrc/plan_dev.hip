@@ -1618,28 +1618,28 @@ __global__ __launch_bounds__(256) void k_publish(const int32_t* __restrict__ fla
 // Cost weights: from the tiles of the previous pass, or from the cost-density grid of the
 // previous frame (plan.cpp: tile_weight(), Plan::wgrid).  All integer.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t tile_weight_dev(const TileDesc& D) {
-  const long long cost = (long long)D.e_loc + 2 * (long long)D.n_ext;
+__device__ __forceinline__ int32_t tile_weight_dev(const TileDesc& D, int mode) {
+  const long long cost = tile_cost(D, mode);
   const long long w = cost * 1024 / max(D.n_own, 1);
   return (int32_t)max(1ll, w);
 }
 
 __global__ __launch_bounds__(256) void k_weights_from_tiles(int32_t V, const int32_t* __restrict__ v_i2o,
                                                             const int32_t* __restrict__ tile_of_int,
-                                                            const TileDesc* __restrict__ tiles, int32_t* w_int) {
+                                                            const TileDesc* __restrict__ tiles, int32_t* w_int, int mode) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k < V) w_int[v_i2o[k]] = tile_weight_dev(tiles[tile_of_int[k]]);
+  if (k < V) w_int[v_i2o[k]] = tile_weight_dev(tiles[tile_of_int[k]], mode);
 }
 
 // refinement pass: w_v <- w_v * cost(tile of v) * ntiles / total cost (plan.cpp, "refine weights")
 __global__ __launch_bounds__(256) void k_weights_scale(int32_t V, const int32_t* __restrict__ v_i2o,
                                                        const int32_t* __restrict__ tile_of_int,
                                                        const TileDesc* __restrict__ tiles, int32_t ntiles,
-                                                       long long total, int32_t* w_int) {
+                                                       long long total, int32_t* w_int, int mode) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= V) return;
   const TileDesc& D = tiles[tile_of_int[k]];
-  const long long cost = (long long)D.e_loc + 2 * (long long)D.n_ext;
+  const long long cost = tile_cost(D, mode);
   const int32_t v = v_i2o[k];
   const long long w = (long long)w_int[v] * cost * ntiles / max(total, 1ll);
   w_int[v] = (int32_t)min(1ll << 28, max(1ll, w));
@@ -1763,7 +1763,7 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
                                                     const int32_t* __restrict__ tile_of_int,
                                                     const TileDesc* __restrict__ tiles,
                                                     const float* __restrict__ bounds,
-                                                    unsigned long long* sum, int32_t* cnt, int32_t* pyr) {
+                                                    unsigned long long* sum, int32_t* cnt, int32_t* pyr, int mode) {
   // vertices that are neighbours in internal order (same tile, Morton order) fall into the same
   // cell: accumulate per workgroup in LDS, flush the touched cells once (integer sums: any order)
   __shared__ unsigned long long s_sum[Plan::kGrid * Plan::kGrid];
@@ -1774,7 +1774,7 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
   if (k < V) {
     const float2 q = pos[v_i2o[k]];
     const int c = grid_cell_dev(bounds, q);
-    atomicAdd(&s_sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]]));
+    atomicAdd(&s_sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]], mode));
     atomicAdd(&s_cnt[c], 1);
     if (pyr) {  // the tile map the next frame's partition is read from (partition reuse)
       const int32_t tv = tile_of_int[k] + 1;
@@ -2970,7 +2970,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
 }
 
 hipError_t DevPlanner::weights_from_tiles(hipStream_t s, int32_t V, const DevPlanArrays& A) {
-  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, w_int_);
+  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, w_int_, tile_cost_mode());
   weight_mode_ = 1;
   return hipGetLastError();
 }
@@ -2978,7 +2978,7 @@ hipError_t DevPlanner::weights_from_tiles(hipStream_t s, int32_t V, const DevPla
 hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntiles, long long total_cost,
                                               const DevPlanArrays& A) {
   hipLaunchKernelGGL(k_weights_scale, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, ntiles, total_cost,
-                     w_int_);
+                     w_int_, tile_cost_mode());
   weight_mode_ = 1;
   return hipGetLastError();
 }
@@ -3101,7 +3101,8 @@ hipError_t DevPlanner::flush_grid(hipEvent_t after) {
   const int32_t V = grid_job_.V;
   zero4(g2, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
   hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, g2, V, grid_job_.pos, grid_job_.v_i2o, tile_of_int_,
-                     grid_job_.tiles, gbbox_, reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_);
+                     grid_job_.tiles, gbbox_, reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_,
+                     tile_cost_mode());
   hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, g2, V, reinterpret_cast<unsigned long long*>(grid_sum_),
                      grid_cnt_, grid_w_, gbbox_, grid_bounds_, cell_pyr_);
   if (s2_) {
