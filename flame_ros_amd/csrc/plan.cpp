@@ -229,7 +229,11 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // (measured: 200 k vertices 5.9 us per iteration by 167 launches of two rounds of tiles -> resident)
   const bool fat = !one_round && opt.resident && opt.tile_own <= 0 && V <= 256 * 940 && opt.batch_voff.empty();
   const int fat_own = (V + 255) / 256;
-  const int auto_own = one_round ? std::max(32, std::min(196, (V + 255) / 256))
+  static const int min_own_env = [] { const char* e = std::getenv("FLAME_HIP_MIN_OWN"); return e ? std::atoi(e) : 0; }();  // dev A/B
+  // (r05, resident tiles: 24 instead of 32 own vertices at least -- more CUs at work, 1-2 % per iteration below 6 k vertices and
+  // on a TUM-sized frame: profiles/r05_min_own_ab.txt; tiles that small take the deeper halo)
+  const int min_own = min_own_env > 0 ? min_own_env : (opt.resident ? 24 : 32);
+  const int auto_own = one_round ? std::max(min_own, std::min(196, (V + 255) / 256))
                        : fat     ? fat_own
                                  : std::max(196, std::min(400, (V + 511) / 512));
   // few tiles (a small lone graph): CUs are idle anyway, so redundant halo work is free and deeper
@@ -243,7 +247,7 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // own vertices on only the 12-byte layout fits and the deepest halo that does wins (160 k: depth 3 2.79, 2 3.10, 1 3.12)
   const int auto_depth = fat ? (fat_own <= 280 ? 4 : (fat_own <= 420 ? 3 : (fat_own <= 540 ? 2 : (fat_own <= 640 ? 3 : (fat_own <= 800 ? 2 : 1)))))
                          : !one_round ? 3
-                         : opt.resident ? (auto_tiles <= 100 ? 5 : 4)
+                         : opt.resident ? ((auto_tiles <= 100 || auto_own < 32) ? 5 : 4)
                                         : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
   int tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own;
   int depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth;

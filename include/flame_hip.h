@@ -101,7 +101,10 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * (default 1: a graph of 2 .. 256 halo tiles -- at most one per CU -- is solved by ONE launch of RESIDENT tiles:
  * neighbours hand their results over through uncached, round-tagged copies of the state arrays every `depth`
  * iterations instead of meeting at a kernel boundary; same bits, any placement of the tiles on the chip; 0: one
- * launch per `depth` iterations; flame_hip_get_info "persist_used" tells whether the last solve ran that way.  The
+ * launch per `depth` iterations; flame_hip_get_info "persist_used" tells whether the last solve ran that way.  r05: with
+ * automatic tile sizes that covers every graph up to ~240 000 vertices -- beyond 256 x 196 the tiles grow FAT (one per CU,
+ * shallower halos, 12-byte incidence slots where 16 do not fit the LDS: flame_hip_get_info "tile_fat", "tile_slot12"); a handle
+ * with "persist" 0 keeps the partition of two rounds of smaller tiles there.  The
  * launch ASSUMES that all its workgroups are on the chip at once.  The library keeps the tile count within the
  * CU count and lets one handle per device and process run such a launch at a time (another handle solving at the
  * same moment uses ordinary launches), but a foreign kernel that holds CUs for long -- another process, another
