@@ -633,7 +633,10 @@ def main():
                        "V": g.V, "E": g.E, "iters_per_step": iters, "parallelism": ("partition%d_halo%d" % (world, args.halo_depth)) if partition else "replicas%d" % world,
                        "path": {1: "global", 2: "tile"}[path], "num_tiles": r.info("num_tiles"),
                        "tile_depth": r.info("tile_depth"), "tile_threads": r.info("tile_threads"),
-                       "hipgraph": not args.no_graph},
+                       "hipgraph": not args.no_graph,
+                       # resident launches that gave up and were repeated by launches (whole queues included, r05) while this
+                       # handle was measured: normally 0; > 0 means some window paid for a repeat -- the value stays valid
+                       "resident_solves_repeated": r.info("persist_recovered") if not partition and not args.batch else None},
             "repeats": ({"windows": len(repeat_ips), "median": repeat_ips[len(repeat_ips) // 2], "min": repeat_ips[0],
                          "max": repeat_ips[-1], "unit": "PD iterations/s",
                          "note": "the same K-step window repeated after the timed one"} if repeat_ips else None),

@@ -345,6 +345,16 @@ struct flame_hip_graph {
   bool init_have_x0 = false;        // the device-built plan's initial state came with an x0 array
   int persist_recovered = 0;        // how many solves were repeated that way (flame_hip_get_info)
   uint64_t solve_serial = 0;        // state_serial right behind the last solve: later state-writing calls move on from it
+  // r05: SEVERAL solves queued behind each other without a synchronising call are repeatable too (a bench window, a caller
+  // that pipelines solves): every solve from the first unchecked resident one on is logged, and when a second one is queued
+  // the source buffers of the first -- which it would overwrite -- are copied aside first (device to device, once per
+  // synchronising call).  A give-up then restores that state and repeats the whole queue by launches.
+  struct QueuedSolve { SolveParams sp; int32_t iters; };
+  std::vector<QueuedSolve> queued;  // since the last look, the first unchecked resident solve first
+  int queued_src = 0;               // the buffer that solve started from
+  uint64_t queued_serial = 0;       // state_serial in front of it
+  float4 *qsnapA = nullptr, *qsnapB = nullptr, *qsnapq = nullptr;
+  bool qsnap_valid = false;
   int stream_depth = 0;        // option "stream_depth": halo depth of small graphs (<= 64 tiles) instead of the
                                // auto depth 8, which is tuned for a RESIDENT graph (fewest launches); a graph
                                // that is solved once pays for its plan, and that is cheapest at depth 4-5
@@ -522,6 +532,7 @@ static hipError_t wait_last_solve(flame_hip_graph* g) {
 // A new upload throws the state of the solves before it away: whether one of their resident launches gave up no longer
 // matters for the results -- only for the lease and the back-off.  (Called behind the upload's own wait for those solves.)
 static void persist_discard(flame_hip_graph* g) {
+  g->queued.clear(); g->qsnap_valid = false;
   if (!g->persist_unchecked) return;
   g->persist_unchecked = false;
   g->persist_unchecked_n = 0;
@@ -1664,10 +1675,42 @@ static int persist_check(flame_hip_graph* g, int own_marks = 0) {
       if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess && ms > 0.f) g->persist_round_us = ms * 1e3f / (float)g->last_rounds;
       else (void)hipGetLastError();
     }
+    g->queued.clear(); g->qsnap_valid = false;
     return 0;
   }
   *g->persist_err = 0;
   persist_lease_drop(g, true);
+  // r05: a queue of solves is repeated as a whole from the state copied aside in front of its second member
+  if (g->queued.size() > 1) {
+    std::vector<flame_hip_graph::QueuedSolve> q;
+    q.swap(g->queued);
+    const bool ok = g->qsnap_valid && g->state_serial == g->queued_serial + (uint64_t)q.size() + (uint64_t)own_marks;
+    g->qsnap_valid = false;
+    g->persist_used = false;
+    if (!ok) { g->uploaded = false; return FLAME_HIP_ERR_STATE; }
+    hipStream_t s = g->last_stream ? g->last_stream : g->stream;
+    const int src = g->queued_src;
+    HIPCHK(hipMemcpyAsync(g->A[src], g->qsnapA, sizeof(float4) * (size_t)g->V, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->B[src], g->qsnapB, sizeof(float4) * (size_t)g->V, hipMemcpyDeviceToDevice, s));
+    if (g->E > 0) HIPCHK(hipMemcpyAsync(g->q[src], g->qsnapq, sizeof(float4) * (size_t)g->E, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipEventRecord(g->ev0, s));
+    int cur = src, total_launches = 0;
+    g->persist_skip_once = true;
+    for (const auto& e : q) {
+      int cur_out = cur, launches = 0;
+      const int rc = enqueue_iterations(g, e.sp, e.iters, s, cur, &cur_out, &launches);
+      if (rc) { g->persist_skip_once = false; return rc; }
+      cur = cur_out; total_launches += launches;
+    }
+    g->persist_skip_once = false;
+    g->cur = cur;
+    g->state_serial++;
+    g->last_launches = total_launches;
+    HIPCHK(hipEventRecord(g->ev1, s));
+    ++g->persist_recovered;
+    return 1;
+  }
+  g->queued.clear(); g->qsnap_valid = false;
   // (several solves queued without a synchronisation in between: an earlier one may have been the one that gave up, and
   // the later ones started from its unfinished result -- nothing to repeat from)
   const bool can = g->persist_used && unchecked <= 1 && g->state_serial == g->solve_serial + (uint64_t)own_marks && g->last_iters > 0;
@@ -1839,6 +1882,21 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
     g->lanes_applied = true;
     g->poll_valid = false;  // (edges moved inside their 64-blocks: a poll record names a position)
   }
+  // r05: a solve queued behind an unchecked resident one -- before it overwrites that one's source, the source is set aside
+  if (g->persist_unchecked_n == 0) { g->queued.clear(); g->qsnap_valid = false; }
+  if (g->queued.size() == 1 && !g->qsnap_valid && g->state_serial == g->queued_serial + 1 && num_iters > 0) {
+    int rc2;
+    if ((rc2 = dev_alloc(g->caps, &g->qsnapA, (size_t)g->V)) || (rc2 = dev_alloc(g->caps, &g->qsnapB, (size_t)g->V)) ||
+        (rc2 = dev_alloc(g->caps, &g->qsnapq, (size_t)std::max(g->E, 1))))
+      return rc2;
+    const int src = g->queued_src;
+    HIPCHK(hipMemcpyAsync(g->qsnapA, g->A[src], sizeof(float4) * (size_t)g->V, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->qsnapB, g->B[src], sizeof(float4) * (size_t)g->V, hipMemcpyDeviceToDevice, s));
+    if (g->E > 0) HIPCHK(hipMemcpyAsync(g->qsnapq, g->q[src], sizeof(float4) * (size_t)g->E, hipMemcpyDeviceToDevice, s));
+    g->qsnap_valid = true;
+  }
+  const int cur_before = g->cur;
+  const uint64_t serial_before = g->state_serial;
   HIPCHK(hipEventRecord(g->ev0, s));
   g->last_sp = sp; g->last_iters = num_iters; g->last_stream = s;
   // (a hipGraph replay or a solve of 0 iterations does not pass through enqueue_iterations(); without this a
@@ -1882,6 +1940,15 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   g->cur = cur_out;
   g->state_serial++;
   g->solve_serial = g->state_serial;
+  if (num_iters > 0 && g->V > 0) {  // (the log of what a give-up would have to repeat)
+    if (g->queued.empty()) {
+      if (g->persist_used) { g->queued.push_back({sp, num_iters}); g->queued_src = cur_before; g->queued_serial = serial_before; }
+    } else if (g->qsnap_valid) {
+      g->queued.push_back({sp, num_iters});
+    } else {
+      g->queued.push_back({sp, num_iters});  // (no copy was taken -- something else wrote the state in between: the check refuses)
+    }
+  }
   g->last_launches = launches;
   g->solves_since_upload++;
   HIPCHK(hipEventRecord(g->ev1, s));
@@ -2456,6 +2523,7 @@ int flame_hip_persist_take_error(flame_hip_graph* g, int32_t* gave_up) {
   const bool had = g->persist_unchecked;
   g->persist_unchecked = false;
   g->persist_unchecked_n = 0;
+  g->queued.clear(); g->qsnap_valid = false;  // (the caller -- the partition mode -- keeps snapshots of its own)
   if (had && g->persist_err && (*g->persist_err != 0 || force_fail)) {
     *g->persist_err = 0;
     persist_lease_drop(g, true);

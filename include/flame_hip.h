@@ -110,9 +110,10 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * same moment uses ordinary launches), but a foreign kernel that holds CUs for long -- another process, another
  * library -- can still keep tiles from starting: every wait inside the launch is bounded (4 ms), a launch that
  * gave up is noticed at the next synchronising call and REPEATED by ordinary launches from its untouched source
- * buffers ("persist_recovered" counts those; FLAME_HIP_ERR_STATE when another call rewrote the state in between, or
- * when SEVERAL resident solves were queued without a synchronising call between them: the error word does not say which
- * one gave up), and the whole process then stays off resident tiles for 16 solves, doubling with every further
+ * buffers ("persist_recovered" counts those; r05: SEVERAL solves queued without a synchronising call between them are
+ * repeated as a whole -- the error word does not say which one gave up, so the source of the first is copied aside when
+ * the second is queued and every solve since is logged; FLAME_HIP_ERR_STATE only when something other than solves wrote
+ * the state in between), and the whole process then stays off resident tiles for 16 solves, doubling with every further
  * give-up ("persist_gave_up").  Dev aid: with option "persist_prof" = <tile + 1> (or FLAME_HIP_PERSIST_PROF in the environment)
  * "persist_prof_0".."persist_prof_3" return that tile's time split of the last solve's rounds in 10 ns ticks:
  * iterations + stores, poll of the halo entries, halo applied + barrier, and the number of rounds),
