@@ -1818,6 +1818,8 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         const float us = to ? (float)std::atof(to) : (g->persist_round_us > 0.f ? std::max(500.f, 8.f * g->persist_round_us) : 4000.f);
         g->persist_timeout_us = (int32_t)std::min(us, 1.0e6f);
         x.timeout_ticks = g->persist_timeout_us * 100;
+        static const char* st = std::getenv("FLAME_HIP_PERSIST_STALL_US");  // test hook: a REAL late tile (tests/test_gpu_persist.py)
+        x.stall_ticks = st ? std::atoi(st) * 100 : 0;
       }
       g->last_rounds = rounds;
       HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,

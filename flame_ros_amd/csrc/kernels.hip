@@ -400,6 +400,8 @@ struct PersistArgs {
   int32_t poll_delay; // units of 256 clocks between a round's stores and its first poll pass
   int32_t timeout_ticks;  // 10 ns ticks a poll may wait before the launch gives up (the host: max(0.5 ms, 8 x the handle's
                           // last measured round), 4 ms while nothing has been measured)
+  int32_t stall_ticks;    // test hook (FLAME_HIP_PERSIST_STALL_US): tile 0 sleeps that long in front of its second round -- a
+                          // REAL late tile for the time-out path (0 = off)
 };
 
 __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the CU's L1, served by the XCD's L2
@@ -640,6 +642,10 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   int done = 0, round = 0;
   int k_pre = 0;  // resident tiles: edge blocks of this wave whose first phase D of the round already ran (interior-first)
   for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
+  if (PERSIST && pa.stall_ticks > 0 && tile_id == 0 && round == 1) {  // (test hook)
+    const unsigned long long ts0 = wall_clock64();
+    while (wall_clock64() - ts0 < (unsigned long long)pa.stall_ticks) __builtin_amdgcn_s_sleep(64);
+  }
   const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
   for (int it = 1; it <= iters; ++it) {
     const int rem = iters - it;
@@ -797,6 +803,12 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     for (int w = 0; w < pa.poll_delay; ++w) __builtin_amdgcn_s_sleep(4);
     const unsigned long long w0 = wall_clock64();
     bool stale = want;
+    // (r05: the bound is wall time AND poll passes.  wall_clock64 keeps counting while the queue is context-switched out by
+    // the driver; every tile is saved and restored together, so nobody is missing -- but a wait that spans the switch has
+    // "timed out" by the clock alone.  A pass takes 0.5-2 us: a launch only gives up after as many passes as the time-out
+    // holds at 2 us each.  One default bench run in ~15 lost a window to a give-up on a quiet GPU before.)
+    const int min_passes = pa.timeout_ticks / 200;
+    int passes = 0;
     for (;;) {
       if (stale) {
         if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice
@@ -853,7 +865,8 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         if (pprof) ++pacc[3];  // (dev aid: poll passes of the profiled wave)
       }
       if (!__any(stale)) break;
-      if (wall_clock64() - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
+      ++passes;
+      if (passes > min_passes && wall_clock64() - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
         s_abort = 1;
         *pa.err_host = 1;
         break;
@@ -1939,6 +1952,7 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   PersistArgs pa{};
   pa.err_host = err_host; pa.base = base; pa.prof = x.prof; pa.poll_delay = x.poll_delay;
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
+  pa.stall_ticks = x.stall_ticks;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
   pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
   pa.need_v = (x.need_valid && a.fat) ? x.need_v : nullptr; pa.need_e = (x.need_valid && a.fat) ? x.need_e : nullptr;

@@ -412,3 +412,41 @@ print("queue ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_PERSIST_FAIL="1"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "queue ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("stall_us,gives_up", [(100, 0), (3000, 1)])
+def test_a_really_late_tile(gpu, stall_us, gives_up):
+    """The time-out path with a REAL late tile, not a forced error word (FLAME_HIP_PERSIST_STALL_US: tile 0 sleeps in front
+    of its second round).  Late by less than the bound (0.5 ms): its neighbours wait, nothing gives up.  Late by more: their
+    polls run out of time AND of passes (r05: the bound is both), the launch gives up within the bound, the queue of solves
+    -- two of them, nobody looked in between -- is repeated by launches.  The oracle's bits both ways."""
+    import os, subprocess, sys
+    code = r'''
+import numpy as np, sys, time
+sys.path.insert(0, %r)
+from flame_ros_amd import graphgen
+from flame_ros_amd.regularizer import GraphRegularizer, default_params
+from oracle import COracle
+from oracle.cbind import default_params as oparams
+g, _ = graphgen.named("5k")
+p = default_params()
+o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
+r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+t0 = time.perf_counter()
+for n in (60, 45):
+    r.step(p, n, sync=False); o.solve(oparams(), n)
+assert r.info("persist_used") == 1
+x, w1, w2, q = r.download()
+ms = (time.perf_counter() - t0) * 1e3
+print("stall %%d us: %%.2f ms, recovered %%d gave_up %%d wait_us_max %%d timeout_us %%d" %% (
+    %d, ms, r.info("persist_recovered"), r.info("persist_gave_up"), r.info("persist_wait_us_max"), r.info("persist_timeout_us")))
+assert r.info("persist_recovered") == %d and r.info("persist_gave_up") == %d
+for a, b, nm in ((x, o.x, "x"), (w1, o.w1, "w1"), (w2, o.w2, "w2"), (q, o.q, "q")):
+    assert np.array_equal(a.view(np.uint32), np.asarray(b, np.float32).view(np.uint32)), nm
+assert ms < 200.0   # bounded either way (first import / plan included)
+print("late tile ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stall_us, gives_up, gives_up)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_PERSIST_STALL_US=str(stall_us), FLAME_HIP_PERSIST_TIMEOUT_US="500"),  # (the bound a handle reaches once it has measured a round; a first launch has 4 ms)
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "late tile ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    _record(out.stdout.strip().splitlines()[0])
