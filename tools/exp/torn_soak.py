@@ -15,7 +15,8 @@ from flame_ros_amd import graphgen  # noqa: E402
 from flame_ros_amd.regularizer import GraphRegularizer, default_params  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-g, it = graphgen.named("50k")
+name = sys.argv[2] if len(sys.argv) > 2 else "50k"  # (r05: "200k", "v100000" ... = the FAT variants' hand-offs)
+g, it = graphgen.named(name)
 p = default_params()
 res = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
 ref = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist=0)
