@@ -1880,7 +1880,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
     int e_max = 0;
     for (const TileDesc& D : g->plan.tiles) e_max = std::max(e_max, D.e_loc);
     if (g->timed) HIPCHK(hipStreamWaitEvent(s, g->ev1, 0));  // (the first solve may have run on another stream)
-    HIPCHK(launch_assign_lanes(s, (int32_t)g->plan.tiles.size(), e_max, g->tiles, g->t_eij, g->t_ew, g->t_emap));
+    HIPCHK(launch_assign_lanes(s, (int32_t)g->plan.tiles.size(), e_max, g->tiles, g->t_eij, g->t_ew, g->t_emap, g->plan.tile_slot12));
     g->lanes_applied = true;
     g->poll_valid = false;  // (edges moved inside their 64-blocks: a poll record names a position)
   }

@@ -231,6 +231,6 @@ class DevPlanner {
 // Conflict-avoiding lane order applied to a finished plan on the device (plan.h PlanOptions::
 // lane_order = 1): every 64-edge block of every tile, in place.
 hipError_t launch_assign_lanes(hipStream_t s, int32_t ntiles, int32_t e_max, const TileDesc* tiles, uint2* t_eij,
-                               float4* t_ew, int32_t* t_emap);
+                               float4* t_ew, int32_t* t_emap, bool slot12 = false);
 
 }  // namespace flamehip

@@ -1229,6 +1229,12 @@ __global__ __launch_bounds__(kSegCap) void k_tile_offsets(int ntiles, int32_t* m
 // (+1) gathered in read group g from bank class c (source and target tables), lane w*8+c the
 // number of stores of write group w into class c (source- and target-slot tables); lookups are
 // lane reads, the winner is found with ballots -- no LDS, no barriers.
+// S12 (r05, the deferred application on a plan with 12-byte slots only -- the build-time order of both builders keeps the model
+// above): a slot store is a ds_write_b64 of the pair array (4 groups of 16 contiguous lanes, the pair of slot s covers banks
+// 2 s, 2 s + 1 of 32: two slots collide when s = s' mod 16) and a ds_write_b32 of the cx array (2 groups of 32 lanes, bank
+// s mod 32).  The b96 model above is worth 0.5 % at 200 k vertices where it is worth 5 % on 16-byte slots at 100 k
+// (profiles/r05_lane_order_sens.txt).
+template <bool S12>
 __device__ __forceinline__ void assign_lanes_block(int lane, int b0, int e_loc, int32_t eoff, int32_t nslots,
                                                    uint2* t_eij, float4* t_ew, int32_t* t_emap) {
   const int hl = lane & 31;
@@ -1240,6 +1246,8 @@ __device__ __forceinline__ void assign_lanes_block(int lane, int b0, int e_loc, 
   const float4 w = t_ew[src_i];
   const int32_t mp = t_emap[src_i];
   int32_t T_rs = 0, T_rt = 0, T_ws = 0, T_wd = 0;
+  int32_t T_ws1 = 0, T_wd1 = 0;  // (S12: the cx array's stores; T_ws / T_wd are the pair array's)
+  const int wg16 = lane >> 4, wg32 = lane >> 5;
   bool used = lane >= c;
   int got = lane;
   for (int k = 0; k < c; ++k) {
@@ -1251,7 +1259,13 @@ __device__ __forceinline__ void assign_lanes_block(int lane, int b0, int e_loc, 
     const uint32_t s1 = ss != 0xffffu ? ss : (uint32_t)(nslots + lane);
     const uint32_t s2 = sd != 0xffffu ? sd : (uint32_t)(nslots + lane);
     const int32_t fs = __shfl(T_rs, rg * 16 + (li & 15), 64), ft = __shfl(T_rt, rg * 16 + (lj & 15), 64);
-    int cost = __shfl(T_ws, wg * 8 + (int)(s1 & 7), 64) + __shfl(T_wd, wg * 8 + (int)(s2 & 7), 64);
+    int cost;
+    if (S12) {
+      cost = __shfl(T_ws, wg16 * 16 + (int)(s1 & 15), 64) + __shfl(T_wd, wg16 * 16 + (int)(s2 & 15), 64) +
+             __shfl(T_ws1, wg32 * 32 + (int)(s1 & 31), 64) + __shfl(T_wd1, wg32 * 32 + (int)(s2 & 31), 64);
+    } else {
+      cost = __shfl(T_ws, wg * 8 + (int)(s1 & 7), 64) + __shfl(T_wd, wg * 8 + (int)(s2 & 7), 64);
+    }
     if (fs != 0 && fs != li + 1) ++cost;
     if (ft != 0 && ft != lj + 1) ++cost;
     int best = -1;
@@ -1267,8 +1281,16 @@ __device__ __forceinline__ void assign_lanes_block(int lane, int b0, int e_loc, 
     if (lane == best) { used = true; got = k; }
     if (lane == rgb * 16 + (li & 15) && T_rs == 0) T_rs = li + 1;
     if (lane == rgb * 16 + (lj & 15) && T_rt == 0) T_rt = lj + 1;
-    if (lane == wgb * 8 + (int)(s1b & 7)) ++T_ws;
-    if (lane == wgb * 8 + (int)(s2b & 7)) ++T_wd;
+    if (S12) {
+      const int g16 = best >> 4, g32 = best >> 5;
+      if (lane == g16 * 16 + (int)(s1b & 15)) ++T_ws;
+      if (lane == g16 * 16 + (int)(s2b & 15)) ++T_wd;
+      if (lane == g32 * 32 + (int)(s1b & 31)) ++T_ws1;
+      if (lane == g32 * 32 + (int)(s2b & 31)) ++T_wd1;
+    } else {
+      if (lane == wgb * 8 + (int)(s1b & 7)) ++T_ws;
+      if (lane == wgb * 8 + (int)(s2b & 7)) ++T_wd;
+    }
   }
   const uint32_t nx = (uint32_t)__shfl((int)rec.x, got, 64), ny = (uint32_t)__shfl((int)rec.y, got, 64);
   const float wx = __shfl(w.x, got, 64), wy = __shfl(w.y, got, 64), wz = __shfl(w.z, got, 64), ww = __shfl(w.w, got, 64);
@@ -1282,12 +1304,13 @@ __device__ __forceinline__ void assign_lanes_block(int lane, int b0, int e_loc, 
 
 // The same on a finished plan (lane_order = 1: when a plan is solved a second time, see
 // flame_hip.cpp): grid (tiles, blocks of 4 edge blocks), one wave per 64-edge block.
+template <bool S12>
 __global__ __launch_bounds__(256) void k_assign_lanes(const TileDesc* __restrict__ tiles, uint2* t_eij, float4* t_ew,
                                                       int32_t* t_emap) {
   const TileDesc D = tiles[blockIdx.x];
   const int b0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 64;
   if (D.n_ext <= 0 || b0 >= D.e_loc) return;
-  assign_lanes_block(threadIdx.x & 63, b0, D.e_loc, D.erec_off, D.nslots, t_eij, t_ew, t_emap);
+  assign_lanes_block<S12>(threadIdx.x & 63, b0, D.e_loc, D.erec_off, D.nslots, t_eij, t_ew, t_emap);
 }
 
 // what a tile's workgroup shares while it is being built
@@ -1466,7 +1489,7 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
   if (O.lane_order && !S.fail) {
     const int32_t nslots = S.gbase[kCapExt / 64];
     for (int b0 = (tid >> 6) * 64; b0 < e_loc; b0 += (NTB / 64) * 64)
-      assign_lanes_block(tid & 63, b0, e_loc, eoff, nslots, O.t_eij, O.t_ew, O.t_emap);
+      assign_lanes_block<false>(tid & 63, b0, e_loc, eoff, nslots, O.t_eij, O.t_ew, O.t_emap);
   }
   if (tid == 0) {
     TileDesc D = {};
@@ -3113,10 +3136,12 @@ hipError_t DevPlanner::flush_grid(hipEvent_t after) {
 }
 
 hipError_t launch_assign_lanes(hipStream_t s, int32_t ntiles, int32_t e_max, const TileDesc* tiles, uint2* t_eij,
-                               float4* t_ew, int32_t* t_emap) {
+                               float4* t_ew, int32_t* t_emap, bool slot12) {
   if (ntiles <= 0 || e_max <= 0) return hipSuccess;
   const unsigned by = (unsigned)((e_max + 255) / 256);
-  hipLaunchKernelGGL(k_assign_lanes, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
+  static const bool s12_model_off = std::getenv("FLAME_HIP_LANE_S12_OFF") != nullptr;  // dev A/B
+  if (slot12 && !s12_model_off) hipLaunchKernelGGL(k_assign_lanes<true>, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
+  else hipLaunchKernelGGL(k_assign_lanes<false>, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
   return hipGetLastError();
 }
 
