@@ -859,7 +859,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   int tile_own = sz.tile_own;
   int depth = sz.depth;
   bool fat = sz.fat;
-  bool slot12 = false, fat_cfg = false;
+  bool slot12 = false, fat_cfg = false, fat_s12 = false;
   bool balanced = false, built = false;
   int refine_left = 0;
   int ntiles = 0, cfg_nt = 0, cfg_ept = 0, cfg_vpt = 0;
@@ -872,7 +872,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
                    g->opt.tile_own == g->reuse_tile_own_opt;
   if (try_reuse && g->reuse_skip > 0) { --g->reuse_skip; try_reuse = false; }  // back-off after rejections
   g->plan_reused = false;
-  const int max_attempts = 8 + kBalanceRefinePasses + (sz.fat ? 4 * (2 + kBalanceRefinePasses) : 0);  // (plan.cpp)
+  const int max_attempts = 8 + kBalanceRefinePasses + (sz.fat ? 7 * (2 + kBalanceRefinePasses) : 0);  // (plan.cpp)
   for (int attempt = 0; attempt < max_attempts && !built; ++attempt) {
     const bool reusing = try_reuse;
     try_reuse = false;
@@ -903,7 +903,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     if (index_error) return FLAME_HIP_ERR_ARG;
     const bool tiles_valid = ok;  // every tile was built (it may still be too large for LDS / a kernel config)
     if (ok) {
-      const TileFit fit = tile_fit(g->opt, fat, tiles);  // (LDS, kernel configuration, 12-byte slots: plan.cpp)
+      const TileFit fit = tile_fit(g->opt, fat, tiles, fat_s12);  // (LDS, kernel configuration, 12-byte slots: plan.cpp)
       ok = fit.ok;
       lds_max = fit.lds_bytes; slot12 = fit.slot12; fat_cfg = fit.fat;
       cfg_nt = fit.nt; cfg_ept = fit.ept; cfg_vpt = fit.vpt;
@@ -954,7 +954,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     g->planner.drop_grid();
     balanced = false;
     refine_left = 0;
-    if (fat && depth > 1 && g->opt.tile_depth <= 0) --depth;  // fat tiles: a shallower halo first, then two rounds of smaller tiles
+    if (fat && fat_next_attempt(g->opt, sz, &depth, &fat_s12)) {}  // fat tiles: shallower / 12-byte slots first (plan.cpp)
     else if (fat) { fat = false; tile_own = sz.fallback_own; depth = sz.fallback_depth; }
     else tile_own = std::max(16, tile_own / 2);
   }

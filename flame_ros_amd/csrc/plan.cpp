@@ -245,7 +245,7 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // fat tiles, measured (profiles/r05_fat_tiles.txt): two edges per thread on 16-byte slots beat three edges / 12-byte slots
   // at one level deeper (80 k: depth 3 1.62 vs depth 4 1.74 us per iteration; 130 k: depth 2 2.22 vs depth 3 2.49); from ~540
   // own vertices on only the 12-byte layout fits and the deepest halo that does wins (160 k: depth 3 2.79, 2 3.10, 1 3.12)
-  const int auto_depth = fat ? (fat_own <= 280 ? 4 : (fat_own <= 420 ? 3 : (fat_own <= 540 ? 2 : (fat_own <= 640 ? 3 : (fat_own <= 800 ? 2 : 1)))))
+  const int auto_depth = fat ? (fat_own <= 280 ? 4 : (fat_own <= 420 ? 3 : (fat_own <= 600 ? 2 : 1)))  // (16-byte slots first)
                          : !one_round ? 3
                          : opt.resident ? ((auto_tiles <= 100 || auto_own < 32) ? 5 : 4)
                                         : (auto_tiles <= 64 ? 8 : (auto_tiles <= 160 ? 5 : 4));
@@ -263,12 +263,24 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   sz.auto_own = auto_own; sz.auto_depth = auto_depth;
   sz.tile_own = tile_own; sz.depth = depth; sz.single = single;
   sz.fat = fat && !single;
+  sz.fat_s12_depth = opt.tile_depth > 0 ? depth : (fat_own <= 640 ? 3 : (fat_own <= 800 ? 2 : 1));
   sz.fallback_own = std::max(196, std::min(400, (V + 511) / 512));
   sz.fallback_depth = opt.tile_depth > 0 ? depth : 3;
   return sz;
 }
 
-TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles) {
+bool fat_next_attempt(const PlanOptions& opt, const PlanSizing& sz, int* depth, bool* allow_slot12) {
+  if (!*allow_slot12) {  // 16-byte slots: one level shallower, then the 12-byte layout from its own first depth
+    if (*depth > 1 && opt.tile_depth <= 0) { --*depth; return true; }
+    *allow_slot12 = true;
+    *depth = sz.fat_s12_depth;
+    return true;
+  }
+  if (*depth > 1 && opt.tile_depth <= 0) { --*depth; return true; }
+  return false;
+}
+
+TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles, bool allow_slot12) {
   TileFit f;
   int e_max = 0, ext_max = 0, upd_max = 0, hv_max = 0;
   int64_t lds16 = 0, lds12 = 0, stage = 0;
@@ -295,7 +307,7 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
     f.fat = cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt);
     if (cfg_ok && tile_persist_cfg(c.nt, c.ept, c.vpt) && lds16 + stage <= opt.lds_bytes) {
       f.ok = true; f.lds_bytes = lds16;
-    } else if (cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt) && lds12 + stage <= opt.lds_bytes) {
+    } else if (allow_slot12 && cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt) && lds12 + stage <= opt.lds_bytes) {
       f.ok = true; f.slot12 = true; f.lds_bytes = lds12;
     }
   }
@@ -359,6 +371,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   const int auto_own = sz.auto_own, auto_depth = sz.auto_depth;
   int tile_own = sz.tile_own, depth = sz.depth;
   bool single = sz.single, fat = sz.fat;
+  bool fat_s12 = false;  // (fat tiles: the attempts with 16-byte slots come first, fat_next_attempt())
   const bool batch = !opt.batch_voff.empty();
   if (batch) {  // every graph of the batch is one isolated tile; edges must not cross graphs
     const std::vector<int32_t>& vo = opt.batch_voff;
@@ -403,7 +416,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     }
   }
   // (fat tiles: every halo depth that does not fit costs a balance sequence of its own before the next one is tried)
-  const int max_attempts = batch ? 1 : 7 + kBalanceRefinePasses + (sz.fat ? 4 * (2 + kBalanceRefinePasses) : 0);
+  const int max_attempts = batch ? 1 : 7 + kBalanceRefinePasses + (sz.fat ? 7 * (2 + kBalanceRefinePasses) : 0);
   for (int attempt = 0; attempt < max_attempts; ++attempt) {
     const int ntiles = batch ? (int)opt.batch_voff.size() - 1 : (V == 0 ? 0 : (V + tile_own - 1) / tile_own);
     // ---- vertex order: RCB leaves = tiles ----
@@ -715,7 +728,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     lap("concat");
     const bool tiles_valid = ok;
     TileFit fit;
-    if (ok) { fit = tile_fit(opt, fat, P.tiles); ok = fit.ok; }
+    if (ok) { fit = tile_fit(opt, fat, P.tiles, fat_s12); ok = fit.ok; }
     // only the LARGEST tile decides whether a partition fits, and before the cost balance that is a
     // border tile: balance first, shrink only if the balanced partition does not fit either
     // (same rule in flame_hip.cpp upload_device_plan)
@@ -803,7 +816,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     P.tiles.clear();
     if (single && opt.single_only) { P.has_tiles = false; return kPlanSingleNoFit; }
     if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }
-    else if (fat && depth > 1 && opt.tile_depth <= 0) --depth;  // fat tiles: a shallower halo first ...
+    else if (fat && fat_next_attempt(opt, sz, &depth, &fat_s12)) {}  // fat tiles: shallower / 12-byte slots first ...
     else if (fat) { fat = false; tile_own = sz.fallback_own; depth = sz.fallback_depth; }  // ... then two rounds of smaller tiles
     else tile_own = std::max(16, tile_own / 2);
   }

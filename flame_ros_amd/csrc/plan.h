@@ -116,6 +116,10 @@ struct PlanSizing {
   // fallback_own / fallback_depth (two rounds of smaller tiles, solved by launches).
   bool fat = false;
   int fallback_own = 0, fallback_depth = 0;
+  // the attempts of a fat partition, in this order: 16-byte slots from `depth` down to 1 (measured: they beat the 12-byte
+  // layout even one or two levels shallower -- 145 k vertices depth 2 / 16 B 2.27 us per iteration vs depth 3 / 12 B 2.66,
+  // 160 k depth 1 / 16 B 2.61 vs 2.75, profiles/r05_fat_tiles.txt), then 12-byte slots from fat_s12_depth down to 1
+  int fat_s12_depth = 0;
 };
 // what one build attempt produced, priced: does it fit (LDS, a kernel configuration), and how
 struct TileFit {
@@ -127,7 +131,9 @@ struct TileFit {
 };
 // e_max / ext_max / upd_max / hv_max: the largest tile's local edges, local vertices, updated vertices, halo vertices;
 // lds16 / lds12: max over the tiles of tile_lds_bytes() (+ the resident tiles' staging area when `resident`)
-TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles);
+TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles, bool allow_slot12 = true);
+// what a fat partition that did not fit tries next (both plan builders): false = nothing left, take the fallback
+bool fat_next_attempt(const PlanOptions& opt, const PlanSizing& sz, int* depth, bool* allow_slot12);
 PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E);
 // smallest instantiated kernel configuration that holds e_max local edges / upd_max local vertices
 bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt);

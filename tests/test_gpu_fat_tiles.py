@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (vertices, expected halo depth, 12-byte slots, may a tile hold more local vertices than threads)
-FAT = [(60000, 4, 0), (100000, 3, 0), (135000, 2, 0), (160000, 3, 1)]
+FAT = [(60000, 4, 0), (100000, 3, 0), (135000, 2, 0), (160000, 1, 0), (200000, 2, 1)]
 
 
 @pytest.mark.parametrize("V,depth,slot12", FAT)
@@ -38,9 +38,9 @@ def test_fat_resident_tiles_match_oracle(gpu, V, depth, slot12):
 
 
 def test_fat_tiles_with_more_local_vertices_than_threads(gpu):
-    """160 k vertices: the largest tiles hold > 1024 local vertices on 1024 threads -- only the updated vertices and the poll
+    """200 k vertices: the largest tiles hold > 1024 local vertices on 1024 threads -- only the updated vertices and the poll
     list's slots need a lane."""
-    g = graphgen.synthetic(160000, seed=160000)
+    g = graphgen.synthetic(200000, seed=200000)
     with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0) as r:
         import ctypes as C
         from flame_ros_amd import lib
@@ -63,7 +63,7 @@ def test_without_resident_tiles_the_two_round_partition_stays(gpu):
         assert_bit_equal(r.download()[0], o.x, "x")
 
 
-@pytest.mark.parametrize("V,slot12", [(160000, 1), (100000, 0)])
+@pytest.mark.parametrize("V,slot12", [(200000, 1), (100000, 0)])
 def test_a_fat_resident_solve_that_gives_up_is_repeated_by_launches(gpu, V, slot12):
     """FLAME_HIP_PERSIST_FAIL (every resident launch counts as failed): the solve is repeated by ordinary launches of the SAME
     fat plan -- 12-byte slots and lane-less outer ring through k_tile -- with the oracle's bits."""

@@ -48,7 +48,8 @@ CASES = [
     ("50k", dict(tile_own=100, tile_depth=3)),
     ("200k", dict()),       # (r05: fat resident tiles, 12-byte slots, depth 2)
     ("v100000", dict()),    # (fat tiles, 16-byte slots, depth 3)
-    ("v160000", dict()),    # (fat tiles with more local vertices than threads)
+    ("v160000", dict()),    # (fat tiles, 16-byte slots at depth 1 after two deeper attempts did not fit)
+    ("v220000", dict()),    # (fat tiles, 12-byte slots at depth 1)
     ("v100000", dict(persist=0)),  # (not resident: two rounds of smaller tiles, as in r04)
 ]
 
