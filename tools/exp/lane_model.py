@@ -9,7 +9,7 @@ def rg(l):
     h = l & 31
     return (0 if (h < 4 or 12 <= h < 16 or 20 <= h < 28) else 1) + 2 * (l >> 5)
 RG = np.array([rg(l) for l in range(64)])
-for lo in (0, 1):
+for lo in (0, 2):
     r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, lane_order=lo)
     td = r.plan_array("tiles", np.int32).reshape(r.info("num_tiles"), -1)
     eij = r.plan_array("t_eij", np.uint32).reshape(-1, 2)
