@@ -51,6 +51,14 @@ struct TileDesc {
 
 // LDS of a tile's workgroup: bar[n_ext] (16 B) + the incidence slots, 16 B each -- or, slot12 (fat tiles), 12 B each as a
 // 4-byte and an 8-byte array, the slot count rounded up to 4 (kernels.hip SlotMem).  Resident tiles add their staging area.
+constexpr int64_t kTileLdsReserve = 64;  // the tile kernels' static LDS (two words) + alignment: a dynamic request of exactly
+                                         // the CU's 160 KiB does not launch (found by the fat-size frame soak, r05)
+// fat tiles keep a margin to the CU's LDS, and 16-byte slots at depth 1 -- the last configuration tried before the 12-byte
+// layout, i.e. the one that ends up closest to 160 KiB -- a larger one: in frame streams of 185-200 k-vertex frames four
+// solves in ~1 900 on such plans (156-160 KiB per tile) took 11-27 ms instead of 0.3 (correct bits, no give-up: some tile
+// started that late; not reproduced on a resident graph, nor with 12-byte slots at 146-150 KiB).  Cause not found; avoided.
+constexpr int64_t kFatLdsMargin = 4096;
+constexpr int64_t kFatLdsMarginDepth1 = 12288;
 inline int64_t tile_lds_bytes(int32_t n_ext, int32_t nslots, bool slot12) {
   const int64_t n = (int64_t)nslots + kDummySlots + 1;
   return slot12 ? (int64_t)n_ext * 16 + ((n + 3) & ~(int64_t)3) * 12 : (int64_t)n_ext * 16 + n * 16;

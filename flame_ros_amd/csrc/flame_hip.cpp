@@ -915,7 +915,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
         size_t stage = 0;
         for (const TileDesc& D : tiles) stage = std::max(stage, persist_stage_bytes(D));
         if (!(slot12 ? tile_slot12_exists(cfg_nt, cfg_ept, cfg_vpt) : tile_persist_exists(cfg_nt, cfg_ept, cfg_vpt)) ||
-            (size_t)lds_max + stage > (size_t)g->opt.lds_bytes)
+            (size_t)lds_max + stage + (size_t)kTileLdsReserve > (size_t)g->opt.lds_bytes)
           ok = false;
       }
     }
@@ -1592,7 +1592,7 @@ static bool persist_applies(const flame_hip_graph* g, int32_t num_iters) {
     stage = std::max(stage, persist_stage_bytes(D));
   }
   // (r05: what a tile polls is delivered through an LDS staging area behind its incidence slots)
-  if ((size_t)P.tile_lds_bytes + stage > (size_t)g->opt.lds_bytes) return false;
+  if ((size_t)P.tile_lds_bytes + stage + (size_t)kTileLdsReserve > (size_t)g->opt.lds_bytes) return false;
   return true;
 }
 

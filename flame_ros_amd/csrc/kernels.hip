@@ -801,14 +801,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     // (the neighbours finish their round at about the same time and their stores take ~0.7 us to land: a poll pass
     // issued at once samples memory too early and costs a second round trip)
     for (int w = 0; w < pa.poll_delay; ++w) __builtin_amdgcn_s_sleep(4);
-    const unsigned long long w0 = wall_clock64();
+    unsigned long long w0 = wall_clock64();
     bool stale = want;
-    // (r05: the bound is wall time AND poll passes.  wall_clock64 keeps counting while the queue is context-switched out by
-    // the driver; every tile is saved and restored together, so nobody is missing -- but a wait that spans the switch has
-    // "timed out" by the clock alone.  A pass takes 0.5-2 us: a launch only gives up after as many passes as the time-out
-    // holds at 2 us each.  One default bench run in ~15 lost a window to a give-up on a quiet GPU before.)
-    const int min_passes = pa.timeout_ticks / 200;
-    int passes = 0;
+    // (r05: time this wave did not run does not count.  wall_clock64 keeps counting while the queue is context-switched out
+    // by the driver; every tile is saved and restored together, so nobody is missing -- but a wait that spans the switch
+    // has "timed out" by the clock alone.  A pass takes 0.5-10 us whatever the contention: a gap of more than 50 us
+    // between two passes is time the wave was off the chip, and the wait's start moves on by it.  One default bench run
+    // in ~15 lost a window to a give-up on a quiet GPU before; a bound on the NUMBER of passes instead let a wait beside
+    // the next frame's builder kernels run to 21 ms -- passes are slow exactly then.)
+    unsigned long long w_last = w0;
     for (;;) {
       if (stale) {
         if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice
@@ -865,8 +866,10 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         if (pprof) ++pacc[3];  // (dev aid: poll passes of the profiled wave)
       }
       if (!__any(stale)) break;
-      ++passes;
-      if (passes > min_passes && wall_clock64() - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
+      const unsigned long long w_now = wall_clock64();
+      if (w_now - w_last > 5000ull) w0 += w_now - w_last;  // (> 50 us since the last pass: not waiting, not running)
+      w_last = w_now;
+      if (w_now - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
         s_abort = 1;
         *pa.err_host = 1;
         break;

@@ -295,7 +295,7 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
   }
   TileCfg c{};
   if (!fat) {
-    f.ok = lds16 <= opt.lds_bytes && pick_cfg(opt.tile_threads, e_max, ext_max, &c);
+    f.ok = lds16 + kTileLdsReserve <= opt.lds_bytes && pick_cfg(opt.tile_threads, e_max, ext_max, &c);
     f.lds_bytes = lds16;
   } else {
     // ... except in fat tiles: a thread per UPDATED vertex and per halo vertex of the poll list is enough (the outermost
@@ -305,9 +305,10 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
     if (!cfg_ok)  // (the lane-less outermost ring is the FAT kernel variants': 1 024 threads)
       cfg_ok = pick_cfg(opt.tile_threads, e_max, std::max(upd_max, hv_max), &c) && tile_slot12_cfg(c.nt, c.ept, c.vpt);
     f.fat = cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt);
-    if (cfg_ok && tile_persist_cfg(c.nt, c.ept, c.vpt) && lds16 + stage <= opt.lds_bytes) {
+    const int64_t margin16 = (!tiles.empty() && tiles[0].depth == 1) ? kFatLdsMarginDepth1 : kFatLdsMargin;
+    if (cfg_ok && tile_persist_cfg(c.nt, c.ept, c.vpt) && lds16 + stage + margin16 <= opt.lds_bytes) {
       f.ok = true; f.lds_bytes = lds16;
-    } else if (allow_slot12 && cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt) && lds12 + stage <= opt.lds_bytes) {
+    } else if (allow_slot12 && cfg_ok && tile_slot12_cfg(c.nt, c.ept, c.vpt) && lds12 + stage + kFatLdsMargin <= opt.lds_bytes) {
       f.ok = true; f.slot12 = true; f.lds_bytes = lds12;
     }
   }

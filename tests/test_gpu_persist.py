@@ -418,7 +418,7 @@ print("queue ok")
 def test_a_really_late_tile(gpu, stall_us, gives_up):
     """The time-out path with a REAL late tile, not a forced error word (FLAME_HIP_PERSIST_STALL_US: tile 0 sleeps in front
     of its second round).  Late by less than the bound (0.5 ms): its neighbours wait, nothing gives up.  Late by more: their
-    polls run out of time AND of passes (r05: the bound is both), the launch gives up within the bound, the queue of solves
+    polls run out of time (r05: time a wave was off the chip does not count), the launch gives up within the bound, the queue of solves
     -- two of them, nobody looked in between -- is repeated by launches.  The oracle's bits both ways."""
     import os, subprocess, sys
     code = r'''

@@ -336,7 +336,7 @@ def test_fat_tile_sizing():
         stage = max(16 * max(t.n_upd - t.n_own, 0) for t in tiles)
         per_slot = 12 if s12 else 16
         need = max(16 * t.n_ext + per_slot * ((t.nslots + 64 + 1 + (3 if s12 else 0)) // (4 if s12 else 1) * (4 if s12 else 1)) for t in tiles)
-        assert need == r.info("tile_lds_bytes") and need + stage <= 160 * 1024
+        assert need == r.info("tile_lds_bytes") and need + stage + 4096 <= 160 * 1024  # (fat tiles keep a margin)
         if V == 200000:
             assert max(t.n_ext for t in tiles) > nt  # the lane-less outermost ring
         if V == 100000:

@@ -23,12 +23,27 @@ for k in range(n):
     if k % 7 in (3, 4, 5) and k > 0:
         V = max(200, int(V * rng.uniform(0.95, 1.05)))
     else:
-        V = int(rng.choice([300, 900, 1100, 1500, 2600, 5000, 12000, 30000], p=[.15, .15, .15, .15, .15, .1, .1, .05]))
+        if len(sys.argv) > 3 and sys.argv[3] == "fat":  # (r05: sizes across the regular / fat tile boundary and the slot layouts)
+            V = int(rng.choice([1100, 5000, 30000, 49000, 52000, 70000, 110000, 150000, 190000, 215000], p=[.1] * 10))
+        else:
+            V = int(rng.choice([300, 900, 1100, 1500, 2600, 5000, 12000, 30000], p=[.15, .15, .15, .15, .15, .1, .1, .05]))
     g = graphgen.synthetic(V, seed=1000 + k)
     var = np.full(g.V, 1e-4, np.float32)
     scale = r.sync_features(g.pos, g.z, var, g.tris, sp)
-    r.step(p, 60, sync=False)
+    try:
+        r.step(p, 60, sync=False)
+    except Exception as e:  # (which plan was it?)
+        print("frame %d V %d E %d: %s | tiles %d depth %d cfg %d/%d/%d lds %d slot12 %d fat %d reused %d on_device %d" % (
+            k, g.V, r.E, e, r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("tile_ept"), r.info("tile_vpt"),
+            r.info("tile_lds_bytes"), r.info("tile_slot12"), r.info("tile_fat"), r.info("plan_reused"), r.info("plan_on_device")), flush=True)
+        raise
     out = r.frame_results(p, Kinv, default_tri_params(g.width, g.height), scale_back=scale, with_edges=True, with_coverage=True)
+    if len(sys.argv) > 3:  # (r05 diagnostics: which frames wait long?)
+        wmax = r.info("persist_wait_us_max")
+        if wmax > 1000:
+            print("frame %4d V %6d: poll wait %d us, solve %.2f ms, tiles %d depth %d cfg %d/%d slot12 %d reused %d timeout %d us" % (
+                k, V, wmax, r.last_solve_ms()[0], r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("tile_ept"),
+                r.info("tile_slot12"), r.info("plan_reused"), r.info("persist_timeout_us")), flush=True)
     reused = reused + r.info("plan_reused") if k else 0
     persisted = (persisted if k else 0) + r.info("persist_used")
     if k % 25 == 0 or (k % 7 == 4 and k % 3 == 0):
