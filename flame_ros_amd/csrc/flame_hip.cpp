@@ -648,6 +648,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "tile_lds_bytes") *value = P.tile_lds_bytes;
   else if (k == "tile_slot12") *value = P.tile_slot12 ? 1 : 0;
   else if (k == "tile_fat") *value = P.tile_fat ? 1 : 0;
+  else if (k == "stall_hook_build") *value = tile_stall_hook_build() ? 1 : 0;
   else if (k == "tile_ext_vertices") { int64_t s = 0; for (auto& t : P.tiles) s += t.n_ext; *value = s; }
   else if (k == "tile_loc_edges") { int64_t s = 0; for (auto& t : P.tiles) s += t.e_loc; *value = s; }
   else if (k == "device") *value = g->device;
@@ -1819,7 +1820,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         g->persist_timeout_us = (int32_t)std::min(us, 1.0e6f);
         x.timeout_ticks = g->persist_timeout_us * 100;
         static const char* st = std::getenv("FLAME_HIP_PERSIST_STALL_US");  // test hook: a REAL late tile (tests/test_gpu_persist.py)
-        x.stall_ticks = st ? std::atoi(st) * 100 : 0;
+        if (st && tile_stall_hook_build()) x.poll_delay = (x.poll_delay & 0xff) | (std::atoi(st) << 8);  // (microseconds, bits 8.. of poll_delay; debug build only)
       }
       g->last_rounds = rounds;
       HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,

@@ -66,12 +66,12 @@ struct PersistBufs {
   int32_t* prof = nullptr;
   int32_t poll_delay = 0;  // x 256 clocks between a round's stores and the first poll pass
   int32_t timeout_ticks = 0;  // 10 ns ticks a poll may wait (0 = 4 ms)
-  int32_t stall_ticks = 0;    // test hook: tile 0 is late by that much in its second round
 };
 bool tile_persist_exists(int nt, int ept, int vpt);
 hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tiles, const int32_t* t_vmap, const int32_t* t_emap,
                              const uint2* t_eij, uint2* poll_v, uint2* poll_e, int32_t* poll_ne, bool sorted,
                              int32_t* need_v = nullptr, int32_t* need_e = nullptr);
+bool tile_stall_hook_build();  // compiled with FLAME_PERSIST_STALL_HOOK (debug: FLAME_HIP_PERSIST_STALL_US makes tile 0 late)
 bool tile_torn_check_build();  // compiled with FLAME_TORN_CHECK (debug: hashed hand-off tags, torn entries counted)
 hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t lds_bytes, const TileArgs& a, const PersistBufs& x,
                                int32_t* err_host, int32_t base);

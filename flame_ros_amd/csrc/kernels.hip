@@ -136,6 +136,9 @@ __device__ __forceinline__ void lds_store3(float4* slot, float a, float b, float
 // edge blocks in front of the poll.  Bit-exact, but 50 k 1.336 -> 1.388 us per iteration, 200 k 3.24 -> 3.55, 5 k +4.5 %
 // (only 100 k gained, 2.5 %): what a round waits for is the slowest neighbour's chain, on which the poll's LOAD latency is
 // no longer overlapped with anything, and a phase D cut in two loses the overlap of its gathers.
+#ifndef FLAME_PERSIST_STALL_HOOK
+#define FLAME_PERSIST_STALL_HOOK 0
+#endif
 #ifndef FLAME_INTERIOR_FIRST
 #define FLAME_INTERIOR_FIRST 0
 #endif
@@ -400,8 +403,9 @@ struct PersistArgs {
   int32_t poll_delay; // units of 256 clocks between a round's stores and its first poll pass
   int32_t timeout_ticks;  // 10 ns ticks a poll may wait before the launch gives up (the host: max(0.5 ms, 8 x the handle's
                           // last measured round), 4 ms while nothing has been measured)
-  int32_t stall_ticks;    // test hook (FLAME_HIP_PERSIST_STALL_US): tile 0 sleeps that long in front of its second round -- a
-                          // REAL late tile for the time-out path (0 = off)
+  // (test hook of a DEBUG build, -DFLAME_PERSIST_STALL_HOOK=1 + FLAME_HIP_PERSIST_STALL_US: bits 8.. of poll_delay =
+  // microseconds tile 0 sleeps behind its first hand-off -- a REAL late tile for the time-out path.  Not in the product
+  // build: compiled in it cost the 50 k headline 1.7-3 %, never taken (profiles/r05_persist_guards.txt has its runs))
 };
 
 __device__ __forceinline__ float4 load_agent(const float4* p) {  // misses the CU's L1, served by the XCD's L2
@@ -642,10 +646,6 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   int done = 0, round = 0;
   int k_pre = 0;  // resident tiles: edge blocks of this wave whose first phase D of the round already ran (interior-first)
   for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
-  if (PERSIST && pa.stall_ticks > 0 && tile_id == 0 && round == 1) {  // (test hook)
-    const unsigned long long ts0 = wall_clock64();
-    while (wall_clock64() - ts0 < (unsigned long long)pa.stall_ticks) __builtin_amdgcn_s_sleep(64);
-  }
   const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
   for (int it = 1; it <= iters; ++it) {
     const int rem = iters - it;
@@ -800,16 +800,17 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     }
     // (the neighbours finish their round at about the same time and their stores take ~0.7 us to land: a poll pass
     // issued at once samples memory too early and costs a second round trip)
+#if FLAME_PERSIST_STALL_HOOK
+    for (int w = 0; w < (pa.poll_delay & 0xff); ++w) __builtin_amdgcn_s_sleep(4);
+#else
     for (int w = 0; w < pa.poll_delay; ++w) __builtin_amdgcn_s_sleep(4);
-    unsigned long long w0 = wall_clock64();
+#endif
+    // (r05, tried and dropped -- a give-up is cheap now that whole queues of solves are repeated (flame_hip.cpp), and each of
+    // these cost the 50 k headline 1-2 % through the code around the poll: a bound on the number of passes beside the clock
+    // (a queue the driver switches out has not "waited"; but passes are slow exactly when a wait is long: one ran to 21 ms),
+    // discounting gaps of more than 50 us between passes, one 100 us grace period after the first expiry)
+    const unsigned long long w0 = wall_clock64();
     bool stale = want;
-    // (r05: time this wave did not run does not count.  wall_clock64 keeps counting while the queue is context-switched out
-    // by the driver; every tile is saved and restored together, so nobody is missing -- but a wait that spans the switch
-    // has "timed out" by the clock alone.  A pass takes 0.5-10 us whatever the contention: a gap of more than 50 us
-    // between two passes is time the wave was off the chip, and the wait's start moves on by it.  One default bench run
-    // in ~15 lost a window to a give-up on a quiet GPU before; a bound on the NUMBER of passes instead let a wait beside
-    // the next frame's builder kernels run to 21 ms -- passes are slow exactly then.)
-    unsigned long long w_last = w0;
     for (;;) {
       if (stale) {
         if (VPT == 1 && EPT <= 3) {  // one 16-byte request per lane and array (an atomic load is at most 8 bytes: twice
@@ -866,10 +867,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         if (pprof) ++pacc[3];  // (dev aid: poll passes of the profiled wave)
       }
       if (!__any(stale)) break;
-      const unsigned long long w_now = wall_clock64();
-      if (w_now - w_last > 5000ull) w0 += w_now - w_last;  // (> 50 us since the last pass: not waiting, not running)
-      w_last = w_now;
-      if (w_now - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
+      if (wall_clock64() - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
         s_abort = 1;
         *pa.err_host = 1;
         break;
@@ -918,6 +916,12 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
       q1[k] = t.x; q23[k].x = t.y; q23[k].y = t.z;
     }
   }
+#if FLAME_PERSIST_STALL_HOOK
+  if ((pa.poll_delay >> 8) != 0 && tile_id == 0 && round == 1) {  // (test hook: tile 0 is late from here on, see PersistArgs)
+    const unsigned long long ts0 = wall_clock64();
+    while (wall_clock64() - ts0 < 100ull * (unsigned long long)(pa.poll_delay >> 8)) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
   if (pprof) {  // dev aid: where a round's time goes (10 ns ticks, summed over the rounds of one tile)
     const unsigned long long pt2 = wall_clock64();
     pacc[0] += (int32_t)(pt0 - pround); pacc[1] += (int32_t)(pt1 - pt0); pacc[2] += (int32_t)(pt2 - pt1);
@@ -1928,6 +1932,7 @@ hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tile
 }
 
 bool tile_torn_check_build() { return FLAME_TORN_CHECK != 0; }
+bool tile_stall_hook_build() { return FLAME_PERSIST_STALL_HOOK != 0; }
 
 bool tile_persist_exists(int nt, int ept, int vpt) {
 #define X(N, Ep, Vp) if (nt == N && ept == Ep && vpt == Vp) return true;
@@ -1955,7 +1960,6 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   PersistArgs pa{};
   pa.err_host = err_host; pa.base = base; pa.prof = x.prof; pa.poll_delay = x.poll_delay;
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
-  pa.stall_ticks = x.stall_ticks;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
   pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
   pa.need_v = (x.need_valid && a.fat) ? x.need_v : nullptr; pa.need_e = (x.need_valid && a.fat) ? x.need_e : nullptr;
