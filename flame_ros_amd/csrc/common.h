@@ -65,15 +65,12 @@ inline int64_t tile_lds_bytes(int32_t n_ext, int32_t nslots, bool slot12) {
 }
 
 // Cost model of a tile for the balance of the partition (both plan builders, integer): a launch / a round lasts as long as its
-// slowest tile.  mode 0: local edges + 2 x local vertices (r02); 1: local edges + 2 x UPDATED vertices (r05 experiment: what
-// a resident tile's iterate time correlates with best at 50 k, profiles/r05_fat_round_profile.txt); FLAME_HIP_COST_MODEL.
+// slowest tile -- local edges + 2 x local vertices (r02).  (r05 tried local edges + 2 x UPDATED vertices, what a resident tile's
+// iterate time correlates with best at 50 k: -1 % there, +6...18 % at 20 k / 100 k / 200 k, profiles/r05_cost_model_ab.txt.)
 #ifdef __HIPCC__
 __host__ __device__
 #endif
-inline long long tile_cost(const TileDesc& D, int mode) {
-  return mode == 1 ? (long long)D.e_loc + 2 * (long long)D.n_upd : (long long)D.e_loc + 2 * (long long)D.n_ext;
-}
-int tile_cost_mode();  // plan.cpp (FLAME_HIP_COST_MODEL, read once)
+inline long long tile_cost(const TileDesc& D) { return (long long)D.e_loc + 2 * (long long)D.n_ext; }
 
 // Local edge record halves.
 //   t_eij[e] = {li | lj << 16, slot_src | slot_dst << 16}   (local vertex ids / incidence slots)

@@ -953,7 +953,10 @@ int delaunay_device(hipStream_t s, DelaunayScratch* sc, int32_t V, const float* 
     hipLaunchKernelGGL(k_dt_order_rows, dim3(1), dim3(256), 0, s, start, G, rowb, rowb + 256);
     hipLaunchKernelGGL(k_dt_order_fill, dim3(gv), dim3(B), 0, s, start, rowb, rowb + 256, G, V, order);
   }
-  static const bool dt_stats = std::getenv("FLAME_HIP_DT_STATS") != nullptr;
+#ifndef FLAME_DT_STATS  // (dev aid, tools/exp/delaunay_stats.py: work per star -- a variant build, -DFLAME_DT_STATS=1)
+#define FLAME_DT_STATS 0
+#endif
+  const bool dt_stats = FLAME_DT_STATS != 0;
   int32_t* dbg = nullptr;
   if (dt_stats) {
     (void)hipMalloc(reinterpret_cast<void**>(&dbg), sizeof(int32_t) * 4 * (size_t)V);

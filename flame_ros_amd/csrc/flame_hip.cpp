@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <roctracer/roctx.h>
 
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -36,6 +37,36 @@ using namespace flamehip;
     hipError_t e__ = (expr);                                     \
     if (e__ != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e__;  \
   } while (0)
+
+// Fault injection for the tests, compiled ONLY into flame_ros_amd/libflame_hip_hooks.so (-DFLAME_HIP_TEST_HOOKS=1, built by
+// flame_ros_amd/build.py beside the product library; tests ask for it by name, tests/util.py hooks_env()).  The product
+// library reads no environment variable and has no such switch.  flame_hip_test_hook(key, value), process-wide:
+//   "persist_fail" 1      every launch of resident tiles counts as having given up (the recovery paths)
+//   "fill_alloc"   0..255 new device allocations are filled with that byte (stale-read detection), -1 off
+//   "persist_stall_us" n  tile 0 is REALLY late by n us behind its first hand-off (needs kernels.hip built with
+//                         -DFLAME_PERSIST_STALL_HOOK=1: tools/exp/build_variant.sh)
+#ifndef FLAME_HIP_TEST_HOOKS
+#define FLAME_HIP_TEST_HOOKS 0
+#endif
+#if FLAME_HIP_TEST_HOOKS
+namespace {
+struct TestHooks { std::atomic<int> persist_fail{0}, fill_alloc{-1}, persist_stall_us{0}; };
+TestHooks& test_hooks() { static TestHooks h; return h; }
+}  // namespace
+extern "C" int flame_hip_test_hook(const char* key, int32_t value) {
+  if (!key) return FLAME_HIP_ERR_ARG;
+  const std::string k(key);
+  if (k == "persist_fail") test_hooks().persist_fail = value;
+  else if (k == "fill_alloc") test_hooks().fill_alloc = value;
+  else if (k == "persist_stall_us") test_hooks().persist_stall_us = value;
+  else return FLAME_HIP_ERR_ARG;
+  return 0;
+}
+#define TEST_HOOK(name, off) (test_hooks().name.load())
+#else
+#define TEST_HOOK(name, off) (off)
+#endif
+int flamehip::test_alloc_fill() { return TEST_HOOK(fill_alloc, -1); }
 
 namespace {
 
@@ -70,7 +101,7 @@ int dev_alloc(CapMap& caps, T** p, size_t n) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), want);
   if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
   if (e != hipSuccess) return FLAME_HIP_ERR_HIP - (int)e;
-  static const int fill = std::getenv("FLAME_HIP_FILL_ALLOC") ? std::atoi(std::getenv("FLAME_HIP_FILL_ALLOC")) : -1;  // dev: 0..255
+  const int fill = flamehip::test_alloc_fill();  // (-1 in the product library)
   if (fill >= 0) (void)hipMemset(*p, fill, want);
   caps[(void*)p] = want;
   return 0;
@@ -326,11 +357,15 @@ struct flame_hip_graph {
   bool snap_valid = false;
   int64_t persist_launches = 0;     // launches of resident tiles so far (info "persist_launches")
   float persist_round_us = 0.f;     // device time of a round of the last resident solve that was looked at (0 = none yet)
+  int32_t persist_round_V = 0;      // ... and the size of the graph it was measured on
   int32_t last_rounds = 0;          // rounds of the last resident launch
   int32_t persist_timeout_us = 0;   // what the last resident launch was given (info "persist_timeout_us")
   int32_t snap_V = 0, snap_E = 0;
   PersistBufs xp;                   // hand-off buffers (uncached, from the process-wide pool: NOT in caps) + dev-aid words
   size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
+  int poll_delay_opt = -1;          // option "poll_delay" (-1 = automatic)
+  int persist_timeout_opt = 0;      // option "persist_timeout_us" (0 = automatic)
+  bool need_marks = true;           // option "need_marks"
   int persist_prof_want = 0, persist_prof_set = 0;  // option "persist_prof": tile + 1 that records its round split (0 = none)
   bool persist_unchecked = false;   // a resident launch is in flight / finished and nobody has looked at persist_err yet
   int persist_unchecked_n = 0;      // ... how many of them (the error word does not say WHICH launch gave up: only when it
@@ -615,12 +650,21 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
     if (value < 0 || value > kMaxDepth) return FLAME_HIP_ERR_ARG;
     g->stream_depth = value;
   } else if (k == "persist") {
-    static const char* force = std::getenv("FLAME_HIP_PERSIST");  // dev A/B: overrides the caller's choice
-    const int v = force ? std::atoi(force) : value;
-    g->persist = v != 0;  // (2 was r03's "also size small frames for it": the automatic tiles do as well now)
+    g->persist = value != 0;  // (2 was r03's "also size small frames for it": the automatic tiles do as well now)
   } else if (k == "persist_prof") {
     if (value < 0) return FLAME_HIP_ERR_ARG;
     g->persist_prof_want = value;
+  } else if (k == "poll_delay") {  // x 256 clocks between a round's stores and its first poll pass; -1 = automatic
+    if (value < -1 || value > 255) return FLAME_HIP_ERR_ARG;
+    g->poll_delay_opt = value;
+  } else if (k == "persist_timeout_us") {  // what a poll may wait before the launch gives up; 0 = automatic
+    if (value < 0) return FLAME_HIP_ERR_ARG;
+    g->persist_timeout_opt = value;
+  } else if (k == "need_marks") {  // fat tiles hand over only what somebody polls (default 1)
+    g->need_marks = value != 0;
+  } else if (k == "plan_timing") {  // diagnostic: the plan builders' stages on stderr (levels: plan_dev.hip)
+    if (value < 0 || value > 5) return FLAME_HIP_ERR_ARG;
+    g->opt.timing = value;
   } else if (k == "profile") {
     g->profile = value != 0;
   } else if (k == "lds_bytes") {
@@ -772,7 +816,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     return 0;
   hipStream_t s = g->stream;
   int rc;
-  static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+  const bool timing = g->opt.timing != 0;  // (option "plan_timing")
   auto tprev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!timing) return;
@@ -946,7 +990,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     if (ok && balanced && refine_left > 0 && ntiles >= 16) {  // refinement passes (plan.cpp)
       --refine_left;
       long long total = 0;
-      for (const TileDesc& D : tiles) total += tile_cost(D, tile_cost_mode());
+      for (const TileDesc& D : tiles) total += tile_cost(D);
       HIPCHK(g->planner.weights_scale_by_tiles(s, V, ntiles, total, A));
       continue;
     }
@@ -964,7 +1008,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
   {  // how even the tiles are (a launch lasts as long as its slowest tile): max / mean of the cost model
     long long sum = 0, mx = 0;
     for (const TileDesc& D : tiles) {
-      const long long c = tile_cost(D, tile_cost_mode());
+      const long long c = tile_cost(D);
       sum += c; mx = std::max(mx, c);
     }
     g->tile_imbalance_pct = sum > 0 ? (int)(100 * mx * (long long)tiles.size() / sum) : 100;
@@ -1184,6 +1228,9 @@ int flame_hip_graph_upload(flame_hip_graph* g, const float* pos, const int32_t* 
 static int finish_upload(flame_hip_graph* g) {
   g->poll_valid = false;  // (new tile arrays: the resident tiles' poll lists are rebuilt at their next launch)
   const int32_t V = g->V, E = g->E;
+  // (the round time the resident launches' time-out follows was measured on ANOTHER graph -- a frame stream's
+  // next frame is about as large and keeps it, a graph of another size starts again from the 4 ms of a first launch)
+  if (g->persist_round_V > 0 && (V > 2 * g->persist_round_V || 2 * V < g->persist_round_V)) { g->persist_round_us = 0.f; g->persist_round_V = 0; }
   const Plan& P = g->plan;
   int rc;
   if ((rc = dev_alloc(g->caps, &g->vtx_normals, (size_t)V))) return rc;
@@ -1259,7 +1306,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
         (rc = dev_alloc(g->caps, &g->in_wgt, (size_t)V)) || (rc = dev_alloc(g->caps, &g->in_x0, (size_t)V)) ||
         (rc = dev_alloc(g->caps, &g->in_edges, 3 * (size_t)T)) || (rc = dev_alloc(g->caps, &g->in_alpha, 3 * (size_t)T)))
       return rc;
-    static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+    const bool timing = g->opt.timing != 0;  // (option "plan_timing")
     auto t_prev = t_entry;
     auto lap = [&](const char* what) {
       if (!timing) return;
@@ -1327,9 +1374,7 @@ int flame_hip_graph_sync(flame_hip_graph* g, const flame_hip_sync_params* sp, in
       // ... or, measured faster still (1.2 k frame 0.452 -> 0.435 ms): no copy command at all, the launch
       // reads the arena through its device mapping (every input is read once, coalesced: ~100 KB over the
       // host link inside the kernel's first phase instead of a DMA + its dependency in front of it)
-      static const bool zero_copy = std::getenv("FLAME_HIP_MINI_STAGED") == nullptr;  // (dev A/B: set = DMA into in_stage)
-      const char* src = zero_copy ? g->pin_in.base : g->in_stage;
-      if (!zero_copy) HIPCHK(hipMemcpyAsync(g->in_stage, g->pin_in.base, in_total, hipMemcpyHostToDevice, s));
+      const char* src = g->pin_in.base;
       lap("H2D all");
       DevPlanner::MiniSync ms;
       ms.tris = tris_dev ? tris_dev : reinterpret_cast<const int32_t*>(src + o_tris);  // (the library's own list: read where it lies)
@@ -1665,7 +1710,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
 // since.  own_marks: state-writing steps the CALLER itself queued behind the solve and will redo (frame_results'
 // un-scaling); anything else that wrote the state since (a graph filter, new data terms) cannot be replayed here
 static int persist_check(flame_hip_graph* g, int own_marks = 0) {
-  static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
+  const bool force_fail = TEST_HOOK(persist_fail, 0) != 0;  // (hooks library only: the recovery path)
   if (force_fail && g->persist_used && g->persist_err) *g->persist_err = 3;
   g->persist_unchecked = false;  // (every caller has synchronised the solve's stream)
   const int unchecked = g->persist_unchecked_n;
@@ -1673,7 +1718,7 @@ static int persist_check(flame_hip_graph* g, int own_marks = 0) {
   if (!g->persist_err || *g->persist_err == 0) {
     if (g->persist_used && g->last_rounds > 0 && unchecked == 1) {  // the round time the next launch's time-out follows
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess && ms > 0.f) g->persist_round_us = ms * 1e3f / (float)g->last_rounds;
+      if (hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess && ms > 0.f) { g->persist_round_us = ms * 1e3f / (float)g->last_rounds; g->persist_round_V = g->V; }
       else (void)hipGetLastError();
     }
     g->queued.clear(); g->qsnap_valid = false;
@@ -1758,7 +1803,6 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         if ((rc = dev_alloc(g->caps, &x.prof, 16))) return rc;
         int32_t w[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         int want = g->persist_prof_want;
-        if (const char* pp = std::getenv("FLAME_HIP_PERSIST_PROF")) want = std::atoi(pp);
         if (want > 0) { w[0] = 1; w[1] = want - 1; }
         HIPCHK(memcpy_sync(s, x.prof, w, sizeof(w), hipMemcpyHostToDevice));
         g->persist_prof_set = g->persist_prof_want;
@@ -1778,9 +1822,8 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
           return rc;
         // (r05: the sorted lists' kernel also marks what anybody polls; the rest of a tile's own entries is not handed over.
         // A plan's first solve -- a frame of a stream -- stores everything and pays neither the marks nor their memsets)
-        static const bool need_off = std::getenv("FLAME_HIP_NO_NEED_MARKS") != nullptr;  // dev A/B
         x.need_valid = false;
-        if (want_sorted && !need_off && P.tile_fat) {  // (the FAT kernel variants read the marks)
+        if (want_sorted && g->need_marks && P.tile_fat) {  // (the FAT kernel variants read the marks)
           if ((rc = dev_alloc(g->caps, &x.need_v, std::max<size_t>((size_t)g->V, 1))) || (rc = dev_alloc(g->caps, &x.need_e, std::max<size_t>((size_t)g->E, 1))))
             return rc;
           HIPCHK(hipMemsetAsync(x.need_v, 0, sizeof(int32_t) * std::max<size_t>((size_t)g->V, 1), s));
@@ -1807,20 +1850,18 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
       a.iters = num_iters;
       {
-        static const char* pd = std::getenv("FLAME_HIP_POLL_DELAY");  // dev A/B
         // (the lists in local order: a pass is long enough, 0; fat tiles with a 1- or 2-iteration round: the hand-off is the
         // larger part of the round and the first pass should not wait -- 200 k 3.02 / 3.05 / 3.13 / 3.15 / 3.23 us per
         // iteration at 0 .. 4, 160 k and 100 k (depth 3) flat: profiles/r05_fat_poll_delay.txt)
         const bool short_fat_round = g->V > 256 * 196 && P.tile_depth <= 2;
-        x.poll_delay = pd ? std::atoi(pd) : ((g->poll_sorted && !short_fat_round) ? kPollDelayDefault : 0);
+        x.poll_delay = g->poll_delay_opt >= 0 ? g->poll_delay_opt : ((g->poll_sorted && !short_fat_round) ? kPollDelayDefault : 0);
         // A poll waits at most max(0.5 ms, 8 x the handle's last measured round) -- r04's flat 4 ms was 5.5 headline
-        // solves; 4 ms while nothing has been measured.  FLAME_HIP_PERSIST_TIMEOUT_US overrides.
-        static const char* to = std::getenv("FLAME_HIP_PERSIST_TIMEOUT_US");
-        const float us = to ? (float)std::atof(to) : (g->persist_round_us > 0.f ? std::max(500.f, 8.f * g->persist_round_us) : 4000.f);
+        // solves; 4 ms while nothing has been measured.  Option "persist_timeout_us" overrides.
+        const float us = g->persist_timeout_opt > 0 ? (float)g->persist_timeout_opt : (g->persist_round_us > 0.f ? std::max(500.f, 8.f * g->persist_round_us) : 4000.f);
         g->persist_timeout_us = (int32_t)std::min(us, 1.0e6f);
         x.timeout_ticks = g->persist_timeout_us * 100;
-        static const char* st = std::getenv("FLAME_HIP_PERSIST_STALL_US");  // test hook: a REAL late tile (tests/test_gpu_persist.py)
-        if (st && tile_stall_hook_build()) x.poll_delay = (x.poll_delay & 0xff) | (std::atoi(st) << 8);  // (microseconds, bits 8.. of poll_delay; debug build only)
+        const int stall_us = TEST_HOOK(persist_stall_us, 0);  // (hooks library: a REAL late tile, tests/test_gpu_persist.py)
+        if (stall_us > 0 && tile_stall_hook_build()) x.poll_delay = (x.poll_delay & 0xff) | (stall_us << 8);  // (microseconds, bits 8.. of poll_delay; debug kernels only)
       }
       g->last_rounds = rounds;
       HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
@@ -1959,10 +2000,7 @@ int flame_hip_solve(flame_hip_graph* g, const flame_hip_params* p, int32_t num_i
   g->timed = true;
   // the maps of the NEXT frame's builder: enqueued behind this frame's iterations -- and, when those run as ONE launch of
   // resident tiles, ordered behind it too (they then overlap the results stage instead of fighting the tiles for CUs)
-  {
-    static const bool maps_beside = std::getenv("FLAME_HIP_MAPS_BESIDE") != nullptr;  // dev A/B
-    HIPCHK(g->planner.flush_grid((g->persist_used && !maps_beside) ? g->ev1 : nullptr));
-  }
+  HIPCHK(g->planner.flush_grid(g->persist_used ? g->ev1 : nullptr));
   return 0;
 }
 
@@ -2177,9 +2215,7 @@ int flame_hip_frame_results(flame_hip_graph* g, const flame_hip_params* p, float
   // Small frames: the kernels write their outputs straight into the page-locked arena (it is mapped into
   // the device's address space) -- no copy command behind the last kernel, which costs more than these
   // few posted writes.  Larger frames go through the device arena and ONE copy.
-  static const size_t direct_max = std::getenv("FLAME_HIP_OUT_DIRECT_MAX") ? (size_t)std::atoll(std::getenv("FLAME_HIP_OUT_DIRECT_MAX"))
-                                                                          : kDirectOutBytes;
-  const bool direct = dev_bytes <= direct_max;
+  const bool direct = dev_bytes <= kDirectOutBytes;
   char* arena = direct ? host : g->fr_dev;
   const bool dev_edges = edges && E > 0 && g->sync_on_device;
   if (dev_edges) {  // not ordered behind the solve: in_edges has been final since the graph sync
@@ -2521,7 +2557,7 @@ int flame_hip_persist_take_error(flame_hip_graph* g, int32_t* gave_up) {
   int rc = require_device(g);
   if (rc) return rc;
   if (!gave_up) return FLAME_HIP_ERR_ARG;
-  static const bool force_fail = std::getenv("FLAME_HIP_PERSIST_FAIL") != nullptr;  // (tests: the recovery path)
+  const bool force_fail = TEST_HOOK(persist_fail, 0) != 0;  // (hooks library only: the recovery path)
   *gave_up = 0;
   const bool had = g->persist_unchecked;
   g->persist_unchecked = false;

@@ -132,18 +132,8 @@ __device__ __forceinline__ void lds_store3(float4* slot, float a, float b, float
 #ifndef FLAME_EARLY_Q
 #define FLAME_EARLY_Q 1
 #endif
-// EXPERIMENT r05, measured and LOST (profiles/r05_interior_first.txt; off): the next round's first phase D on the interior
-// edge blocks in front of the poll.  Bit-exact, but 50 k 1.336 -> 1.388 us per iteration, 200 k 3.24 -> 3.55, 5 k +4.5 %
-// (only 100 k gained, 2.5 %): what a round waits for is the slowest neighbour's chain, on which the poll's LOAD latency is
-// no longer overlapped with anything, and a phase D cut in two loses the overlap of its gathers.
 #ifndef FLAME_PERSIST_STALL_HOOK
 #define FLAME_PERSIST_STALL_HOOK 0
-#endif
-#ifndef FLAME_INTERIOR_FIRST
-#define FLAME_INTERIOR_FIRST 0
-#endif
-#ifndef FLAME_POLL_SKIP
-#define FLAME_POLL_SKIP 1
 #endif
 // Write-back of a tile's results.  FLAME_WT_STORE 1: write-through (sc0 sc1) so the lines drain
 // while slower tiles still compute instead of at the end-of-kernel release (guide, "boundary":
@@ -180,6 +170,22 @@ __device__ __forceinline__ int wave_max(int v) {
 typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
 
+// The tile phases pick one of several straight-line bodies by scalar compares (phase P: "read n slots, then the ordered fma
+// chain" for n = 1 .. kSlotRound).  Left alone, SimplifyCFG sinks the bodies' common tails into shared blocks joined by PHIs:
+// register shuffles and a full lgkmcnt(0) drain in front of the shared tail, on the critical path of every iteration.  A
+// body that ends in an asm statement no other body has (the constant differs) has no common tail to sink; the results pass
+// through it, so nothing of the chain can move below it either.  (r06; -mllvm -simplifycfg-sink-common=false does the same
+// for the whole file and costs the spilling fat-tile kernel 4 %: profiles/r06_tail_marks_ab.txt)
+#ifndef FLAME_TAIL_MARKS
+#define FLAME_TAIL_MARKS 1
+#endif
+template <int ID>
+__device__ __forceinline__ void tail_mark(f2v& w, float& x) {
+#if FLAME_TAIL_MARKS
+  asm volatile("; body %c2" : "+v"(w), "+v"(x) : "n"(ID));
+#endif
+}
+
 // Incidence slots come in two layouts.  S12 = false (the default): one float4 per slot {c1, c2, cx, -}, a slot is named by its
 // LDS address.  S12 = true (r05, FAT tiles: one tile per CU beyond 196 own vertices, where 16 bytes per slot do not fit 160 KiB):
 // 12 bytes per slot, split so that every access stays naturally aligned (a 12-byte slot read as ds_read_b96 off its 16-byte
@@ -214,7 +220,7 @@ __device__ __forceinline__ float4 slot_load(const SlotMem<S12>& m, typename Slot
 
 // Phase D on K of this thread's edges, the O-th on: every gather is issued before the first use.
 // ew = {alpha, beta, dx, dy}; es/ed = the source / target incidence slot.
-template <int O, int K, int EPT, bool S12>
+template <int O, int K, int EPT, bool S12, bool MARK>
 __device__ __forceinline__ void tile_phase_d(const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
                                              const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
@@ -254,40 +260,26 @@ __device__ __forceinline__ void tile_phase_d(const float4* bar, const SlotMem<S1
     const f2v n23 = (-be) * u;
     slot_store<S12>(sm, ed[e], n23.x, n23.y, -ew[e].x * q1[e]);
   }
+#if FLAME_TAIL_MARKS
+  // (the last slot store stays in THIS body, see tail_mark())
+  if constexpr (MARK) asm volatile("; phase D body %c0" : : "n"(16 * O + K) : "memory");
+#endif
 }
 
 // blocks [O, O + n) of this wave's edge blocks, n (wave-uniform) <= K: dispatch to the matching unrolled body
-template <int O, int K, int EPT, bool S12>
+template <int O, int K, int EPT, bool S12, bool MARK>
 struct PhaseD {
   static __device__ __forceinline__ void run(int n, const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
                                              const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
                                              const float4 (&ew)[EPT], float (&q1)[EPT],
                                              f2v (&q23)[EPT], float sigma) {
-    if (n == K) tile_phase_d<O, K, EPT, S12>(bar, sm, eij, es, ed, ew, q1, q23, sigma);
-    else PhaseD<O, K - 1, EPT, S12>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    if (n == K) tile_phase_d<O, K, EPT, S12, MARK>(bar, sm, eij, es, ed, ew, q1, q23, sigma);
+    else PhaseD<O, K - 1, EPT, S12, MARK>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma);
   }
 };
-template <int O, int EPT, bool S12>
-struct PhaseD<O, 0, EPT, S12> {
+template <int O, int EPT, bool S12, bool MARK>
+struct PhaseD<O, 0, EPT, S12, MARK> {
   static __device__ __forceinline__ void run(int, const float4*, const SlotMem<S12>&, const uint32_t (&)[EPT],
-                                             const typename SlotT<S12>::ref (&)[EPT], const typename SlotT<S12>::ref (&)[EPT],
-                                             const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],
-                                             float) {}
-};
-// blocks [lo, hi) (resident tiles: a round's first phase D skips the interior blocks it ran before the hand-off arrived)
-template <int O, int EPT, bool S12>
-struct PhaseDFrom {
-  static __device__ __forceinline__ void run(int lo, int hi, const float4* bar, const SlotMem<S12>& sm, const uint32_t (&eij)[EPT],
-                                             const typename SlotT<S12>::ref (&es)[EPT], const typename SlotT<S12>::ref (&ed)[EPT],
-                                             const float4 (&ew)[EPT], float (&q1)[EPT],
-                                             f2v (&q23)[EPT], float sigma) {
-    if (lo == O) PhaseD<O, EPT - O, EPT, S12>::run(hi - O, bar, sm, eij, es, ed, ew, q1, q23, sigma);
-    else PhaseDFrom<O + 1, EPT, S12>::run(lo, hi, bar, sm, eij, es, ed, ew, q1, q23, sigma);
-  }
-};
-template <int EPT, bool S12>
-struct PhaseDFrom<EPT, EPT, S12> {
-  static __device__ __forceinline__ void run(int, int, const float4*, const SlotMem<S12>&, const uint32_t (&)[EPT],
                                              const typename SlotT<S12>::ref (&)[EPT], const typename SlotT<S12>::ref (&)[EPT],
                                              const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],
                                              float) {}
@@ -314,19 +306,22 @@ __device__ __forceinline__ void sum_slots12(const SlotMem<true>& m, uint32_t row
     x = fmaf(ntau, cx[u], x);
   }
 }
-template <int K>
-struct SlotTail12 {  // n (wave-uniform, < kPRound) remaining slots
+// n in [LO, HI] (wave-uniform) slots, picked by a balanced tree of scalar compares (r06: a linear chain of compares used to sit
+// in front of the reads, on the critical path of every iteration)
+template <int LO, int HI>
+struct SlotSel12 {
   static __device__ __forceinline__ void run(int n, const SlotMem<true>& m, uint32_t row, f2v nt2, float ntau, f2v& w, float& x) {
-    if (n == K) sum_slots12<K>(m, row, nt2, ntau, w, x);
-    else SlotTail12<K - 1>::run(n, m, row, nt2, ntau, w, x);
+    if constexpr (LO == HI) {
+      if constexpr (LO > 0) sum_slots12<LO>(m, row, nt2, ntau, w, x);
+    } else {
+      constexpr int MID = (LO + HI) / 2;
+      if (n <= MID) SlotSel12<LO, MID>::run(n, m, row, nt2, ntau, w, x);
+      else SlotSel12<MID + 1, HI>::run(n, m, row, nt2, ntau, w, x);
+    }
   }
 };
-template <>
-struct SlotTail12<0> {
-  static __device__ __forceinline__ void run(int, const SlotMem<true>&, uint32_t, f2v, float, f2v&, float&) {}
-};
 
-template <int K>
+template <int K, bool MARK>
 __device__ __forceinline__ void sum_slots(const float4* row, f2v nt2, float ntau, f2v& w, float& x) {
   float4 t[K];
 #pragma unroll
@@ -339,17 +334,19 @@ __device__ __forceinline__ void sum_slots(const float4* row, f2v nt2, float ntau
     w = pk_fma(nt2, c, w);
     x = fmaf(ntau, t[u].z, x);
   }
+  if constexpr (MARK) tail_mark<K>(w, x);
 }
-template <int K>
-struct SlotTail {  // n (wave-uniform, < kPRound) remaining slots
+template <int LO, int HI, bool MARK>
+struct SlotSel {
   static __device__ __forceinline__ void run(int n, const float4* row, f2v nt2, float ntau, f2v& w, float& x) {
-    if (n == K) sum_slots<K>(row, nt2, ntau, w, x);
-    else SlotTail<K - 1>::run(n, row, nt2, ntau, w, x);
+    if constexpr (LO == HI) {
+      if constexpr (LO > 0) sum_slots<LO, MARK>(row, nt2, ntau, w, x);
+    } else {
+      constexpr int MID = (LO + HI) / 2;
+      if (n <= MID) SlotSel<LO, MID, MARK>::run(n, row, nt2, ntau, w, x);
+      else SlotSel<MID + 1, HI, MARK>::run(n, row, nt2, ntau, w, x);
+    }
   }
-};
-template <>
-struct SlotTail<0> {
-  static __device__ __forceinline__ void run(int, const float4*, f2v, float, f2v&, float&) {}
 };
 
 // Explicit parameters, hottest first: the first 16 dwords of the kernel arguments are preloaded into
@@ -460,6 +457,9 @@ __device__ __forceinline__ bool tag_ok(const float4& v, int32_t target, int32_t*
 template <int NT, int EPT, int VPT, bool PERSIST, bool S12, bool FAT>
 __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   typedef typename SlotT<S12>::ref slot_t;
+  // tail_mark(): measured -2.6 / -1.2 / -1.3 % per iteration at 1.2 k / 5 k / 10 k vertices (512 threads), +1 % at 50 k and with
+  // three edges per thread more scratch in the fat-tile kernels (1 024 threads): profiles/r06_tail_marks_ab.txt
+  constexpr bool MARK = FLAME_TAIL_MARKS && NT <= 512 && EPT <= 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware block -> tile map (speed only): block b runs on XCD b % 8, tiles are numbered in
   // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
@@ -644,24 +644,34 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   int32_t pacc[4] = {0, 0, 0, 0};
   int32_t wait_max = 0;
   int done = 0, round = 0;
-  int k_pre = 0;  // resident tiles: edge blocks of this wave whose first phase D of the round already ran (interior-first)
-  for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
-  const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
-  for (int it = 1; it <= iters; ++it) {
-    const int rem = iters - it;
+  // r06: what this WAVE does in an iteration depends only on r = min(iterations left in the round, depth): its number of active
+  // edge blocks (3 bits per r) and which of its vertex blocks are active (2 bits per r), tabulated once in two SGPR pairs --
+  // an iteration used to derive them from two v_readlane, a rounding division and a VALU clamp (16 instructions on the
+  // critical path in front of phase D's gathers, tools/exp/iter_prof.py)
+  unsigned long long nk_tab = 0ull, pa_tab = 0ull;
+  for (int r = 0; r <= depth; ++r) {
     // Active sets are prefixes (vertices by ring, edges by level).  Lanes past the cutoff inside
     // an active block keep computing on stale data: by construction that garbage only reaches
     // vertices/edges that are themselves past the cutoff, and nothing past it is written back.
-    const int v_act = __builtin_amdgcn_readlane(cut, min(rem, depth));
-    const int e_act = __builtin_amdgcn_readlane(cut, 32 + min(rem + 1, depth));
+    const int v_act = __builtin_amdgcn_readlane(cut, r);
+    const int e_act = __builtin_amdgcn_readlane(cut, 32 + min(r + 1, depth));
     // wave-uniform: this wave's k-th edge block covers local edges [k NT + wbase, +64)
     const int nk = max(0, min(EPT, (e_act - wbase + NT - 1) / NT));
+    int pa = 0;
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) pa |= (k * NT + wbase < v_act) ? (1 << k) : 0;
+    nk_tab |= (unsigned long long)nk << (3 * r);
+    pa_tab |= (unsigned long long)pa << (2 * r);
+  }
+  static_assert(EPT < 8 && VPT <= 2 && 3 * (kMaxDepth + 1) <= 64, "the per-wave activity tables hold 3 / 2 bits per entry");
+  for (;;) {  // (one pass unless PERSIST: a round = the iterations of one launch)
+  const int iters = PERSIST ? min(depth > 0 ? depth : a.iters, a.iters - done) : a.iters;
+  for (int it = 1; it <= iters; ++it) {
+    const int ri = min(iters - it, depth);
+    const int nk = (int)(nk_tab >> (3 * ri)) & 7;
+    const int pact = (int)(pa_tab >> (2 * ri)) & 3;
     // ---- phase D: dual ascent + scatter of the -K^T q terms into incidence slots ----
-    if (PERSIST && FLAME_INTERIOR_FIRST) {
-      PhaseDFrom<0, EPT, S12>::run(it == 1 ? min(k_pre, nk) : 0, nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
-    } else {
-      PhaseD<0, EPT, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
-    }
+    PhaseD<0, EPT, EPT, S12, MARK>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);
 #if FLAME_EARLY_Q
     // resident tiles: the duals of a round are final after its last phase D -- their hand-off entries (58 % of what
     // a tile hands over) leave now and travel while phase P still runs
@@ -681,7 +691,7 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     // ---- phase P: primal descent (slot order = ascending original edge id), prox, extra-grad ----
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
-      if (k * NT + wbase < v_act) {  // wave-uniform
+      if (pact & (1 << k)) {  // wave-uniform
         const int lv = k * NT + tid;
         const float xp = vx[k];
         const f2v wp = vw[k];
@@ -692,12 +702,15 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
         int j = wdeg[k];  // wave-uniform
         if constexpr (S12) {
           uint32_t row = vrow[k];
-          for (; j >= kPRound; j -= kPRound, row += 4u * kPRound) sum_slots12<kPRound>(sm, row, nt2, ntau, w, x);
-          SlotTail12<kPRound - 1>::run(j, sm, row, nt2, ntau, w, x);
+          for (; j > kPRound; j -= kPRound, row += 4u * kPRound) sum_slots12<kPRound>(sm, row, nt2, ntau, w, x);
+          SlotSel12<0, kPRound>::run(j, sm, row, nt2, ntau, w, x);
         } else {
+          // (batches of kPRound: 8 or 12 slots per batch -- one LDS round trip for the usual longest row of a 64-vertex
+          // group -- measured equal at 1.2 k ... 10 k vertices, r06 profiles/r06_slot_batch_ab.txt: the segment is bound by
+          // the LDS return path, three waves x 9 KB per phase P, not by the round trips)
           const float4* row = vrow[k];
-          for (; j >= kPRound; j -= kPRound, row += kPRound) sum_slots<kPRound>(row, nt2, ntau, w, x);
-          SlotTail<kPRound - 1>::run(j, row, nt2, ntau, w, x);
+          for (; j > kPRound; j -= kPRound, row += kPRound) sum_slots<kPRound, MARK>(row, nt2, ntau, w, x);
+          SlotSel<0, kPRound, MARK>::run(j, row, nt2, ntau, w, x);
         }
         x = prox_l1(x, vz[k], vt[k], x_min, x_max);
         vxb[k] = fmaf(theta, x - xp, x);
@@ -755,18 +768,6 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   done += iters;
   ++round;
   if (done >= a.iters) break;
-#if FLAME_INTERIOR_FIRST
-  // ---- interior first (r05): the next round's first phase D on this wave's edge blocks that lie wholly among the
-  // level-0 edges (both ends own: their inputs -- bar[] of own vertices, own duals -- are final since the barrier above)
-  // runs NOW, while the neighbours' hand-off entries are still on their way (store -> uncached memory -> load ~ 1.3 us);
-  // it touches own vertices' bar[] entries and owned edges' slots only, the poll's deliveries the halo's.  The round's
-  // first iteration then starts its phase D at block k_pre.
-  {
-    const int e0 = __builtin_amdgcn_readlane(cut, 32);  // level_end[0]
-    k_pre = (e0 - wbase - 64 >= 0) ? min(EPT, (e0 - wbase - 64) / NT + 1) : 0;
-    PhaseD<0, EPT, EPT, S12>::run(k_pre, bar, sm, eij, es, ed, ew, q1, q23, sigma);
-  }
-#endif
   // ---- end of a round: the halo state of the next one = the owners' hand-off entries, polled until they carry this
   // round's tag.  A lane re-issues its loads until all of ITS entries are there; every load of a pass goes out before
   // the first one is looked at; entries a lane does not need point at one address per tile (one request per wave) ----
@@ -782,20 +783,11 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
     for (int k = 0; k < VPT; ++k) {
       needv[k] = (k * NT + tid) < n_hv;          // (poll slot j = k NT + tid of this tile's list, not local vertex j)
       needa[k] = needv[k] && (pvr[k].y >> 31);
-#ifdef FLAME_EXP_NO_APOLL  // (timing experiment only -- WRONG results)
-      needa[k] = false;
-#endif
-#ifdef FLAME_EXP_NO_VPOLL  // (timing experiment only -- WRONG results)
-      needv[k] = false; needa[k] = false;
-#endif
       want = want || needv[k];
     }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       neede[k] = (k * NT + tid) < n_he && per[k].x != 0xffffffffu;  // (an unsorted list marks the owned edges invalid)
-#ifdef FLAME_EXP_NO_QPOLL  // (timing experiment only -- WRONG results: what would the hand-off cost without the duals' bytes?)
-      neede[k] = false;
-#endif
       want = want || neede[k];
     }
     // (the neighbours finish their round at about the same time and their stores take ~0.7 us to land: a poll pass
@@ -819,28 +811,27 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
           const float4* p0 = &hq[neede[0] ? (int)per[0].x : estart];
           const float4* p1 = &hq[neede[EPT > 1 ? 1 : 0] ? (int)per[EPT > 1 ? 1 : 0].x : estart];
           const float4* p2 = &hq[neede[EPT - 1] ? (int)per[EPT - 1].x : estart];
-#if FLAME_POLL_SKIP
-          // r05: a request goes out only when a lane of the wave (still) needs that array -- every wave used to issue all
-          // five each pass (80 wave-instructions of 1 KB through the CU's one address path, most of them for the
-          // placeholder address: own vertices have no halo entries, the last lanes no vertices, EPT = 2 no third edge)
+          // a request goes out only when a lane of the wave (still) needs that array (r05: every wave used to issue all five
+          // each pass, most of them for the placeholder address -- own vertices have no halo entries, the last lanes no
+          // vertices, EPT = 2 no third edge; the poll is bound by the CU's request rate).  Loads, their scalar predicates and
+          // the wait are ONE asm block: the compiler does not track vmcnt for loads issued in inline asm, so nothing of its
+          // own (a copy, a spill) may land between a load and the wait.
           f4v r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0, r4 = r0;
-          if (__any(needv[0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r0) : "v"(pb) : "memory");
-          if (__any(needa[0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r1) : "v"(pv) : "memory");
-          if (__any(neede[0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r2) : "v"(p0) : "memory");
-          if (EPT > 1 && __any(neede[EPT > 1 ? 1 : 0])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r3) : "v"(p1) : "memory");
-          if (EPT > 2 && __any(neede[EPT - 1])) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r4) : "v"(p2) : "memory");
-          // (the values are tied to the wait: nothing that reads them can be scheduled in front of it)
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : : "memory");
-#else
-          f4v r0, r1, r2, r3, r4;
+          // (ballots: wave-uniform by construction, so the compiler keeps them in SGPR pairs as the "s" constraints ask)
+          const unsigned long long c0 = __builtin_amdgcn_ballot_w64(needv[0]), c1 = __builtin_amdgcn_ballot_w64(needa[0]);
+          const unsigned long long c2 = __builtin_amdgcn_ballot_w64(neede[0]);
+          const unsigned long long c3 = EPT > 1 ? __builtin_amdgcn_ballot_w64(neede[EPT > 1 ? 1 : 0]) : 0ull;
+          const unsigned long long c4 = EPT > 2 ? __builtin_amdgcn_ballot_w64(neede[EPT - 1]) : 0ull;
           asm volatile(
-              "global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %6, off sc1\n\t"
-              "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %8, off sc1\n\t"
-              "global_load_dwordx4 %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
-              : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
-              : "v"(pb), "v"(pv), "v"(p0), "v"(p1), "v"(p2)
-              : "memory");
-#endif
+              "s_cmp_eq_u64 %10, 0\n\ts_cbranch_scc1 .Lpoll_a%=\n\tglobal_load_dwordx4 %0, %5, off sc1\n.Lpoll_a%=:\n\t"
+              "s_cmp_eq_u64 %11, 0\n\ts_cbranch_scc1 .Lpoll_b%=\n\tglobal_load_dwordx4 %1, %6, off sc1\n.Lpoll_b%=:\n\t"
+              "s_cmp_eq_u64 %12, 0\n\ts_cbranch_scc1 .Lpoll_c%=\n\tglobal_load_dwordx4 %2, %7, off sc1\n.Lpoll_c%=:\n\t"
+              "s_cmp_eq_u64 %13, 0\n\ts_cbranch_scc1 .Lpoll_d%=\n\tglobal_load_dwordx4 %3, %8, off sc1\n.Lpoll_d%=:\n\t"
+              "s_cmp_eq_u64 %14, 0\n\ts_cbranch_scc1 .Lpoll_e%=\n\tglobal_load_dwordx4 %4, %9, off sc1\n.Lpoll_e%=:\n\t"
+              "s_waitcnt vmcnt(0)"
+              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)
+              : "v"(pb), "v"(pv), "v"(p0), "v"(p1), "v"(p2), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4)
+              : "memory", "scc");
           nb[0] = make_float4(r0.x, r0.y, r0.z, r0.w);
           na[0] = make_float4(r1.x, r1.y, r1.z, r1.w);
           nq[0] = make_float4(r2.x, r2.y, r2.z, r2.w);

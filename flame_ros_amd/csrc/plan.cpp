@@ -119,7 +119,7 @@ void rcb_par(const float* pos, const int32_t* w, std::vector<int32_t>& idx, int 
 // Integer cost density of a tile (x 1024): what one own vertex of the tile "costs" a launch --
 // local edges + 2 x local vertices, per own vertex.  Integer so that sums of it are exact.
 int32_t tile_weight(const TileDesc& D) {
-  const int64_t cost = tile_cost(D, tile_cost_mode());
+  const int64_t cost = tile_cost(D);
   return (int32_t)std::max<int64_t>(1, cost * 1024 / std::max(D.n_own, 1));
 }
 
@@ -229,10 +229,9 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // (measured: 200 k vertices 5.9 us per iteration by 167 launches of two rounds of tiles -> resident)
   const bool fat = !one_round && opt.resident && opt.tile_own <= 0 && V <= 256 * 940 && opt.batch_voff.empty();
   const int fat_own = (V + 255) / 256;
-  static const int min_own_env = [] { const char* e = std::getenv("FLAME_HIP_MIN_OWN"); return e ? std::atoi(e) : 0; }();  // dev A/B
   // (r05, resident tiles: 24 instead of 32 own vertices at least -- more CUs at work, 1-2 % per iteration below 6 k vertices and
   // on a TUM-sized frame: profiles/r05_min_own_ab.txt; tiles that small take the deeper halo)
-  const int min_own = min_own_env > 0 ? min_own_env : (opt.resident ? 24 : 32);
+  const int min_own = opt.resident ? 24 : 32;
   const int auto_own = one_round ? std::max(min_own, std::min(196, (V + 255) / 256))
                        : fat     ? fat_own
                                  : std::max(196, std::min(400, (V + 511) / 512));
@@ -316,21 +315,6 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
   return f;
 }
 
-}  // namespace flamehip
-int flamehip::tile_cost_mode() {
-  static const int m = [] { const char* e = std::getenv("FLAME_HIP_COST_MODEL"); return e ? std::atoi(e) : 0; }();
-  return m;
-}
-namespace flamehip {
-
-int balance_refine_passes() {
-  static const int n = [] {
-    const char* e = std::getenv("FLAME_HIP_REFINE_PASSES");
-    return e ? std::max(0, std::min(8, std::atoi(e))) : kBalanceRefinePassesDefault;
-  }();
-  return n;
-}
-
 bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt) {
   TileCfg c{};
   if (!pick_cfg(want_nt, e_max, upd_max, &c)) return false;
@@ -350,7 +334,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
   P.note.clear();
   P.tiles.clear();
   P.t_vmap.clear(); P.t_emap.clear(); P.t_eij.clear(); P.t_ew.clear(); P.t_srow.clear();
-  const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+  const bool timing = opt.timing != 0;  // (flame_hip option "plan_timing": the stages on stderr)
   auto tprev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
     if (!timing) return;
@@ -752,10 +736,10 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     if (ok && balanced && refine_left > 0 && !vweight.empty() && !batch && !single && ntiles >= 16) {
       --refine_left;
       int64_t total = 0;
-      for (int t = 0; t < ntiles; ++t) total += tile_cost(P.tiles[t], tile_cost_mode());
+      for (int t = 0; t < ntiles; ++t) total += tile_cost(P.tiles[t]);
       for (int t = 0; t < ntiles; ++t) {
         const TileDesc& D = P.tiles[t];
-        const int64_t cost = tile_cost(D, tile_cost_mode());
+        const int64_t cost = tile_cost(D);
         for (int32_t k = D.vstart; k < D.vstart + D.n_own; ++k) {
           int32_t& w = vweight[P.v_i2o[k]];
           w = (int32_t)std::min<int64_t>(1 << 28, std::max<int64_t>(1, (int64_t)w * cost * ntiles / std::max<int64_t>(total, 1)));

@@ -32,6 +32,7 @@ struct PlanOptions {
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   bool single_only = false;  // build_plan(): return kPlanSingleNoFit instead of falling back to a
                              // halo'd partition when the isolated tile does not fit after all
+  int timing = 0;        // diagnostic (option "plan_timing"): the builders print their stages' times to stderr (levels: plan_dev.hip)
   int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
                          // this many vertices on its first try (exercises the recovery path)
   // batch of independent graphs (frames axis): nb + 1 vertex offsets; graph b = one isolated tile
@@ -101,9 +102,7 @@ struct Plan {
 };
 
 // cost-balance refinement passes after the first weighted bisection (first upload of a handle only)
-constexpr int kBalanceRefinePassesDefault = 3;  // (r05 sweep, resident tiles: 10 k 1.054 -> 1.019 us per iteration at 3, 50 k +-0; profiles/r05_refine_passes.txt)
-int balance_refine_passes();  // (FLAME_HIP_REFINE_PASSES overrides: dev A/B)
-#define kBalanceRefinePasses (::flamehip::balance_refine_passes())
+constexpr int kBalanceRefinePasses = 3;  // (r05 sweep, resident tiles: 10 k 1.054 -> 1.019 us per iteration at 3, 50 k +-0; profiles/r05_refine_passes.txt)
 
 // Tile sizing shared by the host and the device builder (measured on MI355X).
 struct PlanSizing {

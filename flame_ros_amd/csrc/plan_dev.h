@@ -24,6 +24,8 @@
 
 namespace flamehip {
 
+int test_alloc_fill();  // flame_hip.cpp: the byte new device allocations are filled with in the hooks library, else -1
+
 // Device arrays of a plan.  Owned by the caller (the handle), sized by the caller:
 // V / E / T sized arrays before build, the tile arrays through `alloc_tiles` once their sizes are
 // known (after the first per-tile pass).

@@ -1641,28 +1641,28 @@ __global__ __launch_bounds__(256) void k_publish(const int32_t* __restrict__ fla
 // Cost weights: from the tiles of the previous pass, or from the cost-density grid of the
 // previous frame (plan.cpp: tile_weight(), Plan::wgrid).  All integer.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t tile_weight_dev(const TileDesc& D, int mode) {
-  const long long cost = tile_cost(D, mode);
+__device__ __forceinline__ int32_t tile_weight_dev(const TileDesc& D) {
+  const long long cost = tile_cost(D);
   const long long w = cost * 1024 / max(D.n_own, 1);
   return (int32_t)max(1ll, w);
 }
 
 __global__ __launch_bounds__(256) void k_weights_from_tiles(int32_t V, const int32_t* __restrict__ v_i2o,
                                                             const int32_t* __restrict__ tile_of_int,
-                                                            const TileDesc* __restrict__ tiles, int32_t* w_int, int mode) {
+                                                            const TileDesc* __restrict__ tiles, int32_t* w_int) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
-  if (k < V) w_int[v_i2o[k]] = tile_weight_dev(tiles[tile_of_int[k]], mode);
+  if (k < V) w_int[v_i2o[k]] = tile_weight_dev(tiles[tile_of_int[k]]);
 }
 
 // refinement pass: w_v <- w_v * cost(tile of v) * ntiles / total cost (plan.cpp, "refine weights")
 __global__ __launch_bounds__(256) void k_weights_scale(int32_t V, const int32_t* __restrict__ v_i2o,
                                                        const int32_t* __restrict__ tile_of_int,
                                                        const TileDesc* __restrict__ tiles, int32_t ntiles,
-                                                       long long total, int32_t* w_int, int mode) {
+                                                       long long total, int32_t* w_int) {
   const int32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= V) return;
   const TileDesc& D = tiles[tile_of_int[k]];
-  const long long cost = tile_cost(D, mode);
+  const long long cost = tile_cost(D);
   const int32_t v = v_i2o[k];
   const long long w = (long long)w_int[v] * cost * ntiles / max(total, 1ll);
   w_int[v] = (int32_t)min(1ll << 28, max(1ll, w));
@@ -1786,7 +1786,7 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
                                                     const int32_t* __restrict__ tile_of_int,
                                                     const TileDesc* __restrict__ tiles,
                                                     const float* __restrict__ bounds,
-                                                    unsigned long long* sum, int32_t* cnt, int32_t* pyr, int mode) {
+                                                    unsigned long long* sum, int32_t* cnt, int32_t* pyr) {
   // vertices that are neighbours in internal order (same tile, Morton order) fall into the same
   // cell: accumulate per workgroup in LDS, flush the touched cells once (integer sums: any order)
   __shared__ unsigned long long s_sum[Plan::kGrid * Plan::kGrid];
@@ -1797,7 +1797,7 @@ __global__ __launch_bounds__(256) void k_grid_accum(int32_t V, const float2* __r
   if (k < V) {
     const float2 q = pos[v_i2o[k]];
     const int c = grid_cell_dev(bounds, q);
-    atomicAdd(&s_sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]], mode));
+    atomicAdd(&s_sum[c], (unsigned long long)tile_weight_dev(tiles[tile_of_int[k]]));
     atomicAdd(&s_cnt[c], 1);
     if (pyr) {  // the tile map the next frame's partition is read from (partition reuse)
       const int32_t tv = tile_of_int[k] + 1;
@@ -2421,7 +2421,7 @@ hipError_t dalloc(T** p, size_t n) {
   if (*p) (void)hipFree(*p);
   *p = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T));
-  static const int fill = std::getenv("FLAME_HIP_FILL_ALLOC") ? std::atoi(std::getenv("FLAME_HIP_FILL_ALLOC")) : -1;  // dev: 0..255
+  const int fill = test_alloc_fill();  // (-1 in the product library; flame_hip.cpp, FLAME_HIP_TEST_HOOKS)
   if (e == hipSuccess && fill >= 0) { e = hipMemset(*p, fill, std::max<size_t>(n, 1) * sizeof(T)); }
   return e;
 }
@@ -2499,8 +2499,7 @@ hipError_t DevPlanner::scan_i32(hipStream_t s, int lane, const int32_t* in, int3
                                 void* cub_tmp, size_t cub_bytes) {
   if (n <= 0) return hipSuccess;
   const int64_t nb = (n + kScanTile - 1) / kScanTile;
-  static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B
-  if (nb > kScanMaxBlocks || !scan_agg_[lane] || force_cub) {
+  if (nb > kScanMaxBlocks || !scan_agg_[lane]) {
     size_t tb = cub_bytes;
     return inclusive ? rocprim::inclusive_scan(cub_tmp, tb, in, out, (size_t)((int)n), rocprim::plus<int32_t>(), s)
                      : rocprim::exclusive_scan(cub_tmp, tb, in, out, (int32_t)0, (size_t)((int)n), rocprim::plus<int32_t>(), s);
@@ -2610,10 +2609,12 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
                              const std::function<hipError_t()>& after_partition) {
   *ok = false;
   *index_error = false;
-  // FLAME_HIP_PLAN_TIMING=1: synchronise after every stage and print its wall time (dev aid)
-  static const bool timing = std::getenv("FLAME_HIP_PLAN_TIMING") != nullptr;
+  // option "plan_timing" (diagnostic; PlanOptions::timing): 1 synchronise after every stage and print its wall time; 2 host
+  // enqueue time only; 3 device time of the build beside its host wall time; 4 / 5 the in-kernel stamps of k_mini_plan / of tile 0
+  const int tlevel = opt.timing;
+  const bool timing = tlevel > 0;
   auto tprev = std::chrono::steady_clock::now();
-  static const bool timing_nosync = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] >= '2';  // host enqueue time only
+  const bool timing_nosync = tlevel >= 2;  // host enqueue time only
   auto lap = [&](const char* what) {
     if (!timing) return;
     if (!timing_nosync) (void)hipStreamSynchronize(s);
@@ -2623,8 +2624,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   };
   HIPRET(reserve(V, E, T, ntiles));
   lap("reserve");
-  // FLAME_HIP_PLAN_TIMING=3: device time of the build's launches (events on `s`) beside its host wall time
-  static const bool timing_dev = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '3';
+  const bool timing_dev = tlevel == 3;  // device time of the build's launches (events on `s`) beside its host wall time
   static hipEvent_t tev[2] = {nullptr, nullptr};
   const auto t_build0 = std::chrono::steady_clock::now();
   if (timing_dev) {
@@ -2691,7 +2691,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     a.tris_int = A->tris; a.trow = A->trow; a.tinc = reinterpret_cast<uint32_t*>(A->tinc);
     a.e_i2o = A->e_i2o; a.e_o2i = A->e_o2i; a.eij = A->eij; a.ew = A->ew; a.estart = estart_;
     a.grow = A->grow; a.ginc = reinterpret_cast<uint32_t*>(A->ginc); a.gadj = gadj_; a.ipos = ipos_;
-    static const bool mini_prof = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '4';
+    const bool mini_prof = tlevel == 4;
     a.prof = mini_prof ? reinterpret_cast<long long*>(wscan_) : nullptr;  // (free in this path)
     hipLaunchKernelGGL(k_mini_plan, dim3(1), dim3(kMiniThreads), kMiniLds, s, a);
     if (mini_prof) {
@@ -2759,8 +2759,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_lvl_axis, dim3((unsigned)(((1 << lev) + 255) / 256)), dim3(256), 0, s, nseg + cur, tab[cur], LX[lb], LY[lb],
                        in.pos, axis, lev == 0 ? gbbox_ : nullptr);
     const int64_t scan_blocks = ((int64_t)V + kScanTile - 1) / kScanTile;
-    static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B
-    const bool one_launch_scans = scan_blocks <= kScanMaxBlocks && !force_cub;
+    const bool one_launch_scans = scan_blocks <= kScanMaxBlocks;
     if (weighted) {
       if (one_launch_scans) {  // gather + inclusive scan in one launch
         ScanState st;
@@ -2885,8 +2884,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
   const bool spec = spec_nv_ > 0 && spec_tiles_ >= ntiles;
   if (spec && alloc_tiles(alloc_ctx, (size_t)spec_tiles_, (size_t)spec_nv_, (size_t)spec_ne_, (size_t)spec_ns_) != 0)
     return hipErrorOutOfMemory;
-  static const bool unfused = std::getenv("FLAME_HIP_TILE_UNFUSED") != nullptr;  // dev A/B
-  const bool fused = spec && ntiles <= kScanMaxBlocks && scan_agg_[0] && !unfused;
+  const bool fused = spec && ntiles <= kScanMaxBlocks && scan_agg_[0];
   int32_t* hflags = reinterpret_cast<int32_t*>(hpin_);
   int32_t* huser = reinterpret_cast<int32_t*>(hpin_ + 64);
   TileDesc* htiles = reinterpret_cast<TileDesc*>(hpin_ + 256);
@@ -2894,7 +2892,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     TileOut O;
     O.ew = A->ew; O.tiles = A->tiles; O.t_vmap = A->t_vmap; O.t_emap = A->t_emap; O.t_eij = A->t_eij; O.t_ew = A->t_ew;
     O.t_srow = A->t_srow; O.flags = flags_; O.lane_order = opt.lane_order == 2 ? 1 : 0;
-    static const bool tile_prof = timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '5';
+    const bool tile_prof = tlevel == 5;
     O.prof = tile_prof ? reinterpret_cast<long long*>(wscan_) : nullptr;  // (free by now)
     return O;
   };
@@ -2922,7 +2920,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
     hipLaunchKernelGGL(k_tile_fused, dim3(ntiles), dim3(kP2Threads), lds2, s, G, leaf.lo, leaf.hi, estart_, tile_ext_,
                        tile_meta_, tile_out(), st, spec_nv_, spec_ne_, spec_ns_);
     tiles_built = true;
-    if (timing && std::getenv("FLAME_HIP_PLAN_TIMING")[0] == '5') {
+    if (tlevel == 5) {
       long long h[10] = {0};
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h, wscan_, sizeof(h), hipMemcpyDeviceToHost);
@@ -2993,7 +2991,7 @@ hipError_t DevPlanner::build(hipStream_t s, const PlanOptions& opt, int32_t V, i
 }
 
 hipError_t DevPlanner::weights_from_tiles(hipStream_t s, int32_t V, const DevPlanArrays& A) {
-  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, w_int_, tile_cost_mode());
+  hipLaunchKernelGGL(k_weights_from_tiles, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, w_int_);
   weight_mode_ = 1;
   return hipGetLastError();
 }
@@ -3001,7 +2999,7 @@ hipError_t DevPlanner::weights_from_tiles(hipStream_t s, int32_t V, const DevPla
 hipError_t DevPlanner::weights_scale_by_tiles(hipStream_t s, int32_t V, int ntiles, long long total_cost,
                                               const DevPlanArrays& A) {
   hipLaunchKernelGGL(k_weights_scale, grid1(V), dim3(256), 0, s, V, A.v_i2o, tile_of_int_, A.tiles, ntiles, total_cost,
-                     w_int_, tile_cost_mode());
+                     w_int_);
   weight_mode_ = 1;
   return hipGetLastError();
 }
@@ -3015,8 +3013,7 @@ hipError_t DevPlanner::edges_from_tris(hipStream_t s, int32_t V, int32_t T, cons
   if (T <= 0) return hipSuccess;
   const int32_t n = 3 * T;
   HIPRET(reserve(V, n, T, 1));  // E <= 3T
-  static const bool force_cub = std::getenv("FLAME_HIP_SCAN_CUB") != nullptr;  // dev A/B: the unfused chain
-  const bool fused = ((int64_t)V + 255) / 256 <= kScanMaxBlocks && scan_agg_[0] && !force_cub;
+  const bool fused = ((int64_t)V + 255) / 256 <= kScanMaxBlocks && scan_agg_[0];
   // no round trip: the chain's flags (bit 2 bad index, bit 32 look-back timeout) go to the caller's word
   // nan_flag[2] -- the build() that follows zeroes flags_ with its first launch and reads the caller's
   // words at its first synchronisation
@@ -3124,8 +3121,7 @@ hipError_t DevPlanner::flush_grid(hipEvent_t after) {
   const int32_t V = grid_job_.V;
   zero4(g2, reinterpret_cast<int32_t*>(grid_sum_), 2 * (int64_t)n, grid_cnt_, n, cell_pyr_, kPyrAtomicCells);
   hipLaunchKernelGGL(k_grid_accum, grid1(V), dim3(256), 0, g2, V, grid_job_.pos, grid_job_.v_i2o, tile_of_int_,
-                     grid_job_.tiles, gbbox_, reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_,
-                     tile_cost_mode());
+                     grid_job_.tiles, gbbox_, reinterpret_cast<unsigned long long*>(grid_sum_), grid_cnt_, cell_pyr_);
   hipLaunchKernelGGL(k_grid_final, dim3(1), dim3(1024), 0, g2, V, reinterpret_cast<unsigned long long*>(grid_sum_),
                      grid_cnt_, grid_w_, gbbox_, grid_bounds_, cell_pyr_);
   if (s2_) {
@@ -3139,8 +3135,7 @@ hipError_t launch_assign_lanes(hipStream_t s, int32_t ntiles, int32_t e_max, con
                                float4* t_ew, int32_t* t_emap, bool slot12) {
   if (ntiles <= 0 || e_max <= 0) return hipSuccess;
   const unsigned by = (unsigned)((e_max + 255) / 256);
-  static const bool s12_model_off = std::getenv("FLAME_HIP_LANE_S12_OFF") != nullptr;  // dev A/B
-  if (slot12 && !s12_model_off) hipLaunchKernelGGL(k_assign_lanes<true>, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
+  if (slot12) hipLaunchKernelGGL(k_assign_lanes<true>, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
   else hipLaunchKernelGGL(k_assign_lanes<false>, dim3((unsigned)ntiles, by), dim3(256), 0, s, tiles, t_eij, t_ew, t_emap);
   return hipGetLastError();
 }

@@ -108,20 +108,26 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * launch ASSUMES that all its workgroups are on the chip at once.  The library keeps the tile count within the
  * CU count and lets one handle per device and process run such a launch at a time (another handle solving at the
  * same moment uses ordinary launches), but a foreign kernel that holds CUs for long -- another process, another
- * library -- can still keep tiles from starting: every wait inside the launch is bounded (4 ms), a launch that
+ * library -- can still keep tiles from starting: every wait inside the launch is bounded (4 ms until the handle has measured
+ * a round of the current graph, then max(0.5 ms, 8 x that round); option "persist_timeout_us" > 0 fixes it; flame_hip_get_info
+ * "persist_timeout_us" = what the last launch was given), a launch that
  * gave up is noticed at the next synchronising call and REPEATED by ordinary launches from its untouched source
  * buffers ("persist_recovered" counts those; r05: SEVERAL solves queued without a synchronising call between them are
  * repeated as a whole -- the error word does not say which one gave up, so the source of the first is copied aside when
  * the second is queued and every solve since is logged; FLAME_HIP_ERR_STATE only when something other than solves wrote
  * the state in between), and the whole process then stays off resident tiles for 16 solves, doubling with every further
- * give-up ("persist_gave_up").  Dev aid: with option "persist_prof" = <tile + 1> (or FLAME_HIP_PERSIST_PROF in the environment)
+ * give-up ("persist_gave_up").  Tuning: "poll_delay" (x 256 clocks between a round's stores and its first poll pass, -1 =
+ * automatic), "need_marks" (1 = default: fat tiles hand over only the entries somebody polls).  Diagnostics: "plan_timing" (1-5:
+ * the plan builders print their stages' times to stderr); with option "persist_prof" = <tile + 1>
  * "persist_prof_0".."persist_prof_3" return that tile's time split of the last solve's rounds in 10 ns ticks:
  * iterations + stores, poll of the halo entries, halo applied + barrier, and the number of rounds),
  * "lane_order" (lanes of the tile plan re-assigned against LDS bank conflicts:
  * 0 never, 1 = when an uploaded graph is solved a second time (default; a frame stream never pays),
  * 2 = while the plan is built), "balance", "order_mode", "host_threads", "lds_bytes", "profile",
  * "d_sign" ([UPSTREAM-RECALL] switch: +1 (default) the edge vector entering K1 is d = pos_i - pos_j,
- * -1 it is pos_j - pos_i).  Unknown key -> FLAME_HIP_ERR_ARG. */
+ * -1 it is pos_j - pos_i).  Unknown key -> FLAME_HIP_ERR_ARG.  The library reads NO environment variable: everything that
+ * changes its behaviour is an option of a handle (fault injection for the tests exists only in a library of its own,
+ * libflame_hip_hooks.so, flame_ros_amd/build.py). */
 int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value);
 int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value);
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from flame_ros_amd.regularizer import GraphRegularizer, default_params
-from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params
+from tests.util import assert_bit_equal, graphgen, hooks_env, make_oracle, oracle_params, with_hooks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,7 +65,7 @@ def test_without_resident_tiles_the_two_round_partition_stays(gpu):
 
 @pytest.mark.parametrize("V,slot12", [(200000, 1), (100000, 0)])
 def test_a_fat_resident_solve_that_gives_up_is_repeated_by_launches(gpu, V, slot12):
-    """FLAME_HIP_PERSIST_FAIL (every resident launch counts as failed): the solve is repeated by ordinary launches of the SAME
+    """Test hook persist_fail (hooks library: every resident launch counts as failed): the solve is repeated by ordinary launches of the SAME
     fat plan -- 12-byte slots and lane-less outer ring through k_tile -- with the oracle's bits."""
     code = r'''
 import numpy as np, sys
@@ -89,6 +89,5 @@ for V, s12 in ((%d, %d),):  # (one graph per process: a give-up starts the proce
     r.close()
 print("ok")
 ''' % (ROOT, V, slot12)
-    env = dict(os.environ, FLAME_HIP_PERSIST_FAIL="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", with_hooks(code, persist_fail=1)], env=hooks_env(), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -72,10 +72,10 @@ def test_native_partition_repeats_a_give_up(gpu):
     """VERDICT r04 item 4 / ADVICE r04: a launch of resident tiles that gives up inside a partitioned solve used to be
     FLAME_HIP_ERR_STATE (the halo unpack had rewritten the state, the peers held records of the unfinished solve).  Now
     flame_hip_part_sync rolls every part back to the snapshot in front of the queued solves and repeats them by launches:
-    FLAME_HIP_PERSIST_FAIL makes every resident launch report a give-up; every result must still be the oracle's."""
-    env = dict(os.environ, FLAME_HIP_PERSIST_FAIL="1")
-    out = subprocess.run([sys.executable, "-c", CODE.replace("EXPECT_RECOVERED", "2")], cwd=ROOT, capture_output=True, text=True,
-                         timeout=900, env=env)
+    the hooks library's persist_fail makes every resident launch report a give-up; every result must still be the oracle's."""
+    from tests.util import hooks_env, with_hooks
+    out = subprocess.run([sys.executable, "-c", with_hooks(CODE.replace("EXPECT_RECOVERED", "2"), persist_fail=1)], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900, env=hooks_env())
     assert out.returncode == 0 and "native partition ok" in out.stdout, out.stdout[-3000:] + out.stderr[-5000:]
     import re
     n = int(re.search(r"solves repeated in all: (\d+)", out.stdout).group(1))

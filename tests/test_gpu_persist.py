@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from flame_ros_amd.regularizer import GraphRegularizer, default_params
-from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params
+from tests.util import assert_bit_equal, graphgen, hooks_env, make_oracle, oracle_params, with_hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +70,7 @@ def test_resident_tiles_not_taken_beyond_one_tile_per_cu(gpu):
 
 
 def test_a_resident_solve_that_gives_up_is_repeated_by_launches(gpu):
-    """FLAME_HIP_PERSIST_FAIL makes the library treat every launch of resident tiles as failed (what a time-out
+    """The hooks library's persist_fail makes the library treat every launch of resident tiles as failed (what a time-out
     raises): the solve is repeated by ordinary launches from its untouched source buffers -- through flame_hip_sync
     (download) and through frame_results, on the first solve of a frame and on a later solve of a resident graph -- with
     the oracle's bits; the process then sits out 16 solves before it tries resident tiles again."""
@@ -101,7 +101,7 @@ for k in range(16):  # the back-off: launches, no further give-up
     o.solve(oparams(), 12); r.step(p, 12, sync=False)
     assert r.info("persist_used") == 0, k
 o.solve(oparams(), 12); r.step(p, 12, sync=False)
-assert r.info("persist_used") == 1  # (tried again; FLAME_HIP_PERSIST_FAIL fails it again)
+assert r.info("persist_used") == 1  # (tried again; the hook fails it again)
 x = r.download()[0]
 assert r.info("persist_recovered") == 2 and r.info("persist_gave_up") == 2
 assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)), "resident graph, after the back-off"
@@ -131,8 +131,7 @@ for via, rescale in (("sync", 0), ("frame_results", 0), ("frame_results", 1)):
     r.close()
 print("recovered ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FLAME_HIP_PERSIST_FAIL="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", with_hooks(code, persist_fail=1)], env=hooks_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "recovered ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
@@ -410,13 +409,13 @@ x = r.download()[0]
 assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32))
 print("queue ok")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_PERSIST_FAIL="1"), capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", with_hooks(code, persist_fail=1)], env=hooks_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "queue ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("stall_us,gives_up", [(100, 0), (3000, 1)])
 def test_a_really_late_tile(gpu, stall_us, gives_up):
-    """The time-out path with a REAL late tile, not a forced error word (FLAME_HIP_PERSIST_STALL_US: tile 0 sleeps in front
+    """The time-out path with a REAL late tile, not a forced error word (test hook persist_stall_us: tile 0 sleeps in front
     of its second round).  Late by less than the bound (0.5 ms): its neighbours wait, nothing gives up.  Late by more: their
     polls run out of time, the launch gives up within the bound, the queue of solves
     -- two of them, nobody looked in between -- is repeated by launches.  The oracle's bits both ways."""
@@ -424,7 +423,8 @@ def test_a_really_late_tile(gpu, stall_us, gives_up):
     from flame_ros_amd import lib as _lib
     with GraphRegularizer.empty(device=0) as probe:
         if not probe.info("stall_hook_build"):
-            pytest.skip("needs the debug build (tools/exp/build_variant.sh stall -DFLAME_PERSIST_STALL_HOOK=1, FLAME_HIP_LIB=...): "
+            pytest.skip("needs the debug kernels (tools/exp/build_variant.sh stall -DFLAME_PERSIST_STALL_HOOK=1; FLAME_HIP_LIB=that library "
+                        "FLAME_HIP_HOOKS_IN_LIB=1): "
                         "the hook costs the product kernels 1.7-3 %; its runs are in profiles/r05_persist_guards.txt")
     code = r'''
 import numpy as np, sys, time
@@ -436,7 +436,7 @@ from oracle.cbind import default_params as oparams
 g, _ = graphgen.named("5k")
 p = default_params()
 o = COracle(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt)
-r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0)
+r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, persist_timeout_us=500)  # (the bound a handle reaches once it has measured a round; a first launch has 4 ms)
 t0 = time.perf_counter()
 for n in (60, 45):
     r.step(p, n, sync=False); o.solve(oparams(), n)
@@ -451,7 +451,7 @@ for a, b, nm in ((x, o.x, "x"), (w1, o.w1, "w1"), (w2, o.w2, "w2"), (q, o.q, "q"
 assert ms < 200.0   # bounded either way (first import / plan included)
 print("late tile ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), stall_us, gives_up, gives_up)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_PERSIST_STALL_US=str(stall_us), FLAME_HIP_PERSIST_TIMEOUT_US="500"),  # (the bound a handle reaches once it has measured a round; a first launch has 4 ms)
+    out = subprocess.run([sys.executable, "-c", with_hooks(code, persist_stall_us=stall_us)], env=hooks_env(FLAME_HIP_HOOKS_IN_LIB="1"),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "late tile ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     _record(out.stdout.strip().splitlines()[0])

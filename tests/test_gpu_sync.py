@@ -8,7 +8,7 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_
 from oracle import COracle
 from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync, triangles as oracle_triangles, TriParams as OTri
 from tests.test_graph_sync import features
-from tests.util import assert_bit_equal, graphgen, oracle_params
+from tests.util import assert_bit_equal, graphgen, hooks_env, oracle_params, with_hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -145,7 +145,7 @@ def test_mispredicted_edge_count_on_a_growing_small_frame(gpu):
     early -- the stages behind the launch must then run on a valid (empty) plan, not on the previous frame's tables or,
     when the frame is larger than any before it on the handle, on arrays that were never written.  Frames grow from
     1.0 k to 1.9 k vertices and alternate between disks and meshes with holes, so every other prediction fails on
-    arrays that have just been re-allocated; FLAME_HIP_FILL_ALLOC fills new allocations with 0xff (out-of-range
+    arrays that have just been re-allocated; the hooks library's fill_alloc fills new allocations with 0xff (out-of-range
     indices wherever something reads what it should not).  Every frame: the oracle's edges and bits."""
     import os, subprocess, sys
     code = r'''
@@ -175,7 +175,7 @@ for k in range(14):
 r.close()
 print("frames ok, planned by one launch:", mini)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FLAME_HIP_FILL_ALLOC="255"), capture_output=True,
+    out = subprocess.run([sys.executable, "-c", with_hooks(code, fill_alloc=255)], env=hooks_env(), capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0 and "frames ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 

@@ -1,4 +1,7 @@
 """Shared helpers of the test-suite (tests may use oracle/; the product may not)."""
+import os
+import re
+
 import numpy as np
 
 from flame_ros_amd import graphgen
@@ -36,4 +39,27 @@ def random_state(g, seed):
     return {k: v.astype(np.float32) for k, v in st.items()}
 
 
-__all__ = ["graphgen", "oracle_params", "bits", "assert_bit_equal", "make_oracle", "random_state"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Fault injection lives in a library of its own (flame_ros_amd/build.py: flame_hip.cpp with -DFLAME_HIP_TEST_HOOKS=1); the
+# product library has no such switch.  A test that needs it runs its scenario in a child process on that library ...
+HOOKS_LIB = os.path.join(ROOT, "flame_ros_amd", "libflame_hip_hooks.so")
+
+
+def hooks_env(**extra):
+    """Environment of a child process that loads the hooks library instead of the product's (FLAME_HIP_LIB is the loader's
+    -- flame_ros_amd/lib.py -- not the library's: the library reads no environment variable).  FLAME_HIP_HOOKS_IN_LIB=1: the
+    library FLAME_HIP_LIB already names is a variant build with the hooks in it (tools/exp/build_variant.sh)."""
+    lib = os.environ.get("FLAME_HIP_LIB") if os.environ.get("FLAME_HIP_HOOKS_IN_LIB") else HOOKS_LIB
+    return dict(os.environ, FLAME_HIP_LIB=lib, **extra)
+
+
+def with_hooks(code, **hooks):
+    """... and switches the hooks on right behind its first import of the package (flame_hip_test_hook, process-wide)."""
+    pre = "from flame_ros_amd import lib as _hl\n" + "".join(
+        "assert _hl.load().flame_hip_test_hook(%r, %d) == 0\n" % (k.encode(), int(v)) for k, v in hooks.items())
+    m = re.search(r"^from flame_ros_amd import .*\n", code, re.M)
+    assert m, "no import of the package in the child's code"
+    return code[:m.end()] + pre + code[m.end():]
+
+
+__all__ = ["ROOT", "HOOKS_LIB", "hooks_env", "with_hooks", "graphgen", "oracle_params", "bits", "assert_bit_equal", "make_oracle", "random_state"]

@@ -5,7 +5,7 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params
 p = default_params()
 g, _ = graphgen.named("tum")
 for own, depth in ((75, 5), (50, 5), (38, 5), (50, 4)):
-    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_own=own, tile_depth=depth, persist=1)
+    r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, tile_own=own, tile_depth=depth, persist=1, persist_prof=1)
     for _ in range(3): r.step(p, 200)
     ms, _l = r.last_solve_ms()
     v = [r.info("persist_prof_%d" % i) for i in range(5)]
