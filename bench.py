@@ -75,7 +75,7 @@ def kernel_src_sha():
 
 
 def lds_block(r, us_per_iteration, iters_per_launch, counters=None, iterate_frac=None, measured_hbm_frac=None,
-              contract_frac=None):
+              contract_frac=None, valu_counters=None):
     """The on-chip roofline of a tile-path line: the LDS issue floor of the vertices / edges the
     tiles OWN (from the plan, priced with the guide's LDS table, slowest CU) over the measured shader cycles per
     iteration -- a fraction that cannot exceed 1 -- with the counters' redundancy / busy / conflict shares beside it."""
@@ -85,7 +85,7 @@ def lds_block(r, us_per_iteration, iters_per_launch, counters=None, iterate_frac
     if not fl:
         return None
     blk = S.lds_roofline(fl, us_per_iteration, r.info("clock_khz") / 1e3, iters_per_launch, counters, iterate_frac,
-                         measured_hbm_frac, contract_frac)
+                         measured_hbm_frac, contract_frac, valu_counters)
     blk["lds_floor"] = fl
     return blk
 
@@ -103,13 +103,16 @@ def profiled_counters(workload, kernel):
         except Exception:
             continue
         rec = {"source": os.path.relpath(f, ROOT), "kernel_src_sha": d.get("kernel_src_sha"), "bytes_per_launch": None,
-               "lds": None}
+               "lds": None, "valu": None}
         for k, v in d.get("traffic_bytes_per_launch", {}).items():
             if kernel in k:
                 rec["bytes_per_launch"] = v
         for k, v in d.get("lds_per_launch", {}).items():
             if kernel in k:
                 rec["lds"] = v
+        for k, v in d.get("valu_per_launch", {}).items():
+            if kernel in k:
+                rec["valu"] = v
         best = rec
     if best and best["kernel_src_sha"] != kernel_src_sha():
         return {"source": best["source"], "stale": True, "bytes_per_launch": None, "lds": None}
@@ -314,7 +317,7 @@ def small_graphs(device):
 
 
 def library_partition(rank, world, device, uid, barrier, max_over_ranks, workload=None, parts_per_rank=1, halo_depth=16,
-                      steps=5, pipeline=None):
+                      steps=5, pipeline=None, transport=0):
     """BASELINE configs 4 / 5 through the LIBRARY's partition mode (include/flame_hip.h flame_hip_comm_* / flame_hip_part_*,
     csrc/part.cpp: RCB cut, resident tiles per part, ncclSend / ncclRecv halo records on the solve stream) -- not the torch
     harness: ONE graph strong-scaled over world x parts_per_rank subdomains.  50 k vertices below 8 subdomains, 200 k from
@@ -337,6 +340,9 @@ def library_partition(rank, world, device, uid, barrier, max_over_ranks, workloa
                                  halo_depth=halo_depth) as ps:
             if pipeline is not None:
                 ps.set_option("pipeline", int(pipeline))
+            if transport:  # r06: the peer transport (records written straight into the receivers' inboxes, 2 launches per exchange)
+                ps.set_option("transport", int(transport))
+            out["transport"] = "peer" if transport else "rccl"
             # parity first (fresh state): the partitioned solve against one handle on the whole graph
             ps.step(p, iters)
             x, w1, w2, q = ps.gather_solution()
@@ -701,11 +707,15 @@ def main():
                         "note": "(84E+60V) x iterations per launch / launch duration / 8 TB/s: SURVEY 8d's figure; not a bound for "
                                 "a kernel whose state stays in LDS (may exceed 1)"}
             blk = lds_block(r, launch_us / iters_per_launch, iters_per_launch, (tr or {}).get("lds") if tr and not tr.get("stale") else None,
-                            rl.get("iterate_frac"), rl.get("measured_hbm_frac"), contract["frac"])
+                            rl.get("iterate_frac"), rl.get("measured_hbm_frac"), contract["frac"],
+                            (tr or {}).get("valu") if tr and not tr.get("stale") else None)
             if blk:
                 rl.update(blk)
                 rl["contract"] = contract
-                rl["note"] = ("bound = lds: frac = LDS issue floor of the slowest CU (2 ds_read_b128 + 2 ds_write_b96 per 64 own "
+                rl["note"] = ("bound = the larger of two on-chip issue floors of the work the tiles OWN (r06): lds_frac / valu_frac beside frac; "
+                              "valu floor = 16 (phase D, per 64 own edges) / 16 + 2 per slot (phase P, per 64 own vertices) wave-instructions "
+                              "priced 4 cycles each over 4 SIMDs; contract.frac = SURVEY 8d's HBM figure, NOT a bound: the "
+                              "state is LDS-resident.  lds: frac = LDS issue floor of the slowest CU (2 ds_read_b128 + 2 ds_write_b96 per 64 own "
                               "edges, max-degree slot reads + 1 store per 64 own vertices, priced 4 / 10 cycles: MI355X guide LDS "
                               "table) / measured shader cycles per iteration (HIP events on the solve stream).  work_redundancy = "
                               "executed / useful LDS wave-instructions (halo rings, padding lanes); lds_busy = SQ_LDS_IDX_ACTIVE per "
@@ -781,6 +791,16 @@ def main():
                                          if k in dh}
         except Exception as e:  # noqa: BLE001
             lib_part["halo_depth_x2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        try:  # r06: the same cut through the PEER transport (two launches per exchange, no ncclGroup): RCCL's figures stay beside it
+            box4 = [fpart.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box4, src=0)
+            pt = library_partition(rank, world, local_rank, box4[0], _bar, _max, workload=lib_part.get("workload"),
+                                   halo_depth=args.halo_depth, steps=3, transport=1)
+            lib_part["peer_transport"] = {k: pt[k] for k in ("transport", "halo_depth", "iterations_per_s", "us_per_iteration", "exchanges_per_step",
+                                                             "exchange_us", "exchange_share", "bit_exact_vs_one_gpu", "resident_tiles")
+                                          if k in pt}
+        except Exception as e:  # noqa: BLE001
+            lib_part["peer_transport"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         try:  # the same graph over-decomposed, two parts per rank: the records of part 0 travel while part 1 iterates
             box2 = [fpart.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box2, src=0)

@@ -518,6 +518,7 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
     }
     g->opt.lds_bytes = (int64_t)prop.sharedMemPerBlock > 0 ? (int64_t)prop.sharedMemPerBlock : 64 * 1024;
     g->num_cus = prop.multiProcessorCount;
+    g->opt.num_cus = g->num_cus;
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
@@ -1662,12 +1663,21 @@ static PersistLease& persist_lease(int device) {
   static PersistLease leases[64];
   return leases[(unsigned)device & 63];
 }
-static bool persist_lease_take(flame_hip_graph* g, hipStream_t s) {
+// wait_for_holder: a FAT plan -- halo depth 1 or 2, sized for ONE resident launch -- that finds the lease taken
+// would otherwise run as one 256-workgroup launch per 1-2 iterations, several times slower than waiting for the other
+// handle's solve to end; so it waits for the holder's end event (host side, bounded by that solve) and takes the lease then
+static bool persist_lease_take(flame_hip_graph* g, hipStream_t s, bool wait_for_holder = false) {
   PersistLease& L = persist_lease(g->device);
-  std::lock_guard<std::mutex> lk(L.m);
+  std::unique_lock<std::mutex> lk(L.m);
   if (L.backoff > 0) { --L.backoff; return false; }
-  if (L.holder && L.holder != g && (!L.recorded || (L.holder_stream != s && hipEventQuery(L.holder_done) != hipSuccess)))
-    return false;
+  if (L.holder && L.holder != g && (!L.recorded || (L.holder_stream != s && hipEventQuery(L.holder_done) != hipSuccess))) {
+    if (!wait_for_holder || !L.recorded || !L.holder_done) return false;
+    hipEvent_t ev = L.holder_done;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);  // (the event belongs to a live handle of this process: handles outlive their solves)
+    lk.lock();
+    if (e != hipSuccess || (L.holder && L.holder != g && hipEventQuery(L.holder_done) != hipSuccess)) return false;
+  }
   L.holder = g;
   L.holder_done = g->ev1;
   L.holder_stream = s;
@@ -1792,7 +1802,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
     a.prof = g->prof;
     a.slot12 = P.tile_slot12 ? 1 : 0;
     a.fat = P.tile_fat ? 1 : 0;
-    if (persist_applies(g, num_iters) && persist_lease_take(g, s)) {
+    if (persist_applies(g, num_iters) && persist_lease_take(g, s, P.tile_fat && P.tile_depth <= 2)) {
       PersistBufs& x = g->xp;
       int rc;
       if (!g->persist_err) {
@@ -2505,6 +2515,27 @@ int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* st
   HIPCHK(order_after_state(g, s));
   HIPCHK(launch_halo_unpack(s, g->n_recv_v, g->n_recv_e, g->halo_recv_v, g->halo_recv_e,
                             (const float*)recv_buf_dev, g->A[g->cur], g->B[g->cur], g->q[g->cur]));
+  g->state_serial++;
+  return 0;
+}
+
+int flame_hip_halo_view_get(flame_hip_graph* g, void* stream, flame_hip_halo_view* out) {
+  int rc = require_device(g);
+  if (rc) return rc;
+  if (!out) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(g->device));
+  hipStream_t s = stream ? (hipStream_t)stream : g->stream;
+  HIPCHK(order_after_state(g, s));
+  for (int b = 0; b < 2; ++b) { out->A[b] = g->A[b]; out->B[b] = g->B[b]; out->q[b] = g->q[b]; }
+  out->cur = g->cur;
+  out->n_send_v = g->n_send_v; out->n_send_e = g->n_send_e; out->n_recv_v = g->n_recv_v; out->n_recv_e = g->n_recv_e;
+  out->send_v = g->halo_send_v; out->send_e = g->halo_send_e; out->recv_v = g->halo_recv_v; out->recv_e = g->halo_recv_e;
+  return 0;
+}
+
+int flame_hip_halo_written(flame_hip_graph* g) {
+  int rc = require_device(g);
+  if (rc) return rc;
   g->state_serial++;
   return 0;
 }

@@ -90,6 +90,40 @@ hipError_t launch_halo_pack(hipStream_t s, int32_t nv, int32_t ne, const int32_t
 hipError_t launch_halo_unpack(hipStream_t s, int32_t nv, int32_t ne, const int32_t* vidx,
                               const int32_t* eidx, const float* in, float4* A, float4* B, float4* q);
 
+// ---- r06, the PEER transport of the partition mode (csrc/part.cpp): halo records written straight into the receiving part's
+// inbox -- memory of the same GPU, of another GPU of the node (peer access) or of another process (hipIpc) -- instead of
+// pack -> ncclSend / ncclRecv -> unpack.  One push and one pull launch per exchange for ALL the parts of a rank.  A segment =
+// the vertex (kind 0, kPeerVRec floats each) or edge (kind 1, kPeerERec floats) records of one message; a message's flag word, in the
+// RECEIVER's inbox, takes the exchange's epoch once every record of the exchange has left (release, system scope); the pull
+// waits for the flags of its segments (bounded: timeout_ticks x 10 ns, then *err = 1) before it reads.  Inboxes are uncached
+// memory, two record buffers by epoch parity: a sender can only be one exchange ahead of a receiver (the relation is symmetric).
+constexpr int kPeerVRec = 8, kPeerERec = 4;  // floats per vertex / edge record of the peer transport (whole 16-byte words)
+struct HaloSegDev {
+  const int32_t* idx;  // local vertex / edge ids of the part, `count` of them
+  float* buf[2];       // push: the segment in the receiver's inbox; pull: in this rank's own inbox ([epoch & 1])
+  int32_t* flag;       // the message's flag word (receiver's inbox)
+  const int32_t* didx; // push, the receiving part is a part of THIS rank: the records go straight into its state arrays at
+                       // these local ids (no inbox, no flag, no pull segment: one stream orders the parts of a rank); else null
+  int32_t dpart;
+  int32_t first;       // thread range [first, first + count) of the launch
+  int32_t count;
+  int32_t kind;        // 0 vertex records, 1 edge records
+  int32_t part;        // local part (index into HaloPartDev)
+};
+struct HaloPartDev { float4* A[2]; float4* B[2]; float4* q[2]; };
+struct HaloXArgs {
+  const HaloSegDev* segs;
+  const HaloPartDev* parts;
+  int32_t nsegs, total;   // total = threads that carry a record
+  uint32_t cur_mask;      // bit i: part i's current state buffer
+  int32_t epoch;
+  int32_t* counter;       // push: blocks done (device word, zero between launches)
+  int32_t* err;           // pull: set when a wait timed out
+  int32_t timeout_ticks;
+};
+hipError_t launch_halo_push(hipStream_t s, const HaloXArgs& a);
+hipError_t launch_halo_pull(hipStream_t s, const HaloXArgs& a);
+
 // ---- per-triangle stage ----
 struct TriParamsDev {
   int32_t do_oblique, do_edge, do_idepth;

@@ -1616,7 +1616,107 @@ __global__ __launch_bounds__(256) void k_halo_unpack(int32_t nv, int32_t ne,
   }
 }
 
+// ---- peer transport (kernels.h HaloXArgs) ----
+__device__ __forceinline__ int halo_seg_of(const HaloSegDev* segs, int nsegs, int t) {
+  int lo = 0, hi = nsegs - 1;  // the last segment whose first <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].first <= t) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_halo_push(HaloXArgs a) {
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < a.total) {
+    const HaloSegDev& S = a.segs[halo_seg_of(a.segs, a.nsegs, t)];
+    const HaloPartDev& P = a.parts[S.part];
+    const int c = (a.cur_mask >> S.part) & 1u, r = t - S.first;
+    // records of whole 16-byte words (vertex 2, edge 1: kPeerVRec / kPeerERec floats): the inboxes are UNCACHED memory, where a
+    // 4- or 8-byte store is a memory transaction of its own -- the packed 24 / 12-byte records of the RCCL path took 88 us per
+    // exchange of 0.7 MB this way (profiles/r06_peer_transport_ab.txt)
+    float4* out = reinterpret_cast<float4*>(S.buf[a.epoch & 1]);
+    if (S.didx) {  // a part of this rank: from state to state (what it sends it owns, what the other receives is halo: disjoint)
+      const HaloPartDev& D = a.parts[S.dpart];
+      const int dc = (a.cur_mask >> S.dpart) & 1u;
+      if (S.kind == 0) {
+        const int32_t v = S.idx[r], u = S.didx[r];
+        const float4 x = P.A[c][v], b = P.B[c][v];
+        D.A[dc][u].x = x.x; D.A[dc][u].y = x.y; D.A[dc][u].z = x.z;  // (z and the data weight are the receiver's own constants)
+        D.B[dc][u].x = b.x; D.B[dc][u].y = b.y; D.B[dc][u].z = b.z;
+      } else {
+        const float4 qq = P.q[c][S.idx[r]];
+        D.q[dc][S.didx[r]] = make_float4(qq.x, qq.y, qq.z, 0.f);
+      }
+    } else if (S.kind == 0) {
+      const int32_t v = S.idx[r];
+      const float4 x = P.A[c][v], b = P.B[c][v];
+      out[2 * (size_t)r] = make_float4(x.x, x.y, x.z, b.x);
+      out[2 * (size_t)r + 1] = make_float4(b.y, b.z, 0.f, 0.f);
+    } else {
+      const float4 qq = P.q[c][S.idx[r]];
+      out[r] = make_float4(qq.x, qq.y, qq.z, 0.f);
+    }
+  }
+  // Every record of this block has been ACKNOWLEDGED before the block counts itself done (an inbox that other ranks read while
+  // this kernel runs is uncached memory: an acknowledged store is in memory; the single-process inbox is ordered by the kernel
+  // boundary anyway); the LAST block raises the flags behind ONE system-scope fence.  (A system- or agent-scope release per
+  // block is an L2 write-back each -- buffer_wbl2 -- and cost 76 us over the 755 blocks of a 4 MB exchange: r06_peer_trace.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(a.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (s_last) {
+    __threadfence_system();
+    for (int s = threadIdx.x; s < a.nsegs; s += 256)
+      if (a.segs[s].flag) __hip_atomic_store(a.segs[s].flag, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(a.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_halo_pull(HaloXArgs a) {
+  // every block waits for every incoming message of the rank (a few dozen words at most), then unpacks its records
+  const unsigned long long w0 = wall_clock64();
+  for (int s = threadIdx.x; s < a.nsegs; s += 256) {
+    while (__hip_atomic_load(a.segs[s].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.epoch) {
+      if (wall_clock64() - w0 > (unsigned long long)a.timeout_ticks) { *a.err = 1; break; }  // never hang: the host reports it
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (one acquire per block behind the polls, not one cache invalidate per poll)
+  __syncthreads();
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.total) return;
+  const HaloSegDev& S = a.segs[halo_seg_of(a.segs, a.nsegs, t)];
+  const HaloPartDev& P = a.parts[S.part];
+  const int c = (a.cur_mask >> S.part) & 1u, r = t - S.first;
+  const float4* in = reinterpret_cast<const float4*>(S.buf[a.epoch & 1]);
+  if (S.kind == 0) {
+    const int32_t v = S.idx[r];
+    const float4 r0 = in[2 * (size_t)r], r1 = in[2 * (size_t)r + 1];
+    // (the data term z (A.w) and the data weight (B.w) are constants the receiver already holds)
+    P.A[c][v].x = r0.x; P.A[c][v].y = r0.y; P.A[c][v].z = r0.z;
+    P.B[c][v].x = r0.w; P.B[c][v].y = r1.x; P.B[c][v].z = r1.y;
+  } else {
+    const float4 t4 = in[r];
+    P.q[c][S.idx[r]] = make_float4(t4.x, t4.y, t4.z, 0.0f);
+  }
+}
+
 }  // namespace
+
+hipError_t launch_halo_push(hipStream_t s, const HaloXArgs& a) {
+  if (a.nsegs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_push, dim3((unsigned)std::max(1, (a.total + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_halo_pull(hipStream_t s, const HaloXArgs& a) {
+  if (a.nsegs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_halo_pull, dim3((unsigned)std::max(1, (a.total + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_graph_filter(hipStream_t s, int32_t V, int32_t kind, const int32_t* grow,
                                const int32_t* ginc, const int2* eij, float4* A, float4* B, float* tmp) {

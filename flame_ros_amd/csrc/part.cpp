@@ -8,7 +8,9 @@
 // scheme holds for this file.
 //
 // The reference has no counterpart (single process, reference src/flame_offline_tum.cc:403-563); the contract is
-// BASELINE.json configs 4 / 5.  Layering: this file uses only the public C ABI of the graph handles.
+// BASELINE.json configs 4 / 5.  Layering: this file uses only the public C ABI of the graph handles -- plus, for the r06 PEER
+// transport (two launches per exchange, records written straight into the receivers' inboxes: exchange_peer() below), the two
+// transport kernels of kernels.h.
 //
 // RCCL is loaded with dlopen at the first use (librccl.so.1): the solver library itself keeps no link-time dependency
 // on it, and a process that already holds an RCCL (PyTorch) shares that copy.
@@ -29,6 +31,11 @@
 #include <vector>
 
 #include "../../include/flame_hip.h"
+#include "kernels.h"
+
+using flamehip::HaloPartDev;
+using flamehip::HaloSegDev;
+using flamehip::HaloXArgs;
 
 namespace {
 
@@ -210,6 +217,39 @@ struct P2P {
 
 constexpr int kVRec = 6, kERec = 3;  // floats per vertex / edge record (flame_hip_halo_pack)
 
+// what EVERY part (not only this rank's) receives, peers ascending: 2 counts per peer {vertex records, edge records}.  Every
+// rank derives it from the whole graph, so a sender knows where its records belong in any receiver's inbox.
+struct PartIO {
+  std::vector<int> peers;
+  std::vector<int32_t> recv_cnt;
+};
+
+// ---- peer transport: inboxes.  One block of UNCACHED device memory per rank: [flag words: one per (local part, peer)]
+// [record buffer, parity 0: the parts' receive buffers in the pack layout][the same, parity 1]; every piece 256-byte aligned.
+constexpr size_t kInboxAlign = 256;
+inline size_t align_up(size_t x) { return (x + kInboxAlign - 1) & ~(kInboxAlign - 1); }
+struct InboxLayout {
+  std::vector<size_t> flag_off;     // per local part: byte offset of its first flag word
+  std::vector<size_t> rbuf_off[2];  // per local part, per parity: byte offset of its record buffer
+  size_t bytes = 0;
+};
+// Freed uncached blocks are never handed back to the runtime (flame_hip.cpp UncachedPool: a later ordinary hipMalloc that
+// recycles one misbehaves on ROCm 7.2): inboxes wait here for the next partition of the process.
+struct InboxPool {
+  std::mutex m;
+  struct Block { void* p; size_t bytes; int device; };
+  std::vector<Block> free_blocks;
+};
+InboxPool& inbox_pool() { static InboxPool p; return p; }
+
+struct PeerBlob {  // FLAME_HIP_PEER_BLOB_BYTES = 128
+  uint64_t magic, pid, ptr, bytes;
+  hipIpcMemHandle_t handle;  // 64 bytes
+  char pad[128 - 4 * 8 - sizeof(hipIpcMemHandle_t)];
+};
+static_assert(sizeof(PeerBlob) == FLAME_HIP_PEER_BLOB_BYTES, "blob layout");
+constexpr uint64_t kBlobMagic = 0x464c414d45504552ull;  // "FLAMEPER"
+
 }  // namespace
 
 struct flame_hip_comm {
@@ -222,6 +262,7 @@ struct flame_hip_comm {
   double* red = nullptr;  // device: 2 doubles (cost reduction)
   int32_t* flag = nullptr;  // device: the ranks' "a launch of resident tiles gave up" word (flame_hip_part_sync)
   int rccl_ranks = 0;       // ncclCommCount
+  bool local = false;       // flame_hip_comm_create_local: no RCCL (peer transport only)
   bool shared_gpu = false;  // two ranks of this communicator sit on one GPU: their parts solve by launches (resident
                             // tiles assume the whole chip; dist.py / bench.py guard the same case)
   std::vector<flame_hip_part*> parts;  // the parts built on this communicator (destroyed first, or detached)
@@ -243,6 +284,9 @@ struct flame_hip_part {
   struct Call { flame_hip_params p; int32_t n; };
   std::vector<Call> txn;
   int txn_rings = 0;
+  int64_t txn_exchanges = 0;  // `exchanges` in front of the queued solves (a roll-back discards the ones since)
+  int txn_timed = 0;
+  int64_t exchanges_discarded = 0;  // exchanges of solves that were rolled back and repeated (info "exchanges_discarded")
   int64_t recovered = 0;
   // option "time_exchanges": HIP events around every exchange (pack -> group of sends / receives -> unpack) of the solves
   // that follow, up to kMaxTimed of them; info "exchange_ns" = their mean once the stream has been synchronised
@@ -258,6 +302,28 @@ struct flame_hip_part {
   bool time_exchanges = false;
   std::vector<hipEvent_t> tev;  // 2 per timed exchange
   int timed = 0;
+  // r06 peer transport (option "transport" 1)
+  std::vector<PartIO> io;       // every part of the partition
+  int transport = 0;
+  struct Peer {
+    char* inbox = nullptr;      // this rank's
+    bool inbox_uncached = false;  // ... in uncached memory (ranks in other processes / on other GPUs write into it while kernels
+                                  // of this rank run); a partition whose ranks all sit in ONE process on one stream (world 1)
+                                  // takes ordinary device memory: kernel boundaries order its exchanges, and uncached memory takes
+                                  // 16-byte stores at ~57 GB/s (76 us for the 4.3 MB of a 50 k graph cut in two at halo depth 48)
+    size_t inbox_bytes = 0;
+    std::vector<char*> base;    // every rank's inbox in THIS process' address space (own, same-process pointer, or hipIpc mapping)
+    std::vector<void*> opened;  // hipIpcOpenMemHandle mappings to close
+    bool connected = false, tables = false;
+    HaloSegDev* push_dev = nullptr;
+    HaloSegDev* pull_dev = nullptr;
+    HaloPartDev* parts_dev = nullptr;
+    std::vector<HaloPartDev> parts_host;
+    int n_push = 0, n_pull = 0, total_push = 0, total_pull = 0;
+    int32_t* words = nullptr;   // device: [0] push counter, [1] pull error
+    int32_t epoch = 0;          // exchanges through this transport so far (never rolls back: the flags only grow)
+    int64_t timeouts = 0;
+  } px;
 };
 
 namespace {
@@ -298,6 +364,22 @@ int plan_parts(flame_hip_part* P, const float* pos, const int32_t* edges) {
       if (o != d && (!m[(size_t)o].v.empty() || !m[(size_t)o].e.empty())) {
         m[(size_t)o].src = o; m[(size_t)o].dst = d;
         to[(size_t)d].push_back(std::move(m[(size_t)o]));
+      }
+  }
+  // what every part receives, peers ascending (the peer transport's inbox layout of ANY rank follows from it)
+  P->io.assign((size_t)nparts, PartIO());
+  {
+    std::vector<std::vector<char>> peer((size_t)nparts, std::vector<char>((size_t)nparts, 0));
+    for (int d = 0; d < nparts; ++d)
+      for (const Message& m : to[(size_t)d]) { peer[(size_t)d][(size_t)m.src] = 1; peer[(size_t)m.src][(size_t)d] = 1; }
+    for (int d = 0; d < nparts; ++d)
+      for (int p = 0; p < nparts; ++p) {
+        if (!peer[(size_t)d][(size_t)p]) continue;
+        const Message* in = nullptr;
+        for (const Message& m : to[(size_t)d]) if (m.src == p) in = &m;
+        P->io[(size_t)d].peers.push_back(p);
+        P->io[(size_t)d].recv_cnt.push_back(in ? (int32_t)in->v.size() : 0);
+        P->io[(size_t)d].recv_cnt.push_back(in ? (int32_t)in->e.size() : 0);
       }
   }
   P->parts.clear();
@@ -367,9 +449,281 @@ void build_ops(flame_hip_part* P) {
   P->ops.insert(P->ops.end(), recvs.begin(), recvs.end());
 }
 
+// ---------------------------------------------------------------- peer transport (r06)
+// The inbox of rank r, as every rank computes it (PartIO of its parts).
+InboxLayout inbox_layout(const flame_hip_part* P, int r) {
+  InboxLayout L;
+  size_t off = 0;
+  for (int i = 0; i < P->k; ++i) {
+    L.flag_off.push_back(off);
+    off += sizeof(int32_t) * P->io[(size_t)(r * P->k + i)].peers.size();
+  }
+  off = align_up(std::max<size_t>(off, 4));
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < P->k; ++i) {
+      const PartIO& io = P->io[(size_t)(r * P->k + i)];
+      size_t fl = 0;
+      for (size_t j = 0; j < io.peers.size(); ++j) fl += (size_t)flamehip::kPeerVRec * (size_t)io.recv_cnt[2 * j] + (size_t)flamehip::kPeerERec * (size_t)io.recv_cnt[2 * j + 1];
+      L.rbuf_off[b].push_back(off);
+      off += align_up(sizeof(float) * std::max<size_t>(fl, 1));
+    }
+  L.bytes = off;
+  return L;
+}
+
+// where the records of message src -> dst (kind 0 vertex / 1 edge) lie inside dst's record buffer, in floats (the pack /
+// unpack order: all vertex records, peers in order, then all edge records -- in the peer transport's 32 / 16-byte records),
+// and the index of src among dst's peers
+bool message_slot(const flame_hip_part* P, int src, int dst, int kind, size_t* off_floats, int* peer_index) {
+  const PartIO& io = P->io[(size_t)dst];
+  size_t v_before = 0, e_before = 0, v_all = 0;
+  int idx = -1;
+  for (size_t j = 0; j < io.peers.size(); ++j) {
+    if (io.peers[j] == src) idx = (int)j;
+    if (idx < 0) { v_before += (size_t)io.recv_cnt[2 * j]; e_before += (size_t)io.recv_cnt[2 * j + 1]; }
+    v_all += (size_t)io.recv_cnt[2 * j];
+  }
+  if (idx < 0) return false;
+  *off_floats = kind == 0 ? (size_t)flamehip::kPeerVRec * v_before : (size_t)flamehip::kPeerVRec * v_all + (size_t)flamehip::kPeerERec * e_before;
+  *peer_index = idx;
+  return true;
+}
+
+void peer_release(flame_hip_part* P) {
+  flame_hip_part::Peer& X = P->px;
+  for (void* p : X.opened) (void)hipIpcCloseMemHandle(p);
+  X.opened.clear();
+  if (X.push_dev) (void)hipFree(X.push_dev);
+  if (X.pull_dev) (void)hipFree(X.pull_dev);
+  if (X.parts_dev) (void)hipFree(X.parts_dev);
+  if (X.words) (void)hipFree(X.words);
+  X.push_dev = X.pull_dev = nullptr; X.parts_dev = nullptr; X.words = nullptr;
+  if (X.inbox && X.inbox_uncached) {
+    std::lock_guard<std::mutex> lk(inbox_pool().m);
+    try { inbox_pool().free_blocks.push_back({X.inbox, X.inbox_bytes, P->device}); } catch (...) {}  // (leaked rather than freed)
+  } else if (X.inbox) {
+    (void)hipFree(X.inbox);
+  }
+  X.inbox = nullptr; X.inbox_bytes = 0; X.base.clear(); X.connected = X.tables = false;
+}
+
+// this rank's inbox, zeroed (flags 0 = nothing has arrived; epochs start at 1)
+int peer_alloc_inbox(flame_hip_part* P) {
+  flame_hip_part::Peer& X = P->px;
+  if (X.inbox) return 0;
+  const size_t want = inbox_layout(P, P->rank).bytes;
+  X.inbox_uncached = P->world > 1;
+  if (!X.inbox_uncached) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
+    HIPCHK(e);
+    X.inbox = (char*)p; X.inbox_bytes = want;
+  } else {
+    std::lock_guard<std::mutex> lk(inbox_pool().m);
+    auto& fb = inbox_pool().free_blocks;
+    for (size_t i = 0; i < fb.size(); ++i)
+      if (fb[i].device == P->device && fb[i].bytes >= want) { X.inbox = (char*)fb[i].p; X.inbox_bytes = fb[i].bytes; fb.erase(fb.begin() + (long)i); break; }
+  }
+  if (!X.inbox) {
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, want, hipDeviceMallocUncached);
+    if (e == hipErrorOutOfMemory) return FLAME_HIP_ERR_ALLOC;
+    HIPCHK(e);
+    X.inbox = (char*)p; X.inbox_bytes = want;
+  }
+  HIPCHK(hipMemsetAsync(X.inbox, 0, X.inbox_bytes, P->comm->stream));
+  HIPCHK(hipStreamSynchronize(P->comm->stream));
+  try { X.base.assign((size_t)P->world, nullptr); } catch (...) { return FLAME_HIP_ERR_ALLOC; }
+  X.base[(size_t)P->rank] = X.inbox;
+  if (P->world == 1) X.connected = true;
+  return 0;
+}
+
+int peer_make_blob(flame_hip_part* P, PeerBlob* b) {
+  int rc = peer_alloc_inbox(P);
+  if (rc) return rc;
+  std::memset(b, 0, sizeof(*b));
+  b->magic = kBlobMagic; b->pid = (uint64_t)getpid(); b->ptr = (uint64_t)(uintptr_t)P->px.inbox; b->bytes = P->px.inbox_bytes;
+  HIPCHK(hipIpcGetMemHandle(&b->handle, P->px.inbox));
+  return 0;
+}
+
+int peer_connect(flame_hip_part* P, const PeerBlob* blobs) {
+  flame_hip_part::Peer& X = P->px;
+  int rc = peer_alloc_inbox(P);
+  if (rc) return rc;
+  for (int r = 0; r < P->world; ++r) {
+    if (r == P->rank) continue;
+    const PeerBlob& b = blobs[r];
+    if (b.magic != kBlobMagic || b.bytes < inbox_layout(P, r).bytes) return FLAME_HIP_ERR_ARG;
+    if (b.pid == (uint64_t)getpid()) {  // a rank of this very process (threads, tests): its pointer is ours
+      X.base[(size_t)r] = (char*)(uintptr_t)b.ptr;
+    } else {
+      void* p = nullptr;
+      HIPCHK(hipIpcOpenMemHandle(&p, b.handle, hipIpcMemLazyEnablePeerAccess));
+      try { X.opened.push_back(p); } catch (...) { (void)hipIpcCloseMemHandle(p); return FLAME_HIP_ERR_ALLOC; }
+      X.base[(size_t)r] = (char*)p;
+    }
+  }
+  X.connected = true;
+  X.tables = false;
+  return 0;
+}
+
+// the library's own gathering of the blobs, over the communicator's RCCL (collective)
+int peer_connect_rccl(flame_hip_part* P) {
+  flame_hip_comm* C = P->comm;
+  PeerBlob mine;
+  int rc = peer_make_blob(P, &mine);
+  if (rc) return rc;
+  char* dev = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(PeerBlob) * (size_t)P->world));
+  std::vector<PeerBlob> all((size_t)P->world);
+  hipError_t e = hipMemcpyAsync(dev + sizeof(PeerBlob) * (size_t)P->rank, &mine, sizeof(mine), hipMemcpyHostToDevice, C->stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = rccl().AllGather(dev + sizeof(PeerBlob) * (size_t)P->rank, dev, sizeof(PeerBlob), ncclChar, C->comm, C->stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(all.data(), dev, sizeof(PeerBlob) * (size_t)P->world, hipMemcpyDeviceToHost, C->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+  (void)hipFree(dev);
+  if (r != ncclSuccess) return FLAME_HIP_ERR_RCCL - (int)r;
+  HIPCHK(e);
+  return peer_connect(P, all.data());
+}
+
+// the segment tables of the two transport kernels (device), from the parts' registered lists
+int peer_build_tables(flame_hip_part* P, const std::vector<flame_hip_halo_view>& views) {
+  flame_hip_part::Peer& X = P->px;
+  std::vector<HaloSegDev> push, pull;
+  const InboxLayout mine = inbox_layout(P, P->rank);
+  std::vector<InboxLayout> lay((size_t)P->world);
+  int32_t tp = 0, tl = 0;
+  try {
+    for (int r = 0; r < P->world; ++r) lay[(size_t)r] = inbox_layout(P, r);
+    for (int i = 0; i < P->k; ++i) {
+      const LocalPart& L = P->parts[(size_t)i];
+      const int me = L.sub.part_id;
+      const flame_hip_halo_view& V = views[(size_t)i];
+      size_t sv = 0, se = 0, rv = 0, re = 0;  // running offsets into the part's registered lists (peers in order)
+      for (size_t j = 0; j < L.peers.size(); ++j) {
+        const int p = L.peers[j], pr = p / P->k, pi = p % P->k;
+        const int32_t a = L.send_cnt[2 * j], b = L.send_cnt[2 * j + 1], c = L.recv_cnt[2 * j], d = L.recv_cnt[2 * j + 1];
+        for (int kind = 0; kind < 2; ++kind) {
+          const int32_t n_out = kind == 0 ? a : b, n_in = kind == 0 ? c : d;
+          if (n_out > 0) {  // me -> p: into p's inbox on rank pr
+            size_t off = 0; int pidx = -1;
+            if (!message_slot(P, me, p, kind, &off, &pidx) || !X.base[(size_t)pr]) return FLAME_HIP_ERR_STATE;
+            HaloSegDev s;
+            s.idx = kind == 0 ? V.send_v + sv : V.send_e + se;
+            for (int par = 0; par < 2; ++par) s.buf[par] = reinterpret_cast<float*>(X.base[(size_t)pr] + lay[(size_t)pr].rbuf_off[par][(size_t)pi]) + off;
+            s.flag = reinterpret_cast<int32_t*>(X.base[(size_t)pr] + lay[(size_t)pr].flag_off[(size_t)pi]) + pidx;
+            s.didx = nullptr; s.dpart = 0;
+            if (pr == P->rank) {  // a part of this rank: straight into its state arrays, at ITS registered receive ids
+              const LocalPart& D = P->parts[(size_t)pi];
+              size_t dv = 0, de = 0;
+              for (size_t jj = 0; jj < D.peers.size() && D.peers[jj] != me; ++jj) { dv += (size_t)D.recv_cnt[2 * jj]; de += (size_t)D.recv_cnt[2 * jj + 1]; }
+              s.didx = kind == 0 ? views[(size_t)pi].recv_v + dv : views[(size_t)pi].recv_e + de;
+              s.dpart = pi;
+              s.flag = nullptr;
+            }
+            s.first = tp; s.count = n_out; s.kind = kind; s.part = i;
+            tp += n_out;
+            push.push_back(s);
+          }
+          if (n_in > 0 && pr != P->rank) {  // p -> me from ANOTHER rank: out of this rank's own inbox
+            size_t off = 0; int pidx = -1;
+            if (!message_slot(P, p, me, kind, &off, &pidx)) return FLAME_HIP_ERR_STATE;
+            HaloSegDev s;
+            s.idx = kind == 0 ? V.recv_v + rv : V.recv_e + re;
+            for (int par = 0; par < 2; ++par) s.buf[par] = reinterpret_cast<float*>(X.inbox + mine.rbuf_off[par][(size_t)i]) + off;
+            s.flag = reinterpret_cast<int32_t*>(X.inbox + mine.flag_off[(size_t)i]) + pidx;
+            s.didx = nullptr; s.dpart = 0;
+            s.first = tl; s.count = n_in; s.kind = kind; s.part = i;
+            tl += n_in;
+            pull.push_back(s);
+          }
+        }
+        sv += (size_t)a; se += (size_t)b; rv += (size_t)c; re += (size_t)d;
+      }
+    }
+    X.parts_host.assign((size_t)P->k, HaloPartDev());
+  } catch (const std::bad_alloc&) { return FLAME_HIP_ERR_ALLOC; }
+  for (int i = 0; i < P->k; ++i)
+    for (int b = 0; b < 2; ++b) {
+      X.parts_host[(size_t)i].A[b] = (float4*)views[(size_t)i].A[b];
+      X.parts_host[(size_t)i].B[b] = (float4*)views[(size_t)i].B[b];
+      X.parts_host[(size_t)i].q[b] = (float4*)views[(size_t)i].q[b];
+    }
+  if (X.push_dev) (void)hipFree(X.push_dev);
+  if (X.pull_dev) (void)hipFree(X.pull_dev);
+  if (X.parts_dev) (void)hipFree(X.parts_dev);
+  X.push_dev = X.pull_dev = nullptr; X.parts_dev = nullptr;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&X.push_dev), sizeof(HaloSegDev) * std::max<size_t>(push.size(), 1)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&X.pull_dev), sizeof(HaloSegDev) * std::max<size_t>(pull.size(), 1)));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&X.parts_dev), sizeof(HaloPartDev) * (size_t)P->k));
+  if (!X.words) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&X.words), 2 * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(X.words, 0, 2 * sizeof(int32_t), P->comm->stream));
+  }
+  hipStream_t s = P->comm->stream;
+  if (!push.empty()) HIPCHK(hipMemcpyAsync(X.push_dev, push.data(), sizeof(HaloSegDev) * push.size(), hipMemcpyHostToDevice, s));
+  if (!pull.empty()) HIPCHK(hipMemcpyAsync(X.pull_dev, pull.data(), sizeof(HaloSegDev) * pull.size(), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(X.parts_dev, X.parts_host.data(), sizeof(HaloPartDev) * (size_t)P->k, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // (the host vectors go out of scope)
+  X.n_push = (int)push.size(); X.n_pull = (int)pull.size(); X.total_push = tp; X.total_pull = tl;
+  X.tables = true;
+  return 0;
+}
+
+// One exchange through the peer transport: ONE push launch (every record of every local part, straight into the receivers'
+// inboxes, then the messages' flags) and ONE pull launch (wait for this rank's incoming flags, unpack) on the solve stream.
+int exchange_peer(flame_hip_part* P) {
+  flame_hip_comm* C = P->comm;
+  flame_hip_part::Peer& X = P->px;
+  if (P->k > 32) return FLAME_HIP_ERR_ARG;  // (the kernels take the parts' current buffers as one 32-bit mask)
+  if (!X.connected) return FLAME_HIP_ERR_STATE;  // (flame_hip_part_peer_connect has not happened)
+  int rc;
+  std::vector<flame_hip_halo_view> views;
+  try { views.resize((size_t)P->k); } catch (...) { return FLAME_HIP_ERR_ALLOC; }
+  uint32_t cur = 0;
+  bool moved = !X.tables;
+  for (int i = 0; i < P->k; ++i) {
+    if ((rc = flame_hip_halo_view_get(P->parts[(size_t)i].g, C->stream, &views[(size_t)i]))) return rc;
+    cur |= (uint32_t)(views[(size_t)i].cur & 1) << i;
+    if (X.tables && (X.parts_host[(size_t)i].A[0] != views[(size_t)i].A[0] || X.parts_host[(size_t)i].q[1] != views[(size_t)i].q[1])) moved = true;
+  }
+  if (moved && (rc = peer_build_tables(P, views))) return rc;  // (first exchange, or a part's buffers were re-allocated)
+  const bool timed = P->time_exchanges && P->timed < flame_hip_part::kMaxTimed;
+  if (timed) {
+    while ((int)P->tev.size() < 2 * (P->timed + 1)) {
+      hipEvent_t e = nullptr;
+      HIPCHK(hipEventCreate(&e));
+      try { P->tev.push_back(e); } catch (...) { (void)hipEventDestroy(e); return FLAME_HIP_ERR_ALLOC; }
+    }
+    HIPCHK(hipEventRecord(P->tev[2 * (size_t)P->timed], C->stream));
+  }
+  HaloXArgs a;
+  a.parts = X.parts_dev; a.cur_mask = cur; a.epoch = ++X.epoch; a.counter = X.words; a.err = X.words + 1;
+  a.timeout_ticks = 500000000;  // 5 s: a rank may be a whole exchange ahead of a neighbour that is still planning
+  a.segs = X.push_dev; a.nsegs = X.n_push; a.total = X.total_push;
+  HIPCHK(flamehip::launch_halo_push(C->stream, a));
+  a.segs = X.pull_dev; a.nsegs = X.n_pull; a.total = X.total_pull;
+  HIPCHK(flamehip::launch_halo_pull(C->stream, a));
+  for (LocalPart& L : P->parts)
+    if ((rc = flame_hip_halo_written(L.g))) return rc;
+  if (timed) {
+    HIPCHK(hipEventRecord(P->tev[2 * (size_t)P->timed + 1], C->stream));
+    ++P->timed;
+  }
+  ++P->exchanges;
+  return 0;
+}
+
 int exchange(flame_hip_part* P) {
   flame_hip_comm* C = P->comm;
   if (P->world * P->k == 1 || P->ops.empty()) return 0;
+  if (P->transport == 1) return exchange_peer(P);
+  if (!C->comm) return FLAME_HIP_ERR_NORCCL;  // (a local communicator has the peer transport only)
   int rc;
   const bool timed = P->time_exchanges && P->timed < flame_hip_part::kMaxTimed;
   if (timed) {
@@ -482,6 +836,30 @@ int flame_hip_comm_info(const flame_hip_comm* c, const char* key, int64_t* value
   return 0;
 }
 
+// A communicator WITHOUT RCCL: the ranks exchange through the peer transport only (flame_hip_part_peer_blob / _connect).
+int flame_hip_comm_create_local(flame_hip_comm** out, int device, int rank, int world) {
+  if (!out || world < 1 || rank < 0 || rank >= world) return FLAME_HIP_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return FLAME_HIP_ERR_NODEVICE;
+  flame_hip_comm* c = new (std::nothrow) flame_hip_comm();
+  if (!c) return FLAME_HIP_ERR_ALLOC;
+  c->device = device; c->rank = rank; c->world = world; c->local = true;
+  c->shared_gpu = world > 1;  // (nothing tells where the other ranks sit, and without an all-reduce the ranks cannot agree on a
+                              // give-up of resident tiles: the parts solve by launches)
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->red), 2 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->flag), sizeof(int32_t));
+  if (e != hipSuccess) { flame_hip_comm_destroy(c); return FLAME_HIP_ERR_HIP - (int)e; }
+  c->rccl_ranks = 0;
+  *out = c;
+  return 0;
+}
+
 void flame_hip_comm_destroy(flame_hip_comm* c) {
   if (!c) return;
   if (c->device >= 0) (void)hipSetDevice(c->device);
@@ -516,6 +894,7 @@ void flame_hip_part_destroy(flame_hip_part* P) {
     if (L.rbuf) (void)hipFree(L.rbuf);
   }
   for (hipEvent_t e : P->tev) (void)hipEventDestroy(e);
+  peer_release(P);
   delete P;
 }
 
@@ -634,7 +1013,7 @@ static int run_iterations(flame_hip_part* P, const flame_hip_params* p, int32_t 
     }
     const int32_t n = std::min<int32_t>(P->rings_left, num_iters - done);
     // this chunk uses the rings up and the call goes on: the exchange behind it is certain -- pipeline it
-    const bool pipe = (P->pipeline < 0 ? P->k >= 4 : P->pipeline != 0) && P->k >= 2 && !P->ops.empty() && P->rings_left == n && done + n < num_iters && !P->time_exchanges;
+    const bool pipe = P->transport == 0 && (P->pipeline < 0 ? P->k >= 4 : P->pipeline != 0) && P->k >= 2 && !P->ops.empty() && P->rings_left == n && done + n < num_iters && !P->time_exchanges;
     for (size_t i = 0; i < P->parts.size(); ++i) {
       LocalPart& L = P->parts[i];
       if ((rc = flame_hip_solve(L.g, p, n, C->stream))) return rc;
@@ -668,6 +1047,8 @@ int flame_hip_part_solve(flame_hip_part* P, const flame_hip_params* p, int32_t n
     for (LocalPart& L : P->parts)
       if ((rc = flame_hip_state_snapshot(L.g, P->comm->stream))) return rc;
     P->txn_rings = P->rings_left;
+    P->txn_exchanges = P->exchanges;
+    P->txn_timed = P->timed;
   }
   if (P->persist) {
     try { P->txn.push_back({*p, num_iters}); } catch (...) { return FLAME_HIP_ERR_ALLOC; }
@@ -690,8 +1071,20 @@ int flame_hip_part_sync(flame_hip_part* P) {
     if ((rc = flame_hip_persist_take_error(L.g, &one))) return rc;
     bad |= one;
   }
-  if (P->txn.empty()) return 0;  // (nothing queued since the last call: no rank has anything to agree on)
-  if (C->world > 1) {
+  // (nothing queued since the last call: no rank has anything to agree on.  flame_hip_part_solve / _sync are COLLECTIVE: every
+  // rank of the communicator makes the same calls in the same order -- the exchanges inside a solve already require it -- so
+  // the queue is empty on all ranks or on none; a rank whose solve returned an error must not go on using the partition)
+  if (P->px.words && P->px.epoch > 0) {  // peer transport: did a pull give up waiting for a neighbour's records?
+    int32_t w[2] = {0, 0};
+    HIPCHK(hipMemcpy(w, P->px.words, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[1]) {
+      ++P->px.timeouts;
+      HIPCHK(hipMemset(P->px.words + 1, 0, sizeof(int32_t)));
+      return FLAME_HIP_ERR_STATE;  // (a neighbour rank is gone or minutes behind: the state holds records that never arrived)
+    }
+  }
+  if (P->txn.empty()) return 0;
+  if (C->world > 1 && C->comm) {
     HIPCHK(hipMemcpyAsync(C->flag, &bad, sizeof(bad), hipMemcpyHostToDevice, C->stream));
     NCCLCHK(rccl().AllReduce(C->flag, C->flag, 1, ncclInt32, ncclMax, C->comm, C->stream));
     HIPCHK(hipMemcpyAsync(&bad, C->flag, sizeof(bad), hipMemcpyDeviceToHost, C->stream));
@@ -700,15 +1093,23 @@ int flame_hip_part_sync(flame_hip_part* P) {
   std::vector<flame_hip_part::Call> calls;
   calls.swap(P->txn);
   if (!bad) return 0;
-  for (LocalPart& L : P->parts)
-    if ((rc = flame_hip_state_rollback(L.g, C->stream)) || (rc = flame_hip_set_option(L.g, "persist", 0))) return rc;
+  std::vector<int64_t> was(P->parts.size(), 1);  // (the parts' "persist" option as the caller left it: restored below)
+  for (size_t i = 0; i < P->parts.size(); ++i) {
+    LocalPart& L = P->parts[i];
+    if ((rc = flame_hip_get_info(L.g, "persist", &was[i])) || (rc = flame_hip_state_rollback(L.g, C->stream)) ||
+        (rc = flame_hip_set_option(L.g, "persist", 0)))
+      return rc;
+  }
   P->rings_left = P->txn_rings;
+  P->exchanges_discarded += P->exchanges - P->txn_exchanges;  // (the discarded exchanges are not counted twice)
+  P->exchanges = P->txn_exchanges;
+  P->timed = P->txn_timed;
   for (const flame_hip_part::Call& c : calls)
     if ((rc = run_iterations(P, &c.p, c.n))) return rc;
   HIPCHK(hipStreamSynchronize(C->stream));
-  for (LocalPart& L : P->parts) {
+  for (size_t i = 0; i < P->parts.size(); ++i) {
     int32_t one = 0;
-    if ((rc = flame_hip_persist_take_error(L.g, &one)) || (rc = flame_hip_set_option(L.g, "persist", 1))) return rc;
+    if ((rc = flame_hip_persist_take_error(P->parts[i].g, &one)) || (rc = flame_hip_set_option(P->parts[i].g, "persist", (int32_t)was[i]))) return rc;
   }
   P->recovered += (int64_t)calls.size();
   return 0;
@@ -734,10 +1135,12 @@ int flame_hip_part_costs(flame_hip_part* P, const flame_hip_params* p, double* s
     if ((rc = flame_hip_costs_masked(L.g, p, L.vmask.data(), L.sub.e_owned.data(), &s, &d))) return rc;
     acc[0] += s; acc[1] += d;
   }
-  HIPCHK(hipMemcpyAsync(C->red, acc, sizeof(acc), hipMemcpyHostToDevice, C->stream));
-  NCCLCHK(rccl().AllReduce(C->red, C->red, 2, ncclDouble, ncclSum, C->comm, C->stream));
-  HIPCHK(hipMemcpyAsync(acc, C->red, sizeof(acc), hipMemcpyDeviceToHost, C->stream));
-  HIPCHK(hipStreamSynchronize(C->stream));
+  if (C->comm) {  // (a local communicator: this rank's owned sums, the application adds the ranks')
+    HIPCHK(hipMemcpyAsync(C->red, acc, sizeof(acc), hipMemcpyHostToDevice, C->stream));
+    NCCLCHK(rccl().AllReduce(C->red, C->red, 2, ncclDouble, ncclSum, C->comm, C->stream));
+    HIPCHK(hipMemcpyAsync(acc, C->red, sizeof(acc), hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipStreamSynchronize(C->stream));
+  }
   if (smooth) *smooth = acc[0];
   if (data) *data = acc[1];
   return 0;
@@ -765,7 +1168,7 @@ int flame_hip_part_gather(flame_hip_part* P, float* x, float* w1, float* w2, flo
     for (size_t k = 0; k < ne; ++k)
       if (s.e_owned[k]) std::memcpy(&all[3 * V + 3 * (size_t)s.eid[k]], &lq[3 * k], 3 * sizeof(float));
   }
-  if (C->world > 1) {
+  if (C->world > 1 && C->comm) {  // (a local communicator: what this rank owns, zero elsewhere)
     int32_t* dev = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), total * sizeof(int32_t)));
     hipError_t e = hipMemcpyAsync(dev, all.data(), total * sizeof(float), hipMemcpyHostToDevice, C->stream);
@@ -790,7 +1193,37 @@ int flame_hip_part_set_option(flame_hip_part* P, const char* key, int32_t value)
   const std::string k(key);
   if (k == "time_exchanges") { P->time_exchanges = value != 0; P->timed = 0; return 0; }
   if (k == "pipeline") { P->pipeline = value < 0 ? -1 : (value != 0 ? 1 : 0); return 0; }
+  if (k == "transport") {  // 0 RCCL (the contract's path), 1 peer (include/flame_hip.h); COLLECTIVE when the ranks are connected over RCCL
+    if (!P->comm || (value != 0 && value != 1)) return FLAME_HIP_ERR_ARG;
+    if (value == 0 && !P->comm->comm && P->world * P->k > 1) return FLAME_HIP_ERR_NORCCL;  // (a local communicator has no RCCL to go back to)
+    if (value == 1 && !P->px.connected) {
+      HIPCHK(hipSetDevice(P->comm->device));
+      int rc = P->world == 1 ? peer_alloc_inbox(P) : (P->comm->comm ? peer_connect_rccl(P) : peer_alloc_inbox(P));
+      if (rc) return rc;  // (local communicator, world > 1: connected by flame_hip_part_peer_connect)
+    }
+    P->transport = value;
+    return 0;
+  }
   return FLAME_HIP_ERR_ARG;
+}
+
+int flame_hip_part_peer_blob(flame_hip_part* P, char blob[FLAME_HIP_PEER_BLOB_BYTES]) {
+  if (!P || !P->comm || !blob) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(P->comm->device));
+  PeerBlob b;
+  const int rc = peer_make_blob(P, &b);
+  if (rc) return rc;
+  std::memcpy(blob, &b, sizeof(b));
+  return 0;
+}
+
+int flame_hip_part_peer_connect(flame_hip_part* P, const char* blobs) {
+  if (!P || !P->comm || !blobs) return FLAME_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(P->comm->device));
+  std::vector<PeerBlob> all;
+  try { all.resize((size_t)P->world); } catch (...) { return FLAME_HIP_ERR_ALLOC; }
+  std::memcpy(all.data(), blobs, sizeof(PeerBlob) * (size_t)P->world);
+  return peer_connect(P, all.data());
 }
 
 // Introspection (tests, bench): scalars and arrays of the plan.  local_part in [0, parts_per_rank).
@@ -798,8 +1231,14 @@ int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_
   if (!P || !key || !value) return FLAME_HIP_ERR_ARG;
   const std::string k(key);
   if (k == "num_parts") { *value = (int64_t)P->world * P->k; return 0; }
+  if (k == "transport") { *value = P->transport; return 0; }
+  if (k == "peer_connected") { *value = P->px.connected ? 1 : 0; return 0; }
+  if (k == "peer_epoch") { *value = P->px.epoch; return 0; }
+  if (k == "peer_timeouts") { *value = P->px.timeouts; return 0; }
+  if (k == "inbox_bytes") { *value = (int64_t)P->px.inbox_bytes; return 0; }
   if (k == "parts_per_rank") { *value = P->k; return 0; }
   if (k == "exchanges") { *value = P->exchanges; return 0; }
+  if (k == "exchanges_discarded") { *value = P->exchanges_discarded; return 0; }
   if (k == "p2p_ops") { *value = (int64_t)P->ops.size(); return 0; }
   if (k == "rings_left") { *value = P->rings_left; return 0; }
   if (k == "recovered") { *value = P->recovered; return 0; }

@@ -227,7 +227,9 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   const bool one_round = V <= 256 * 196;
   // r05: beyond that, a caller that solves by resident tiles keeps one tile per CU as long as the FAT tiles fit at some depth
   // (measured: 200 k vertices 5.9 us per iteration by 167 launches of two rounds of tiles -> resident)
-  const bool fat = !one_round && opt.resident && opt.tile_own <= 0 && V <= 256 * 940 && opt.batch_voff.empty();
+  // (fat tiles are 256 of them, one per CU -- a device with fewer CUs could never make them resident and would
+  // run the shallow fat plan launch by launch: it keeps the r04 partition)
+  const bool fat = !one_round && opt.resident && opt.tile_own <= 0 && V <= 256 * 940 && opt.batch_voff.empty() && opt.num_cus >= 256;
   const int fat_own = (V + 255) / 256;
   // (r05, resident tiles: 24 instead of 32 own vertices at least -- more CUs at work, 1-2 % per iteration below 6 k vertices and
   // on a TUM-sized frame: profiles/r05_min_own_ab.txt; tiles that small take the deeper halo)

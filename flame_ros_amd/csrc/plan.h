@@ -32,6 +32,7 @@ struct PlanOptions {
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   bool single_only = false;  // build_plan(): return kPlanSingleNoFit instead of falling back to a
                              // halo'd partition when the isolated tile does not fit after all
+  int num_cus = 256;     // compute units of the device the plan will run on (a host-only plan: MI355X)
   int timing = 0;        // diagnostic (option "plan_timing"): the builders print their stages' times to stderr (levels: plan_dev.hip)
   int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
                          // this many vertices on its first try (exercises the recovery path)

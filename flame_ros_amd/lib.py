@@ -83,6 +83,11 @@ SYMBOLS = {
     "flame_hip_halo_bytes": (C.c_int, [_VP, C.POINTER(_I64), C.POINTER(_I64)]),
     "flame_hip_halo_pack": (C.c_int, [_VP, _VP, _VP]),
     "flame_hip_halo_unpack": (C.c_int, [_VP, _VP, _VP]),
+    "flame_hip_halo_view_get": (C.c_int, [_VP, _VP, _VP]),
+    "flame_hip_halo_written": (C.c_int, [_VP]),
+    "flame_hip_comm_create_local": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int, C.c_int]),
+    "flame_hip_part_peer_blob": (C.c_int, [_VP, _VP]),
+    "flame_hip_part_peer_connect": (C.c_int, [_VP, _VP]),
     "flame_hip_rccl_available": (C.c_int, []),
     "flame_hip_comm_get_unique_id": (C.c_int, [_VP]),
     "flame_hip_comm_create": (C.c_int, [C.POINTER(_VP), C.c_int, C.c_int, C.c_int, _VP]),

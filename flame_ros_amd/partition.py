@@ -8,6 +8,7 @@ import numpy as np
 from . import lib as _l
 
 ID_BYTES = 128
+PEER_BLOB_BYTES = 128
 
 
 def rccl_available():
@@ -22,11 +23,17 @@ def unique_id():
 
 
 class Communicator:
+    """uid = None: a communicator WITHOUT RCCL (flame_hip_comm_create_local) -- its partitions exchange through the peer
+    transport only (Partition.peer_blob / peer_connect between processes)."""
+
     def __init__(self, device, rank, world, uid):
         self._lib = _l.load()
         self._h = C.c_void_p()
-        self._uid = C.create_string_buffer(uid, ID_BYTES)
-        _l.check(self._lib.flame_hip_comm_create(C.byref(self._h), device, rank, world, self._uid), "flame_hip_comm_create")
+        if uid is None:
+            _l.check(self._lib.flame_hip_comm_create_local(C.byref(self._h), device, rank, world), "flame_hip_comm_create_local")
+        else:
+            self._uid = C.create_string_buffer(uid, ID_BYTES)
+            _l.check(self._lib.flame_hip_comm_create(C.byref(self._h), device, rank, world, self._uid), "flame_hip_comm_create")
         self.rank, self.world = rank, world
 
     def info(self, key):
@@ -90,7 +97,20 @@ class Partition:
         return x, w1, w2, q
 
     def set_option(self, key, value):
+        """"transport" 0 RCCL / 1 peer (records written straight into the receivers' inboxes; collective over RCCL when the
+        communicator has one), "time_exchanges", "pipeline"."""
         _l.check(self._lib.flame_hip_part_set_option(self._h, key.encode(), int(value)), "flame_hip_part_set_option(%s)" % key)
+
+    def peer_blob(self):
+        """This rank's inbox handle (128 bytes) for the peer transport between processes: gather every rank's, in rank order,
+        and hand the concatenation to peer_connect()."""
+        buf = C.create_string_buffer(PEER_BLOB_BYTES)
+        _l.check(self._lib.flame_hip_part_peer_blob(self._h, buf), "flame_hip_part_peer_blob")
+        return buf.raw
+
+    def peer_connect(self, blobs):
+        buf = C.create_string_buffer(bytes(blobs), len(blobs))
+        _l.check(self._lib.flame_hip_part_peer_connect(self._h, buf), "flame_hip_part_peer_connect")
 
     def info(self, key, local_part=0):
         v = C.c_int64()

@@ -161,6 +161,11 @@ class Communicator {
     reset();
     return flame_hip_comm_create(&c_, device, rank, world, id);
   }
+  // a communicator WITHOUT RCCL: its graphs exchange through the peer transport only (PartitionedGraph::peerBlob / peerConnect)
+  int initLocal(int device, int rank, int world) {
+    reset();
+    return flame_hip_comm_create_local(&c_, device, rank, world);
+  }
   void reset() { if (c_) flame_hip_comm_destroy(c_); c_ = nullptr; }
   flame_hip_comm* handle() const { return c_; }
 
@@ -189,6 +194,13 @@ class PartitionedGraph {
   int32_t numEdges() const { return E_; }
   // the whole solution on every rank (any pointer may be null; q is 3E interleaved)
   int gather(float* x, float* w1, float* w2, float* q) { return p_ ? flame_hip_part_gather(p_, x, w1, w2, q) : FLAME_HIP_ERR_STATE; }
+  // Transport of the halo records: RCCL send / receive (default), or the peer transport -- one kernel writes them straight into
+  // the receiving parts' inboxes (same GPU, hipIpc, xGMI peer access), one kernel waits for the messages' flags and unpacks.
+  // Collective over RCCL when the communicator has one; between processes without RCCL: peerBlob() of every rank, gathered in
+  // rank order by the application, to peerConnect(), then setPeerTransport(true).
+  int setPeerTransport(bool on) { return p_ ? flame_hip_part_set_option(p_, "transport", on ? 1 : 0) : FLAME_HIP_ERR_STATE; }
+  int peerBlob(char blob[FLAME_HIP_PEER_BLOB_BYTES]) { return p_ ? flame_hip_part_peer_blob(p_, blob) : FLAME_HIP_ERR_STATE; }
+  int peerConnect(const char* blobs) { return p_ ? flame_hip_part_peer_connect(p_, blobs) : FLAME_HIP_ERR_STATE; }
   flame_hip_part* handle() const { return p_; }
 
  private:

@@ -313,6 +313,26 @@ int flame_hip_halo_unpack(flame_hip_graph* g, const void* recv_buf_dev, void* st
  * every part back and repeats those solves by launches.  take_error: call after synchronising the solve's stream;
  * *gave_up = 1 when a launch of resident tiles of this handle timed out since the last look (the word is cleared, the
  * device's lease backs off; nothing is repeated here). */
+/* r06, for a transport that moves the halo records itself (the partition mode's PEER transport below): the handle's state
+ * arrays and registered lists as DEVICE pointers -- A / B / q [2]: {x, w1, w2, z} / {x_bar, w1_bar, w2_bar, wgt} / {q1, q2, q3, -}
+ * float4 per vertex / vertex / edge, indexed by the handle's INTERNAL ids; the registered lists come in those ids too (the
+ * library translated them at flame_hip_halo_register), so a transport never needs the permutation; `cur` = the buffer that
+ * holds the state now.  The call orders `stream` behind any state-writing work
+ * of the handle's own stream; the pointers stay valid until the next upload / resize.  flame_hip_halo_written: the caller's
+ * kernels on that stream have written halo state into the current buffers (what flame_hip_halo_unpack does itself). */
+typedef struct {
+  void* A[2];
+  void* B[2];
+  void* q[2];
+  int32_t cur;
+  int32_t n_send_v, n_send_e, n_recv_v, n_recv_e;
+  const int32_t* send_v;
+  const int32_t* send_e;
+  const int32_t* recv_v;
+  const int32_t* recv_e;
+} flame_hip_halo_view;
+int flame_hip_halo_view_get(flame_hip_graph* g, void* stream, flame_hip_halo_view* out);
+int flame_hip_halo_written(flame_hip_graph* g);
 int flame_hip_state_snapshot(flame_hip_graph* g, void* stream);
 int flame_hip_state_rollback(flame_hip_graph* g, void* stream);
 int flame_hip_persist_take_error(flame_hip_graph* g, int32_t* gave_up);
@@ -359,12 +379,28 @@ int flame_hip_part_update_data(flame_hip_part* p, const float* z, const float* w
 int flame_hip_part_costs(flame_hip_part* p, const flame_hip_params* params, double* smooth, double* data);
 /* the whole solution on every rank (x, w1, w2: V; q: 3E interleaved; any may be NULL).  Synchronises. */
 int flame_hip_part_gather(flame_hip_part* p, float* x, float* w1, float* w2, float* q);
-/* "time_exchanges" 0 / 1: HIP events around the next (up to 64) exchanges -- pack, the group of sends / receives, unpack;
+/* r06 PEER TRANSPORT ("transport" 1; 0 = RCCL, the default and the contract's path): the records of an exchange are written
+ * by ONE kernel of the sending rank straight into the receiving parts' inboxes -- uncached device memory of the same GPU, of
+ * another process (hipIpc) or of another GPU of the node (peer access over xGMI) --, a per-message flag word takes the exchange's
+ * epoch behind them (release, system scope), and ONE kernel of the receiving rank waits for its flags (bounded) and unpacks:
+ * two launches per exchange whatever the number of parts and neighbours, no host synchronisation, no ncclGroup (35-70 us on
+ * one GPU against ~20 us of resident compute per 16 iterations: profiles/r05_part_halo_depth.txt).  Two record buffers by
+ * epoch parity (a sender can be at most one exchange ahead).  Same bits.  Ranks of ONE process / world 1 need nothing else;
+ * ranks in different processes exchange their inbox handles once: every rank calls flame_hip_part_peer_blob, the application
+ * gathers the blobs of all ranks in rank order (the library does it itself over RCCL when the communicator has one:
+ * flame_hip_part_set_option "transport" 1 is then collective) and hands them to flame_hip_part_peer_connect.
+ * flame_hip_comm_create_local: a communicator WITHOUT RCCL for that case (peer transport only; flame_hip_part_costs then
+ * returns this rank's owned sums, and the parts solve by launches -- the give-up agreement of resident tiles is an all-reduce). */
+#define FLAME_HIP_PEER_BLOB_BYTES 128
+int flame_hip_comm_create_local(flame_hip_comm** out, int device, int rank, int world);
+int flame_hip_part_peer_blob(flame_hip_part* p, char blob[FLAME_HIP_PEER_BLOB_BYTES]);
+int flame_hip_part_peer_connect(flame_hip_part* p, const char* blobs /* world x FLAME_HIP_PEER_BLOB_BYTES */);
+/* "transport" 0 / 1 (above); "time_exchanges" 0 / 1: HIP events around the next (up to 64) exchanges -- pack, the group of sends / receives, unpack;
  * "pipeline" (-1 = automatic, the default: on from 4 parts per rank; 0 / 1 force it; acts with parts_per_rank >= 2): inside a solve call the halo records of part i leave -- an ncclGroup of
  * their own on the communicator's second stream -- while part i + 1 iterates (overlap compute with the exchange, by
  * over-decomposition); info "exchanges_pipelined" counts them.  Same bits either way. */
 int flame_hip_part_set_option(flame_hip_part* p, const char* key, int32_t value);
-/* keys: "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left", "exchanges_timed", "exchange_ns" (mean device
+/* keys: "transport", "peer_connected", "num_parts", "parts_per_rank", "exchanges", "p2p_ops", "rings_left", "exchanges_timed", "exchange_ns" (mean device
  * time of the timed exchanges; synchronise first), "recovered" (solves repeated by launches after
  * a give-up of resident tiles on any rank), "persist" (the parts solve with resident tiles); per local part: "part_id",
  * "n_own", "n_ext", "e_loc", "num_peers", "send_bytes", "recv_bytes", "persist_used" (the part's LAST local solve was one launch

@@ -47,6 +47,22 @@ def cpu_model():
     return "unknown"
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max, v1 cfs quota / period), or None when unlimited: the
+    OpenMP legs cannot scale past it whatever `host_cores` says (r05: best at 8 threads under a 16-CPU quota on a 256-core host)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="50k")
@@ -105,7 +121,8 @@ def main():
                   "-ffp-contract=off (oracle/nltgv2_oracle.c)" % (done, g.V, g.E),
         "threads_its_per_s": threads, "best_threads": int(best_t), "best_value": threads[best_t],
         "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "omp_places": os.environ.get("OMP_PLACES"),
-        "host_cores": ncpu, "cpu_model": cpu_model()}))
+        "host_cores": ncpu, "cgroup_cpu_quota": cgroup_cpu_quota(), "cpu_model": cpu_model(),
+        "note": "quote absolutes: the OpenMP legs are bound by the container's CPU quota, not by host_cores"}))
 
 
 if __name__ == "__main__":

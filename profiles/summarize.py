@@ -25,6 +25,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CYC_READ_B128 = 4    # ds_read_b128: 4 lane groups x 1 LDS cycle
 CYC_WRITE_B96 = 10   # ds_write_b96: bound by the 4-dword operand transfer (LDS array: 8)
 TILE_DESC_WORDS = 13 + 17 + 17  # csrc/common.h TileDesc
+# r06, the second on-chip resource: VALU issue.  Wave-instructions of the tile kernel's iteration, counted in the gfx950 ISA of
+# k_tile_persist<512,2,1> (hipcc -S): phase D per 64-edge block 10 plain + 6 packed fp32 instructions,
+# phase P per 64-vertex block 14 plain + 2 packed (prox, clamp, extrapolation) and 1 plain + 1 packed per incidence slot of
+# the longest row.  Priced 4 cycles per wave64 instruction per SIMD, plain or packed -- what the counters of this kernel say
+# (profiles/r06_*_summary: SQ_ACTIVE_INST_VALU, in quad-cycles, equals SQ_INSTS_VALU to three digits) --; a CU has 4 SIMDs.
+VALU_D_PLAIN, VALU_D_PACKED = 10, 6
+VALU_P_PLAIN, VALU_P_PACKED = 14, 2
+VALU_SLOT_PLAIN, VALU_SLOT_PACKED = 1, 1
+CYC_VALU_PLAIN, CYC_VALU_PACKED, SIMDS_PER_CU = 4, 4, 4
 
 
 def lds_floor(tiles, srow, num_cus=256):
@@ -62,7 +71,29 @@ def lds_floor(tiles, srow, num_cus=256):
     per_cu = np.zeros(min(nt, num_cus))
     for k in range(nt):  # (b % CUs: how a grid larger than the chip is dealt out; one tile per CU otherwise)
         per_cu[k % len(per_cu)] += cyc[k]
+    # VALU issue floor of the same OWN work, spread perfectly over the CU's four SIMDs (r06)
+    vcyc, vins = [], []
+    for t in tiles:
+        n_own, e_own, srow_off = int(t[1]), int(t[4]), int(t[11])
+        eb = -(-e_own // 64)
+        plain, packed = eb * VALU_D_PLAIN, eb * VALU_D_PACKED
+        deg = (srow[srow_off:srow_off + n_own] >> 16).astype(np.int64)
+        for b in range(0, n_own, 64):
+            m = int(deg[b:b + 64].max())
+            plain += VALU_P_PLAIN + m * VALU_SLOT_PLAIN
+            packed += VALU_P_PACKED + m * VALU_SLOT_PACKED
+        vcyc.append((plain * CYC_VALU_PLAIN + packed * CYC_VALU_PACKED) / float(SIMDS_PER_CU))
+        vins.append(plain + packed)
+    vper_cu = np.zeros(len(per_cu))
+    for k in range(nt):
+        vper_cu[k % len(vper_cu)] += vcyc[k]
     return {"floor_cycles_per_iteration_slowest_cu": float(per_cu.max()),
+            "valu_floor_cycles_per_iteration_slowest_cu": float(vper_cu.max()),
+            "useful_valu_insts_per_iteration_chip": float(np.sum(vins)),
+            "valu_pricing": {"plain_wave64": CYC_VALU_PLAIN, "packed_wave64": CYC_VALU_PACKED, "simds_per_cu": SIMDS_PER_CU,
+                             "phase_d_per_64_edges": [VALU_D_PLAIN, VALU_D_PACKED], "phase_p_per_64_vertices": [VALU_P_PLAIN, VALU_P_PACKED],
+                             "per_slot": [VALU_SLOT_PLAIN, VALU_SLOT_PACKED],
+                             "source": "ISA of k_tile_persist<512,2,1>; 4 cycles per wave64 VALU instruction (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles)"},
             "floor_cycles_per_iteration_mean_tile": float(cyc.mean()),
             "useful_lds_insts_per_iteration_chip": float(ins.sum()),
             "num_tiles": int(nt), "busy_cus": int(len(per_cu)),
@@ -71,19 +102,25 @@ def lds_floor(tiles, srow, num_cus=256):
 
 
 def lds_roofline(floor, us_per_iteration, clock_mhz, iterations_per_launch, lds_counters=None, iterate_frac=None,
-                 measured_hbm_frac=None, contract_frac=None):
+                 measured_hbm_frac=None, contract_frac=None, valu_counters=None):
     """The `roofline` block of a tile-path bench line.  bound = "lds": frac = floor cycles of the slowest CU / measured
     shader cycles per iteration -- <= 1 by construction (the kernel issues at least the floor's instructions).  The
     counters (one launch, summed over the chip: SQ_INSTS_LDS, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT) give, beside it,
     how much LDS work was executed per useful instruction (halo redundancy + padding lanes), how busy the LDS array was
     and what share of that was bank conflicts."""
     meas = us_per_iteration * clock_mhz
-    frac = floor["floor_cycles_per_iteration_slowest_cu"] / max(meas, 1e-9)
-    out = {"bound": "lds",
-           "achieved": floor["floor_cycles_per_iteration_slowest_cu"] / max(us_per_iteration, 1e-12) / 1e3,
-           "peak": clock_mhz / 1e3, "unit": "Gcycle/s of LDS issue on the slowest CU (useful work only)",
+    lds_f = floor["floor_cycles_per_iteration_slowest_cu"]
+    valu_f = floor.get("valu_floor_cycles_per_iteration_slowest_cu", 0.0)
+    # r06 (VERDICT r05 item 1a): two on-chip resources, the larger floor is the bound
+    top, bound = (lds_f, "lds") if lds_f >= valu_f else (valu_f, "valu")
+    frac = top / max(meas, 1e-9)
+    out = {"bound": bound,
+           "achieved": top / max(us_per_iteration, 1e-12) / 1e3,
+           "peak": clock_mhz / 1e3, "unit": "Gcycle/s of %s issue on the slowest CU (useful work only)" % bound.upper(),
            "frac": frac,
-           "floor_cycles_per_iteration": floor["floor_cycles_per_iteration_slowest_cu"],
+           "lds_frac": lds_f / max(meas, 1e-9), "valu_frac": valu_f / max(meas, 1e-9),
+           "floor_cycles_per_iteration": top,
+           "lds_floor_cycles_per_iteration": lds_f, "valu_floor_cycles_per_iteration": valu_f,
            "floor_cycles_per_iteration_mean_tile": floor["floor_cycles_per_iteration_mean_tile"],
            "measured_cycles_per_iteration": meas, "clock_mhz": clock_mhz,
            "floor_pricing": floor["pricing"]}
@@ -98,6 +135,20 @@ def lds_roofline(floor, us_per_iteration, clock_mhz, iterations_per_launch, lds_
         out["bank_conflict_share"] = conf / max(act, 1.0)
         out["executed_lds_insts_per_iteration_per_cu"] = insts / its / cus
         out["lds_array_cycles_per_iteration_per_cu"] = act / its / cus
+    if valu_counters:
+        # SQ_* "cycle" counters are in quad-cycles, summed over the waves (guide, rocprofv3 PMC slots): shares of the waves' time
+        wc = max(valu_counters.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+        its = float(max(iterations_per_launch, 1))
+        cus = float(floor["busy_cus"])
+        out["valu_insts_per_iteration_per_cu"] = valu_counters.get("SQ_INSTS_VALU", 0.0) / its / cus
+        out["valu_redundancy"] = valu_counters.get("SQ_INSTS_VALU", 0.0) / its / max(floor.get("useful_valu_insts_per_iteration_chip", 1.0), 1.0)
+        out["wave_time_shares"] = {
+            "waiting (s_waitcnt / barrier: SQ_WAIT_ANY)": valu_counters.get("SQ_WAIT_ANY", 0.0) / wc,
+            "issue stall (SQ_WAIT_INST_ANY)": valu_counters.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+            "issuing (SQ_ACTIVE_INST_ANY)": valu_counters.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+            "of which VALU (SQ_ACTIVE_INST_VALU)": valu_counters.get("SQ_ACTIVE_INST_VALU", 0.0) / wc}
+        # VALU busy of a SIMD: quad-cycles a VALU instruction was issuing x 4 / (SIMD-cycles of the launch)
+        out["valu_busy"] = valu_counters.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (cus * SIMDS_PER_CU * its * max(meas, 1e-9))
     if iterate_frac is not None:
         out["handoff_share"] = 1.0 - iterate_frac
     if measured_hbm_frac is not None:
@@ -136,15 +187,18 @@ def roofline_from_summary(path):
         raise SystemExit("%s holds no lds_floor / bench line (a summary of r05 or later is needed)" % path)
     rl = b["roofline"]
     kern = rl.get("kernel", "k_tile")
-    cnt, hbm = None, rl.get("measured_hbm_frac")
+    cnt, vcnt, hbm = None, None, rl.get("measured_hbm_frac")
     for k, v in s.get("lds_per_launch", {}).items():
         if kern + "<" in k:
             cnt = v
+    for k, v in s.get("valu_per_launch", {}).items():
+        if kern + "<" in k:
+            vcnt = v
     for k, v in s.get("traffic_bytes_per_launch", {}).items():  # this summary's own FETCH x2 + WRITE passes
         if kern + "<" in k and v > 0:
             hbm = v / (rl["launch_us"] * 1e-6) / 1e9 / 8000.0
     out = lds_roofline(fl, rl["launch_us"] / rl["iters_per_launch"], rl["clock_mhz"], rl["iters_per_launch"], cnt,
-                       rl.get("iterate_frac"), hbm, (rl.get("contract") or {}).get("frac", rl.get("contract_frac")))
+                       rl.get("iterate_frac"), hbm, (rl.get("contract") or {}).get("frac", rl.get("contract_frac")), vcnt)
     out["kernel"] = kern
     return out
 
@@ -214,7 +268,29 @@ def summarize(d):
                 per.get("SQ_INSTS_LDS", 0), per.get("SQ_WAIT_INST_LDS", 0), per.get("SQ_ACTIVE_INST_LDS", 0),
                 per.get("SQ_WAVE_CYCLES", 0), per.get("SQ_BUSY_CYCLES", 0)))
 
-    out = {"kernel_src_sha": kernel_src_sha(), "lds_per_launch": lds, "traffic_bytes_per_launch": summary, "kernels": [dict(zip(
+    # VALU / issue-stall counters (r06: their own PMC pass), per launch, summed over the chip
+    valu = {}
+    f = find("pmc_valu", "*counter_collection.csv")
+    if f:
+        acc, disp = defaultdict(lambda: defaultdict(float)), defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[r["Kernel_Name"]].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
+        names = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+        lines.append("\n## VALU / wait counters (separate --pmc pass), per launch, summed over the chip (cycle counters in quad-cycles)\n")
+        lines.append("| kernel | launches | " + " | ".join(names) + " | waiting | issue stall | issuing | VALU |\n|---|---|" + "---|" * (len(names) + 4))
+        for k, c in acc.items():
+            n = max(len(disp[k]), 1)
+            if c.get("SQ_INSTS_VALU", 0) <= 0:
+                continue
+            per = {name: v / n for name, v in c.items()}
+            valu[k] = dict(per, launches=n)
+            wc = max(per.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+            lines.append("| `%s` | %d | %s | %.2f | %.2f | %.2f | %.2f |" % (
+                short_name(k, 60), n, " | ".join("%.4g" % per.get(x, 0.0) for x in names), per.get("SQ_WAIT_ANY", 0) / wc,
+                per.get("SQ_WAIT_INST_ANY", 0) / wc, per.get("SQ_ACTIVE_INST_ANY", 0) / wc, per.get("SQ_ACTIVE_INST_VALU", 0) / wc))
+
+    out = {"kernel_src_sha": kernel_src_sha(), "lds_per_launch": lds, "valu_per_launch": valu, "traffic_bytes_per_launch": summary, "kernels": [dict(zip(
         ("kernel", "calls", "avg_us", "min_us", "median_us", "max_us", "total_ms"), r)) for r in rows]}
     bj = os.path.join(d, "bench.json")
     if os.path.exists(bj) and os.path.getsize(bj):

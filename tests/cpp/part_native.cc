@@ -1,7 +1,7 @@
 // tests/cpp/part_native.cc -- partition mode from C++, no Python in the data path: the same random
 // graph solved (i) on one handle and (ii) cut into `parts` subdomains on ONE rank of an RCCL communicator of world size 1
 // (every halo record = ncclSend / ncclRecv of the rank with itself), through include/flame/optimizers/
-// nltgv2_l1_graph_regularizer.h.  Every bit of x, w1, w2, q and the costs must agree.  argv: device parts depth iters V.
+// nltgv2_l1_graph_regularizer.h.  Every bit of x, w1, w2, q and the costs must agree.  argv: device parts depth iters V [peer transport 0 / 1].
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +19,7 @@ int main(int argc, char** argv) {
   const int device = argc > 1 ? std::atoi(argv[1]) : 0, parts = argc > 2 ? std::atoi(argv[2]) : 2;
   const int depth = argc > 3 ? std::atoi(argv[3]) : 8, iters = argc > 4 ? std::atoi(argv[4]) : 60;
   const int V = argc > 5 ? std::atoi(argv[5]) : 8000;
+  const bool peer = argc > 6 && std::atoi(argv[6]) != 0;  // the r06 peer transport instead of RCCL's send / receive
   std::mt19937 rng(7);
   std::uniform_real_distribution<float> ux(0.f, 640.f), uy(0.f, 480.f);
   std::normal_distribution<float> noise(0.f, 0.02f);
@@ -67,6 +68,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "part build: %s\n", flame_hip_strerror(rc));
     return 4;
   }
+  if (peer && (rc = pg.setPeerTransport(true))) { std::fprintf(stderr, "peer transport: %s\n", flame_hip_strerror(rc)); return 4; }
   if ((rc = reg::step(prm, &pg, iters / 3)) || (rc = reg::step(prm, &pg, iters - iters / 3))) {
     std::fprintf(stderr, "part step: %s\n", flame_hip_strerror(rc));
     return 4;

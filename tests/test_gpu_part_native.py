@@ -82,8 +82,8 @@ def test_native_partition_repeats_a_give_up(gpu):
     assert n >= 2, out.stdout[-3000:]  # (the 6 k graph's first two solves and its second frame; later graphs sit out the back-off)
 
 
-@pytest.mark.parametrize("parts,depth,iters,V", [(2, 8, 60, 8000), (3, 4, 25, 12000)])
-def test_partitioned_graph_from_cpp(gpu, tmp_path, parts, depth, iters, V):
+@pytest.mark.parametrize("parts,depth,iters,V,peer", [(2, 8, 60, 8000, 0), (3, 4, 25, 12000, 0), (3, 4, 25, 12000, 1)])
+def test_partitioned_graph_from_cpp(gpu, tmp_path, parts, depth, iters, V, peer):
     """tests/cpp/part_native.cc: the C++ mirror (flame::optimizers::nltgv2_l1_graph_regularizer::Communicator /
     PartitionedGraph / step / costs) against a single Graph handle on the same random Delaunay graph -- every bit."""
     exe = str(tmp_path / "part_native")
@@ -91,5 +91,5 @@ def test_partitioned_graph_from_cpp(gpu, tmp_path, parts, depth, iters, V):
                            os.path.join(ROOT, "tests", "cpp", "part_native.cc"), "-o", exe,
                            "-L" + os.path.join(ROOT, "flame_ros_amd"), "-lflame_hip",
                            "-Wl,-rpath," + os.path.join(ROOT, "flame_ros_amd"), "-pthread"])
-    p = subprocess.run([exe, "0", str(parts), str(depth), str(iters), str(V)], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([exe, "0", str(parts), str(depth), str(iters), str(V), str(peer)], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "bit_exact 1 costs_ok 1" in p.stdout, (p.returncode, p.stdout, p.stderr)

@@ -143,4 +143,7 @@ def test_bench_partition_glue_at_world_1(gpu):
     assert pt["halo_depth_x2"].get("bit_exact_vs_one_gpu") is True and pt["halo_depth_x2"]["halo_depth"] == 32, pt["halo_depth_x2"]
     assert pt["two_parts_per_rank_pipelined"].get("bit_exact_vs_one_gpu") is True, pt["two_parts_per_rank_pipelined"]
     assert pt["two_parts_per_rank_pipelined"]["exchanges_pipelined"] > 0
+    # r06: the same cut through the peer transport, RCCL's figures beside it
+    assert pt["peer_transport"].get("bit_exact_vs_one_gpu") is True and pt["peer_transport"]["transport"] == "peer", pt["peer_transport"]
+    assert pt["transport"] == "rccl"  # (one part on one rank at world 1: no exchange to time on either transport)
     assert d["n_gpus"] == 1 and d["value"] > 0

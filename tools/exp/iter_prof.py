@@ -53,6 +53,7 @@ for name in (sys.argv[1:] or ["tum", "5k", "euroc", "50k"]):
                     seg.append("dual+stores %4d" % (x[2] - (x[1] if has_d else x[0])))
                     seg.append("bar1 %4d" % (x[3] - x[2]))
                     seg.append("slots %4d" % (x[4] - x[3]) if has_p else "slots    -")
+                    if has_p and x[7]: seg.append("(reads landed %4d, chain %4d)" % (x[7] - x[3], x[4] - x[7]))
                     seg.append("prox+store %4d" % (x[5] - x[4]) if has_p else "prox+store    -")
                     seg.append("bar2 %4d" % (x[6] - (x[5] if has_p else x[3])))
                     print("      wave %2d: %s" % (w, " | ".join(seg)))

@@ -32,15 +32,25 @@ rep("                                             f2v (&q23)[EPT], float sigma) 
     "                                             f2v (&q23)[EPT], float sigma, int itp = -1) {\n  float4 bi[K], bj[K];")
 rep("  for (int k = 0; k < K; ++k) { keep_w(bi[k]); keep_w(bj[k]); }\n  const f2v sg = {sigma, sigma};",
     "  for (int k = 0; k < K; ++k) { keep_w(bi[k]); keep_w(bj[k]); }\n  itp_stamp(itp, 1);\n  const f2v sg = {sigma, sigma};")
-rep("                                             f2v (&q23)[EPT], float sigma) {\n    if (n == K) tile_phase_d<O, K, EPT, S12>(bar, sm, eij, es, ed, ew, q1, q23, sigma);\n    else PhaseD<O, K - 1, EPT, S12>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma);",
-    "                                             f2v (&q23)[EPT], float sigma, int itp = -1) {\n    if (n == K) tile_phase_d<O, K, EPT, S12>(bar, sm, eij, es, ed, ew, q1, q23, sigma, itp);\n    else PhaseD<O, K - 1, EPT, S12>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma, itp);")
+rep("                                             f2v (&q23)[EPT], float sigma) {\n    if (n == K) tile_phase_d<O, K, EPT, S12, MARK>(bar, sm, eij, es, ed, ew, q1, q23, sigma);\n    else PhaseD<O, K - 1, EPT, S12, MARK>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma);",
+    "                                             f2v (&q23)[EPT], float sigma, int itp = -1) {\n    if (n == K) tile_phase_d<O, K, EPT, S12, MARK>(bar, sm, eij, es, ed, ew, q1, q23, sigma, itp);\n    else PhaseD<O, K - 1, EPT, S12, MARK>::run(n, bar, sm, eij, es, ed, ew, q1, q23, sigma, itp);")
 rep("                                             const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],\n                                             float) {}",
     "                                             const float4 (&)[EPT], float (&)[EPT], f2v (&)[EPT],\n                                             float, int = -1) {}")
 rep("  int done = 0, round = 0;\n", "  int done = 0, round = 0;\n  const bool itp_tile = PERSIST && tile_id == g_itp_cfg[0];\n  const int itp_round = g_itp_cfg[1];\n")
 rep("    const int ri = min(iters - it, depth);\n", "    const int ri = min(iters - it, depth);\n    const int itp = (itp_tile && round == itp_round && it <= 8) ? ((tid >> 6) * 8 + (it - 1)) * 8 : -1;\n    itp_stamp(itp, 0);\n")
-rep("    PhaseD<0, EPT, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);\n", "    PhaseD<0, EPT, EPT, S12>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma, itp);\n    itp_stamp(itp, 2);\n")
+rep("    PhaseD<0, EPT, EPT, S12, MARK>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma);\n", "    PhaseD<0, EPT, EPT, S12, MARK>::run(nk, bar, sm, eij, es, ed, ew, q1, q23, sigma, itp);\n    itp_stamp(itp, 2);\n")
 rep("    __syncthreads();\n    if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it] = __builtin_readcyclecounter();\n",
     "    __syncthreads();\n    itp_stamp(itp, 3);\n")
+# phase P: a stamp behind the landed slot reads (7), in front of the ordered chain
+rep("__device__ __forceinline__ void sum_slots(const float4* row, f2v nt2, float ntau, f2v& w, float& x) {",
+    "__device__ __forceinline__ void sum_slots(const float4* row, f2v nt2, float ntau, f2v& w, float& x, int itp = -1) {")
+rep("  for (int u = 0; u < K; ++u) keep_w(t[u]);\n#pragma unroll\n  for (int u = 0; u < K; ++u) {\n    const f2v c = {t[u].x, t[u].y};",
+    "  for (int u = 0; u < K; ++u) keep_w(t[u]);\n  itp_stamp(itp, 7);\n#pragma unroll\n  for (int u = 0; u < K; ++u) {\n    const f2v c = {t[u].x, t[u].y};")
+rep("  static __device__ __forceinline__ void run(int n, const float4* row, f2v nt2, float ntau, f2v& w, float& x) {\n    if constexpr (LO == HI) {\n      if constexpr (LO > 0) sum_slots<LO, MARK>(row, nt2, ntau, w, x);",
+    "  static __device__ __forceinline__ void run(int n, const float4* row, f2v nt2, float ntau, f2v& w, float& x, int itp = -1) {\n    if constexpr (LO == HI) {\n      if constexpr (LO > 0) sum_slots<LO, MARK>(row, nt2, ntau, w, x, itp);")
+rep("      if (n <= MID) SlotSel<LO, MID, MARK>::run(n, row, nt2, ntau, w, x);\n      else SlotSel<MID + 1, HI, MARK>::run(n, row, nt2, ntau, w, x);",
+    "      if (n <= MID) SlotSel<LO, MID, MARK>::run(n, row, nt2, ntau, w, x, itp);\n      else SlotSel<MID + 1, HI, MARK>::run(n, row, nt2, ntau, w, x, itp);")
+rep("          SlotSel<0, kPRound, MARK>::run(j, row, nt2, ntau, w, x);", "          SlotSel<0, kPRound, MARK>::run(j, row, nt2, ntau, w, x, k == 0 ? itp : -1);")
 rep("        x = prox_l1(x, vz[k], vt[k], x_min, x_max);\n", "        asm volatile(\"\" : \"+v\"(x), \"+v\"(w));\n        if (k == 0) itp_stamp(itp, 4);\n        x = prox_l1(x, vz[k], vt[k], x_min, x_max);\n")
 rep("        if (lv < n_upd) lds_store3(&bar[lv], vwb[k].x, vwb[k].y, vxb[k]);\n", "        if (lv < n_upd) lds_store3(&bar[lv], vwb[k].x, vwb[k].y, vxb[k]);\n        if (k == 0) itp_stamp(itp, 5);\n")
 rep("    __syncthreads();\n    if (prof && tid == 0 && it <= kMaxDepth) prof[2 * it + 1] = __builtin_readcyclecounter();\n",
