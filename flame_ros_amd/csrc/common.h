@@ -64,6 +64,24 @@ inline int64_t tile_lds_bytes(int32_t n_ext, int32_t nslots, bool slot12) {
   return slot12 ? (int64_t)n_ext * 16 + ((n + 3) & ~(int64_t)3) * 12 : (int64_t)n_ext * 16 + n * 16;
 }
 
+// ---- incidence-slot layout of a tile: ONE statement for every plan builder (plan.cpp on the host; plan_dev.hip's fused tile pass,
+// pass 2 and the one-launch mini plan on the device) and for what the kernels assume (kernels.hip phase P).  One row per
+// UPDATED local vertex; the 64 vertices a wavefront updates together (local ids 64 g .. 64 g + 63) share one pitch = their
+// largest degree made ODD, so that a column read -- lane l reads row_l[j] -- touches 64 different 16-byte slots, a multiple of
+// an odd number apart: conflict-free for ds_read_b128 (and for the split 12-byte layout's b64 / b32 reads); rows are
+// zero-padded up to the pitch (phase P sums the wave's longest row from every row: fmaf(-tau, +0, x) == x).  A group takes 64
+// pitches even when it holds fewer vertices (the last group of a tile).  Slot numbers are 16 bits (edge records pack two).
+#ifdef __HIPCC__
+#define FLAME_HD __host__ __device__
+#else
+#define FLAME_HD
+#endif
+FLAME_HD inline int32_t slot_group_pitch(int32_t max_degree_of_group) { return (max_degree_of_group < 1 ? 1 : max_degree_of_group) | 1; }
+FLAME_HD inline int32_t slot_group_span(int32_t pitch) { return 64 * pitch; }
+FLAME_HD inline bool slot_group_fits(int32_t base, int32_t pitch) { return base + slot_group_span(pitch) + kDummySlots <= 65535; }
+FLAME_HD inline int32_t slot_row_start(int32_t group_base, int32_t lv, int32_t pitch) { return group_base + (lv & 63) * pitch; }
+FLAME_HD inline uint32_t slot_row_word(int32_t row_start, int32_t degree) { return (uint32_t)row_start | ((uint32_t)degree << 16); }  // t_srow
+
 // Cost model of a tile for the balance of the partition (both plan builders, integer): a launch / a round lasts as long as its
 // slowest tile -- local edges + 2 x local vertices (r02).  (r05 tried local edges + 2 x UPDATED vertices, what a resident tile's
 // iterate time correlates with best at 50 k: -1 % there, +6...18 % at 20 k / 100 k / 200 k, profiles/r05_cost_model_ab.txt.)

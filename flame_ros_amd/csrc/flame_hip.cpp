@@ -918,7 +918,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
                    g->opt.tile_own == g->reuse_tile_own_opt;
   if (try_reuse && g->reuse_skip > 0) { --g->reuse_skip; try_reuse = false; }  // back-off after rejections
   g->plan_reused = false;
-  const int max_attempts = 8 + kBalanceRefinePasses + (sz.fat ? 7 * (2 + kBalanceRefinePasses) : 0);  // (plan.cpp)
+  const int max_attempts = 10 + kBalanceRefinePasses + (sz.fat ? 7 * (2 + kBalanceRefinePasses) : 0);  // (plan.cpp)
   for (int attempt = 0; attempt < max_attempts && !built; ++attempt) {
     const bool reusing = try_reuse;
     try_reuse = false;
@@ -1002,6 +1002,7 @@ static int upload_device_plan(flame_hip_graph* g, const float* pos, const int32_
     refine_left = 0;
     if (fat && fat_next_attempt(g->opt, sz, &depth, &fat_s12)) {}  // fat tiles: shallower / 12-byte slots first (plan.cpp)
     else if (fat) { fat = false; tile_own = sz.fallback_own; depth = sz.fallback_depth; }
+    else if (regular_next_attempt(g->opt, sz, V, &tile_own, &depth)) {}  // (plan.cpp)
     else tile_own = std::max(16, tile_own / 2);
   }
   if (!built) return 0;

@@ -1264,8 +1264,7 @@ int flame_hip_part_info(const flame_hip_part* P, const char* key, int32_t local_
   else if (k == "num_peers") *value = (int64_t)L.peers.size();
   else if (k == "send_bytes") *value = 4 * (int64_t)(kVRec * L.send_v.size() + kERec * L.send_e.size());
   else if (k == "recv_bytes") *value = 4 * (int64_t)(kVRec * L.recv_v.size() + kERec * L.recv_e.size());
-  else if (k == "persist_used" || k == "persist_launches") { return L.g ? flame_hip_get_info(L.g, key, value) : FLAME_HIP_ERR_STATE; }
-  else return FLAME_HIP_ERR_ARG;
+  else return L.g ? flame_hip_get_info(L.g, key, value) : FLAME_HIP_ERR_ARG;  // ("persist_used", "persist_launches", "num_tiles", "tile_depth", ...: the part's own handle)
   return 0;
 }
 

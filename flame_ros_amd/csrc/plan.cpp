@@ -281,6 +281,16 @@ bool fat_next_attempt(const PlanOptions& opt, const PlanSizing& sz, int* depth, 
   return false;
 }
 
+bool regular_next_attempt(const PlanOptions& opt, const PlanSizing& sz, int32_t V, int* tile_own, int* depth) {
+  const int own = std::max(*tile_own, 1);
+  const int64_t ntiles = ((int64_t)V + own - 1) / own;
+  const bool sized_for_resident = opt.resident && opt.tile_own <= 0 && opt.tile_depth <= 0 && !sz.single && *tile_own == sz.auto_own &&
+                                  ntiles >= 2 && ntiles <= std::min(256, opt.num_cus) && 2 * ntiles > std::min(256, opt.num_cus);
+  if (sized_for_resident && *depth > 2) { --*depth; return true; }
+  if (sized_for_resident) *depth = sz.depth;  // (no depth fits: smaller tiles by launches, at the automatic depth again)
+  return false;
+}
+
 TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles, bool allow_slot12) {
   TileFit f;
   int e_max = 0, ext_max = 0, upd_max = 0, hv_max = 0;
@@ -297,6 +307,11 @@ TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& 
   TileCfg c{};
   if (!fat) {
     f.ok = lds16 + kTileLdsReserve <= opt.lds_bytes && pick_cfg(opt.tile_threads, e_max, ext_max, &c);
+    // (r06 / ADVICE r05: tiles that are meant to be resident must fit the way the resident launch needs them -- with its
+    // staging area, in a configuration that has a resident kernel -- or the caller tries a shallower halo: regular_next_attempt())
+    if (f.ok && wants_resident(opt, tiles.size()) && opt.tile_own <= 0 && opt.tile_depth <= 0 && opt.batch_voff.empty() && tiles[0].depth > 0 &&
+        (lds16 + stage + kTileLdsReserve > opt.lds_bytes || !tile_persist_cfg(c.nt, c.ept, c.vpt)))
+      f.ok = false;
     f.lds_bytes = lds16;
   } else {
     // ... except in fat tiles: a thread per UPDATED vertex and per halo vertex of the poll list is enough (the outermost
@@ -403,7 +418,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     }
   }
   // (fat tiles: every halo depth that does not fit costs a balance sequence of its own before the next one is tried)
-  const int max_attempts = batch ? 1 : 7 + kBalanceRefinePasses + (sz.fat ? 7 * (2 + kBalanceRefinePasses) : 0);
+  const int max_attempts = batch ? 1 : 9 + kBalanceRefinePasses + (sz.fat ? 7 * (2 + kBalanceRefinePasses) : 0);  // (+ 2: regular_next_attempt())
   for (int attempt = 0; attempt < max_attempts; ++attempt) {
     const int ntiles = batch ? (int)opt.batch_voff.size() - 1 : (V == 0 ? 0 : (V + tile_own - 1) / tile_own);
     // ---- vertex order: RCB leaves = tiles ----
@@ -649,13 +664,13 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
           const int32_t g1 = std::min(g0 + 64, D.n_upd);
           int32_t width = 1;
           for (int32_t lv = g0; lv < g1; ++lv) width = std::max(width, P.grow[ext[lv] + 1] - P.grow[ext[lv]]);
-          width |= 1;
-          if (base + 64 * width + kDummySlots > 65535) { O.ok = false; break; }
+          width = slot_group_pitch(width);  // (common.h: the layout's one statement)
+          if (!slot_group_fits(base, width)) { O.ok = false; break; }
           for (int32_t lv = g0; lv < g1 && O.ok; ++lv) {
             const int32_t v = ext[lv];
             const int32_t deg = P.grow[v + 1] - P.grow[v];
-            const int32_t s0 = base + (lv - g0) * width;
-            O.srow.push_back((uint32_t)s0 | ((uint32_t)deg << 16));
+            const int32_t s0 = slot_row_start(base, lv, width);
+            O.srow.push_back(slot_row_word(s0, deg));
             int32_t j = 0;
             for (int32_t s = P.grow[v]; s < P.grow[v + 1]; ++s, ++j) {
               const int32_t k = P.ginc[s] & 0x7fffffff;
@@ -664,7 +679,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
               if (P.ginc[s] < 0) slot_dst[eloc[k]] = slot; else slot_src[eloc[k]] = slot;
             }
           }
-          base += 64 * width;
+          base += slot_group_span(width);
         }
         D.nslots = base;
         if (!O.ok) continue;
@@ -805,6 +820,7 @@ int build_plan(const PlanOptions& opt, int32_t V, int32_t E, int32_t T, const fl
     if (single) { single = false; tile_own = opt.tile_own > 0 ? opt.tile_own : auto_own; depth = opt.tile_depth > 0 ? std::min(opt.tile_depth, kMaxDepth) : auto_depth; }
     else if (fat && fat_next_attempt(opt, sz, &depth, &fat_s12)) {}  // fat tiles: shallower / 12-byte slots first ...
     else if (fat) { fat = false; tile_own = sz.fallback_own; depth = sz.fallback_depth; }  // ... then two rounds of smaller tiles
+    else if (regular_next_attempt(opt, sz, V, &tile_own, &depth)) {}  // resident-sized regular tiles: a shallower halo first
     else tile_own = std::max(16, tile_own / 2);
   }
   P.has_tiles = false;

@@ -134,6 +134,15 @@ struct TileFit {
 TileFit tile_fit(const PlanOptions& opt, bool fat, const std::vector<TileDesc>& tiles, bool allow_slot12 = true);
 // what a fat partition that did not fit tries next (both plan builders): false = nothing left, take the fallback
 bool fat_next_attempt(const PlanOptions& opt, const PlanSizing& sz, int* depth, bool* allow_slot12);
+// r06, regular tiles sized for ONE resident launch (automatic sizes, at most one tile per CU) that do not fit -- LDS with the
+// resident launch's staging area, a kernel configuration that has a resident variant --: halving the tiles would put more
+// tiles than CUs on the chip and the solve on launches (4 x slower), so the same tiles are first tried one halo level
+// shallower, down to depth 2 (the subdomains of a partitioned 200 k graph: 46-48 k local vertices with ragged halo bands,
+// half of them fell back to 511-515 tiles or to four edges per thread, profiles/r06_partition_parts_resident.txt).  Returns
+// true when *depth was lowered; else the caller halves *tile_own (and this call has restored the automatic depth).
+bool regular_next_attempt(const PlanOptions& opt, const PlanSizing& sz, int32_t V, int* tile_own, int* depth);
+// the tiles of a partition are meant to be resident: the caller solves that way and there is at most one tile per CU
+inline bool wants_resident(const PlanOptions& opt, size_t ntiles) { return opt.resident && ntiles >= 2 && (int64_t)ntiles <= std::min(256, opt.num_cus); }
 PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E);
 // smallest instantiated kernel configuration that holds e_max local edges / upd_max local vertices
 bool pick_tile_config(int want_nt, int e_max, int upd_max, int* nt, int* ept, int* vpt);

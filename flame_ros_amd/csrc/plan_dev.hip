@@ -1393,8 +1393,8 @@ __device__ __forceinline__ int tile_walk(const TileGraph& G, const TileLds& L, T
         const int32_t le = cnt[f == 2 ? b_next : b_same] + (f == 2 ? run_next : run_same) + before;
         const int32_t k = ent;
         uint32_t ss = 0xffffu, sd = 0xffffu;
-        if (lv < E->n_upd) { const int g = lv >> 6; ss = (uint32_t)(S.gbase[g] + (lv - (g << 6)) * S.gw[g] + G.ipos[2 * k]); ++found; }
-        if (ldst < E->n_upd) { const int g = ldst >> 6; sd = (uint32_t)(S.gbase[g] + (ldst - (g << 6)) * S.gw[g] + G.ipos[2 * k + 1]); ++found; }
+        if (lv < E->n_upd) { const int g = lv >> 6; ss = (uint32_t)(slot_row_start(S.gbase[g], lv, S.gw[g]) + G.ipos[2 * k]); ++found; }
+        if (ldst < E->n_upd) { const int g = ldst >> 6; sd = (uint32_t)(slot_row_start(S.gbase[g], ldst, S.gw[g]) + G.ipos[2 * k + 1]); ++found; }
         if (le < E->e_own && k != E->es + le) S.fail = 1;  // owned edges = the prefix, in internal order
         E->O->t_emap[E->eoff + le] = k;
         E->O->t_eij[E->eoff + le] = make_uint2((uint32_t)lv | ((uint32_t)ldst << 16), (ss & 0xffffu) | (sd << 16));
@@ -1459,11 +1459,11 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
     int32_t base = 0;
     const int ng = (n_upd + 63) >> 6;
     for (int g = 0; g < ng; ++g) {
-      const int32_t w = S.gw[g] | 1;
+      const int32_t w = slot_group_pitch(S.gw[g]);  // (common.h: the layout's one statement)
       S.gw[g] = w;
       S.gbase[g] = base;
-      if (base + 64 * w + kDummySlots > 65535) { S.fail = 1; break; }
-      base += 64 * w;
+      if (!slot_group_fits(base, w)) { S.fail = 1; break; }
+      base += slot_group_span(w);
     }
     S.gbase[kCapExt / 64] = base;
   }
@@ -1471,7 +1471,7 @@ __device__ __forceinline__ void tile_emit(const TileGraph& G, const TileLds& L, 
   for (int lv = tid; lv < n_upd; lv += NTB) {
     const int32_t v = L.ext[lv];
     const int g = lv >> 6;
-    O.t_srow[soff + lv] = (uint32_t)(S.gbase[g] + (lv - (g << 6)) * S.gw[g]) | ((uint32_t)(G.grow[v + 1] - G.grow[v]) << 16);
+    O.t_srow[soff + lv] = slot_row_word(slot_row_start(S.gbase[g], lv, S.gw[g]), G.grow[v + 1] - G.grow[v]);
   }
   TILE_STAMP(O, 7);
   // ---- local edge records with their two slots (the slot of an incidence = its vertex's row start + its
