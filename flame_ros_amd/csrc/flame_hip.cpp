@@ -363,6 +363,16 @@ struct flame_hip_graph {
   int32_t snap_V = 0, snap_E = 0;
   PersistBufs xp;                   // hand-off buffers (uncached, from the process-wide pool: NOT in caps) + dev-aid words
   size_t xp_cap[6] = {0, 0, 0, 0, 0, 0};
+  // r06, option "one_xcd" (default 1): a graph of up to 32 resident tiles keeps them on ONE XCD -- the launch has 8 x ntiles
+  // workgroups of which every 8th carries a tile -- and hands over through ORDINARY memory, i.e. that XCD's L2 (0.5 us per
+  // load instead of 0.9 through uncached memory: 1.2 k vertices 0.89 -> 0.81 us per iteration).  Which XCD a workgroup lands on
+  // is the dispatcher's habit, not a guarantee: tiles on different XCDs would never see each other's tags, time out, and the
+  // solve is repeated by launches like any give-up -- after which the device's lease never tries the mode again.
+  bool one_xcd_opt = true, one_xcd_used = false;
+  float4* cA[2] = {nullptr, nullptr};  // the hand-off copies in ordinary memory
+  float4* cB[2] = {nullptr, nullptr};
+  float4* cq[2] = {nullptr, nullptr};
+  void* c_zeroed[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the allocations that have been zeroed (tag 0 is never a round's)
   int poll_delay_opt = -1;          // option "poll_delay" (-1 = automatic)
   int persist_timeout_opt = 0;      // option "persist_timeout_us" (0 = automatic)
   bool need_marks = true;           // option "need_marks"
@@ -535,6 +545,7 @@ int flame_hip_graph_create(flame_hip_graph** out, int device, int32_t V, int32_t
 static void persist_lease_drop(flame_hip_graph* g, bool gave_up);
 static int persist_gave_up_count(int device);
 static int persist_backoff(int device);
+static bool one_xcd_allowed(int device);
 
 void flame_hip_graph_destroy(flame_hip_graph* g) {
   if (!g) return;
@@ -655,6 +666,8 @@ int flame_hip_set_option(flame_hip_graph* g, const char* key, int32_t value) {
   } else if (k == "persist_prof") {
     if (value < 0) return FLAME_HIP_ERR_ARG;
     g->persist_prof_want = value;
+  } else if (k == "one_xcd") {
+    g->one_xcd_opt = value != 0;
   } else if (k == "poll_delay") {  // x 256 clocks between a round's stores and its first poll pass; -1 = automatic
     if (value < -1 || value > 255) return FLAME_HIP_ERR_ARG;
     g->poll_delay_opt = value;
@@ -705,6 +718,8 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "stream_depth") *value = g->stream_depth;
   else if (k == "persist") *value = g->persist ? 1 : 0;
   else if (k == "persist_used") *value = g->persist_used ? 1 : 0;
+  else if (k == "one_xcd_used") *value = (g->persist_used && g->one_xcd_used) ? 1 : 0;
+  else if (k == "one_xcd") *value = g->one_xcd_opt ? 1 : 0;
   else if (k == "persist_recovered") *value = g->persist_recovered;
   else if (k == "persist_launches") *value = g->persist_launches;
   else if (k == "persist_timeout_us") *value = g->persist_timeout_us;
@@ -792,6 +807,7 @@ struct GraphOptScope {
     // whether resident tiles can actually be taken -- not while the device's lease sits out a back-off after a give-up, not
     // under the in-kernel timeline -- because depth 5 by ordinary launches is the slower configuration)
     g->opt.resident = g->persist && !g->prof && (g->device < 0 || persist_backoff(g->device) == 0);
+    g->opt.one_xcd = g->opt.resident && g->one_xcd_opt && g->opt.num_cus >= 256 && one_xcd_allowed(g->device);
     if (g->stream_depth > 0 && g->opt.tile_depth == 0 && g->opt.tile_own <= 0 && g->opt.batch_voff.empty() && V <= 64 * 32)
       g->opt.tile_depth = g->stream_depth;
   }
@@ -1656,6 +1672,7 @@ struct PersistLease {
   hipStream_t holder_stream = nullptr;  // the stream its launch went to: a launch queued BEHIND it on the same stream can
                                      // never be co-resident with it (the partition mode's parts of one rank)
   bool recorded = false;             // the holder's end event has been recorded behind its launch (until then: busy)
+  bool one_xcd_broken = false;       // a one-XCD launch gave up on this device: the mode is off for the rest of the process
   int backoff = 0;                   // solves (of any handle) to sit out
   int backoff_next = 16;
   int gave_up = 0;                   // give-ups seen on this device (info "persist_gave_up")
@@ -1700,10 +1717,17 @@ static int persist_backoff(int device) {
   std::lock_guard<std::mutex> lk(L.m);
   return L.backoff;
 }
+static bool one_xcd_allowed(int device) {
+  if (device < 0) return true;  // (a host-only plan: sized as the MI355X would)
+  PersistLease& L = persist_lease(device);
+  std::lock_guard<std::mutex> lk(L.m);
+  return !L.one_xcd_broken;
+}
 static void persist_lease_drop(flame_hip_graph* g, bool gave_up) {
   PersistLease& L = persist_lease(g->device);
   std::lock_guard<std::mutex> lk(L.m);
   if (L.holder == g) { L.holder = nullptr; L.holder_done = nullptr; L.holder_stream = nullptr; }
+  if (gave_up && g->one_xcd_used) L.one_xcd_broken = true;
   if (gave_up) {
     ++L.gave_up;
     L.backoff = L.backoff_next;
@@ -1857,6 +1881,24 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
           if (fresh || rezero) HIPCHK(hipMemsetAsync(*pp[k], 0, g->xp_cap[3 * b + k], s));
         }
       }
+      PersistBufs xl = x;  // (what this launch gets)
+      g->one_xcd_used = false;
+      if (g->one_xcd_opt && P.tiles.size() <= (size_t)kOneXcdTiles && g->num_cus >= 256 && one_xcd_allowed(g->device)) {
+        for (int b = 0; b < 2; ++b) {
+          float4** pp[3] = {&g->cA[b], &g->cB[b], &g->cq[b]};
+          const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
+          for (int k = 0; k < 3; ++k) {
+            if ((rc = dev_alloc(g->caps, pp[k], nn[k]))) return rc;
+            if (g->c_zeroed[3 * b + k] != (void*)*pp[k] || rezero) {  // (a new or re-grown allocation: garbage could pass for a tag)
+              HIPCHK(hipMemsetAsync(*pp[k], 0, g->caps[(void*)pp[k]], s));
+              g->c_zeroed[3 * b + k] = (void*)*pp[k];
+            }
+          }
+          xl.hA[b] = g->cA[b]; xl.hB[b] = g->cB[b]; xl.hq[b] = g->cq[b];
+        }
+        xl.one_xcd = 1;
+        g->one_xcd_used = true;
+      }
       a.A_src = g->A[cur]; a.B_src = g->B[cur]; a.q_src = g->q[cur];
       a.A_dst = g->A[cur ^ 1]; a.B_dst = g->B[cur ^ 1]; a.q_dst = g->q[cur ^ 1];
       a.iters = num_iters;
@@ -1875,7 +1917,10 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
         if (stall_us > 0 && tile_stall_hook_build()) x.poll_delay = (x.poll_delay & 0xff) | (stall_us << 8);  // (microseconds, bits 8.. of poll_delay; debug kernels only)
       }
       g->last_rounds = rounds;
-      HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, x, g->persist_err,
+      // (one XCD: a pass through the L2 is short and cheap -- no pause in front of the first one, profiles/r06_one_xcd_ab.txt)
+      xl.poll_delay = (xl.one_xcd && g->poll_delay_opt < 0) ? 0 : x.poll_delay;
+      xl.timeout_ticks = x.timeout_ticks;
+      HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, xl, g->persist_err,
                                  g->persist_base));
       g->persist_base += rounds - 1;
       g->persist_used = true;

@@ -398,6 +398,8 @@ struct PersistArgs {
   int32_t* prof;      // device memory (16 words), dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]; [7] the
                       // longest poll wait (10 ns ticks); [8] torn entries seen (FLAME_TORN_CHECK builds)
   int32_t poll_delay; // units of 256 clocks between a round's stores and its first poll pass
+  int32_t one_xcd;    // EXPERIMENT r06: the grid is 8 x ntiles blocks and only every 8th -- the ones the dispatcher puts on XCD 0 --
+                      // carries a tile: the hand-off copies are then ORDINARY memory, met in that XCD's L2
   int32_t timeout_ticks;  // 10 ns ticks a poll may wait before the launch gives up (the host: max(0.5 ms, 8 x the handle's
                           // last measured round), 4 ms while nothing has been measured)
   // (test hook of a DEBUG build, -DFLAME_PERSIST_STALL_HOOK=1 + FLAME_HIP_PERSIST_STALL_US: bits 8.. of poll_delay =
@@ -465,7 +467,9 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
   // bisection order (neighbours adjacent), so giving XCD k the k-th contiguous eighth of the tiles
   // makes tiles that share halo vertices / edges share one L2.  Bijective for any tile count.
   const int nt_all = a.ntiles, xq = nt_all >> 3, xr = nt_all & 7, xcd = blockIdx.x & 7;
-  const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
+  if (PERSIST && pa.one_xcd && xcd != 0) return;
+  const int tile_id = (PERSIST && pa.one_xcd) ? (int)(blockIdx.x >> 3)
+                                              : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (int)(blockIdx.x >> 3);
   const TileDesc& D = a.tiles[tile_id];
   const int tid = threadIdx.x;
   // the whole descriptor header up front, before anything with side effects: the compiler then
@@ -2040,7 +2044,7 @@ hipError_t launch_tile_persist_t(hipStream_t s, size_t lds, const TileArgs& a, c
     if (e != hipSuccess) return e;
   }
   // the launches' grid: one workgroup per tile, all of them resident (the caller keeps ntiles <= the number of CUs)
-  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, S12, FAT>), dim3(a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
+  hipLaunchKernelGGL((k_tile_persist<NT, EPT, VPT, S12, FAT>), dim3(pa.one_xcd ? 8 * a.ntiles : a.ntiles), dim3(NT), lds, s, a.tiles, a.ntiles, a.iters, a.t_vmap,
                      a.t_srow, a.t_eij, a.t_emap, a.t_ew, a.B_src, a.A_src, a.q_src, a.A_dst, a.B_dst, a.q_dst, pa, a.p);
   return hipGetLastError();
 }
@@ -2051,6 +2055,7 @@ hipError_t launch_tile_persist(hipStream_t s, int nt, int ept, int vpt, size_t l
   PersistArgs pa{};
   pa.err_host = err_host; pa.base = base; pa.prof = x.prof; pa.poll_delay = x.poll_delay;
   pa.timeout_ticks = x.timeout_ticks > 0 ? x.timeout_ticks : 400000;
+  pa.one_xcd = x.one_xcd;
   for (int b = 0; b < 2; ++b) { pa.hA[b] = x.hA[b]; pa.hB[b] = x.hB[b]; pa.hq[b] = x.hq[b]; }
   pa.poll_v = x.poll_v; pa.poll_e = x.poll_e; pa.poll_ne = x.poll_ne;
   pa.need_v = (x.need_valid && a.fat) ? x.need_v : nullptr; pa.need_e = (x.need_valid && a.fat) ? x.need_e : nullptr;

@@ -234,7 +234,12 @@ PlanSizing plan_sizing(const PlanOptions& opt, int32_t V, int32_t E) {
   // (r05, resident tiles: 24 instead of 32 own vertices at least -- more CUs at work, 1-2 % per iteration below 6 k vertices and
   // on a TUM-sized frame: profiles/r05_min_own_ab.txt; tiles that small take the deeper halo)
   const int min_own = opt.resident ? 24 : 32;
-  const int auto_own = one_round ? std::max(min_own, std::min(196, (V + 255) / 256))
+  // r06: a resident graph of up to 32 x 40 vertices takes 32 tiles -- all on ONE XCD, hand-offs through its L2 (flame_hip.cpp
+  // "one_xcd"; 1.2 k vertices: 50 tiles of 24 over all XCDs 0.89 us per iteration, 32 tiles of 38 on one 0.81)
+  const bool one_xcd = opt.one_xcd && opt.resident && opt.tile_own <= 0 && opt.batch_voff.empty() && V > kOneXcdTiles * min_own &&
+                       V <= kOneXcdTiles * kOneXcdMaxOwn;
+  const int auto_own = one_xcd ? (V + kOneXcdTiles - 1) / kOneXcdTiles
+                       : one_round ? std::max(min_own, std::min(196, (V + 255) / 256))
                        : fat     ? fat_own
                                  : std::max(196, std::min(400, (V + 511) / 512));
   // few tiles (a small lone graph): CUs are idle anyway, so redundant halo work is free and deeper

@@ -32,6 +32,7 @@ struct PlanOptions {
   int single_max = 512;  // auto: a lone graph up to this many vertices becomes ONE isolated tile
   bool single_only = false;  // build_plan(): return kPlanSingleNoFit instead of falling back to a
                              // halo'd partition when the isolated tile does not fit after all
+  bool one_xcd = false;  // the caller keeps graphs of <= kOneXcdTiles resident tiles on ONE XCD (flame_hip option "one_xcd"): sized for it
   int num_cus = 256;     // compute units of the device the plan will run on (a host-only plan: MI355X)
   int timing = 0;        // diagnostic (option "plan_timing"): the builders print their stages' times to stderr (levels: plan_dev.hip)
   int debug_sub_cap = 0; // test hook: the device builder's subtree kernel reports an overflow above
@@ -40,6 +41,8 @@ struct PlanOptions {
   std::vector<int32_t> batch_voff;
 };
 
+constexpr int kOneXcdTiles = 32;     // an XCD has 32 CUs: one resident tile each
+constexpr int kOneXcdMaxOwn = 40;    // ... worth it up to 32 x 40 vertices (1.5 k vertices on 32 tiles of 47: +-0 against 63 tiles of 24)
 constexpr int kPlanSingleNoFit = 1;  // build_plan() with single_only: the caller partitions elsewhere
 
 struct Float4 { float x, y, z, w; };

@@ -116,7 +116,12 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * repeated as a whole -- the error word does not say which one gave up, so the source of the first is copied aside when
  * the second is queued and every solve since is logged; FLAME_HIP_ERR_STATE only when something other than solves wrote
  * the state in between), and the whole process then stays off resident tiles for 16 solves, doubling with every further
- * give-up ("persist_gave_up").  Tuning: "poll_delay" (x 256 clocks between a round's stores and its first poll pass, -1 =
+ * give-up ("persist_gave_up").  "one_xcd" (r06, default 1): a graph of up to 32 resident tiles -- automatic sizes give 32 tiles to
+ * graphs of 770 .. 1 280 vertices -- keeps them on ONE XCD (the launch has 8 x ntiles workgroups, every 8th carries a tile) and hands
+ * over through ordinary memory, i.e. that XCD's L2, instead of uncached memory: 1.2 k vertices 0.89 -> 0.82 us per iteration.  Which
+ * XCD a workgroup lands on is the dispatcher's habit, not a guarantee; the round tags and the bounded polls keep the result right
+ * regardless: tiles that cannot see each other time out, the solve is repeated by launches and the device's lease drops the mode for
+ * the rest of the process (flame_hip_get_info "one_xcd_used").  Tuning: "poll_delay" (x 256 clocks between a round's stores and its first poll pass, -1 =
  * automatic), "need_marks" (1 = default: fat tiles hand over only the entries somebody polls).  Diagnostics: "plan_timing" (1-5:
  * the plan builders print their stages' times to stderr); with option "persist_prof" = <tile + 1>
  * "persist_prof_0".."persist_prof_3" return that tile's time split of the last solve's rounds in 10 ns ticks:
