@@ -735,8 +735,8 @@ def main():
                                               "tools/facade_bench.cc; targets 0.6 / 1.0 / 2.2 ms")
             out["frames_axis"] = frames_axis(local_rank)
             out["small_graph_us_per_iteration"] = small_graphs(local_rank)
-            out["other_configs"] = {w: config_line(w, local_rank) for w in ("5k", "euroc", "200k") if w != args.workload}
-            out["other_configs"]["note"] = ("BASELINE configs 2 / 3 / 5 on one GPU, resident graph, library defaults: device time "
+            out["other_configs"] = {w: config_line(w, local_rank) for w in ("tum", "5k", "euroc", "200k") if w != args.workload}
+            out["other_configs"]["note"] = ("BASELINE configs 1 (TUM-shaped, 1.2 k vertices) / 2 / 3 / 5 on one GPU, resident graph, library defaults: device time "
                                             "of the median solve; contract_frac = (84E+60V) x iterations / time / 8 TB/s")
         if not args.no_cpu and world == 1:  # contract: rank 0 at N=1 only
             cb = cpu_baseline(args.workload, args.batch_win if args.batch else 0, iters, args.cpu_budget)

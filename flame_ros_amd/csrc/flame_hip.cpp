@@ -372,7 +372,8 @@ struct flame_hip_graph {
   float4* cA[2] = {nullptr, nullptr};  // the hand-off copies in ordinary memory
   float4* cB[2] = {nullptr, nullptr};
   float4* cq[2] = {nullptr, nullptr};
-  void* c_zeroed[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the allocations that have been zeroed (tag 0 is never a round's)
+  void* c_zeroed[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the allocations that have been zeroed (tag 0 is never a
+  size_t c_zeroed_cap[6] = {0, 0, 0, 0, 0, 0};                                 // round's): address AND capacity, i.e. no reallocation since
   int poll_delay_opt = -1;          // option "poll_delay" (-1 = automatic)
   int persist_timeout_opt = 0;      // option "persist_timeout_us" (0 = automatic)
   bool need_marks = true;           // option "need_marks"
@@ -1889,9 +1890,11 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
           const size_t nn[3] = {(size_t)g->V, (size_t)g->V, (size_t)std::max(g->E, 1)};
           for (int k = 0; k < 3; ++k) {
             if ((rc = dev_alloc(g->caps, pp[k], nn[k]))) return rc;
-            if (g->c_zeroed[3 * b + k] != (void*)*pp[k] || rezero) {  // (a new or re-grown allocation: garbage could pass for a tag)
-              HIPCHK(hipMemsetAsync(*pp[k], 0, g->caps[(void*)pp[k]], s));
+            const size_t cap_now = g->caps[(void*)pp[k]];
+            if (g->c_zeroed[3 * b + k] != (void*)*pp[k] || g->c_zeroed_cap[3 * b + k] != cap_now || rezero) {  // (a new or re-grown
+              HIPCHK(hipMemsetAsync(*pp[k], 0, cap_now, s));                                                   // allocation: garbage could pass for a tag)
               g->c_zeroed[3 * b + k] = (void*)*pp[k];
+              g->c_zeroed_cap[3 * b + k] = cap_now;
             }
           }
           xl.hA[b] = g->cA[b]; xl.hB[b] = g->cB[b]; xl.hq[b] = g->cq[b];
