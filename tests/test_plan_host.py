@@ -346,6 +346,42 @@ def test_fat_tile_sizing():
             assert r1.info("num_tiles") > 256 and r1.info("tile_slot12") == 0
 
 
+def test_one_xcd_sizing():
+    """r06: a resident graph of 770 .. 1 280 vertices takes 32 tiles (an XCD has 32 CUs: the tiles hand over through its L2,
+    option "one_xcd"); below, the 24-vertex floor already gives at most 32; above, and with the option off or without resident
+    tiles, the sizes of all XCDs apply."""
+    for V, ntiles in ((700, 30), (800, 32), (1200, 32), (1280, 32), (1300, 55), (1500, 63)):
+        g = graphgen.synthetic(V, seed=V)
+        r = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1)
+        assert r.info("num_tiles") == ntiles, (V, r.info("num_tiles"))
+        assert r.info("tile_threads") == 512 and r.info("tile_ept") in (2, 3) and r.info("tile_vpt") == 1  # a resident configuration
+    g = graphgen.synthetic(1200, seed=1200)
+    assert GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, one_xcd=0).info("num_tiles") == 50
+    assert GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, persist=0).info("num_tiles") == 38
+    assert GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, device=-1, tile_own=30).info("num_tiles") == 40
+
+
+def test_peer_transport_inboxes_are_consistent_across_ranks():
+    """r06 peer transport: every rank derives every rank's inbox layout from the whole graph (no request lists travel).  Host-only
+    plans of the 3 ranks of a 3 x 2 partition: what rank a sends to part d is exactly what the rank of d expects from it."""
+    from flame_ros_amd import partition
+    g = graphgen.synthetic(6000, seed=3)
+    world, k = 3, 2
+    plans = [partition.Partition(None, g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, parts_per_rank=k, halo_depth=4, plan_rank=r, plan_world=world)
+             for r in range(world)]
+    info = {}
+    for r, ps in enumerate(plans):
+        for i in range(k):
+            me = ps.info("part_id", i)
+            peers, sc, rc = ps.array("peers", i), ps.array("send_cnt", i).reshape(-1, 2), ps.array("recv_cnt", i).reshape(-1, 2)
+            info[me] = {int(p): (tuple(sc[j]), tuple(rc[j])) for j, p in enumerate(peers)}
+    assert sorted(info) == list(range(world * k))
+    for a, d in info.items():
+        for b, (sent, recv) in d.items():
+            assert a in info[b], (a, b)          # the peer relation is symmetric
+            assert info[b][a][1] == sent and info[b][a][0] == recv, (a, b, sent, recv, info[b][a])
+
+
 def test_batch_plan():
     gs = [graphgen.dataset_shaped(640, 480, 16, seed=s) for s in range(3)] + [graphgen.synthetic(200, seed=1)]
     r = GraphRegularizer.from_batch(gs, device=-1)
