@@ -594,6 +594,7 @@ int peer_connect_rccl(flame_hip_part* P) {
 // the segment tables of the two transport kernels (device), from the parts' registered lists
 int peer_build_tables(flame_hip_part* P, const std::vector<flame_hip_halo_view>& views) {
   flame_hip_part::Peer& X = P->px;
+  X.tables = false;  // (until everything below has succeeded)
   std::vector<HaloSegDev> push, pull;
   const InboxLayout mine = inbox_layout(P, P->rank);
   std::vector<InboxLayout> lay((size_t)P->world);
