@@ -492,7 +492,7 @@ struct flame_hip_graph {
 
 extern "C" {
 
-int flame_hip_version(void) { return 401; }
+int flame_hip_version(void) { return 402; }  // (402, r06: halo view, peer transport, local communicator, handle options instead of environment switches)
 
 const char* flame_hip_strerror(int code) {
   switch (code) {
