@@ -265,7 +265,11 @@ struct PhaseD<O, 0, EPT, S12, MARK> {
                                              float) {}
 };
 
-constexpr int kPRound = kSlotRound;  // incidence slots read per round of phase P
+constexpr int kPRound = kSlotRound;  // incidence slots read per batch of phase P (12-byte slots)
+// ... 16-byte slots: 7 -- one batch covers more of the usual longest rows (8-10) and the 1 024-thread kernels still fit 128
+// VGPRs: 1.2 k and 50 k -1 % each against 6; the fat-tile kernels with 12-byte slots lose 4.5 % with 7, 8 spills
+// (profiles/r06_slot_round_sweep.txt)
+constexpr int kPRound16 = kSlotRound + 1;
 
 // Phase P: K consecutive incidence slots of this lane's row, all reads issued before the first use
 // (constant offsets: no address arithmetic), then the dependent fma chain in slot order.
@@ -691,8 +695,8 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
           // group -- measured equal at 1.2 k ... 10 k vertices, r06 profiles/r06_slot_batch_ab.txt: the segment is bound by
           // the LDS return path, three waves x 9 KB per phase P, not by the round trips)
           const float4* row = vrow[k];
-          for (; j > kPRound; j -= kPRound, row += kPRound) sum_slots<kPRound, MARK>(row, nt2, ntau, w, x);
-          SlotSel<0, kPRound, MARK>::run(j, row, nt2, ntau, w, x);
+          for (; j > kPRound16; j -= kPRound16, row += kPRound16) sum_slots<kPRound16, MARK>(row, nt2, ntau, w, x);
+          SlotSel<0, kPRound16, MARK>::run(j, row, nt2, ntau, w, x);
         }
         x = prox_l1(x, vz[k], vt[k], x_min, x_max);
         vxb[k] = fmaf(theta, x - xp, x);
