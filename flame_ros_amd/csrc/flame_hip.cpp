@@ -390,6 +390,11 @@ struct flame_hip_graph {
   hipStream_t last_stream = nullptr;
   bool init_have_x0 = false;        // the device-built plan's initial state came with an x0 array
   int persist_recovered = 0;        // how many solves were repeated that way (flame_hip_get_info)
+  // the last give-up of this handle, for whoever has to find out why (info "persist_gave_up_tile" / _round / _behind /
+  // _behind_round / _waiting / _tiles / _one_xcd / _timeout_us): the tile that timed out in the earliest round, that round,
+  // the tile that owns an entry it waited for and the round THAT one timed out in (-1: it never did -- not started, or stuck
+  // somewhere else), how many of the launch's tiles timed out
+  struct GiveUp { int32_t tile = -1, round = -1, behind = -1, behind_round = -1, waiting = 0, tiles = 0, one_xcd = 0, timeout_us = 0; } give_up;
   uint64_t solve_serial = 0;        // state_serial right behind the last solve: later state-writing calls move on from it
   // r05: SEVERAL solves queued behind each other without a synchronising call are repeatable too (a bench window, a caller
   // that pipelines solves): every solve from the first unchecked resident one on is logged, and when a second one is queued
@@ -577,6 +582,34 @@ static hipError_t wait_last_solve(flame_hip_graph* g) {
   return hipEventSynchronize(g->ev1);
 }
 
+// A launch of resident tiles gave up: keep what its record says before it is cleared (cold path).  The tile that timed out in
+// the EARLIEST round stood next to whoever was late (tiles further away got a round further before their own neighbours
+// stopped delivering), and the entry it waited for names that one.
+static void persist_note_give_up(flame_hip_graph* g) {
+  int32_t* w = g->persist_err;
+  flame_hip_graph::GiveUp u;
+  u.tiles = (int32_t)g->plan.tiles.size();
+  u.one_xcd = g->one_xcd_used ? 1 : 0;
+  u.timeout_us = g->persist_timeout_us;
+  const int nt = std::min(u.tiles, (int32_t)kGiveUpTiles);
+  const int32_t* m = w + kGiveUpWords;
+  for (int t = 0; t < nt; ++t) {
+    if (m[2 * t] == 0) continue;
+    ++u.waiting;
+    if (u.tile < 0 || m[2 * t] - 1 < u.round) { u.tile = t; u.round = m[2 * t] - 1; }
+  }
+  if (u.tile >= 0) {  // (a forced failure of the hooks library has no record)
+    const int32_t entry = m[2 * u.tile + 1];
+    for (int t = 0; t < u.tiles && entry != INT32_MIN; ++t) {
+      const TileDesc& T = g->plan.tiles[t];
+      const bool in = entry >= 0 ? (entry >= T.vstart && entry < T.vstart + T.n_own) : (-1 - entry >= T.estart && -1 - entry < T.estart + T.e_own);
+      if (in) { u.behind = t; u.behind_round = t < nt ? m[2 * t] - 1 : -1; break; }
+    }
+  }
+  g->give_up = u;
+  std::memset(w + 1, 0, sizeof(int32_t) * (kGiveUpWords + 2 * kGiveUpTiles - 1));
+}
+
 // A new upload throws the state of the solves before it away: whether one of their resident launches gave up no longer
 // matters for the results -- only for the lease and the back-off.  (Called behind the upload's own wait for those solves.)
 static void persist_discard(flame_hip_graph* g) {
@@ -585,6 +618,7 @@ static void persist_discard(flame_hip_graph* g) {
   g->persist_unchecked = false;
   g->persist_unchecked_n = 0;
   if (g->persist_err && *g->persist_err != 0) {
+    persist_note_give_up(g);
     *g->persist_err = 0;
     persist_lease_drop(g, true);
   }
@@ -739,6 +773,14 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
     *value = v / 100;
   }
   else if (k == "persist_gave_up") *value = persist_gave_up_count(g->device);  // (give-ups of any handle on this device)
+  else if (k == "persist_gave_up_tile") *value = g->give_up.tile;        // (this handle's last give-up, see GiveUp)
+  else if (k == "persist_gave_up_round") *value = g->give_up.round;
+  else if (k == "persist_gave_up_behind") *value = g->give_up.behind;
+  else if (k == "persist_gave_up_behind_round") *value = g->give_up.behind_round;
+  else if (k == "persist_gave_up_waiting") *value = g->give_up.waiting;
+  else if (k == "persist_gave_up_tiles") *value = g->give_up.tiles;
+  else if (k == "persist_gave_up_one_xcd") *value = g->give_up.one_xcd;
+  else if (k == "persist_gave_up_timeout_us") *value = g->give_up.timeout_us;
   else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF=<tile + 1>): 10 ns ticks of that tile, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
     int32_t v = 0;
@@ -1760,6 +1802,7 @@ static int persist_check(flame_hip_graph* g, int own_marks = 0) {
     g->queued.clear(); g->qsnap_valid = false;
     return 0;
   }
+  persist_note_give_up(g);
   *g->persist_err = 0;
   persist_lease_drop(g, true);
   // r05: a queue of solves is repeated as a whole from the state copied aside in front of its second member
@@ -1832,8 +1875,8 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       PersistBufs& x = g->xp;
       int rc;
       if (!g->persist_err) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
-        *g->persist_err = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), sizeof(int32_t) * (kGiveUpWords + 2 * kGiveUpTiles), hipHostMallocDefault));
+        std::memset(g->persist_err, 0, sizeof(int32_t) * (kGiveUpWords + 2 * kGiveUpTiles));
       }
       if (!x.prof || g->persist_prof_set != g->persist_prof_want) {  // dev aid: which tile (if any) splits its rounds' time
         if ((rc = dev_alloc(g->caps, &x.prof, 16))) return rc;
@@ -2644,6 +2687,7 @@ int flame_hip_persist_take_error(flame_hip_graph* g, int32_t* gave_up) {
   g->persist_unchecked_n = 0;
   g->queued.clear(); g->qsnap_valid = false;  // (the caller -- the partition mode -- keeps snapshots of its own)
   if (had && g->persist_err && (*g->persist_err != 0 || force_fail)) {
+    persist_note_give_up(g);
     *g->persist_err = 0;
     persist_lease_drop(g, true);
     g->persist_used = false;
