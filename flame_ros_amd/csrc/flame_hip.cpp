@@ -390,11 +390,11 @@ struct flame_hip_graph {
   hipStream_t last_stream = nullptr;
   bool init_have_x0 = false;        // the device-built plan's initial state came with an x0 array
   int persist_recovered = 0;        // how many solves were repeated that way (flame_hip_get_info)
-  // the last give-up of this handle, for whoever has to find out why (info "persist_gave_up_tile" / _round / _behind /
-  // _behind_round / _waiting / _tiles / _one_xcd / _timeout_us): the tile that timed out in the earliest round, that round,
-  // the tile that owns an entry it waited for and the round THAT one timed out in (-1: it never did -- not started, or stuck
-  // somewhere else), how many of the launch's tiles timed out
-  struct GiveUp { int32_t tile = -1, round = -1, behind = -1, behind_round = -1, waiting = 0, tiles = 0, one_xcd = 0, timeout_us = 0; } give_up;
+  // the last give-up of this handle, for whoever has to find out why (info "persist_gave_up_tile" / _round / _front_round /
+  // _not_started / _rounds / _tiles / _one_xcd / _timeout_us, persist_note_give_up()): the tile that had handed over the fewest
+  // rounds and how many, the most any tile had, the tiles that had handed over none, the launch's rounds
+  struct GiveUp { int32_t tile = -1, round = -1, front_round = 0, not_started = 0, rounds = 0, tiles = 0, one_xcd = 0, timeout_us = 0; } give_up;
+  int32_t give_up_base = 0;         // persist_base of the last resident launch (its tags are give_up_base + 1 ..)
   uint64_t solve_serial = 0;        // state_serial right behind the last solve: later state-writing calls move on from it
   // r05: SEVERAL solves queued behind each other without a synchronising call are repeatable too (a bench window, a caller
   // that pipelines solves): every solve from the first unchecked resident one on is logged, and when a second one is queued
@@ -582,32 +582,40 @@ static hipError_t wait_last_solve(flame_hip_graph* g) {
   return hipEventSynchronize(g->ev1);
 }
 
-// A launch of resident tiles gave up: keep what its record says before it is cleared (cold path).  The tile that timed out in
-// the EARLIEST round stood next to whoever was late (tiles further away got a round further before their own neighbours
-// stopped delivering), and the entry it waited for names that one.
-static void persist_note_give_up(flame_hip_graph* g) {
-  int32_t* w = g->persist_err;
+// A launch of resident tiles gave up: say how far its tiles got (cold path, nothing in the kernel -- a per-tile record written at
+// the time-out cost every size 3-5 % through the poll loop's registers and code layout, profiles/r06_giveup_record_ab.txt).
+// The x_bar hand-off copies of both parities still hold what the LAST launch's tiles stored: a tile's highest tag above the
+// launch's base is the last round it handed over.  The tile with the lowest one is the late one (0 rounds: it never started) or,
+// when the late one caught up after its neighbours had stopped, stood next to it.  analyse = false: the plan is no longer the
+// launch's (a new upload), only the launch's own numbers are kept.
+static void persist_note_give_up(flame_hip_graph* g, bool analyse = true) {
   flame_hip_graph::GiveUp u;
   u.tiles = (int32_t)g->plan.tiles.size();
   u.one_xcd = g->one_xcd_used ? 1 : 0;
   u.timeout_us = g->persist_timeout_us;
-  const int nt = std::min(u.tiles, (int32_t)kGiveUpTiles);
-  const int32_t* m = w + kGiveUpWords;
-  for (int t = 0; t < nt; ++t) {
-    if (m[2 * t] == 0) continue;
-    ++u.waiting;
-    if (u.tile < 0 || m[2 * t] - 1 < u.round) { u.tile = t; u.round = m[2 * t] - 1; }
-  }
-  if (u.tile >= 0) {  // (a forced failure of the hooks library has no record)
-    const int32_t entry = m[2 * u.tile + 1];
-    for (int t = 0; t < u.tiles && entry != INT32_MIN; ++t) {
-      const TileDesc& T = g->plan.tiles[t];
-      const bool in = entry >= 0 ? (entry >= T.vstart && entry < T.vstart + T.n_own) : (-1 - entry >= T.estart && -1 - entry < T.estart + T.e_own);
-      if (in) { u.behind = t; u.behind_round = t < nt ? m[2 * t] - 1 : -1; break; }
-    }
+  u.rounds = g->last_rounds;
+  const int32_t V = g->V, base = g->give_up_base;
+  float4* const* hB = g->one_xcd_used ? g->cB : g->xp.hB;
+  if (analyse && V > 0 && hB[0] && hB[1] && g->persist_used && *g->persist_err == 1) {  // (a forced failure of the hooks library: nothing to look at)
+    std::vector<float4> e0((size_t)V), e1((size_t)V);
+    if (hipMemcpy(e0.data(), hB[0], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(e1.data(), hB[1], sizeof(float4) * (size_t)V, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int t = 0; t < u.tiles; ++t) {
+        const TileDesc& T = g->plan.tiles[t];
+        int32_t last = 0;
+        for (int32_t v = T.vstart; v < T.vstart + T.n_own && v < V; ++v)
+          for (const float4* e : {&e0[(size_t)v], &e1[(size_t)v]}) {
+            int32_t tag;
+            std::memcpy(&tag, &e->w, sizeof(tag));
+            if (tag > base && tag - base <= u.rounds) last = std::max(last, tag - base);
+          }
+        if (last == 0) ++u.not_started;
+        if (u.tile < 0 || last < u.round) { u.tile = t; u.round = last; }
+        u.front_round = std::max(u.front_round, last);
+      }
+    } else (void)hipGetLastError();
   }
   g->give_up = u;
-  std::memset(w + 1, 0, sizeof(int32_t) * (kGiveUpWords + 2 * kGiveUpTiles - 1));
 }
 
 // A new upload throws the state of the solves before it away: whether one of their resident launches gave up no longer
@@ -618,7 +626,7 @@ static void persist_discard(flame_hip_graph* g) {
   g->persist_unchecked = false;
   g->persist_unchecked_n = 0;
   if (g->persist_err && *g->persist_err != 0) {
-    persist_note_give_up(g);
+    persist_note_give_up(g, false);
     *g->persist_err = 0;
     persist_lease_drop(g, true);
   }
@@ -775,9 +783,9 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "persist_gave_up") *value = persist_gave_up_count(g->device);  // (give-ups of any handle on this device)
   else if (k == "persist_gave_up_tile") *value = g->give_up.tile;        // (this handle's last give-up, see GiveUp)
   else if (k == "persist_gave_up_round") *value = g->give_up.round;
-  else if (k == "persist_gave_up_behind") *value = g->give_up.behind;
-  else if (k == "persist_gave_up_behind_round") *value = g->give_up.behind_round;
-  else if (k == "persist_gave_up_waiting") *value = g->give_up.waiting;
+  else if (k == "persist_gave_up_front_round") *value = g->give_up.front_round;
+  else if (k == "persist_gave_up_not_started") *value = g->give_up.not_started;
+  else if (k == "persist_gave_up_rounds") *value = g->give_up.rounds;
   else if (k == "persist_gave_up_tiles") *value = g->give_up.tiles;
   else if (k == "persist_gave_up_one_xcd") *value = g->give_up.one_xcd;
   else if (k == "persist_gave_up_timeout_us") *value = g->give_up.timeout_us;
@@ -1875,8 +1883,8 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       PersistBufs& x = g->xp;
       int rc;
       if (!g->persist_err) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), sizeof(int32_t) * (kGiveUpWords + 2 * kGiveUpTiles), hipHostMallocDefault));
-        std::memset(g->persist_err, 0, sizeof(int32_t) * (kGiveUpWords + 2 * kGiveUpTiles));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g->persist_err), 64, hipHostMallocDefault));
+        *g->persist_err = 0;
       }
       if (!x.prof || g->persist_prof_set != g->persist_prof_want) {  // dev aid: which tile (if any) splits its rounds' time
         if ((rc = dev_alloc(g->caps, &x.prof, 16))) return rc;
@@ -1968,6 +1976,7 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       xl.timeout_ticks = x.timeout_ticks;
       HIPCHK(launch_tile_persist(s, P.tile_threads, P.tile_ept, P.tile_vpt, (size_t)P.tile_lds_bytes, a, xl, g->persist_err,
                                  g->persist_base));
+      g->give_up_base = g->persist_base;
       g->persist_base += rounds - 1;
       g->persist_used = true;
       g->persist_unchecked = true;

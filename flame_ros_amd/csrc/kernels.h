@@ -45,12 +45,9 @@ hipError_t prepare_tile(int nt, int ept, int vpt, size_t lds_bytes, bool slot12 
 // iterations inside; neighbours hand their results over through uncached, round-tagged copies of the state arrays
 // (kernels.hip PersistArgs).  The caller owns the buffers: hA / hB / hq [2] (V / V / E float4, same indices as the
 // state arrays) in hipDeviceMallocUncached memory, zeroed once; prof: 8 ints of device memory (dev aid, zero = off);
-// err_host: a page-locked record of kGiveUpWords + 2 kGiveUpTiles words -- [0] != 0: a wait timed out; per tile t that timed
-// out [kGiveUpWords + 2 t] = its round + 1 and [.. + 1] = an entry it still waited for (a vertex id, or -1 - edge id); a tile
-// with no mark had not started, or was not waiting.  `base` grows by rounds - 1 per launch (tags base + 1 .. base + rounds - 1 never repeat).
+// err_host: a page-locked word.  `base` grows by rounds - 1 per launch (tags base + 1 .. base + rounds - 1 never repeat).
 // The result lands in a.A_dst / B_dst / q_dst whatever the number of rounds; the source buffers are only read.
 constexpr int kPersistMaxTiles = 256;
-constexpr int kGiveUpWords = 16, kGiveUpTiles = kPersistMaxTiles;
 struct PersistBufs {
   float4* hA[2] = {nullptr, nullptr};
   float4* hB[2] = {nullptr, nullptr};

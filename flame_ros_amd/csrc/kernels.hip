@@ -377,7 +377,7 @@ struct PersistArgs {
   // A fat tile hands over a third of what it owns (200 k vertices: 4.0 GB of hand-off stores per 500 iterations before).
   const int32_t* need_v;
   const int32_t* need_e;
-  int32_t* err_host;  // page-locked record (kernels.h, kGiveUpWords + kGiveUpTiles words): [0] set when a wait timed out
+  int32_t* err_host;  // page-locked: set when a wait timed out
   int32_t base;       // tags of this launch are base + 1 .. base + rounds - 1 (they only grow)
   int32_t* prof;      // device memory (16 words), dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]; [7] the
                       // longest poll wait (10 ns ticks); [8] torn entries seen (FLAME_TORN_CHECK builds)
@@ -844,21 +844,6 @@ __device__ __forceinline__ void tile_body(TileArgs& a, const PersistArgs& pa) {
       if (!__any(stale)) break;
       if (wall_clock64() - w0 > (unsigned long long)pa.timeout_ticks) {  // give up, never hang (the host repeats the solve by launches)
         s_abort = 1;
-        // what the host needs to say WHO was late (info "persist_gave_up_*"; plain stores into the page-locked record, a
-        // cold path): per tile that timed out its round and one entry a lane of it still waits for
-        if (tile_id < kGiveUpTiles) {
-          pa.err_host[kGiveUpWords + 2 * tile_id] = round + 1;
-          if (stale) {
-            int32_t missing = INT32_MIN;  // (none found: the pass after the last stale one)
-#pragma unroll
-            for (int k = 0; k < VPT; ++k)
-              if (needv[k] && !(tag_ok(nb[k], target, pa.prof + 8) && (!needa[k] || tag_ok(na[k], target, pa.prof + 8)))) missing = (int32_t)pvr[k].x;
-#pragma unroll
-            for (int k = 0; k < EPT; ++k)
-              if (neede[k] && !tag_ok(nq[k], target, pa.prof + 8)) missing = -1 - (int32_t)per[k].x;
-            pa.err_host[kGiveUpWords + 2 * tile_id + 1] = missing;
-          }
-        }
         *pa.err_host = 1;
         break;
       }

@@ -116,10 +116,10 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * repeated as a whole -- the error word does not say which one gave up, so the source of the first is copied aside when
  * the second is queued and every solve since is logged; FLAME_HIP_ERR_STATE only when something other than solves wrote
  * the state in between), and the whole process then stays off resident tiles for 16 solves, doubling with every further
- * give-up ("persist_gave_up").  Who was late in a handle's last give-up: "persist_gave_up_tile" / "_round" = the tile that timed
- * out in the earliest round (it stood next to whoever was late), "_behind" = the tile that owns an entry it still waited for,
- * "_behind_round" = the round THAT one timed out in (-1: never -- it had not started, or hung elsewhere), "_waiting" of "_tiles"
- * tiles timed out, "_one_xcd", "_timeout_us".  "one_xcd" (r06, default 1): a graph of up to 32 resident tiles -- automatic sizes give 32 tiles to
+ * give-up ("persist_gave_up").  How far the tiles of a handle's last give-up got, read from the hand-off copies afterwards:
+ * "persist_gave_up_tile" / "_round" = the tile that had handed over the fewest rounds (0: it never started; otherwise it is the
+ * late one or stood next to it) and how many, "_front_round" the most any tile had, "_not_started" tiles that had handed over
+ * none, "_rounds" / "_tiles" / "_one_xcd" / "_timeout_us" the launch's own numbers.  "one_xcd" (r06, default 1): a graph of up to 32 resident tiles -- automatic sizes give 32 tiles to
  * graphs of 770 .. 1 280 vertices -- keeps them on ONE XCD (the launch has 8 x ntiles workgroups, every 8th carries a tile) and hands
  * over through ordinary memory, i.e. that XCD's L2, instead of uncached memory: 1.2 k vertices 0.89 -> 0.82 us per iteration.  Which
  * XCD a workgroup lands on is the dispatcher's habit, not a guarantee; the round tags and the bounded polls keep the result right
