@@ -1904,7 +1904,8 @@ static int enqueue_iterations(flame_hip_graph* g, const SolveParams& sp, int32_t
       if (!g->poll_valid || (want_sorted && !g->poll_sorted)) {
         size_t nv_loc = 0, ne_loc = 0;
         for (const TileDesc& D : P.tiles) { nv_loc += (size_t)D.n_ext; ne_loc += (size_t)D.e_loc; }
-        if ((rc = dev_alloc(g->caps, &x.poll_v, std::max<size_t>(nv_loc, 1))) || (rc = dev_alloc(g->caps, &x.poll_e, std::max<size_t>(ne_loc, 1))) ||
+        // (+ 1: a tile without local edges still reads the list's entry at its own offset -- the last tile's is one past the end)
+        if ((rc = dev_alloc(g->caps, &x.poll_v, nv_loc + 1)) || (rc = dev_alloc(g->caps, &x.poll_e, ne_loc + 1)) ||
             (rc = dev_alloc(g->caps, &x.poll_ne, P.tiles.size())))
           return rc;
         // (r05: the sorted lists' kernel also marks what anybody polls; the rest of a tile's own entries is not handed over.
