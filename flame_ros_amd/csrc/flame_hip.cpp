@@ -186,7 +186,7 @@ int h2d(hipStream_t s, T* dst, const std::vector<T>& src) {
 // runtime, call by call -- ~10 us each, the larger part of a small frame's upload).
 // frame_results: outputs up to this size are written to host memory by the kernels themselves (measured on
 // the facade stream, direct vs one copy: 1.2 k -14 us, 5 k -10 us, 10 k (185 KB) -15 us, 50 k (925 KB) +65 us)
-constexpr int kPollDelayDefault = 2;  // x 256 clocks.  r05, address-sorted poll: a pass is short enough to sample memory before the neighbours' stores have landed (passes per round 1.35 at 0, 1.10 at 2, 1.01 at 3; 50 k 1.316 / 1.319 / 1.304 / 1.303 / 1.357 us per iteration at 0 / 1 / 2 / 3 / 4, profiles/r05_sorted_poll_delay.txt); FLAME_HIP_POLL_DELAY overrides
+constexpr int kPollDelayDefault = 2;  // x 256 clocks.  r05, address-sorted poll: a pass is short enough to sample memory before the neighbours' stores have landed (passes per round 1.35 at 0, 1.10 at 2, 1.01 at 3; 50 k 1.316 / 1.319 / 1.304 / 1.303 / 1.357 us per iteration at 0 / 1 / 2 / 3 / 4, profiles/r05_sorted_poll_delay.txt; swept again in r06 behind the one-block poll: 1.313 / 1.334 / 1.309 / 1.329 / 1.350); option "poll_delay" overrides
 constexpr int kMapMinTiles = 6;  // partitions of at least this many tiles leave a tile map for the next frame (partition reuse)
 constexpr size_t kDirectOutBytes = 256 * 1024;
 
@@ -789,7 +789,7 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
   else if (k == "persist_gave_up_tiles") *value = g->give_up.tiles;
   else if (k == "persist_gave_up_one_xcd") *value = g->give_up.one_xcd;
   else if (k == "persist_gave_up_timeout_us") *value = g->give_up.timeout_us;
-  else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (FLAME_HIP_PERSIST_PROF=<tile + 1>): 10 ns ticks of that tile, summed over rounds
+  else if (k.rfind("persist_prof_", 0) == 0) {  // dev aid (option "persist_prof" = <tile + 1>): 10 ns ticks of that tile, summed over rounds
     const int i = std::atoi(k.c_str() + 13);
     int32_t v = 0;
     if (i < 0 || i > 4 || !g->xp.prof) return FLAME_HIP_ERR_ARG;

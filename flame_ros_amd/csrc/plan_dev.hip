@@ -1323,7 +1323,7 @@ struct TileShared {
 struct TileOut {
   const float4* ew; TileDesc* tiles; int32_t* t_vmap; int32_t* t_emap; uint2* t_eij; float4* t_ew; uint32_t* t_srow;
   int32_t* flags; int lane_order;
-  long long* prof;  // dev aid (FLAME_HIP_PLAN_TIMING=5): phase stamps of tile 0, or null
+  long long* prof;  // dev aid (option "plan_timing" = 5): phase stamps of tile 0, or null
 };
 #define TILE_STAMP(O, n) do { if ((O).prof && blockIdx.x == 0 && threadIdx.x == 0) (O).prof[n] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
@@ -2006,7 +2006,7 @@ struct MiniArgs {
   int32_t* tris_int; int32_t* trow; uint32_t* tinc;
   int32_t* e_i2o; int32_t* e_o2i; int2* eij; float4* ew; int32_t* estart;
   int32_t* grow; uint32_t* ginc; int32_t* gadj; int32_t* ipos;
-  long long* prof;               // dev aid (FLAME_HIP_PLAN_TIMING=4): 20 phase stamps, or null
+  long long* prof;               // dev aid (option "plan_timing" = 4): 20 phase stamps, or null
 };
 
 // exclusive scan of a[0 .. n) in place (LDS), 1024 threads, n <= 5 * 1024; returns the total.  Every
