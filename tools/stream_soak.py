@@ -44,6 +44,13 @@ for k in range(n):
             print("frame %4d V %6d: poll wait %d us, solve %.2f ms, tiles %d depth %d cfg %d/%d slot12 %d reused %d timeout %d us" % (
                 k, V, wmax, r.last_solve_ms()[0], r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("tile_ept"),
                 r.info("tile_slot12"), r.info("plan_reused"), r.info("persist_timeout_us")), flush=True)
+    rec_now = r.info("persist_recovered")
+    if rec_now != (rec_seen if k else 0):  # r06: a resident launch gave up and was repeated -- how far had its tiles got?
+        print("frame %4d V %6d: REPEATED by launches; solve %.2f ms; tiles %d depth %d cfg %d/%d slot12 %d fat %d lds %d reused %d | give-up %s" % (
+            k, V, r.last_solve_ms()[0], r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("tile_ept"), r.info("tile_slot12"),
+            r.info("tile_fat"), r.info("tile_lds_bytes"), r.info("plan_reused"),
+            {q: r.info("persist_gave_up_" + q) for q in ("tile", "round", "front_round", "not_started", "rounds", "tiles", "one_xcd", "timeout_us")}), flush=True)
+    rec_seen = rec_now
     reused = reused + r.info("plan_reused") if k else 0
     persisted = (persisted if k else 0) + r.info("persist_used")
     if k % 25 == 0 or (k % 7 == 4 and k % 3 == 0):
