@@ -119,6 +119,59 @@ def profiled_counters(workload, kernel):
     return best
 
 
+def live_hbm_traffic(kernel, child_args, budget_s=110.0):
+    """HBM bytes per launch of `kernel` measured IN THIS RUN: two short child runs of this script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; FETCH x 2
+    is the guide's gfx950 correction, both counters in KiB), averaged over the kernel's launches.  Bounded in time and
+    never fatal: None when rocprofv3 is missing, a pass overruns its share of `budget_s`, or nothing of the kernel was
+    counted -- the caller then quotes the committed profile of the same sources instead (profiled_counters)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if os.environ.get("FLAME_BENCH_CHILD") or not shutil.which("rocprofv3"):
+        return None
+    t_end = time.perf_counter() + budget_s
+    vals, launches = {}, 0
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = t_end - time.perf_counter()
+        if left < 20.0:
+            return None
+        d = tempfile.mkdtemp(prefix="flame_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", name, "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-facade", "--steps", "4", "--warmup", "1"] + child_args
+        try:
+            pr = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, FLAME_BENCH_CHILD="1", TMPDIR="/tmp"),
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=min(left - 5.0, 75.0))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)  # (the group this call started: rocprofv3 and its child)
+                except OSError:
+                    pass
+                pr.wait(timeout=10)
+                return None
+            acc = cnt = 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", ""):
+                        acc += float(r["Counter_Value"])
+                        cnt += 1
+            if cnt == 0:
+                return None
+            vals[name] = acc / cnt
+            launches = cnt
+        except Exception:  # noqa: BLE001 -- a side measurement: the committed profile is quoted instead
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (%d launches each; FETCH x 2, KiB)" % launches}
+
+
 def tile_phase_split(g, iters, device, opts, launch_us):
     """In-kernel timeline of ONE tile launch (s_memtime stamps written by the kernel when the handle
     has profile=1; tools/tile_timeline.py prints the long form): p50 over tiles of the load phase,
@@ -400,6 +453,7 @@ def main():
                     help="extra library option (flame_hip_graph_set_option), repeatable")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-facade", action="store_true", help="skip the facade frame-latency and frames-axis side measurements")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not measure roofline.traffic by two rocprofv3 PMC child runs (quote the committed profile)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "partition"],
                     help="N>1: independent frames per GPU (default) or ONE graph cut into N "
@@ -679,8 +733,20 @@ def main():
             rl["halo_redundancy"] = {"vertices": nv / g.V, "edges": ne / max(g.E, 1)}
         tr = profiled_counters("batch%d" % args.batch if args.batch else args.workload,
                                ("k_tile_persist<" if resident else "k_tile<") if path == 2 else "k_primal")
+        kern_sub = ("k_tile_persist<" if resident else "k_tile<") if path == 2 else "k_primal"
+        live = None
+        if world == 1 and not args.no_live_traffic and not (args.tile_own or args.tile_depth or args.tile_threads or partition or args.opt or args.host_plan):
+            # r06 (VERDICT r05 "evidence hygiene"): the line's HBM bytes are THIS run's counters, not a committed profile's
+            child = ["--workload", args.workload] + (["--iters", str(args.iters)] if args.iters else []) + \
+                    (["--batch", str(args.batch), "--batch-win", str(args.batch_win)] if args.batch else [])
+            live = live_hbm_traffic(kern_sub, child)
+        if live:  # (the LDS / VALU counters beside it stay the committed passes' -- when those were taken from these sources)
+            base = tr if (tr and not tr.get("stale")) else {"lds": None, "valu": None}
+            tr = dict(base, bytes_per_launch=live["bytes_per_launch"], source=live["source"], committed_source=base.get("source"), stale=False)
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
             rl["traffic_source"] = tr["source"] + (" (stale: other kernel sources, not quoted)" if tr.get("stale") else "")
+            if live and tr.get("committed_source"):
+                rl["counters_source"] = tr["committed_source"]  # (the LDS / VALU counters beside it: the committed passes of the same sources)
             if tr.get("bytes_per_launch"):
                 rl["traffic"] = tr["bytes_per_launch"]
                 rl["measured_hbm_gbps"] = tr["bytes_per_launch"] / (launch_us * 1e-6) / 1e9
@@ -720,8 +786,9 @@ def main():
                               "table) / measured shader cycles per iteration (HIP events on the solve stream).  work_redundancy = "
                               "executed / useful LDS wave-instructions (halo rings, padding lanes); lds_busy = SQ_LDS_IDX_ACTIVE per "
                               "CU / cycles; handoff_share = 1 - iterate_frac (round_split); contract_frac = the SURVEY 8d HBM figure; "
-                              "measured_hbm_frac = PMC FETCH x2 + WRITE per launch / time / 8 TB/s.  Counters come from the committed "
-                              "rocprofv3 --pmc pass of the same sources (traffic_source); profiles/summarize.py --roofline recomputes.")
+                              "measured_hbm_frac = PMC FETCH x2 + WRITE per launch / time / 8 TB/s.  traffic is measured IN this run when rocprofv3 is there "
+                              "(two short child runs under --pmc FETCH_SIZE / WRITE_SIZE: traffic_source says so); the LDS / VALU counters come "
+                              "from the committed rocprofv3 --pmc passes of the same sources (counters_source); profiles/summarize.py --roofline recomputes.")
         if args.batch:
             out["metric"] = "primal-dual iterations/sec over a batch of %d independent %d-vertex graphs" % (
                 args.batch, frames[0].V)
