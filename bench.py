@@ -119,12 +119,16 @@ def profiled_counters(workload, kernel):
     return best
 
 
+LDS_PMC = ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES")
+VALU_PMC = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+
+
 def live_hbm_traffic(kernel, child_args, budget_s=110.0):
-    """HBM bytes per launch of `kernel` measured IN THIS RUN: two short child runs of this script under
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes; FETCH x 2
-    is the guide's gfx950 correction, both counters in KiB), averaged over the kernel's launches.  Bounded in time and
-    never fatal: None when rocprofv3 is missing, a pass overruns its share of `budget_s`, or nothing of the kernel was
-    counted -- the caller then quotes the committed profile of the same sources instead (profiled_counters)."""
+    """Counters of `kernel` measured IN THIS RUN: short child runs of this script under `rocprofv3 --kernel-trace --pmc ...`, one
+    pass per counter set as profiles/collect.sh (FETCH_SIZE and WRITE_SIZE separately, as MI355X_MICROARCH.md prescribes --
+    FETCH x 2 is the guide's gfx950 correction, both in KiB; then the LDS and the VALU / wait sets), per launch.  Bounded in time
+    and never fatal: None when rocprofv3 is missing or the HBM passes fail -- the caller then quotes the committed profile of
+    the same sources (profiled_counters); the LDS / VALU sets are optional extras of the same kind ("lds" / "valu" = None)."""
     import csv
     import glob
     import shutil
@@ -134,13 +138,13 @@ def live_hbm_traffic(kernel, child_args, budget_s=110.0):
     if os.environ.get("FLAME_BENCH_CHILD") or not shutil.which("rocprofv3"):
         return None
     t_end = time.perf_counter() + budget_s
-    vals, launches = {}, 0
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+
+    def one_pass(names):
         left = t_end - time.perf_counter()
         if left < 20.0:
             return None
         d = tempfile.mkdtemp(prefix="flame_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--kernel-trace", "--pmc", name, "--output-format", "csv", "-d", d, "-o", "p", "--",
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(names) + ["--output-format", "csv", "-d", d, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-facade", "--steps", "4", "--warmup", "1"] + child_args
         try:
             pr = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, FLAME_BENCH_CHILD="1", TMPDIR="/tmp"),
@@ -154,22 +158,35 @@ def live_hbm_traffic(kernel, child_args, budget_s=110.0):
                     pass
                 pr.wait(timeout=10)
                 return None
-            acc = cnt = 0
+            acc, rows, disp = {}, 0, set()
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r.get("Counter_Name") == name and kernel in r.get("Kernel_Name", ""):
-                        acc += float(r["Counter_Value"])
-                        cnt += 1
-            if cnt == 0:
+                    if r.get("Counter_Name") in names and kernel in r.get("Kernel_Name", ""):
+                        acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                        rows += 1
+                        disp.add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
+            if not rows or not disp:
                 return None
-            vals[name] = acc / cnt
-            launches = cnt
+            return {k: v / len(disp) for k, v in acc.items()}, len(disp)
         except Exception:  # noqa: BLE001 -- a side measurement: the committed profile is quoted instead
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-            "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (%d launches each; FETCH x 2, KiB)" % launches}
+
+    fe, wr = one_pass(("FETCH_SIZE",)), None
+    if fe:
+        wr = one_pass(("WRITE_SIZE",))
+    if not fe or not wr:
+        return None
+    out = {"bytes_per_launch": (2.0 * fe[0]["FETCH_SIZE"] + wr[0]["WRITE_SIZE"]) * 1024.0, "lds": None, "valu": None,
+           "source": "live: rocprofv3 --pmc passes of this run (FETCH_SIZE, WRITE_SIZE separately, %d launches each; FETCH x 2, KiB)" % fe[1]}
+    lds = one_pass(LDS_PMC)
+    if lds and lds[0].get("SQ_INSTS_LDS", 0) > 0:
+        out["lds"] = dict(lds[0], launches=lds[1])
+    valu = one_pass(VALU_PMC)
+    if valu and valu[0].get("SQ_INSTS_VALU", 0) > 0:
+        out["valu"] = dict(valu[0], launches=valu[1])
+    return out
 
 
 def tile_phase_split(g, iters, device, opts, launch_us):
@@ -739,14 +756,18 @@ def main():
             # r06 (VERDICT r05 "evidence hygiene"): the line's HBM bytes are THIS run's counters, not a committed profile's
             child = ["--workload", args.workload] + (["--iters", str(args.iters)] if args.iters else []) + \
                     (["--batch", str(args.batch), "--batch-win", str(args.batch_win)] if args.batch else [])
-            live = live_hbm_traffic(kern_sub, child)
-        if live:  # (the LDS / VALU counters beside it stay the committed passes' -- when those were taken from these sources)
+            # (the exact variant: the child's side measurements launch other instantiations of the same template)
+            kern_live = ("k_tile_persist<%d, %d, %d," % (r.info("tile_threads"), r.info("tile_ept"), r.info("tile_vpt"))) if (path == 2 and resident) else kern_sub
+            live = live_hbm_traffic(kern_live, child)
+        if live:  # (an LDS / VALU pass that did not come stays the committed one's -- when that was taken from these sources)
             base = tr if (tr and not tr.get("stale")) else {"lds": None, "valu": None}
-            tr = dict(base, bytes_per_launch=live["bytes_per_launch"], source=live["source"], committed_source=base.get("source"), stale=False)
+            tr = dict(base, bytes_per_launch=live["bytes_per_launch"], source=live["source"], stale=False,
+                      lds=live["lds"] or base.get("lds"), valu=live["valu"] or base.get("valu"),
+                      committed_source=None if (live["lds"] and live["valu"]) else base.get("source"))
         if tr and not (args.tile_own or args.tile_depth or args.tile_threads or partition):
             rl["traffic_source"] = tr["source"] + (" (stale: other kernel sources, not quoted)" if tr.get("stale") else "")
             if live and tr.get("committed_source"):
-                rl["counters_source"] = tr["committed_source"]  # (the LDS / VALU counters beside it: the committed passes of the same sources)
+                rl["counters_source"] = tr["committed_source"]  # (an LDS / VALU set that was not measured live: the committed passes of the same sources)
             if tr.get("bytes_per_launch"):
                 rl["traffic"] = tr["bytes_per_launch"]
                 rl["measured_hbm_gbps"] = tr["bytes_per_launch"] / (launch_us * 1e-6) / 1e9
@@ -786,9 +807,9 @@ def main():
                               "table) / measured shader cycles per iteration (HIP events on the solve stream).  work_redundancy = "
                               "executed / useful LDS wave-instructions (halo rings, padding lanes); lds_busy = SQ_LDS_IDX_ACTIVE per "
                               "CU / cycles; handoff_share = 1 - iterate_frac (round_split); contract_frac = the SURVEY 8d HBM figure; "
-                              "measured_hbm_frac = PMC FETCH x2 + WRITE per launch / time / 8 TB/s.  traffic is measured IN this run when rocprofv3 is there "
-                              "(two short child runs under --pmc FETCH_SIZE / WRITE_SIZE: traffic_source says so); the LDS / VALU counters come "
-                              "from the committed rocprofv3 --pmc passes of the same sources (counters_source); profiles/summarize.py --roofline recomputes.")
+                              "measured_hbm_frac = PMC FETCH x2 + WRITE per launch / time / 8 TB/s.  the counters are measured IN this run when rocprofv3 is there "
+                              "(four short child runs under --pmc: FETCH_SIZE, WRITE_SIZE, the LDS set, the VALU / wait set; traffic_source says so); a set "
+                              "that did not come is the committed rocprofv3 pass of the same sources (counters_source); profiles/summarize.py --roofline recomputes.")
         if args.batch:
             out["metric"] = "primal-dual iterations/sec over a batch of %d independent %d-vertex graphs" % (
                 args.batch, frames[0].V)
