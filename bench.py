@@ -147,7 +147,9 @@ def live_hbm_traffic(kernel, child_args, budget_s=110.0):
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + list(names) + ["--output-format", "csv", "-d", d, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-facade", "--steps", "4", "--warmup", "1"] + child_args
         try:
-            pr = subprocess.Popen(cmd, cwd=ROOT, env=dict(os.environ, FLAME_BENCH_CHILD="1", TMPDIR="/tmp"),
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                    "MASTER_ADDR", "MASTER_PORT", "FLAME_BENCH_FORCE_PARTITION")}
+            pr = subprocess.Popen(cmd, cwd=ROOT, env=dict(env, FLAME_BENCH_CHILD="1", TMPDIR="/tmp"),
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 pr.wait(timeout=min(left - 5.0, 75.0))

@@ -147,3 +147,9 @@ def test_bench_partition_glue_at_world_1(gpu):
     assert pt["peer_transport"].get("bit_exact_vs_one_gpu") is True and pt["peer_transport"]["transport"] == "peer", pt["peer_transport"]
     assert pt["transport"] == "rccl"  # (one part on one rank at world 1: no exchange to time on either transport)
     assert d["n_gpus"] == 1 and d["value"] > 0
+    # r06: the line's HBM bytes per launch are this run's own counters (rocprofv3 PMC child passes of bench.py) -- or, where the
+    # profiler cannot count, the committed profile of the same sources: a number either way, and a plausible one
+    rl = d["roofline"]
+    assert rl.get("traffic") and rl.get("traffic_source"), {k: rl.get(k) for k in ("traffic", "traffic_source", "counters_source")}
+    assert 0.02 < rl["measured_hbm_frac"] < 1.0 and 0.05 < rl["frac"] <= 1.0, (rl["measured_hbm_frac"], rl["frac"])
+    print("traffic source:", rl["traffic_source"], "| counters:", rl.get("counters_source"))
