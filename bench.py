@@ -137,6 +137,8 @@ def live_hbm_traffic(kernel, child_args, budget_s=110.0):
     import tempfile
     if os.environ.get("FLAME_BENCH_CHILD") or not shutil.which("rocprofv3"):
         return None
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None  # (this run is itself being profiled: no profiler inside a profiler)
     t_end = time.perf_counter() + budget_s
 
     def one_pass(names):
