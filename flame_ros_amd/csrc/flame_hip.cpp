@@ -781,6 +781,8 @@ int flame_hip_get_info(const flame_hip_graph* g, const char* key, int64_t* value
     *value = v / 100;
   }
   else if (k == "persist_gave_up") *value = persist_gave_up_count(g->device);  // (give-ups of any handle on this device)
+  else if (k == "persist_backoff") *value = g->device >= 0 ? persist_backoff(g->device) : 0;  // solves the device's lease still sits out (plans uploaded meanwhile are sized for launches)
+  else if (k == "one_xcd_allowed") *value = one_xcd_allowed(g->device) ? 1 : 0;  // 0: a one-XCD launch gave up in this process, the mode is off
   else if (k == "persist_gave_up_tile") *value = g->give_up.tile;        // (this handle's last give-up, see GiveUp)
   else if (k == "persist_gave_up_round") *value = g->give_up.round;
   else if (k == "persist_gave_up_front_round") *value = g->give_up.front_round;

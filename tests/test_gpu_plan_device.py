@@ -9,7 +9,7 @@ import pytest
 
 from flame_ros_amd import lib as _l
 from flame_ros_amd.regularizer import GraphRegularizer, default_params
-from tests.util import assert_bit_equal, graphgen, make_oracle, oracle_params
+from tests.util import assert_bit_equal, graphgen, host_reference_opts, make_oracle, oracle_params
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ CASES = [
 @pytest.mark.parametrize("name,opts", CASES)
 def test_device_plan_equals_host_plan(gpu, name, opts):
     g, _ = graphgen.named(name)
-    host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **opts)
+    host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **{**host_reference_opts(), **opts})
     dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, **opts)
     compare_plans(host, dev, "%s %s" % (name, opts))
     host.close(); dev.close()
@@ -134,7 +134,7 @@ def _irregular(kind):
 def test_device_plan_irregular_graphs(gpu, kind):
     g, edges, alpha, beta, tris = _irregular(kind)
     opts = dict(tile_own=64, tile_depth=3)
-    host = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=-1, **opts)
+    host = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=-1, **{**host_reference_opts(), **opts})
     dev = GraphRegularizer(g.pos, edges, alpha, beta, g.z, g.wgt, tris=tris, device=0, **opts)
     compare_plans(host, dev, kind)
     if kind == "hubs":
@@ -181,7 +181,7 @@ def test_device_plan_frame_stream(gpu):
     for k, V in enumerate((20000, 20600, 19500, 20000, 5000, 5100)):
         g = graphgen.synthetic(V, seed=40 + k)
         if host is None:
-            host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
+            host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **host_reference_opts())
             # (plan_reuse=0: the partition-reuse shortcut of frame streams is the device builder's own;
             # the array-for-array comparison is about the exact bisection both builders implement)
             dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, plan_reuse=0)
@@ -417,7 +417,7 @@ def test_device_plan_growing_frames(gpu):
     for k, V in enumerate((3000, 9000, 27000, 2500)):
         g = graphgen.synthetic(V, seed=60 + k)
         if host is None:
-            host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
+            host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **host_reference_opts())
             dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, plan_reuse=0)
         else:
             host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)
@@ -435,7 +435,7 @@ def test_device_plan_subtree_overflow_recovery(gpu):
     debug_sub_cap test hook; in production: very uneven weighted splits): the builder hands over
     one level later and the plan still equals the host builder's."""
     g, _ = graphgen.named("50k")
-    host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1)
+    host = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=-1, **host_reference_opts())
     dev = GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0, debug_sub_cap=2000, plan_reuse=0)
     compare_plans(host, dev, "overflow recovery")
     host.reupload(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris)

@@ -62,4 +62,18 @@ def with_hooks(code, **hooks):
     return code[:m.end()] + pre + code[m.end():]
 
 
-__all__ = ["ROOT", "HOOKS_LIB", "hooks_env", "with_hooks", "graphgen", "oracle_params", "bits", "assert_bit_equal", "make_oracle", "random_state"]
+def host_reference_opts():
+    """Options a plan-only handle (device = -1: "sized as the MI355X would") needs to size like a DEVICE handle of this very
+    process does right now: after a resident launch gave up -- beside another test's foreign kernels, say -- the device's lease
+    sits out a back-off (uploads are sized for launches) and, when it was a one-XCD launch, drops that mode for good."""
+    from flame_ros_amd.regularizer import GraphRegularizer
+    with GraphRegularizer.empty(device=0) as probe:
+        kw = {}
+        if probe.info("persist_backoff") > 0:
+            kw["persist"] = 0
+        if not probe.info("one_xcd_allowed"):
+            kw["one_xcd"] = 0
+    return kw
+
+
+__all__ = ["host_reference_opts", "ROOT", "HOOKS_LIB", "hooks_env", "with_hooks", "graphgen", "oracle_params", "bits", "assert_bit_equal", "make_oracle", "random_state"]
