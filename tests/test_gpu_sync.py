@@ -8,7 +8,7 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_
 from oracle import COracle
 from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync, triangles as oracle_triangles, TriParams as OTri
 from tests.test_graph_sync import features
-from tests.util import assert_bit_equal, graphgen, hooks_env, oracle_params, with_hooks
+from tests.util import assert_bit_equal, graphgen, hooks_env, oracle_params, settle_lease, with_hooks
 
 pytestmark = pytest.mark.gpu
 
@@ -186,6 +186,7 @@ def test_large_frames_take_the_unfused_chains(gpu):
     (plain pass 1 / offsets / pass 2) -- the same edges and the oracle's bits all the same.  (persist = 0: a handle that solves
     by resident tiles gets 256 FAT tiles at this size since r05 -- the second handle below, same frames, same bits.)"""
     sp, p = default_sync_params(), default_params()
+    settle_lease()  # (the assertions below are about a free lease: resident sizing, persist_used)
     for k in range(2):
         g = graphgen.synthetic(120000, 1280, 1024, seed=90 + k)
         var = np.full(g.V, 1e-4, np.float32)

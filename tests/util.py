@@ -76,4 +76,21 @@ def host_reference_opts():
     return kw
 
 
-__all__ = ["host_reference_opts", "ROOT", "HOOKS_LIB", "hooks_env", "with_hooks", "graphgen", "oracle_params", "bits", "assert_bit_equal", "make_oracle", "random_state"]
+def settle_lease(max_solves=5000):
+    """Sit the device's back-off out (a resident launch of an EARLIER test gave up beside that test's foreign kernels): a test
+    that asserts resident sizing / `persist_used` starts from a lease that is free.  Solves of a small resident-capable graph
+    count the back-off down."""
+    from flame_ros_amd.regularizer import GraphRegularizer, default_params
+    with GraphRegularizer.empty(device=0) as probe:
+        if probe.info("persist_backoff") == 0:
+            return 0
+    g, _ = graphgen.named("tum")
+    n = 0
+    with GraphRegularizer(g.pos, g.edges, g.alpha, g.beta, g.z, g.wgt, tris=g.tris, device=0) as r:
+        while r.info("persist_backoff") > 0 and n < max_solves:
+            r.step(default_params(), 12)
+            n += 1
+    return n
+
+
+__all__ = ["host_reference_opts", "settle_lease", "ROOT", "HOOKS_LIB", "hooks_env", "with_hooks", "graphgen", "oracle_params", "bits", "assert_bit_equal", "make_oracle", "random_state"]
