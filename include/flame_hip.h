@@ -119,7 +119,8 @@ int flame_hip_graph_resize(flame_hip_graph* g, int32_t V, int32_t E, int32_t T);
  * give-up ("persist_gave_up").  How far the tiles of a handle's last give-up got, read from the hand-off copies afterwards:
  * "persist_gave_up_tile" / "_round" = the tile that had handed over the fewest rounds (0: it never started; otherwise it is the
  * late one or stood next to it) and how many, "_front_round" the most any tile had, "_not_started" tiles that had handed over
- * none, "_rounds" / "_tiles" / "_one_xcd" / "_timeout_us" the launch's own numbers.  "one_xcd" (r06, default 1): a graph of up to 32 resident tiles -- automatic sizes give 32 tiles to
+ * none, "_rounds" / "_tiles" / "_one_xcd" / "_timeout_us" the launch's own numbers; "persist_backoff" = solves the device's lease still
+ * sits out (plans uploaded meanwhile are sized for launches), "one_xcd_allowed" = 0 once a one-XCD launch has given up.  "one_xcd" (r06, default 1): a graph of up to 32 resident tiles -- automatic sizes give 32 tiles to
  * graphs of 770 .. 1 280 vertices -- keeps them on ONE XCD (the launch has 8 x ntiles workgroups, every 8th carries a tile) and hands
  * over through ordinary memory, i.e. that XCD's L2, instead of uncached memory: 1.2 k vertices 0.89 -> 0.82 us per iteration.  Which
  * XCD a workgroup lands on is the dispatcher's habit, not a guarantee; the round tags and the bounded polls keep the result right
