@@ -66,7 +66,7 @@ struct PersistBufs {
   int32_t* prof = nullptr;
   int32_t poll_delay = 0;  // x 256 clocks between a round's stores and the first poll pass
   int32_t timeout_ticks = 0;  // 10 ns ticks a poll may wait (0 = 4 ms)
-  int32_t one_xcd = 0;     // EXPERIMENT r06 (kernels.hip PersistArgs::one_xcd): hA / hB / hq are ordinary memory then
+  int32_t one_xcd = 0;     // r06 one-XCD mode (kernels.hip PersistArgs::one_xcd; graphs of <= 32 tiles): hA / hB / hq are ordinary memory then
 };
 bool tile_persist_exists(int nt, int ept, int vpt);
 hipError_t launch_poll_lists(hipStream_t s, int32_t ntiles, const TileDesc* tiles, const int32_t* t_vmap, const int32_t* t_emap,

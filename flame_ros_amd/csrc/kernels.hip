@@ -382,7 +382,7 @@ struct PersistArgs {
   int32_t* prof;      // device memory (16 words), dev aid: [0] != 0: tile [1] sums where its rounds' time goes into [2..6]; [7] the
                       // longest poll wait (10 ns ticks); [8] torn entries seen (FLAME_TORN_CHECK builds)
   int32_t poll_delay; // units of 256 clocks between a round's stores and its first poll pass
-  int32_t one_xcd;    // EXPERIMENT r06: the grid is 8 x ntiles blocks and only every 8th -- the ones the dispatcher puts on XCD 0 --
+  int32_t one_xcd;    // r06 one-XCD mode: the grid is 8 x ntiles blocks and only every 8th -- the ones the dispatcher puts on XCD 0 --
                       // carries a tile: the hand-off copies are then ORDINARY memory, met in that XCD's L2
   int32_t timeout_ticks;  // 10 ns ticks a poll may wait before the launch gives up (the host: max(0.5 ms, 8 x the handle's
                           // last measured round), 4 ms while nothing has been measured)
