@@ -1,5 +1,6 @@
 """r06: keep-mode flame_hip_delaunay with T handed out before the stars (option delaunay_early_T = 1) against after them (0):
-host milliseconds of delaunay_keep / sync_features / 50 iterations + download, frame after frame on one handle."""
+host milliseconds of delaunay_keep / sync_features / 50 iterations + download, frame after frame on one handle.
+(Needs a library built with tools/exp/early_T.patch applied: the product has no such option.)"""
 import os
 import sys
 import time

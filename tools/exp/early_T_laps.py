@@ -1,3 +1,4 @@
+"""r06 experiment aid (tools/exp/early_T.patch applied): one keep-mode frame stream with / without the early T, plan_timing on at the end."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
