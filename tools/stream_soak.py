@@ -9,6 +9,23 @@ from flame_ros_amd.regularizer import GraphRegularizer, default_params, default_
 from oracle.cbind import SyncParams as OSync, graph_sync as oracle_sync
 from oracle import COracle
 from tests.util import oracle_params, bits
+def kfd_stats():
+    """The kernel driver's per-process counters (all KFD processes that own queues: pids here are the host's): milliseconds the
+    process' queues were EVICTED, page faults / migrations -- what a whole-launch stall would show up in."""
+    import glob
+    out = {"evicted_ms": 0, "faults": 0, "page_in": 0, "page_out": 0}
+    for d in glob.glob("/sys/class/kfd/kfd/proc/*"):
+        if not os.path.isdir(os.path.join(d, "queues")):
+            continue
+        for key, pat in (("evicted_ms", "stats_*/evicted_ms"), ("faults", "counters_*/faults"), ("page_in", "counters_*/page_in"), ("page_out", "counters_*/page_out")):
+            for f in glob.glob(os.path.join(d, pat)):
+                try:
+                    out[key] += int(open(f).read().strip() or 0)
+                except Exception:
+                    pass
+    return out
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(11)
 # (argv[2] = "facade": the options flame::Flame sets -- small frames on halo tiles, 0.9-1.28 k vertices on persistent tiles)
@@ -17,6 +34,8 @@ r = GraphRegularizer.empty(device=0, **opts)
 Kinv = np.linalg.inv(np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]])).astype(np.float32)
 p, sp = default_params(), default_sync_params()
 free0 = torch.cuda.mem_get_info()[0]
+kfd0 = kfd_stats(); kfd_prev = dict(kfd0)
+print("kfd counters at start:", kfd0, flush=True)
 t0 = time.perf_counter(); bad = 0
 for k in range(n):
     # random sizes, with runs of similar frames in between (partition reuse kicks in on those)
@@ -50,6 +69,9 @@ for k in range(n):
             k, V, r.last_solve_ms()[0], r.info("num_tiles"), r.info("tile_depth"), r.info("tile_threads"), r.info("tile_ept"), r.info("tile_slot12"),
             r.info("tile_fat"), r.info("tile_lds_bytes"), r.info("plan_reused"),
             {q: r.info("persist_gave_up_" + q) for q in ("tile", "round", "front_round", "not_started", "rounds", "tiles", "one_xcd", "timeout_us")}), flush=True)
+        kn = kfd_stats()
+        print("           kfd counters since the last event / start: %s" % {q: kn[q] - kfd_prev[q] for q in kn}, flush=True)
+        kfd_prev = kn
     rec_seen = rec_now
     reused = reused + r.info("plan_reused") if k else 0
     persisted = (persisted if k else 0) + r.info("persist_used")
@@ -60,6 +82,8 @@ for k in range(n):
         print("frame %4d V %6d  plan_on_device %d reused %d  bad words %d" % (k, V, r.info("plan_on_device"), r.info("plan_reused"), nb), flush=True)
 dt = time.perf_counter() - t0
 free1 = torch.cuda.mem_get_info()[0]
+kn = kfd_stats()
+print("kfd counters over the run:", {q: kn[q] - kfd0[q] for q in kn}, flush=True)
 print("torn-read debug build: %d; torn hand-off entries counted: %d; longest poll wait %d us (time-out %d us)" % (
     r.info("torn_check_build"), r.info("persist_torn"), r.info("persist_wait_us_max"), r.info("persist_timeout_us")))
 print("frames %d in %.1f s (incl. graph generation); %d plans from a reused partition; device memory in use changed by %.1f MiB; bad words %d; %d solves on persistent tiles, %d of them repeated" % (n, dt, reused, (free0 - free1) / 2**20, bad, persisted, r.info("persist_recovered")))
